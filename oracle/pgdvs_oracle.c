@@ -1,0 +1,723 @@
+/*
+ * pgdvs_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the PGDVS per-target-view rendering inner loop
+ * (SURVEY.md section 8a rows A1..A12).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library; the product path
+ * (ml-pgdvs_amd/) never does.
+ *
+ * Every function cites the reference file:line (relative to the upstream
+ * apple/ml-pgdvs tree) whose behaviour it restates.  Arithmetic is IEEE fp32
+ * (fp64 for the static-aggregation row, which is float64 numpy upstream) with
+ * a fixed left-to-right operation order and no FMA contraction: build with
+ *     gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC
+ * so that the HIP kernels, which use the same operation order, can be compared
+ * bit-for-bit on the integer / index paths.
+ *
+ * Parity pinning:
+ *   - rows A1..A8, A11, A12 are pinned against golden vectors produced by
+ *     importing the reference itself (tests/golden/make_golden.py).
+ *   - rows A9 (point rasteriser + norm-weighted compositor) and the kNN used
+ *     by A4 restate pytorch3d 0.7.4 (un-vendored third-party dependency,
+ *     README.md:38 of the reference); pytorch3d is not installable here, so
+ *     for A9 parity is UNPINNED (restated from its published algorithm:
+ *     pytorch3d/csrc/rasterize_points/rasterize_points_cpu.cpp
+ *     RasterizePointsNaiveCpu, pytorch3d/csrc/compositing/
+ *     norm_weighted_sum_cpu.cpp, pytorch3d/renderer/points/renderer.py).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ */
+/* Camera block: derived per-camera constants.                          */
+/* layout (floats):                                                     */
+/*   [ 0: 9]  Kinv   = inverse(K[:3,:3])                                 */
+/*   [ 9:18]  M      = c2w[:3,:3] @ Kinv     (ray direction matrix)      */
+/*   [18:21]  o      = c2w[:3,3]                                         */
+/*   [21:37]  P      = K(4x4) @ inverse(c2w) (projection matrix)         */
+/*   [37:53]  w2c    = inverse(c2w)                                      */
+/*   [53:62]  R      = c2w[:3,:3]                                        */
+/*   [62:64]  h, w                                                       */
+/*   [64:80]  K (4x4) as given                                           */
+/* ------------------------------------------------------------------ */
+#define CAM_KINV 0
+#define CAM_M 9
+#define CAM_O 18
+#define CAM_P 21
+#define CAM_W2C 37
+#define CAM_R 53
+#define CAM_HW 62
+#define CAM_K 64
+#define CAM_BLOCK 80
+
+/* Gauss-Jordan inverse with partial pivoting in fp64 (n <= 4). */
+static int inv_f64(const double *a, double *out, int n) {
+  double m[4][8];
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) {
+      m[i][j] = a[i * n + j];
+      m[i][n + j] = (i == j) ? 1.0 : 0.0;
+    }
+  }
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    double best = fabs(m[c][c]);
+    for (int r = c + 1; r < n; ++r) {
+      double v = fabs(m[r][c]);
+      if (v > best) {
+        best = v;
+        piv = r;
+      }
+    }
+    if (best == 0.0) return -1;
+    if (piv != c) {
+      for (int j = 0; j < 2 * n; ++j) {
+        double t = m[c][j];
+        m[c][j] = m[piv][j];
+        m[piv][j] = t;
+      }
+    }
+    double d = m[c][c];
+    for (int j = 0; j < 2 * n; ++j) m[c][j] = m[c][j] / d;
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      double f = m[r][c];
+      if (f == 0.0) continue;
+      for (int j = 0; j < 2 * n; ++j) m[r][j] = m[r][j] - f * m[c][j];
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) out[i * n + j] = m[i][n + j];
+  return 0;
+}
+
+ORC_API int orc_inv_f64(const double *a, double *out, int n) {
+  return inv_f64(a, out, n);
+}
+
+/*
+ * flat_cam[34] = [h, w, K(4x4 row-major), c2w(4x4 row-major)]
+ * (pgdvs/renderers/pgdvs_renderer.py:354-357, pgdvs/datasets/nvidia_eval.py:827-832).
+ * Derived matrices follow pgdvs_renderer_base.py:40-45 (M = c2w[:3,:3] @ inv(K[:3,:3]))
+ * and gnt/projector.py:49-60 (P = K @ inv(c2w)).  torch.inverse is fp32 LU upstream;
+ * here the inverse is formed in fp64 and rounded once to fp32 (|delta| ~ 1 ulp).
+ */
+ORC_API int orc_cam_prep(const float *flat_cam, float *blk) {
+  const float *K = flat_cam + 2;
+  const float *c2w = flat_cam + 18;
+  double k3[9], k3i[9], c4[16], c4i[16];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) k3[i * 3 + j] = (double)K[i * 4 + j];
+  for (int i = 0; i < 16; ++i) c4[i] = (double)c2w[i];
+  if (inv_f64(k3, k3i, 3) != 0) return -1;
+  if (inv_f64(c4, c4i, 4) != 0) return -2;
+  float kinv[9], w2c[16];
+  for (int i = 0; i < 9; ++i) kinv[i] = (float)k3i[i];
+  for (int i = 0; i < 16; ++i) w2c[i] = (float)c4i[i];
+  for (int i = 0; i < 9; ++i) blk[CAM_KINV + i] = kinv[i];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      float s = c2w[i * 4 + 0] * kinv[0 * 3 + j];
+      s = s + c2w[i * 4 + 1] * kinv[1 * 3 + j];
+      s = s + c2w[i * 4 + 2] * kinv[2 * 3 + j];
+      blk[CAM_M + i * 3 + j] = s;
+      blk[CAM_R + i * 3 + j] = c2w[i * 4 + j];
+    }
+    blk[CAM_O + i] = c2w[i * 4 + 3];
+  }
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 4; ++j) {
+      float s = K[i * 4 + 0] * w2c[0 * 4 + j];
+      s = s + K[i * 4 + 1] * w2c[1 * 4 + j];
+      s = s + K[i * 4 + 2] * w2c[2 * 4 + j];
+      s = s + K[i * 4 + 3] * w2c[3 * 4 + j];
+      blk[CAM_P + i * 4 + j] = s;
+    }
+  }
+  for (int i = 0; i < 16; ++i) blk[CAM_W2C + i] = w2c[i];
+  blk[CAM_HW + 0] = flat_cam[0];
+  blk[CAM_HW + 1] = flat_cam[1];
+  for (int i = 0; i < 16; ++i) blk[CAM_K + i] = K[i];
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* A1: get_batched_rays (pgdvs/renderers/pgdvs_renderer_base.py:17-57)  */
+/* integer pixel centres (no +0.5), rays_d un-normalised, stride.       */
+/* outputs: rays_o[n,3], rays_d[n,3], uvs[n,2], n = rh*rw               */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_get_rays(const float *blk, int H, int W, int stride, float *rays_o,
+                          float *rays_d, float *uvs) {
+  const float *M = blk + CAM_M;
+  const float *o = blk + CAM_O;
+  int rh = (H + stride - 1) / stride, rw = (W + stride - 1) / stride;
+#pragma omp parallel for
+  for (int r = 0; r < rh; ++r) {
+    for (int c = 0; c < rw; ++c) {
+      int i = r * rw + c;
+      float u = (float)(c * stride), v = (float)(r * stride);
+      for (int k = 0; k < 3; ++k) {
+        float d = M[k * 3 + 0] * u;
+        d = d + M[k * 3 + 1] * v;
+        d = d + M[k * 3 + 2];
+        rays_d[i * 3 + k] = d;
+        rays_o[i * 3 + k] = o[k];
+      }
+      uvs[i * 2 + 0] = u;
+      uvs[i * 2 + 1] = v;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* A2 + A3: unproject + flow-guided temporal warp, dense over [H,W]     */
+/* (pgdvs/renderers/pgdvs_renderer_dyn.py:299-388).                     */
+/*   mask_eff[p]  : dyn_mask_1 after optional flow-consistency (:304-308)*/
+/*   valid[p]     : mask_eff && 0<=uv2<=(W-1,H-1)        (:309-316)      */
+/*   pcl[p,3]     : time-lerped world point               (:318-320,385-388)*/
+/*   rgbf[p,3]    : colour attached to the point          (:333-337,350-356)*/
+/* grid_sample restated from ATen GridSampler (CUDA flavour):            */
+/*   unnormalize(align_corners=False) = ((g + 1) * size - 1) / 2         */
+/*   nearest = nearbyint (round-half-even), zero padding.                */
+/* ------------------------------------------------------------------ */
+static inline float fclampf(float x, float lo, float hi) {
+  return x < lo ? lo : (x > hi ? hi : x);
+}
+
+ORC_API void orc_dyn_warp(int H, int W, const float *dyn_mask1, const float *occ,
+                          int use_flow_consistency, const float *flow12,
+                          const float *depth1, const float *depth2, const float *rgb1,
+                          const float *rgb2, const float *cam1, const float *cam2,
+                          float t1, float t2, float tt, uint8_t *mask_eff, uint8_t *valid,
+                          float *pcl, float *rgbf) {
+  const float *M1 = cam1 + CAM_M, *o1 = cam1 + CAM_O;
+  const float *Kinv2 = cam2 + CAM_KINV, *R2 = cam2 + CAM_R, *o2 = cam2 + CAM_O;
+  const float fw = (float)W, fh = (float)H;
+  const int same_time = (t1 == t2);
+  float w1 = 0.f, w2 = 0.f;
+  if (!same_time) {
+    w1 = (t2 - tt) / (t2 - t1);
+    w2 = (tt - t1) / (t2 - t1);
+  }
+#pragma omp parallel for
+  for (int r = 0; r < H; ++r) {
+    for (int c = 0; c < W; ++c) {
+      int p = r * W + c;
+      float u = (float)c, v = (float)r;
+      int m = dyn_mask1[p] != 0.0f;
+      if (use_flow_consistency) m = m && !(occ[p] > 0.0f);
+      mask_eff[p] = (uint8_t)m;
+      float ux = u + flow12[p * 2 + 0];
+      float uy = v + flow12[p * 2 + 1];
+      int ok = m && (ux >= 0.0f) && (ux <= fw - 1.0f) && (uy >= 0.0f) && (uy <= fh - 1.0f);
+      valid[p] = (uint8_t)ok;
+      float X1[3];
+      for (int k = 0; k < 3; ++k) {
+        float d = M1[k * 3 + 0] * u;
+        d = d + M1[k * 3 + 1] * v;
+        d = d + M1[k * 3 + 2];
+        X1[k] = o1[k] + d * depth1[p];
+      }
+      if (!ok) {
+        for (int k = 0; k < 3; ++k) {
+          pcl[p * 3 + k] = 0.0f;
+          rgbf[p * 3 + k] = 0.0f;
+        }
+        continue;
+      }
+      if (same_time) {
+        for (int k = 0; k < 3; ++k) {
+          pcl[p * 3 + k] = X1[k];
+          rgbf[p * 3 + k] = rgb1[p * 3 + k];
+        }
+        continue;
+      }
+      /* grid = 2*uv/raw_shape - 1 (:341), default align_corners=False */
+      float gx = 2.0f * ux / fw - 1.0f;
+      float gy = 2.0f * uy / fh - 1.0f;
+      float ix = ((gx + 1.0f) * fw - 1.0f) / 2.0f;
+      float iy = ((gy + 1.0f) * fh - 1.0f) / 2.0f;
+      /* nearest depth (:342-348) */
+      float nx = nearbyintf(ix), ny = nearbyintf(iy);
+      float dsamp = 0.0f;
+      if (nx >= 0.0f && nx <= fw - 1.0f && ny >= 0.0f && ny <= fh - 1.0f)
+        dsamp = depth2[(int)ny * W + (int)nx];
+      /* bilinear rgb (:350-356), zero padding */
+      float x0f = floorf(ix), y0f = floorf(iy);
+      int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+      float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+      float wne = (ix - (float)x0) * ((float)y1 - iy);
+      float wsw = ((float)x1 - ix) * (iy - (float)y0);
+      float wse = (ix - (float)x0) * (iy - (float)y0);
+      float col[3] = {0.f, 0.f, 0.f};
+      for (int k = 0; k < 3; ++k) {
+        float acc = 0.0f;
+        if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H) acc = acc + rgb2[(y0 * W + x0) * 3 + k] * wnw;
+        if (x1 >= 0 && x1 < W && y0 >= 0 && y0 < H) acc = acc + rgb2[(y0 * W + x1) * 3 + k] * wne;
+        if (x0 >= 0 && x0 < W && y1 >= 0 && y1 < H) acc = acc + rgb2[(y1 * W + x0) * 3 + k] * wsw;
+        if (x1 >= 0 && x1 < W && y1 >= 0 && y1 < H) acc = acc + rgb2[(y1 * W + x1) * 3 + k] * wse;
+        col[k] = acc;
+      }
+      /* frame-2 ray: c2w_2[:3,:3] @ (inv(K_2[:3,:3]) @ [uv2,1]) (:358-372) */
+      float kq[3];
+      for (int k = 0; k < 3; ++k) {
+        float s = Kinv2[k * 3 + 0] * ux;
+        s = s + Kinv2[k * 3 + 1] * uy;
+        s = s + Kinv2[k * 3 + 2];
+        kq[k] = s;
+      }
+      for (int k = 0; k < 3; ++k) {
+        float d = R2[k * 3 + 0] * kq[0];
+        d = d + R2[k * 3 + 1] * kq[1];
+        d = d + R2[k * 3 + 2] * kq[2];
+        float X2 = o2[k] + d * dsamp;
+        pcl[p * 3 + k] = w1 * X1[k] + w2 * X2;
+        rgbf[p * 3 + k] = col[k];
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* A4: brute-force kNN mean squared distance                            */
+/* (pgdvs_renderer_dyn.py:405-419; pytorch3d.ops.knn_points semantics: */
+/* K nearest by squared L2, ascending).  out[i] = mean of the K         */
+/* smallest squared distances after dropping the smallest one (column   */
+/* 0 = the point itself).  When N < K+1 the missing columns are zero    */
+/* (pytorch3d pads dists with 0).                                       */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_knn_mean_dist(const float *pts, int64_t N, int K, float *out) {
+  int KK = K + 1;
+#pragma omp parallel
+  {
+    float *best = (float *)malloc(sizeof(float) * (size_t)KK);
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t i = 0; i < N; ++i) {
+      int cnt = 0;
+      float qx = pts[i * 3], qy = pts[i * 3 + 1], qz = pts[i * 3 + 2];
+      for (int64_t j = 0; j < N; ++j) {
+        float dx = qx - pts[j * 3], dy = qy - pts[j * 3 + 1], dz = qz - pts[j * 3 + 2];
+        float d = dx * dx;
+        d = d + dy * dy;
+        d = d + dz * dz;
+        if (cnt < KK) {
+          int k = cnt++;
+          while (k > 0 && best[k - 1] > d) {
+            best[k] = best[k - 1];
+            --k;
+          }
+          best[k] = d;
+        } else if (d < best[KK - 1]) {
+          int k = KK - 1;
+          while (k > 0 && best[k - 1] > d) {
+            best[k] = best[k - 1];
+            --k;
+          }
+          best[k] = d;
+        }
+      }
+      /* torch.mean over K columns (cols 1..K), sequential fp32 sum */
+      float s = 0.0f;
+      for (int k = 1; k < KK; ++k) s = s + (k < cnt ? best[k] : 0.0f);
+      out[i] = s / (float)K;
+    }
+    free(best);
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* A5: project world points into the target camera                     */
+/* (gnt/projector.py:41-73 as called from pgdvs_renderer_dyn.py:470-475)*/
+/*   p = P @ [X,1];  uv = p[:2] / clamp(p[2], min=1e-8); clamp +-1e6    */
+/* ------------------------------------------------------------------ */
+static inline void project_pt(const float *P, const float *X, float *uv) {
+  float p[3];
+  for (int i = 0; i < 3; ++i) {
+    float s = P[i * 4 + 0] * X[0];
+    s = s + P[i * 4 + 1] * X[1];
+    s = s + P[i * 4 + 2] * X[2];
+    s = s + P[i * 4 + 3];
+    p[i] = s;
+  }
+  float z = p[2] < 1e-8f ? 1e-8f : p[2];
+  uv[0] = fclampf(p[0] / z, -1e6f, 1e6f);
+  uv[1] = fclampf(p[1] / z, -1e6f, 1e6f);
+}
+
+ORC_API void orc_project(const float *cam_tgt, const float *pts, int64_t N, float *uv) {
+  const float *P = cam_tgt + CAM_P;
+#pragma omp parallel for
+  for (int64_t i = 0; i < N; ++i) project_pt(P, pts + i * 3, uv + i * 2);
+}
+
+/* dense variant: flow_1_to_tgt[p] = proj(pcl[p]) - uv1[p] for keep[p]!=0, else 0
+ * (pgdvs_renderer_dyn.py:477-503) */
+ORC_API void orc_project_flow_dense(int H, int W, const float *cam_tgt, const float *pcl,
+                                    const uint8_t *keep, float *flow_1_to_tgt,
+                                    float *valid_mask) {
+  const float *P = cam_tgt + CAM_P;
+#pragma omp parallel for
+  for (int r = 0; r < H; ++r) {
+    for (int c = 0; c < W; ++c) {
+      int p = r * W + c;
+      if (keep[p]) {
+        float uv[2];
+        project_pt(P, pcl + p * 3, uv);
+        flow_1_to_tgt[p * 2 + 0] = uv[0] - (float)c;
+        flow_1_to_tgt[p * 2 + 1] = uv[1] - (float)r;
+        valid_mask[p] = 1.0f;
+      } else {
+        flow_1_to_tgt[p * 2 + 0] = 0.0f;
+        flow_1_to_tgt[p * 2 + 1] = 0.0f;
+        valid_mask[p] = 0.0f;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* A6: softsplat importance metric                                     */
+/* (pgdvs_renderer_base.py:68-87 L1 + clip, :91-138 backwarp).          */
+/* inputs NCHW planes: rgb1[3,H,W] rgb2[3,H,W] flow[2,H,W]              */
+/* out l1[H,W] (= softsplat_metric_src1_to_src2)                        */
+/* backwarp grid: linspace(-1,1,W)[x] + flow_x / ((W-1)/2),             */
+/* grid_sample(bilinear, zeros, align_corners=True):                    */
+/*   unnormalize = ((g + 1) / 2) * (size - 1)                           */
+/* linspace restated from ATen: step=(end-start)/(steps-1);             */
+/*   i < steps/2 ? start + step*i : end - step*(steps-1-i)              */
+/* ------------------------------------------------------------------ */
+static inline float linspace_m1_1(int i, int steps) {
+  if (steps == 1) return -1.0f;
+  float step = (1.0f - (-1.0f)) / (float)(steps - 1);
+  if (i < steps / 2) return -1.0f + step * (float)i;
+  return 1.0f - step * (float)(steps - 1 - i);
+}
+
+ORC_API void orc_backwarp_l1(int H, int W, const float *rgb1, const float *rgb2,
+                             const float *flow, float *l1) {
+  const float hw_x = ((float)W - 1.0f) / 2.0f, hw_y = ((float)H - 1.0f) / 2.0f;
+  const int P = H * W;
+#pragma omp parallel for
+  for (int r = 0; r < H; ++r) {
+    for (int c = 0; c < W; ++c) {
+      int p = r * W + c;
+      float gx = linspace_m1_1(c, W) + flow[p] / hw_x;
+      float gy = linspace_m1_1(r, H) + flow[P + p] / hw_y;
+      float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+      float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+      float x0f = floorf(ix), y0f = floorf(iy);
+      int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+      float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+      float wne = (ix - (float)x0) * ((float)y1 - iy);
+      float wsw = ((float)x1 - ix) * (iy - (float)y0);
+      float wse = (ix - (float)x0) * (iy - (float)y0);
+      /* non-finite coordinates: ATen casts to int (UB); treat as out of bounds */
+      int fin = isfinite(ix) && isfinite(iy);
+      float s = 0.0f;
+      for (int k = 0; k < 3; ++k) {
+        const float *pl = rgb2 + (size_t)k * P;
+        float acc = 0.0f;
+        if (fin) {
+          if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H) acc = acc + pl[y0 * W + x0] * wnw;
+          if (x1 >= 0 && x1 < W && y0 >= 0 && y0 < H) acc = acc + pl[y0 * W + x1] * wne;
+          if (x0 >= 0 && x0 < W && y1 >= 0 && y1 < H) acc = acc + pl[y1 * W + x0] * wsw;
+          if (x1 >= 0 && x1 < W && y1 >= 0 && y1 < H) acc = acc + pl[y1 * W + x1] * wse;
+        }
+        s = s + fabsf(rgb1[(size_t)k * P + p] - acc);
+      }
+      l1[p] = s / 3.0f;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* A7: softsplat forward = kernel softsplat_out                        */
+/* (pgdvs/utils/softsplat.py:352-402).  in[B,C,H,W] flow[B,2,H,W]       */
+/* out[B,C,H,W] must be zeroed by the caller (new_zeros, :343-345).     */
+/* Accumulation order here is source-pixel raster order per (n,c) plane */
+/* (the CUDA kernel's atomicAdd order is unspecified).                  */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_softsplat_fwd(const float *in, const float *flow, float *out, int B, int C,
+                               int H, int W) {
+  const size_t P = (size_t)H * W;
+#pragma omp parallel for collapse(2)
+  for (int n = 0; n < B; ++n) {
+    for (int ch = 0; ch < C; ++ch) {
+      const float *src = in + ((size_t)n * C + ch) * P;
+      float *dst = out + ((size_t)n * C + ch) * P;
+      const float *fx = flow + ((size_t)n * 2 + 0) * P;
+      const float *fy = flow + ((size_t)n * 2 + 1) * P;
+      for (int y = 0; y < H; ++y) {
+        for (int x = 0; x < W; ++x) {
+          size_t p = (size_t)y * W + x;
+          float X = (float)x + fx[p];
+          float Y = (float)y + fy[p];
+          if (!isfinite(X) || !isfinite(Y)) continue;
+          float v = src[p];
+          /* (int) floor(): values outside the int range are UB upstream; the
+           * bounds test below rejects them either way, so clamp first. */
+          float flx = floorf(X), fly = floorf(Y);
+          if (flx < -2.0f || flx > (float)W || fly < -2.0f || fly > (float)H) continue;
+          int nwx = (int)flx, nwy = (int)fly;
+          int nex = nwx + 1, ney = nwy;
+          int swx = nwx, swy = nwy + 1;
+          int sex = nwx + 1, sey = nwy + 1;
+          float wnw = ((float)sex - X) * ((float)sey - Y);
+          float wne = (X - (float)swx) * ((float)swy - Y);
+          float wsw = ((float)nex - X) * (Y - (float)ney);
+          float wse = (X - (float)nwx) * (Y - (float)nwy);
+          if (nwx >= 0 && nwx < W && nwy >= 0 && nwy < H) dst[(size_t)nwy * W + nwx] += v * wnw;
+          if (nex >= 0 && nex < W && ney >= 0 && ney < H) dst[(size_t)ney * W + nex] += v * wne;
+          if (swx >= 0 && swx < W && swy >= 0 && swy < H) dst[(size_t)swy * W + swx] += v * wsw;
+          if (sex >= 0 && sex < W && sey >= 0 && sey < H) dst[(size_t)sey * W + sex] += v * wse;
+        }
+      }
+    }
+  }
+}
+
+/* corner indices of the splat (the bit-exact integer path): idx[p,4] = flat
+ * destination index y*W+x of NW,NE,SW,SE or -1 if dropped. */
+ORC_API void orc_softsplat_corners(const float *flow, int H, int W, int32_t *idx) {
+  const size_t P = (size_t)H * W;
+#pragma omp parallel for
+  for (int y = 0; y < H; ++y) {
+    for (int x = 0; x < W; ++x) {
+      size_t p = (size_t)y * W + x;
+      int32_t *o = idx + p * 4;
+      o[0] = o[1] = o[2] = o[3] = -1;
+      float X = (float)x + flow[p];
+      float Y = (float)y + flow[P + p];
+      if (!isfinite(X) || !isfinite(Y)) continue;
+      float flx = floorf(X), fly = floorf(Y);
+      if (flx < -2.0f || flx > (float)W || fly < -2.0f || fly > (float)H) continue;
+      int nwx = (int)flx, nwy = (int)fly;
+      int xs[4] = {nwx, nwx + 1, nwx, nwx + 1};
+      int ys[4] = {nwy, nwy, nwy + 1, nwy + 1};
+      for (int k = 0; k < 4; ++k)
+        if (xs[k] >= 0 && xs[k] < W && ys[k] >= 0 && ys[k] < H) o[k] = ys[k] * W + xs[k];
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* A9: naive point rasteriser + norm-weighted compositor               */
+/* pytorch3d 0.7.4 semantics (see file header: parity UNPINNED).        */
+/* Call sites: pgdvs/renderers/st_geo_renderer.py:77-120,               */
+/*             pgdvs/renderers/pgdvs_renderer_dyn.py:671-724.           */
+/* Camera conversion: pgdvs/utils/pytorch3d_utils.py:5-47               */
+/*   s = min(W,H)/2; f_ndc = f/s; p0 = -(pp - (W,H)/2)/s;               */
+/*   view = w2c applied then x,y negated.                               */
+/* Point -> NDC: x_ndc = (fx_ndc*xv + p0x*zv)/zv (4x4 projective        */
+/* transform then homogeneous divide), z = zv.                          */
+/* Pixel -> NDC (rasterization_utils.cuh PixToNonSquareNdc):            */
+/*   xf(xi) with xidx = W-1-xi : -off + (range*xidx + off)/W ...        */
+/* A point covers a pixel iff dist2 < radius^2 (strict) and z >= 0.     */
+/* Per pixel keep the K smallest by (z, idx) ascending.                 */
+/* outputs idx[H,W,K] int64 (-1 pad), zbuf[H,W,K] (-1 pad),             */
+/* dist2[H,W,K] (-1 pad).                                               */
+/* ------------------------------------------------------------------ */
+static inline float pix_to_ndc(int i, int S1, int S2) {
+  /* S1 = size along this axis, S2 = the other axis */
+  float range = S1 > S2 ? 2.0f * (float)S1 / (float)S2 : 2.0f;
+  float offset = range / 2.0f;
+  return -offset + (range * (float)i + offset) / (float)S1;
+}
+
+/* points (world) -> NDC x,y and view z; ndc[N,3] */
+ORC_API void orc_points_to_ndc(const float *cam, int H, int W, const float *pts, int64_t N,
+                               int64_t stride, float *ndc) {
+  const float *w2c = cam + CAM_W2C;
+  const float fx = cam[CAM_K + 0], fy = cam[CAM_K + 5];
+  const float cx = cam[CAM_K + 2], cy = cam[CAM_K + 6];
+  float s = (float)(W < H ? W : H) / 2.0f;
+  float fxn = fx / s, fyn = fy / s;
+  float p0x = -(cx - (float)W / 2.0f) / s;
+  float p0y = -(cy - (float)H / 2.0f) / s;
+#pragma omp parallel for
+  for (int64_t i = 0; i < N; ++i) {
+    const float *X = pts + i * stride;
+    float v[3];
+    for (int k = 0; k < 3; ++k) {
+      float a = w2c[k * 4 + 0] * X[0];
+      a = a + w2c[k * 4 + 1] * X[1];
+      a = a + w2c[k * 4 + 2] * X[2];
+      a = a + w2c[k * 4 + 3];
+      v[k] = a;
+    }
+    float xv = -v[0], yv = -v[1], zv = v[2];
+    ndc[i * 3 + 0] = (fxn * xv + p0x * zv) / zv;
+    ndc[i * 3 + 1] = (fyn * yv + p0y * zv) / zv;
+    ndc[i * 3 + 2] = zv;
+  }
+}
+
+ORC_API void orc_raster_points_naive(const float *ndc, int64_t N, int H, int W, float radius,
+                                     int K, int64_t *idx, float *zbuf, float *dist2) {
+  const float r2 = radius * radius;
+#pragma omp parallel
+  {
+    float *qz = (float *)malloc(sizeof(float) * (size_t)K);
+    float *qd = (float *)malloc(sizeof(float) * (size_t)K);
+    int64_t *qi = (int64_t *)malloc(sizeof(int64_t) * (size_t)K);
+#pragma omp for schedule(dynamic, 4)
+    for (int yi = 0; yi < H; ++yi) {
+      float yf = pix_to_ndc(H - 1 - yi, H, W);
+      for (int xi = 0; xi < W; ++xi) {
+        float xf = pix_to_ndc(W - 1 - xi, W, H);
+        int cnt = 0;
+        for (int64_t p = 0; p < N; ++p) {
+          float pz = ndc[p * 3 + 2];
+          if (pz < 0.0f) continue;
+          float dx = ndc[p * 3 + 0] - xf;
+          float dy = ndc[p * 3 + 1] - yf;
+          float d2 = dx * dx + dy * dy;
+          if (!(d2 < r2)) continue;
+          /* insert keeping ascending (z, idx); p increases so ties keep order */
+          if (cnt < K) {
+            int k = cnt++;
+            while (k > 0 && qz[k - 1] > pz) {
+              qz[k] = qz[k - 1];
+              qi[k] = qi[k - 1];
+              qd[k] = qd[k - 1];
+              --k;
+            }
+            qz[k] = pz;
+            qi[k] = p;
+            qd[k] = d2;
+          } else if (pz < qz[K - 1]) {
+            int k = K - 1;
+            while (k > 0 && qz[k - 1] > pz) {
+              qz[k] = qz[k - 1];
+              qi[k] = qi[k - 1];
+              qd[k] = qd[k - 1];
+              --k;
+            }
+            qz[k] = pz;
+            qi[k] = p;
+            qd[k] = d2;
+          }
+        }
+        size_t o = ((size_t)yi * W + xi) * K;
+        for (int k = 0; k < K; ++k) {
+          if (k < cnt) {
+            idx[o + k] = qi[k];
+            zbuf[o + k] = qz[k];
+            dist2[o + k] = qd[k];
+          } else {
+            idx[o + k] = -1;
+            zbuf[o + k] = -1.0f;
+            dist2[o + k] = -1.0f;
+          }
+        }
+      }
+    }
+    free(qz);
+    free(qd);
+    free(qi);
+  }
+}
+
+/* NormWeightedCompositor: weights = 1 - dist2/(r*r) (points/renderer.py),
+ * t = max(sum_k w_k, 1e-4); out[c] = sum_k w_k * feat[idx_k][c] / t
+ * (norm_weighted_sum_cpu.cpp).  feat[N, fstride] (first C used); out[H,W,C]. */
+ORC_API void orc_norm_weighted_composite(const int64_t *idx, const float *dist2, int H, int W,
+                                         int K, float radius, const float *feat,
+                                         int64_t fstride, int C, float *out) {
+  const float r2 = radius * radius;
+#pragma omp parallel for
+  for (int64_t p = 0; p < (int64_t)H * W; ++p) {
+    float t = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      if (idx[p * K + k] < 0) continue;
+      float w = 1.0f - dist2[p * K + k] / r2;
+      t = t + w;
+    }
+    t = t > 1e-4f ? t : 1e-4f;
+    for (int c = 0; c < C; ++c) {
+      float acc = 0.0f;
+      for (int k = 0; k < K; ++k) {
+        int64_t n = idx[p * K + k];
+        if (n < 0) continue;
+        float w = 1.0f - dist2[p * K + k] / r2;
+        float f = feat ? feat[n * fstride + c] : 1.0f;
+        acc = acc + w * f / t;
+      }
+      out[p * C + c] = acc;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* A12: static point-cloud aggregation helpers (float64 numpy upstream) */
+/* _compute_pcl_proj_mask (pgdvs/datasets/nvidia_eval_pure_geo.py:257-277):*/
+/*   verts_cam = w2c @ [X,1]; /= w ; pix = K3 @ verts_cam ; /= z         */
+/*   closed bounds 0<=col<=W-1, 0<=row<=H-1 ; astype(int) truncation     */
+/*   NO z>0 test, NO epsilon.  pcl is fp32 (rays are FloatTensor), the    */
+/*   matrices are float64.                                               */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_static_proj_mask(const float *pcl, int64_t N, int64_t stride,
+                                  const double *K3, const double *w2c, int H, int W,
+                                  uint8_t *mask) {
+  for (int64_t i = 0; i < N; ++i) {
+    const float *X = pcl + i * stride;
+    double x = (double)X[0], y = (double)X[1], z = (double)X[2];
+    double vc[4];
+    for (int k = 0; k < 4; ++k) {
+      double s = w2c[k * 4 + 0] * x;
+      s = s + w2c[k * 4 + 1] * y;
+      s = s + w2c[k * 4 + 2] * z;
+      s = s + w2c[k * 4 + 3];
+      vc[k] = s;
+    }
+    double cx = vc[0] / vc[3], cy = vc[1] / vc[3], cz = vc[2] / vc[3];
+    double pp[3];
+    for (int k = 0; k < 3; ++k) {
+      double s = K3[k * 3 + 0] * cx;
+      s = s + K3[k * 3 + 1] * cy;
+      s = s + K3[k * 3 + 2] * cz;
+      pp[k] = s;
+    }
+    double col = pp[0] / pp[2], row = pp[1] / pp[2];
+    if (!(row >= 0.0 && row <= (double)(H - 1))) continue;
+    if (!(col >= 0.0 && col <= (double)(W - 1))) continue;
+    mask[(int64_t)row * W + (int64_t)col] = 1;
+  }
+}
+
+/* _compute_pcl (pgdvs/datasets/nvidia_eval.py:840-847) with
+ * _get_rays_single_image (pgdvs/datasets/base.py:507-546): K, c2w are cast to
+ * fp32 (torch.FloatTensor), rays_d = c2w[:3,:3] @ inv(K) @ [u,v,1] at integer
+ * pixel centres, pcl = rays_o + rays_d * depth.  cam = block of orc_cam_prep. */
+ORC_API void orc_compute_pcl(const float *cam, int H, int W, const float *depth, float *pcl) {
+  const float *M = cam + CAM_M, *o = cam + CAM_O;
+#pragma omp parallel for
+  for (int r = 0; r < H; ++r) {
+    for (int c = 0; c < W; ++c) {
+      int p = r * W + c;
+      float u = (float)c, v = (float)r;
+      for (int k = 0; k < 3; ++k) {
+        float d = M[k * 3 + 0] * u;
+        d = d + M[k * 3 + 1] * v;
+        d = d + M[k * 3 + 2];
+        pcl[p * 3 + k] = o[k] + d * depth[p];
+      }
+    }
+  }
+}
+
+ORC_API int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

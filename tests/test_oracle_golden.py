@@ -1,0 +1,95 @@
+"""CPU: the oracle (oracle/) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  Float rows: tolerance stated per test.  Integer /
+index rows: bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+def _load(golden_dir, name):
+    return dict(np.load(golden_dir / name))
+
+
+@pytest.mark.parametrize("name", ["rays_a.npz", "rays_b.npz"])
+def test_rays(golden_dir, name):
+    g = _load(golden_dir, name)
+    ro, rd, uv, shape = orc.get_batched_rays(g["flat_cam"], int(g["H"]), int(g["W"]), int(g["stride"]))
+    assert tuple(shape) == tuple(g["render_hw"])
+    assert np.array_equal(uv, g["uvs"])  # integer pixel centres: exact
+    assert np.array_equal(ro, g["rays_o"])
+    np.testing.assert_allclose(rd, g["rays_d"], rtol=2e-6, atol=2e-6)
+
+
+def test_project(golden_dir):
+    g = _load(golden_dir, "project.npz")
+    uv = orc.project(g["flat_cam"], g["xyz"])
+    # points behind the camera are clamped to +-1e6 by both
+    np.testing.assert_allclose(uv, g["uv"], rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_compute_dyn_pcl(golden_dir, case):
+    g = _load(golden_dir, f"dyn_pcl_{case}.npz")
+    r = orc.compute_dyn_pcl(
+        dyn_mask_1=g["dyn_mask_1"], rgb_1=g["rgb_1"], depth_1=g["depth_1"], flow_12=g["flow_12"],
+        flow_12_occ_mask=g["flow_12_occ_mask"], rgb_2=g["rgb_2"], depth_2=g["depth_2"],
+        flat_cam_1=g["flat_cam_1"], flat_cam_2=g["flat_cam_2"], flat_cam_tgt=g["flat_cam_tgt"],
+        time_1=float(g["time_1"]), time_2=float(g["time_2"]), time_tgt=float(g["time_tgt"]),
+        dyn_render_use_flow_consistency=bool(g["use_flow_consistency"]),
+        dyn_pcl_remove_outlier=bool(g["remove_outlier"]), dyn_pcl_outlier_knn=int(g["outlier_knn"]),
+        dyn_pcl_outlier_std_thres=float(g["outlier_std_thres"]),
+    )
+    # integer path: which pixels survive (mask compaction + bounds + outlier flags)
+    assert np.array_equal(r["valid_dyn_mask_1"], g["out_valid_dyn_mask_1"])
+    assert r["pcl"].shape == g["out_pcl"].shape
+    np.testing.assert_allclose(r["pcl"], g["out_pcl"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r["pcl_rgbs"], g["out_pcl_rgbs"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r["pcl_nn_dist_thres"], g["out_nn_dist_thres"], rtol=1e-4)
+    np.testing.assert_allclose(r["flow_1_to_tgt"], g["out_flow_1_to_tgt"], rtol=1e-4, atol=2e-4)
+
+
+def test_backwarp_l1(golden_dir):
+    g = _load(golden_dir, "backwarp_l1.npz")
+    l1 = orc.backwarp_l1(g["rgb1"][0], g["rgb2"][0], g["flow"][0])
+    np.testing.assert_allclose(l1, g["l1"][0, 0], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("mode", ["sum", "avg", "linear", "soft", "soft-zeroeps", "soft-clipeps"])
+def test_softsplat_modes(golden_dir, mode):
+    g = _load(golden_dir, "softsplat_modes.npz")
+    metric = None if mode in ("sum", "avg") else (g["ten_metric"] if mode != "linear" else np.abs(g["ten_metric"]) + 0.1)
+    out = orc.softsplat(g["ten_in"], g["ten_flow"], metric, mode)
+    ref = g["out_" + mode.replace("-", "_")]
+    np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["forward_a.npz", "forward_b.npz"])
+def test_forward(golden_dir, name):
+    g = _load(golden_dir, name)
+    data = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
+    cfg = dict(
+        dyn_render_use_flow_consistency=bool(g["use_flow_consistency"]), dyn_pcl_remove_outlier=bool(g["remove_outlier"]),
+        dyn_pcl_outlier_knn=int(g["outlier_knn"]), dyn_pcl_outlier_std_thres=float(g["outlier_std_thres"]),
+        dyn_render_type="softsplat",
+    )
+    ret = orc.render_view(data, cfg, static_noise=g["static_noise"], alpha=100.0)
+    assert np.array_equal(ret["render_dyn_mask"], g["out_render_dyn_mask"])  # thresholded mask: exact
+    for k in ["render_dyn_rgb", "combined_rgb", "combined_rgb_static", "combined_rgb_dyn"]:
+        np.testing.assert_allclose(ret[k], g["out_" + k], rtol=0, atol=1e-4, err_msg=k)
+
+
+def test_static_aggregation(golden_dir):
+    g = _load(golden_dir, "static_agg.npz")
+    S, H, W = g["depths"].shape
+    K3s = np.stack([orc.hwf_to_K(*g["hwf"][i]) for i in range(S)])
+    pcl1 = orc.compute_pcl(H, W, K3s[1], g["c2ws"][1], g["depths"][1])
+    np.testing.assert_allclose(pcl1, g["pcl_frame1"], rtol=1e-5, atol=1e-6)
+    # occupancy bitmap: integer path, exact (fed with the reference's own points)
+    pm = orc.static_proj_mask(g["pcl_frame1"], K3s[2], np.linalg.inv(g["c2ws"][2]), H, W)
+    assert np.array_equal(pm, g["proj_mask_1_into_2"])
+    rgbs = g["imgs"].astype(np.float32) / 255.0
+    st = orc.aggregate_static_pcl(rgbs, g["depths"], g["dyn_masks"], K3s, g["c2ws"])
+    assert st.shape == g["st_pcl_rgb"].shape  # same point set size => same occupancy decisions
+    np.testing.assert_allclose(st[:, :3], g["st_pcl_rgb"][:, :3], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st[:, 3:], g["st_pcl_rgb"][:, 3:], rtol=0, atol=1e-6)

@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: novel-view frames/s of the PGDVS rendering hot path on MI355X.
+
+A *step* renders one novel view at H x W from S source frames that are already resident
+in HBM: static point-cloud aggregation over the S frames (A12), point z-buffer
+rasterisation + compositing of that cloud into the target view (A9), the dynamic branch
+(unproject + flow warp + kNN outlier filter + projection, A1-A5), softmax splatting with
+its metric (A6-A8) and the static/dynamic composite (A11).  Nothing is cached between
+steps.  Default workload = BASELINE.json configs[2]: 1080p, 24 source frames.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line
+on rank 0; for N > 1 it is launched through torch.distributed.run (one rank per GPU, RCCL),
+frames are sharded across ranks (weak scaling: K views per rank) and the final image
+stacks are gathered to rank 0 inside the timed region.
+"""
+import argparse
+import ctypes
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "ml-pgdvs_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--views", type=int, default=4, help="distinct target views kept resident and cycled")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel pass")
+    ap.add_argument("--pts-per-pixel", type=int, default=3)
+    ap.add_argument("--no-outlier", action="store_true", help="dyn_pcl_remove_outlier=false (YAML default)")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(name, H, W, S, n_static, n_dyn, K):
+    """Algorithmic HBM bytes of ONE launch of kernel `name` (kernel table):
+    reference fp32 layouts, every input read once and every output written once."""
+    P = H * W
+    avg_acc = n_static * 0.5 if S > 1 else 0  # mean accumulated-cloud size seen by agg_mark
+    table = {
+        "agg_mark": 12 * (n_static * (S - 1) / max(S, 1)) if S > 1 else 0,  # xyz of the accumulated cloud (upper bound: final size)
+        "agg_flags": 2 * P + P,
+        "agg_append": (n_static / S) * (4 + 12 + 24 + 4),
+        "compact_count": P,
+        "compact_scatter": P + 4 * P * 0.5,
+        "raster_project_count": n_static * (12 + 16),
+        "raster_fill": n_static * (16 + 4 * 2.8),
+        "raster_tile": n_static * 2.8 * 20 + P * 16 + P * K * 12,
+        "dyn_warp": P * (4 + 1 + 1) + n_dyn * (8 + 4 + 12 + 4 + 4 * 12 + 24),
+        "project_flow_dense": P * (1 + 12) + n_dyn * 12,
+        "dyn_splat_scatter": P * (12 + 8 + 8 + 4 + 12 + 4 * 12) + P * 4 * 4 + n_dyn * 4 * 4 * 5,
+        "dyn_splat_finish": P * (20 + 12 + 16 + 36),
+        "knn_mean_dist": n_dyn * 12 + n_dyn * 4,
+        "gather_rows": n_dyn * (4 + 12 + 12),
+        "scatter_keep": n_dyn * 6,
+    }
+    del avg_acc
+    return float(table.get(name, 0.0))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pgdvs_amd import _lib, dist as pdist, ops, synth
+    from pgdvs_amd.instantiate import load_config
+    from pgdvs_amd.renderers.pgdvs_renderer import PGDVSRenderer
+
+    lib = _lib.load()
+    H, W, S, K = args.height, args.width, args.frames, args.pts_per_pixel
+    # ---------------- synthetic, seeded inputs (no datasets offline) -> resident in HBM
+    video = synth.make_video(S, H, W, seed=1234)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rgbs, depths, masks = T(video["rgbs"]), T(video["depths"]), T(video["dyn_masks"])
+    K3s, c2ws = video["K3s"], video["c2ws"]
+    n_views = max(1, min(args.views, S - 1))
+    view_ids = [int(round(j * (S - 2) / max(n_views - 1, 1))) for j in range(n_views)]
+    # each rank starts at a different view so that ranks do different work (frame sharding)
+    views = [synth.to_torch(synth.make_view(video, i, frac=0.4, seed=5), dev) for i in view_ids]
+
+    cfg = load_config(static_renderer="geo", overrides={
+        "engine.engine_cfg.render_cfg.dyn_pcl_remove_outlier": not args.no_outlier,
+        "engine.engine_cfg.render_cfg.st_render_pcl_pts_per_pixel": K,
+    })
+    rc = cfg.engine.engine_cfg.render_cfg
+    model = PGDVSRenderer(cfg, render_cfg=rc, softsplat_metric_abs_alpha=100.0).to(dev).eval()
+    cap = S * H * W
+
+    def step(j):
+        data = dict(views[(j + rank) % n_views])
+        cloud, cnt = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=cap)
+        data["st_pcl_rgb"] = cloud[None]
+        data["st_pcl_rgb_count"] = cnt
+        with torch.no_grad():
+            ret = model.forward(data, render_cfg=rc, disable_tqdm=True)
+        return ret["combined_rgb"], cnt
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    def timed(n_steps, profile):
+        lib.pgdvs_prof_enable(1 if profile else 0)
+        imgs = []
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(n_steps):
+            img, cnt = step(j)
+            imgs.append(img)
+        stack = torch.cat(imgs, 0)
+        gathered = pdist.gather_image_stack(stack, n_steps * world) if world > 1 else stack
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        lib.pgdvs_prof_enable(0)
+        return t1 - t0, gathered, cnt
+
+    for j in range(args.warmup):
+        step(j)
+    torch.cuda.synchronize()
+
+    elapsed, gathered, cnt = timed(args.steps, profile=False)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    n_static = int(cnt.item())
+    n_dyn = int(views[0]["dyn_mask_src_temporal"][0, 0].sum().item())
+
+    # ---------------- per-kernel durations with HIP events on the launch stream
+    kernels = {}
+    roofline = None
+    if not args.no_kernel_timing and rank == 0:
+        n_prof = min(args.steps, 5)
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.pgdvs_prof_report(buf, len(buf))  # clear
+        timed(n_prof, profile=True) if world == 1 else None
+        if world == 1:
+            lib.pgdvs_prof_report(buf, len(buf))
+            for line in buf.value.decode().strip().splitlines():
+                name, calls, total_ms = line.split()
+                calls, total_ms = int(calls), float(total_ms)
+                ab = algorithmic_bytes(name, H, W, S, n_static, n_dyn, K)
+                avg_ms = total_ms / calls
+                kernels[name] = {
+                    "launches_per_step": calls / n_prof, "avg_ms": round(avg_ms, 5),
+                    "ms_per_step": round(total_ms / n_prof, 4),
+                    "alg_GBps": round(ab / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 and ab > 0 else None}
+            dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+            ab = algorithmic_bytes(dom, H, W, S, n_static, n_dyn, K)
+            ach = ab / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                        "alg_bytes_per_launch": ab, "avg_launch_ms": kernels[dom]["avg_ms"]}
+
+    # ---------------- CPU baseline: the oracle (port of the reference algorithm) on host cores
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+
+        sh, sw, ss = max(H // 4, 8), max(W // 4, 8), max(S // 4, 2)
+        sv = synth.make_video(ss, sh, sw, seed=1234)
+        sd = synth.make_view(sv, 0, frac=0.4, seed=5)
+        c0 = time.perf_counter()
+        o_cloud = orc.aggregate_static_pcl(sv["rgbs"], sv["depths"], sv["dyn_masks"], sv["K3s"], sv["c2ws"])
+        od = dict(sd)
+        od["st_pcl_rgb"] = o_cloud[None]
+        orc.render_view(od, dict(rc), static_noise=sd["static_noise"], alpha=100.0)
+        c1 = time.perf_counter()
+        cpu_fps = 1.0 / (c1 - c0)
+        scale = (sh * sw * ss) / float(H * W * S)
+        cpu_baseline = {
+            "value": round(cpu_fps, 4), "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"1 view at {sw}x{sh} with {ss} source frames ({scale:.4f} of the source pixels of the GPU workload); "
+                      f"naive O(pixels x points) rasteriser as in pytorch3d bin_size=0",
+            "seconds": round(c1 - c0, 2),
+            "value_scaled_linear_to_full": round(cpu_fps * scale, 6)}
+
+    if rank == 0:
+        frames = args.steps * world
+        fps = frames / elapsed
+        alg_total = (20 * S + 120) * H * W
+        out = {
+            "metric": "novel-view frames/s at 1080p x 24 src frames; achieved HBM GB/s vs gfx950 peak",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{W}x{H} target view, {S} source frames resident in HBM: static aggregation (A12) + "
+                            f"point z-buffer raster K={K} (A9) + flow-warped dynamic splat (A1-A8, outlier filter "
+                            f"{'on' if not args.no_outlier else 'off'}) + composite (A11)",
+                "height": H, "width": W, "src_frames": S, "static_points": n_static, "dyn_pixels": n_dyn,
+                "parallelism": f"frames sharded over {world} GPU(s), RCCL gather of the image stack" if world > 1 else "1 GPU",
+                "whole_view_alg_bytes": alg_total,
+                "whole_view_alg_GBps": round(alg_total * fps / 1e9 / max(world, 1), 2),
+            },
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,204 @@
+/*
+ * pgdvs_hip.h -- C ABI of libpgdvs_hip.so: the MI355X (gfx950) implementation of
+ * the PGDVS per-target-view rendering inner loop.
+ *
+ * The reference (apple/ml-pgdvs) has no C FFI: its hot path is Python/torch plus
+ * three CUDA kernels embedded as strings (pgdvs/utils/softsplat.py) and the
+ * un-vendored pytorch3d ops.  Each entry point below names the reference
+ * function (file:line, relative to the upstream tree) it replaces; the Python
+ * host layer (ml-pgdvs_amd/pgdvs_amd) binds them with ctypes and keeps the
+ * reference's renderer plugin API on top.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter is documented "host";
+ *   - all buffers are caller-allocated, contiguous, fp32 unless stated otherwise;
+ *   - `stream` is a hipStream_t (NULL = default stream); every call only enqueues
+ *     work on it and never synchronises or allocates;
+ *   - return value: 0 on success, negative pgdvs_status on error, message via
+ *     pgdvs_last_error() (thread-local);
+ *   - no global mutable state; re-entrant per stream.
+ *
+ * Camera block: 80 floats of derived per-camera constants produced by
+ * pgdvs_cam_prep from the reference's flat_cam[34] = [h, w, K(4x4), c2w(4x4)]
+ * (pgdvs/renderers/pgdvs_renderer.py:354-357).  Layout: see PGDVS_CAM_* below.
+ */
+#ifndef PGDVS_HIP_H_
+#define PGDVS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *pgdvs_stream_t; /* hipStream_t */
+
+enum pgdvs_status {
+  PGDVS_OK = 0,
+  PGDVS_ERR_INVALID = -1,   /* bad argument */
+  PGDVS_ERR_LAUNCH = -2,    /* HIP launch / runtime error */
+  PGDVS_ERR_WORKSPACE = -3, /* workspace too small */
+  PGDVS_ERR_UNSUPPORTED = -4
+};
+
+#define PGDVS_CAM_KINV 0 /* [9]  inverse(K[:3,:3])                 */
+#define PGDVS_CAM_M 9    /* [9]  c2w[:3,:3] @ Kinv                 */
+#define PGDVS_CAM_O 18   /* [3]  c2w[:3,3]                         */
+#define PGDVS_CAM_P 21   /* [16] K(4x4) @ inverse(c2w)             */
+#define PGDVS_CAM_W2C 37 /* [16] inverse(c2w)                      */
+#define PGDVS_CAM_R 53   /* [9]  c2w[:3,:3]                        */
+#define PGDVS_CAM_HW 62  /* [2]  h, w                              */
+#define PGDVS_CAM_K 64   /* [16] K as given                        */
+#define PGDVS_CAM_BLOCK 80
+
+const char *pgdvs_last_error(void);
+/* library/ABI version and the gfx target the device code was built for */
+int pgdvs_abi_version(void);
+const char *pgdvs_build_arch(void);
+
+/* Optional per-kernel timing: when enabled every kernel launch is bracketed by HIP events
+ * on its launch stream.  pgdvs_prof_report synchronises them, writes "name calls total_ms"
+ * lines into buf and clears the records; returns the number of distinct names.  Process-
+ * wide switch meant for bench.py; leave it off in production. */
+void pgdvs_prof_enable(int on);
+int pgdvs_prof_report(char *buf, int buf_len);
+
+/* ---- cameras ------------------------------------------------------------- */
+/* flat_cams[n,34] -> cam_blocks[n,80].  Replaces the torch.inverse / bmm chains of
+ * pgdvs/renderers/pgdvs_renderer_base.py:40-45 and pgdvs/models/gnt/projector.py:49-60. */
+int pgdvs_cam_prep(const float *flat_cams, int n, float *cam_blocks, pgdvs_stream_t stream);
+
+/* A1: PGDVSBaseRenderer.get_batched_rays, batch_size=1
+ * (pgdvs/renderers/pgdvs_renderer_base.py:17-57).  n = ceil(H/stride)*ceil(W/stride);
+ * rays_o[n,3] rays_d[n,3] uvs[n,2]. */
+int pgdvs_get_rays(const float *cam_block, int H, int W, int stride, float *rays_o,
+                   float *rays_d, float *uvs, pgdvs_stream_t stream);
+
+/* ---- dynamic branch -------------------------------------------------------- */
+/* A2+A3: unproject frame 1, follow the flow into frame 2, unproject there, lerp in
+ * time -- the dense part of PGDVSDynamicRenderer.compute_dyn_pcl
+ * (pgdvs/renderers/pgdvs_renderer_dyn.py:299-388).
+ *   dyn_mask1[H,W] occ[H,W] flow12[H,W,2] depth1[H,W] depth2[H,W] rgb1[H,W,3] rgb2[H,W,3]
+ *   times[3] = (time_1, time_2, time_tgt) on the device
+ *   mask_eff[H,W] u8 : dyn mask after the optional flow-consistency test (:304-308)
+ *   valid[H,W]    u8 : mask_eff && flow target inside the image (:309-316)
+ *   pcl[H,W,3], rgbf[H,W,3] : world point / attached colour, written where valid. */
+int pgdvs_dyn_warp(int H, int W, const float *dyn_mask1, const float *occ,
+                   int use_flow_consistency, const float *flow12, const float *depth1,
+                   const float *depth2, const float *rgb1, const float *rgb2,
+                   const float *cam1, const float *cam2, const float *times,
+                   uint8_t *mask_eff, uint8_t *valid, float *pcl, float *rgbf,
+                   pgdvs_stream_t stream);
+
+/* Ordered stream compaction: idx_out[0..count) = ascending positions p with flags[p]!=0
+ * (the boolean-mask indexing / torch.nonzero of pgdvs_renderer_dyn.py:309-320,477).
+ * count_out: one int32 on the device.  workspace >= pgdvs_compact_workspace_bytes(n). */
+int64_t pgdvs_compact_workspace_bytes(int64_t n);
+int pgdvs_compact_u8(const uint8_t *flags, int64_t n, int32_t *idx_out, int32_t *count_out,
+                     void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream);
+
+/* gather rows: dst[i,:] = src[idx[i],:] for i < *count (row = `width` floats). */
+int pgdvs_gather_rows(const float *src, const int32_t *idx, const int32_t *count,
+                      int64_t capacity, int width, float *dst, pgdvs_stream_t stream);
+
+/* A4: statistical outlier filter = pytorch3d.ops.knn_points(X, X, K+1) + mean of the K
+ * non-self squared distances (pgdvs_renderer_dyn.py:405-419, st_geo_renderer.py:37-51).
+ * pts[capacity,3], *count points used (count on device); avg_out[capacity]. */
+int pgdvs_knn_mean_dist(const float *pts, const int32_t *count, int64_t capacity, int K,
+                        float *avg_out, pgdvs_stream_t stream);
+
+/* threshold = lower-median(avg) + unbiased-std(avg) * std_thres; flag = avg < threshold
+ * (pgdvs_renderer_dyn.py:419-427).  thres_out: 1 float; flag_out[capacity] u8.
+ * remove_outlier == 0 -> all flags 1 (:453-457), threshold still produced. */
+int64_t pgdvs_outlier_workspace_bytes(int64_t capacity);
+int pgdvs_outlier_flags(const float *avg, const int32_t *count, int64_t capacity,
+                        float std_thres, int remove_outlier, float *thres_out,
+                        uint8_t *flag_out, void *workspace, int64_t workspace_bytes,
+                        pgdvs_stream_t stream);
+
+/* keep[P] u8 <- 0 everywhere, 1 at idx[i] where flag[i] (i < *count). */
+int pgdvs_scatter_keep(const int32_t *idx, const uint8_t *flag, const int32_t *count,
+                       int64_t capacity, uint8_t *keep, int64_t P, pgdvs_stream_t stream);
+
+/* A5: project the surviving points into the target camera and scatter the dense
+ * flow (pgdvs/models/gnt/projector.py:41-73 via pgdvs_renderer_dyn.py:470-503).
+ * flow_1_to_tgt[2,H,W] (planar x then y), valid_dyn_mask_1[H,W] (0/1 floats). */
+int pgdvs_project_flow_dense(int H, int W, const float *cam_tgt, const float *pcl,
+                             const uint8_t *keep, float *flow_1_to_tgt,
+                             float *valid_dyn_mask_1, pgdvs_stream_t stream);
+/* sparse form: uv[n,2] = projection of pts[n,3] (Projector.compute_projections). */
+int pgdvs_project_points(const float *cam_tgt, const float *pts, int64_t n, float *uv,
+                         pgdvs_stream_t stream);
+
+/* A6: softsplat importance metric, mean_c |rgb1 - backwarp(rgb2, flow)|
+ * (pgdvs/renderers/pgdvs_renderer_base.py:68-78,91-138).  NCHW planar:
+ * rgb1[B,3,H,W] rgb2[B,3,H,W] flow[B,2,H,W] -> l1[B,1,H,W]. */
+int pgdvs_backwarp_l1(const float *rgb1, const float *rgb2, const float *flow, float *l1,
+                      int B, int H, int W, pgdvs_stream_t stream);
+
+/* A7: softsplat.softsplat / kernel softsplat_out (pgdvs/utils/softsplat.py:280-333,
+ * 352-402).  in[B,C,H,W] flow[B,2,H,W] metric[B,1,H,W] (NULL for sum/avg) -> out[B,C,H,W].
+ * mode: 0 sum, 1 avg, 2 linear, 3 soft; eps: 0 addeps (default), 1 zeroeps, 2 clipeps.
+ * workspace >= pgdvs_softsplat_workspace_bytes(B,C,H,W,mode). */
+int64_t pgdvs_softsplat_workspace_bytes(int B, int C, int H, int W, int mode);
+int pgdvs_softsplat_fwd(const float *in, const float *flow, const float *metric, float *out,
+                        int B, int C, int H, int W, int mode, int eps, void *workspace,
+                        int64_t workspace_bytes, pgdvs_stream_t stream);
+
+/* A6+A7+A8+A11 fused for the renderer: noise-fill of static texels, metric, soft
+ * splat of rgb and mask with the shared metric, threshold 1e-3, masking and the
+ * final static/dynamic composite (pgdvs_renderer_dyn.py:157-202, pgdvs_renderer.py:169-178).
+ *   rgb1[H,W,3] rgb2[H,W,3] (channels-last, as in the data dict), flow12[H,W,2],
+ *   flow_1_to_tgt[2,H,W], valid_dyn_mask_1[H,W], noise[3,H,W] (un-clamped randn, may be NULL = 0),
+ *   static_rgb[3,H,W] (may be NULL -> combined outputs skipped)
+ *   outputs (planar): render_dyn_rgb[3,H,W] render_dyn_mask[H,W]
+ *                     combined[3,H,W] combined_static[3,H,W] combined_dyn[3,H,W] (nullable)
+ *   workspace >= pgdvs_dyn_splat_workspace_bytes(H,W). */
+int64_t pgdvs_dyn_splat_workspace_bytes(int H, int W);
+int pgdvs_dyn_splat_composite(int H, int W, const float *rgb1, const float *rgb2,
+                              const float *flow12, const float *flow_1_to_tgt,
+                              const float *valid_dyn_mask_1, const float *noise, float alpha,
+                              const float *static_rgb, float *render_dyn_rgb,
+                              float *render_dyn_mask, float *combined, float *combined_static,
+                              float *combined_dyn, void *workspace, int64_t workspace_bytes,
+                              pgdvs_stream_t stream);
+
+/* ---- static branch --------------------------------------------------------- */
+/* A9: pytorch3d PointsRasterizer(bin_size=0) + PointsRenderer + NormWeightedCompositor
+ * as used by StaticGeoPointRenderer.forward (pgdvs/renderers/st_geo_renderer.py:77-120)
+ * and render_dyn_pcl (pgdvs/renderers/pgdvs_renderer_dyn.py:671-724).
+ *   points: xyz at pts[i*pts_stride..+3), features at feat[i*feat_stride..+3)
+ *   n_points: host count; n_points_dev (nullable): device int64 count that overrides
+ *   it (n_points is then the capacity)
+ *   outputs (any may be NULL): idx[H,W,K] int64 (-1 pad), zbuf[H,W,K] (-1 pad),
+ *   dist2[H,W,K] (-1 pad), rgb ([H,W,3] if rgb_planar == 0, [3,H,W] otherwise),
+ *   mask[H,W] ((ones-render) > 0 as 0/1 floats).  K (points_per_pixel) in [1, 8]. */
+int64_t pgdvs_points_raster_workspace_bytes(int64_t n_points, int H, int W, float radius);
+int pgdvs_points_raster(const float *pts, int64_t pts_stride, const float *feat,
+                        int64_t feat_stride, int64_t n_points, const int64_t *n_points_dev,
+                        const float *cam_tgt, float radius, int K, int H, int W, int64_t *idx,
+                        float *zbuf, float *dist2, float *rgb, int rgb_planar, float *mask,
+                        void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream);
+
+/* A12: static point-cloud aggregation across the S frames of a video with the
+ * projection-occupancy dedup (pgdvs/datasets/nvidia_eval_pure_geo.py:183-277,
+ * pgdvs/datasets/nvidia_eval.py:840-847, pgdvs/datasets/base.py:507-546).
+ *   rgbs[S,H,W,3] in [0,1]; depths[S,H,W]; dyn_masks[S,H,W] u8 (non-zero = dynamic)
+ *   K3s: HOST double[S,9]; c2ws: HOST double[S,16]   (float64 numpy upstream)
+ *   out[capacity,6] (xyz,rgb) in the reference's order; count_out: device int64. */
+int64_t pgdvs_static_aggregate_workspace_bytes(int H, int W);
+int pgdvs_static_aggregate(const float *rgbs, const float *depths, const uint8_t *dyn_masks,
+                           const double *K3s_host, const double *c2ws_host, int S, int H, int W,
+                           float *out, int64_t capacity, int64_t *count_out, void *workspace,
+                           int64_t workspace_bytes, pgdvs_stream_t stream);
+
+/* A11 alone: combined = (1-m)*static + m*dyn (pgdvs_renderer.py:169-178), n elements per
+ * channel, planar [3,n] with mask [n]. */
+int pgdvs_combine(const float *static_rgb, const float *dyn_rgb, const float *dyn_mask,
+                  int64_t n, float *combined, float *combined_static, float *combined_dyn,
+                  pgdvs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGDVS_HIP_H_ */

@@ -1,0 +1,184 @@
+// Shared helpers for the gfx950 kernels of libpgdvs_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pgdvs_hip.h"
+
+#define PGDVS_API extern "C" __attribute__((visibility("default")))
+
+namespace pgdvs {
+
+void set_error(const char *fmt, ...);
+
+inline hipStream_t as_stream(pgdvs_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return PGDVS_ERR_LAUNCH;
+  }
+  return PGDVS_OK;
+}
+
+// Optional per-kernel timing with HIP events on the launch stream (off by default;
+// pgdvs_prof_enable).  A ProfScope brackets one or more launches under a name.
+bool prof_enabled();
+void prof_begin(const char *name, hipStream_t s);
+void prof_end(hipStream_t s);
+struct ProfScope {
+  hipStream_t s;
+  bool on;
+  ProfScope(const char *name, hipStream_t st) : s(st), on(prof_enabled()) {
+    if (on) prof_begin(name, s);
+  }
+  ~ProfScope() {
+    if (on) prof_end(s);
+  }
+};
+
+#define PGDVS_LAUNCH(name, kernel, grid, block, lds, stream, ...)       \
+  do {                                                                   \
+    pgdvs::ProfScope _ps(name, stream);                                  \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);   \
+  } while (0)
+
+#define PGDVS_REQUIRE(cond, ...)      \
+  do {                                \
+    if (!(cond)) {                    \
+      pgdvs::set_error(__VA_ARGS__);  \
+      return PGDVS_ERR_INVALID;       \
+    }                                 \
+  } while (0)
+
+constexpr int kWave = 64;
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int64_t align_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
+
+// Camera block kept in registers/SGPRs: loaded through a uniform pointer so the
+// compiler can use scalar loads.
+struct CamBlock {
+  float v[PGDVS_CAM_BLOCK];
+};
+
+// Gauss-Jordan inverse with partial pivoting, fp64, n <= 4.  Same operation order
+// as the CPU oracle so that derived camera constants agree bit-for-bit.
+__host__ __device__ inline int inv_f64(const double *a, double *out, int n) {
+  double m[4][8];
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) {
+      m[i][j] = a[i * n + j];
+      m[i][n + j] = (i == j) ? 1.0 : 0.0;
+    }
+  }
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    double best = fabs(m[c][c]);
+    for (int r = c + 1; r < n; ++r) {
+      double v = fabs(m[r][c]);
+      if (v > best) {
+        best = v;
+        piv = r;
+      }
+    }
+    if (best == 0.0) return -1;
+    if (piv != c) {
+      for (int j = 0; j < 2 * n; ++j) {
+        double t = m[c][j];
+        m[c][j] = m[piv][j];
+        m[piv][j] = t;
+      }
+    }
+    double d = m[c][c];
+    for (int j = 0; j < 2 * n; ++j) m[c][j] = m[c][j] / d;
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      double f = m[r][c];
+      if (f == 0.0) continue;
+      for (int j = 0; j < 2 * n; ++j) m[r][j] = m[r][j] - f * m[c][j];
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) out[i * n + j] = m[i][n + j];
+  return 0;
+}
+
+// flat_cam[34] -> camera block.  fp64 inverses rounded once to fp32, products in
+// fp32 with a fixed left-to-right order (no FMA contraction in this library).
+__host__ __device__ inline int cam_block_from_flat(const float *flat_cam, float *blk) {
+  const float *K = flat_cam + 2;
+  const float *c2w = flat_cam + 18;
+  double k3[9], k3i[9], c4[16], c4i[16];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) k3[i * 3 + j] = (double)K[i * 4 + j];
+  for (int i = 0; i < 16; ++i) c4[i] = (double)c2w[i];
+  int bad = 0;
+  if (inv_f64(k3, k3i, 3) != 0) bad = 1;
+  if (inv_f64(c4, c4i, 4) != 0) bad = 1;
+  float kinv[9], w2c[16];
+  for (int i = 0; i < 9; ++i) kinv[i] = bad ? __builtin_nanf("") : (float)k3i[i];
+  for (int i = 0; i < 16; ++i) w2c[i] = bad ? __builtin_nanf("") : (float)c4i[i];
+  for (int i = 0; i < 9; ++i) blk[PGDVS_CAM_KINV + i] = kinv[i];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      float s = c2w[i * 4 + 0] * kinv[0 * 3 + j];
+      s = s + c2w[i * 4 + 1] * kinv[1 * 3 + j];
+      s = s + c2w[i * 4 + 2] * kinv[2 * 3 + j];
+      blk[PGDVS_CAM_M + i * 3 + j] = s;
+      blk[PGDVS_CAM_R + i * 3 + j] = c2w[i * 4 + j];
+    }
+    blk[PGDVS_CAM_O + i] = c2w[i * 4 + 3];
+  }
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 4; ++j) {
+      float s = K[i * 4 + 0] * w2c[0 * 4 + j];
+      s = s + K[i * 4 + 1] * w2c[1 * 4 + j];
+      s = s + K[i * 4 + 2] * w2c[2 * 4 + j];
+      s = s + K[i * 4 + 3] * w2c[3 * 4 + j];
+      blk[PGDVS_CAM_P + i * 4 + j] = s;
+    }
+  }
+  for (int i = 0; i < 16; ++i) blk[PGDVS_CAM_W2C + i] = w2c[i];
+  blk[PGDVS_CAM_HW + 0] = flat_cam[0];
+  blk[PGDVS_CAM_HW + 1] = flat_cam[1];
+  for (int i = 0; i < 16; ++i) blk[PGDVS_CAM_K + i] = K[i];
+  return bad ? -1 : 0;
+}
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) {
+  return x < lo ? lo : (x > hi ? hi : x);
+}
+
+// 3-vector  M(3x3,row-major) * (a,b,c) with ((m0*a + m1*b) + m2*c) ordering
+__device__ __forceinline__ float dot3(const float *m, float a, float b, float c) {
+  float s = m[0] * a;
+  s = s + m[1] * b;
+  s = s + m[2] * c;
+  return s;
+}
+
+// p = P(4x4) @ [X,1]; uv = p[:2] / clamp(p[2], min=1e-8); clamp +-1e6
+// (pgdvs/models/gnt/projector.py:58-67)
+__device__ __forceinline__ void project_point(const float *P, float x, float y, float z,
+                                              float &u, float &v) {
+  float p[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float s = P[i * 4 + 0] * x;
+    s = s + P[i * 4 + 1] * y;
+    s = s + P[i * 4 + 2] * z;
+    s = s + P[i * 4 + 3];
+    p[i] = s;
+  }
+  float zz = p[2] < 1e-8f ? 1e-8f : p[2];
+  u = clampf(p[0] / zz, -1e6f, 1e6f);
+  v = clampf(p[1] / zz, -1e6f, 1e6f);
+}
+
+// wave-level inclusive/exclusive helpers (64-wide wavefront)
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+}  // namespace pgdvs

@@ -1,0 +1,362 @@
+// Dynamic-branch kernels: camera prep, rays, unproject + flow warp, projection to
+// the target view, softsplat metric.  One thread per pixel, coalesced streaming
+// loads; all of these are HBM-bound byte movers (see DESIGN.md for bytes/pixel).
+#include "common.h"
+
+namespace pgdvs {
+
+// ---------------------------------------------------------------------------
+__global__ void cam_prep_kernel(const float *__restrict__ flat_cams, int n,
+                                float *__restrict__ blocks) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float fc[34], blk[PGDVS_CAM_BLOCK];
+  for (int k = 0; k < 34; ++k) fc[k] = flat_cams[i * 34 + k];
+  cam_block_from_flat(fc, blk);
+  for (int k = 0; k < PGDVS_CAM_BLOCK; ++k) blocks[i * PGDVS_CAM_BLOCK + k] = blk[k];
+}
+
+// A1 -- pgdvs_renderer_base.py:17-57
+__global__ void get_rays_kernel(const float *__restrict__ cam, int rh, int rw, int stride,
+                                float *__restrict__ rays_o, float *__restrict__ rays_d,
+                                float *__restrict__ uvs) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rh * rw) return;
+  int r = i / rw, c = i - r * rw;
+  float u = (float)(c * stride), v = (float)(r * stride);
+  const float *M = cam + PGDVS_CAM_M;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float d = M[k * 3 + 0] * u;
+    d = d + M[k * 3 + 1] * v;
+    d = d + M[k * 3 + 2];
+    rays_d[(size_t)i * 3 + k] = d;
+    rays_o[(size_t)i * 3 + k] = cam[PGDVS_CAM_O + k];
+  }
+  uvs[(size_t)i * 2 + 0] = u;
+  uvs[(size_t)i * 2 + 1] = v;
+}
+
+// A2 + A3 -- pgdvs_renderer_dyn.py:299-388
+__global__ void __launch_bounds__(256)
+dyn_warp_kernel(int H, int W, const float *__restrict__ dyn_mask1, const float *__restrict__ occ,
+                int use_fc, const float *__restrict__ flow12, const float *__restrict__ depth1,
+                const float *__restrict__ depth2, const float *__restrict__ rgb1,
+                const float *__restrict__ rgb2, const float *__restrict__ cam1,
+                const float *__restrict__ cam2, const float *__restrict__ times,
+                uint8_t *__restrict__ mask_eff, uint8_t *__restrict__ valid,
+                float *__restrict__ pcl, float *__restrict__ rgbf) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= H * W) return;
+  int r = p / W, c = p - r * W;
+  float u = (float)c, v = (float)r;
+  const float fw = (float)W, fh = (float)H;
+  bool m = dyn_mask1[p] != 0.0f;
+  if (use_fc) m = m && !(occ[p] > 0.0f);
+  mask_eff[p] = (uint8_t)m;
+  if (!m) {
+    valid[p] = 0;
+    return;
+  }
+  float2 fl = reinterpret_cast<const float2 *>(flow12)[p];
+  float ux = u + fl.x, uy = v + fl.y;
+  bool ok = (ux >= 0.0f) && (ux <= fw - 1.0f) && (uy >= 0.0f) && (uy <= fh - 1.0f);
+  valid[p] = (uint8_t)ok;
+  if (!ok) return;
+  const float t1 = times[0], t2 = times[1], tt = times[2];
+  const float *M1 = cam1 + PGDVS_CAM_M;
+  float d1 = depth1[p];
+  float X1[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float d = M1[k * 3 + 0] * u;
+    d = d + M1[k * 3 + 1] * v;
+    d = d + M1[k * 3 + 2];
+    X1[k] = cam1[PGDVS_CAM_O + k] + d * d1;
+  }
+  if (t1 == t2) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      pcl[(size_t)p * 3 + k] = X1[k];
+      rgbf[(size_t)p * 3 + k] = rgb1[(size_t)p * 3 + k];
+    }
+    return;
+  }
+  float w1 = (t2 - tt) / (t2 - t1);
+  float w2 = (tt - t1) / (t2 - t1);
+  // grid = 2*uv/(W,H) - 1, grid_sample(align_corners=False): ((g+1)*size-1)/2
+  float gx = 2.0f * ux / fw - 1.0f;
+  float gy = 2.0f * uy / fh - 1.0f;
+  float ix = ((gx + 1.0f) * fw - 1.0f) / 2.0f;
+  float iy = ((gy + 1.0f) * fh - 1.0f) / 2.0f;
+  float nx = nearbyintf(ix), ny = nearbyintf(iy);
+  float dsamp = 0.0f;
+  if (nx >= 0.0f && nx <= fw - 1.0f && ny >= 0.0f && ny <= fh - 1.0f)
+    dsamp = depth2[(int)ny * W + (int)nx];
+  float x0f = floorf(ix), y0f = floorf(iy);
+  int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+  float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+  float wne = (ix - (float)x0) * ((float)y1 - iy);
+  float wsw = ((float)x1 - ix) * (iy - (float)y0);
+  float wse = (ix - (float)x0) * (iy - (float)y0);
+  bool inx0 = x0 >= 0 && x0 < W, inx1 = x1 >= 0 && x1 < W;
+  bool iny0 = y0 >= 0 && y0 < H, iny1 = y1 >= 0 && y1 < H;
+  float col[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float acc = 0.0f;
+    if (inx0 && iny0) acc = acc + rgb2[((size_t)y0 * W + x0) * 3 + k] * wnw;
+    if (inx1 && iny0) acc = acc + rgb2[((size_t)y0 * W + x1) * 3 + k] * wne;
+    if (inx0 && iny1) acc = acc + rgb2[((size_t)y1 * W + x0) * 3 + k] * wsw;
+    if (inx1 && iny1) acc = acc + rgb2[((size_t)y1 * W + x1) * 3 + k] * wse;
+    col[k] = acc;
+  }
+  const float *Kinv2 = cam2 + PGDVS_CAM_KINV;
+  const float *R2 = cam2 + PGDVS_CAM_R;
+  float kq[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float s = Kinv2[k * 3 + 0] * ux;
+    s = s + Kinv2[k * 3 + 1] * uy;
+    s = s + Kinv2[k * 3 + 2];
+    kq[k] = s;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float d = R2[k * 3 + 0] * kq[0];
+    d = d + R2[k * 3 + 1] * kq[1];
+    d = d + R2[k * 3 + 2] * kq[2];
+    float X2 = cam2[PGDVS_CAM_O + k] + d * dsamp;
+    pcl[(size_t)p * 3 + k] = w1 * X1[k] + w2 * X2;
+    rgbf[(size_t)p * 3 + k] = col[k];
+  }
+}
+
+// A5 dense -- pgdvs_renderer_dyn.py:470-503, planar flow output
+__global__ void __launch_bounds__(256)
+project_flow_dense_kernel(int H, int W, const float *__restrict__ cam_tgt,
+                          const float *__restrict__ pcl, const uint8_t *__restrict__ keep,
+                          float *__restrict__ flow_1_to_tgt, float *__restrict__ valid_mask) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int P = H * W;
+  if (p >= P) return;
+  float fx = 0.0f, fy = 0.0f, vm = 0.0f;
+  if (keep[p]) {
+    int r = p / W, c = p - r * W;
+    float u, v;
+    project_point(cam_tgt + PGDVS_CAM_P, pcl[(size_t)p * 3], pcl[(size_t)p * 3 + 1],
+                  pcl[(size_t)p * 3 + 2], u, v);
+    fx = u - (float)c;
+    fy = v - (float)r;
+    vm = 1.0f;
+  }
+  flow_1_to_tgt[p] = fx;
+  flow_1_to_tgt[(size_t)P + p] = fy;
+  valid_mask[p] = vm;
+}
+
+__global__ void project_points_kernel(const float *__restrict__ cam_tgt,
+                                      const float *__restrict__ pts, int64_t n,
+                                      float *__restrict__ uv) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float u, v;
+  project_point(cam_tgt + PGDVS_CAM_P, pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], u, v);
+  uv[i * 2] = u;
+  uv[i * 2 + 1] = v;
+}
+
+// torch.linspace(-1, 1, steps)[i] as ATen computes it
+__device__ __forceinline__ float linspace_m1_1(int i, int steps) {
+  if (steps == 1) return -1.0f;
+  float step = (1.0f - (-1.0f)) / (float)(steps - 1);
+  if (i < steps / 2) return -1.0f + step * (float)i;
+  return 1.0f - step * (float)(steps - 1 - i);
+}
+
+// A6 -- pgdvs_renderer_base.py:68-78,91-138 on NCHW planes
+__global__ void __launch_bounds__(256)
+backwarp_l1_kernel(const float *__restrict__ rgb1, const float *__restrict__ rgb2,
+                   const float *__restrict__ flow, float *__restrict__ l1, int H, int W) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int P = H * W;
+  if (p >= P) return;
+  int b = blockIdx.y;
+  rgb1 += (size_t)b * 3 * P;
+  rgb2 += (size_t)b * 3 * P;
+  flow += (size_t)b * 2 * P;
+  int r = p / W, c = p - r * W;
+  const float hw_x = ((float)W - 1.0f) / 2.0f, hw_y = ((float)H - 1.0f) / 2.0f;
+  float gx = linspace_m1_1(c, W) + flow[p] / hw_x;
+  float gy = linspace_m1_1(r, H) + flow[(size_t)P + p] / hw_y;
+  float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+  float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+  float x0f = floorf(ix), y0f = floorf(iy);
+  bool fin = isfinite(ix) && isfinite(iy) && fabsf(ix) < 1e9f && fabsf(iy) < 1e9f;
+  int x0 = fin ? (int)x0f : -10, y0 = fin ? (int)y0f : -10, x1 = x0 + 1, y1 = y0 + 1;
+  float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+  float wne = (ix - (float)x0) * ((float)y1 - iy);
+  float wsw = ((float)x1 - ix) * (iy - (float)y0);
+  float wse = (ix - (float)x0) * (iy - (float)y0);
+  bool inx0 = x0 >= 0 && x0 < W, inx1 = x1 >= 0 && x1 < W;
+  bool iny0 = y0 >= 0 && y0 < H, iny1 = y1 >= 0 && y1 < H;
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float *pl = rgb2 + (size_t)k * P;
+    float acc = 0.0f;
+    if (inx0 && iny0) acc = acc + pl[y0 * W + x0] * wnw;
+    if (inx1 && iny0) acc = acc + pl[y0 * W + x1] * wne;
+    if (inx0 && iny1) acc = acc + pl[y1 * W + x0] * wsw;
+    if (inx1 && iny1) acc = acc + pl[y1 * W + x1] * wse;
+    s = s + fabsf(rgb1[(size_t)k * P + p] - acc);
+  }
+  l1[(size_t)b * P + p] = s / 3.0f;
+}
+
+// A11 -- pgdvs_renderer.py:169-178
+__global__ void combine_kernel(const float *__restrict__ st, const float *__restrict__ dy,
+                               const float *__restrict__ m, int64_t n, float *__restrict__ comb,
+                               float *__restrict__ comb_st, float *__restrict__ comb_dy) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float mm = m[i];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float a = (1.0f - mm) * st[(size_t)k * n + i];
+    float b = mm * dy[(size_t)k * n + i];
+    if (comb_st) comb_st[(size_t)k * n + i] = a;
+    if (comb_dy) comb_dy[(size_t)k * n + i] = b;
+    comb[(size_t)k * n + i] = a + b;
+  }
+}
+
+__global__ void gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx,
+                                   const int32_t *__restrict__ count, int width,
+                                   float *__restrict__ dst) {
+  int64_t n = *count;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t s = idx[i];
+    for (int k = 0; k < width; ++k) dst[i * width + k] = src[s * width + k];
+  }
+}
+
+__global__ void scatter_keep_kernel(const int32_t *__restrict__ idx,
+                                    const uint8_t *__restrict__ flag,
+                                    const int32_t *__restrict__ count,
+                                    uint8_t *__restrict__ keep) {
+  int64_t n = *count;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (flag[i]) keep[idx[i]] = 1;
+  }
+}
+
+}  // namespace pgdvs
+
+using namespace pgdvs;
+
+PGDVS_API int pgdvs_cam_prep(const float *flat_cams, int n, float *cam_blocks,
+                             pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(flat_cams && cam_blocks && n >= 0, "pgdvs_cam_prep: bad arguments");
+  if (n == 0) return PGDVS_OK;
+  PGDVS_LAUNCH("cam_prep", cam_prep_kernel, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, as_stream(stream),
+                     flat_cams, n, cam_blocks);
+  return check_launch("cam_prep");
+}
+
+PGDVS_API int pgdvs_get_rays(const float *cam_block, int H, int W, int stride, float *rays_o,
+                             float *rays_d, float *uvs, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(cam_block && rays_o && rays_d && uvs && H > 0 && W > 0 && stride > 0,
+                "pgdvs_get_rays: bad arguments");
+  int rh = (H + stride - 1) / stride, rw = (W + stride - 1) / stride;
+  PGDVS_LAUNCH("get_rays", get_rays_kernel, dim3((unsigned)cdiv((int64_t)rh * rw, 256)), dim3(256), 0,
+                     as_stream(stream), cam_block, rh, rw, stride, rays_o, rays_d, uvs);
+  return check_launch("get_rays");
+}
+
+PGDVS_API int pgdvs_dyn_warp(int H, int W, const float *dyn_mask1, const float *occ,
+                             int use_flow_consistency, const float *flow12, const float *depth1,
+                             const float *depth2, const float *rgb1, const float *rgb2,
+                             const float *cam1, const float *cam2, const float *times,
+                             uint8_t *mask_eff, uint8_t *valid, float *pcl, float *rgbf,
+                             pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), "pgdvs_dyn_warp: bad H/W");
+  PGDVS_REQUIRE(dyn_mask1 && flow12 && depth1 && depth2 && rgb1 && rgb2 && cam1 && cam2 &&
+                    times && mask_eff && valid && pcl && rgbf,
+                "pgdvs_dyn_warp: null pointer");
+  PGDVS_REQUIRE(!use_flow_consistency || occ, "pgdvs_dyn_warp: occ mask required");
+  PGDVS_LAUNCH("dyn_warp", dyn_warp_kernel, dim3((unsigned)cdiv((int64_t)H * W, 256)), dim3(256), 0,
+                     as_stream(stream), H, W, dyn_mask1, occ, use_flow_consistency, flow12,
+                     depth1, depth2, rgb1, rgb2, cam1, cam2, times, mask_eff, valid, pcl, rgbf);
+  return check_launch("dyn_warp");
+}
+
+PGDVS_API int pgdvs_project_flow_dense(int H, int W, const float *cam_tgt, const float *pcl,
+                                       const uint8_t *keep, float *flow_1_to_tgt,
+                                       float *valid_dyn_mask_1, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(H > 0 && W > 0 && cam_tgt && pcl && keep && flow_1_to_tgt && valid_dyn_mask_1,
+                "pgdvs_project_flow_dense: bad arguments");
+  PGDVS_LAUNCH("project_flow_dense", project_flow_dense_kernel, dim3((unsigned)cdiv((int64_t)H * W, 256)),
+                     dim3(256), 0, as_stream(stream), H, W, cam_tgt, pcl, keep, flow_1_to_tgt,
+                     valid_dyn_mask_1);
+  return check_launch("project_flow_dense");
+}
+
+PGDVS_API int pgdvs_project_points(const float *cam_tgt, const float *pts, int64_t n, float *uv,
+                                   pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(cam_tgt && n >= 0 && (n == 0 || (pts && uv)), "pgdvs_project_points: bad arguments");
+  if (n == 0) return PGDVS_OK;
+  PGDVS_LAUNCH("project_points", project_points_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0,
+                     as_stream(stream), cam_tgt, pts, n, uv);
+  return check_launch("project_points");
+}
+
+PGDVS_API int pgdvs_backwarp_l1(const float *rgb1, const float *rgb2, const float *flow, float *l1,
+                                int B, int H, int W, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(rgb1 && rgb2 && flow && l1 && B > 0 && H > 0 && W > 0,
+                "pgdvs_backwarp_l1: bad arguments");
+  PGDVS_LAUNCH("backwarp_l1", backwarp_l1_kernel, dim3((unsigned)cdiv((int64_t)H * W, 256), B), dim3(256),
+                     0, as_stream(stream), rgb1, rgb2, flow, l1, H, W);
+  return check_launch("backwarp_l1");
+}
+
+PGDVS_API int pgdvs_combine(const float *static_rgb, const float *dyn_rgb, const float *dyn_mask,
+                            int64_t n, float *combined, float *combined_static,
+                            float *combined_dyn, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(static_rgb && dyn_rgb && dyn_mask && combined && n >= 0,
+                "pgdvs_combine: bad arguments");
+  if (n == 0) return PGDVS_OK;
+  PGDVS_LAUNCH("combine", combine_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream),
+                     static_rgb, dyn_rgb, dyn_mask, n, combined, combined_static, combined_dyn);
+  return check_launch("combine");
+}
+
+PGDVS_API int pgdvs_gather_rows(const float *src, const int32_t *idx, const int32_t *count,
+                                int64_t capacity, int width, float *dst, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(src && idx && count && dst && width > 0 && capacity >= 0,
+                "pgdvs_gather_rows: bad arguments");
+  if (capacity == 0) return PGDVS_OK;
+  unsigned grid = (unsigned)(cdiv(capacity, 256) < 2048 ? cdiv(capacity, 256) : 2048);
+  PGDVS_LAUNCH("gather_rows", gather_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, idx,
+                     count, width, dst);
+  return check_launch("gather_rows");
+}
+
+PGDVS_API int pgdvs_scatter_keep(const int32_t *idx, const uint8_t *flag, const int32_t *count,
+                                 int64_t capacity, uint8_t *keep, int64_t P,
+                                 pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(idx && flag && count && keep && P >= 0, "pgdvs_scatter_keep: bad arguments");
+  if (P == 0) return PGDVS_OK;
+  hipError_t e = hipMemsetAsync(keep, 0, (size_t)P, as_stream(stream));
+  if (e != hipSuccess) {
+    set_error("scatter_keep memset: %s", hipGetErrorString(e));
+    return PGDVS_ERR_LAUNCH;
+  }
+  if (capacity == 0) return PGDVS_OK;
+  unsigned grid = (unsigned)(cdiv(capacity, 256) < 2048 ? cdiv(capacity, 256) : 2048);
+  PGDVS_LAUNCH("scatter_keep", scatter_keep_kernel, dim3(grid), dim3(256), 0, as_stream(stream), idx, flag,
+                     count, keep);
+  return check_launch("scatter_keep");
+}

@@ -1,0 +1,108 @@
+// Thread-local error string + version entry points of libpgdvs_hip.so.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <stdio.h>
+
+#include "../../include/pgdvs_hip.h"
+
+namespace pgdvs {
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- per-kernel timing (pgdvs_prof_*) --------------------------------------
+struct ProfRec {
+  const char *name;
+  hipEvent_t a, b;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+static thread_local ProfRec g_prof_cur;
+
+bool prof_enabled() { return g_prof_on; }
+
+static hipEvent_t prof_event() {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void prof_begin(const char *name, hipStream_t s) {
+  g_prof_cur.name = name;
+  g_prof_cur.a = prof_event();
+  g_prof_cur.b = prof_event();
+  (void)hipEventRecord(g_prof_cur.a, s);
+}
+
+void prof_end(hipStream_t s) {
+  (void)hipEventRecord(g_prof_cur.b, s);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_recs.push_back(g_prof_cur);
+}
+}  // namespace pgdvs
+
+extern "C" __attribute__((visibility("default"))) void pgdvs_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(pgdvs::g_prof_mu);
+  pgdvs::g_prof_on = on != 0;
+}
+
+// Synchronises the recorded events, writes "name calls total_ms\n" lines into buf
+// (truncated to buf_len) and clears the records.  Returns the number of distinct names.
+extern "C" __attribute__((visibility("default"))) int pgdvs_prof_report(char *buf, int buf_len) {
+  using namespace pgdvs;
+  std::vector<ProfRec> recs;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    recs.swap(g_prof_recs);
+  }
+  std::map<std::string, std::pair<int, double>> agg;
+  for (auto &r : recs) {
+    (void)hipEventSynchronize(r.b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    auto &e = agg[r.name];
+    e.first += 1;
+    e.second += ms;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_pool.push_back(r.a);
+    g_prof_pool.push_back(r.b);
+  }
+  std::string out;
+  for (auto &kv : agg) {
+    char line[256];
+    snprintf(line, sizeof(line), "%s %d %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+    out += line;
+  }
+  if (buf && buf_len > 0) {
+    strncpy(buf, out.c_str(), (size_t)buf_len - 1);
+    buf[buf_len - 1] = 0;
+  }
+  return (int)agg.size();
+}
+
+extern "C" __attribute__((visibility("default"))) const char *pgdvs_last_error(void) {
+  return pgdvs::g_err;
+}
+extern "C" __attribute__((visibility("default"))) int pgdvs_abi_version(void) { return 1; }
+extern "C" __attribute__((visibility("default"))) const char *pgdvs_build_arch(void) {
+  return "gfx950";
+}

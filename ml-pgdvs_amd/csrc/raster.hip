@@ -1,0 +1,407 @@
+// A9: point z-buffer rasteriser + norm-weighted compositor.
+// Semantics: pytorch3d 0.7.4 PointsRasterizer(bin_size=0) -> PointsRenderer ->
+// NormWeightedCompositor as driven by StaticGeoPointRenderer.forward
+// (pgdvs/renderers/st_geo_renderer.py:77-120) and render_dyn_pcl
+// (pgdvs/renderers/pgdvs_renderer_dyn.py:671-724); camera convention from
+// pgdvs/utils/pytorch3d_utils.py:5-47.
+//
+// The reference path is pytorch3d's NAIVE rasteriser: every pixel scans every point,
+// O(H*W*N).  Here points are binned to 16x16-pixel tiles first (count -> scan -> fill,
+// lists hold point ids), then one 256-thread workgroup per tile stages its list through
+// LDS and every pixel keeps its K nearest (z, id) in registers.  Per-pixel results do
+// not depend on list order because selection uses the total order (z, id), which is
+// also pytorch3d's priority-queue order -- so idx/zbuf/dist2 are deterministic.
+// blockIdx -> tile is swizzled so the 8 XCDs each walk a contiguous band of tiles
+// (neighbouring tiles share points in that XCD's L2).
+#include "common.h"
+
+namespace pgdvs {
+
+constexpr int kTile = 16;
+constexpr int kRasterMaxK = 8;
+
+struct RasterCam {
+  float w2c[12];  // first 3 rows of inverse(c2w)
+  float fxn, fyn, p0x, p0y;
+  // pixel <-> NDC (rasterization_utils PixToNonSquareNdc)
+  float range_x, range_y;
+};
+
+__device__ __forceinline__ float pix_to_ndc(int i, int S1, float range) {
+  float offset = range / 2.0f;
+  return -offset + (range * (float)i + offset) / (float)S1;
+}
+
+__device__ __forceinline__ RasterCam make_raster_cam(const float *__restrict__ cam, int H, int W) {
+  RasterCam rc;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) rc.w2c[i] = cam[PGDVS_CAM_W2C + i];
+  const float fx = cam[PGDVS_CAM_K + 0], fy = cam[PGDVS_CAM_K + 5];
+  const float cx = cam[PGDVS_CAM_K + 2], cy = cam[PGDVS_CAM_K + 6];
+  float s = (float)(W < H ? W : H) / 2.0f;
+  rc.fxn = fx / s;
+  rc.fyn = fy / s;
+  rc.p0x = -(cx - (float)W / 2.0f) / s;
+  rc.p0y = -(cy - (float)H / 2.0f) / s;
+  rc.range_x = W > H ? 2.0f * (float)W / (float)H : 2.0f;
+  rc.range_y = H > W ? 2.0f * (float)H / (float)W : 2.0f;
+  return rc;
+}
+
+// world point -> (x_ndc, y_ndc, z_view)
+__device__ __forceinline__ float3 point_to_ndc(const RasterCam &rc, float x, float y, float z) {
+  float v[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float a = rc.w2c[k * 4 + 0] * x;
+    a = a + rc.w2c[k * 4 + 1] * y;
+    a = a + rc.w2c[k * 4 + 2] * z;
+    a = a + rc.w2c[k * 4 + 3];
+    v[k] = a;
+  }
+  float xv = -v[0], yv = -v[1], zv = v[2];
+  float3 r;
+  r.x = (rc.fxn * xv + rc.p0x * zv) / zv;
+  r.y = (rc.fyn * yv + rc.p0y * zv) / zv;
+  r.z = zv;
+  return r;
+}
+
+struct TileBox {
+  int tx0, tx1, ty0, ty1;  // inclusive; empty if tx0 > tx1
+};
+
+// conservative tile bounding box of the disc of NDC radius `radius` around (x,y)
+__device__ __forceinline__ TileBox tile_box(const RasterCam &rc, float3 p, float radius, int H,
+                                            int W, int ntx, int nty) {
+  TileBox b;
+  b.tx0 = 1;
+  b.tx1 = 0;
+  b.ty0 = 1;
+  b.ty1 = 0;
+  if (!(p.z >= 0.0f) || !isfinite(p.x) || !isfinite(p.y)) return b;
+  // invert PixToNonSquareNdc (pixel index reversed: xidx = W-1-xi)
+  float offx = rc.range_x / 2.0f, offy = rc.range_y / 2.0f;
+  float xc = (float)(W - 1) - ((p.x + offx) * (float)W - offx) / rc.range_x;
+  float yc = (float)(H - 1) - ((p.y + offy) * (float)H - offy) / rc.range_y;
+  float rpx = radius * (float)W / rc.range_x + 1.5f;
+  float rpy = radius * (float)H / rc.range_y + 1.5f;
+  float x0 = floorf(xc - rpx), x1 = ceilf(xc + rpx);
+  float y0 = floorf(yc - rpy), y1 = ceilf(yc + rpy);
+  if (x1 < 0.0f || y1 < 0.0f || x0 > (float)(W - 1) || y0 > (float)(H - 1)) return b;
+  int ix0 = x0 < 0.0f ? 0 : (int)x0, iy0 = y0 < 0.0f ? 0 : (int)y0;
+  int ix1 = x1 > (float)(W - 1) ? W - 1 : (int)x1, iy1 = y1 > (float)(H - 1) ? H - 1 : (int)y1;
+  b.tx0 = ix0 / kTile;
+  b.tx1 = ix1 / kTile;
+  b.ty0 = iy0 / kTile;
+  b.ty1 = iy1 / kTile;
+  (void)ntx;
+  (void)nty;
+  return b;
+}
+
+__global__ void __launch_bounds__(256)
+raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_host,
+                            const int64_t *__restrict__ n_dev, const float *__restrict__ cam,
+                            float radius, int H, int W, int ntx, int nty,
+                            float4 *__restrict__ ndc4, int32_t *__restrict__ tile_count) {
+  const int64_t n = n_dev ? *n_dev : n_host;
+  RasterCam rc = make_raster_cam(cam, H, W);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float *X = pts + i * pts_stride;
+    float3 p = point_to_ndc(rc, X[0], X[1], X[2]);
+    ndc4[i] = make_float4(p.x, p.y, p.z, 0.0f);
+    TileBox b = tile_box(rc, p, radius, H, W, ntx, nty);
+    for (int ty = b.ty0; ty <= b.ty1; ++ty)
+      for (int tx = b.tx0; tx <= b.tx1; ++tx) atomicAdd(&tile_count[ty * ntx + tx], 1);
+  }
+}
+
+// single-block exclusive scan: offsets[i] = sum_{j<i} counts[j], offsets[n] = total
+__global__ void __launch_bounds__(1024)
+raster_scan_kernel(const int32_t *__restrict__ counts, int n, int32_t *__restrict__ offsets) {
+  __shared__ int wave_sums[1024 / kWave];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int start = 0; start < n; start += 1024) {
+    int i = start + threadIdx.x;
+    int v = i < n ? counts[i] : 0;
+    int x = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      int y = __shfl_up(x, off, 64);
+      if ((threadIdx.x & 63) >= off) x += y;
+    }
+    int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wave_sums[wave] = x;
+    __syncthreads();
+    int wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += wave_sums[w];
+    int incl = carry + wave_off + x;
+    if (i < n) offsets[i] = incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) offsets[n] = carry;
+}
+
+__global__ void __launch_bounds__(256)
+raster_fill_kernel(int64_t n_host, const int64_t *__restrict__ n_dev,
+                   const float *__restrict__ cam, float radius, int H, int W, int ntx, int nty,
+                   const float4 *__restrict__ ndc4, const int32_t *__restrict__ offsets,
+                   int32_t *__restrict__ cursor, int32_t *__restrict__ lists,
+                   int64_t list_capacity) {
+  const int64_t n = n_dev ? *n_dev : n_host;
+  RasterCam rc = make_raster_cam(cam, H, W);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 q = ndc4[i];
+    float3 p = make_float3(q.x, q.y, q.z);
+    TileBox b = tile_box(rc, p, radius, H, W, ntx, nty);
+    for (int ty = b.ty0; ty <= b.ty1; ++ty)
+      for (int tx = b.tx0; tx <= b.tx1; ++tx) {
+        int t = ty * ntx + tx;
+        int64_t pos = (int64_t)offsets[t] + atomicAdd(&cursor[t], 1);
+        if (pos < list_capacity) lists[pos] = (int32_t)i;
+      }
+  }
+}
+
+template <int K>
+struct TopK {
+  float z[K];
+  float d[K];
+  int id[K];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      z[k] = __builtin_inff();
+      d[k] = -1.0f;
+      id[k] = 0x7fffffff;
+    }
+  }
+  // keep the K smallest by (z, id)
+  __device__ __forceinline__ void insert(float pz, int pid, float pd) {
+    if (!(pz < z[K - 1] || (pz == z[K - 1] && pid < id[K - 1]))) return;
+    z[K - 1] = pz;
+    id[K - 1] = pid;
+    d[K - 1] = pd;
+#pragma unroll
+    for (int k = K - 1; k > 0; --k) {
+      bool sw = z[k] < z[k - 1] || (z[k] == z[k - 1] && id[k] < id[k - 1]);
+      if (sw) {
+        float tz = z[k]; z[k] = z[k - 1]; z[k - 1] = tz;
+        float td = d[k]; d[k] = d[k - 1]; d[k - 1] = td;
+        int ti = id[k]; id[k] = id[k - 1]; id[k - 1] = ti;
+      }
+    }
+  }
+};
+
+template <int K>
+__global__ void __launch_bounds__(256)
+raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ offsets,
+                   const int32_t *__restrict__ lists, int64_t list_capacity,
+                   const float *__restrict__ feat, int64_t feat_stride, float radius, int H, int W,
+                   int ntx, int nty, int tiles_per_xcd, int64_t *__restrict__ idx_out,
+                   float *__restrict__ zbuf_out, float *__restrict__ dist_out,
+                   float *__restrict__ rgb_out, int rgb_planar, float *__restrict__ mask_out) {
+  __shared__ float4 s_pt[256];
+  // XCD-aware mapping: blocks b, b+8, ... share an XCD -> give them a contiguous tile band
+  const int ntiles = ntx * nty;
+  int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= tiles_per_xcd || tile >= ntiles) return;
+  const int ty = tile / ntx, tx = tile - ty * ntx;
+  const int lx = threadIdx.x & (kTile - 1), ly = threadIdx.x >> 4;
+  const int xi = tx * kTile + lx, yi = ty * kTile + ly;
+  const bool inside = xi < W && yi < H;
+  const float range_x = W > H ? 2.0f * (float)W / (float)H : 2.0f;
+  const float range_y = H > W ? 2.0f * (float)H / (float)W : 2.0f;
+  const float xf = pix_to_ndc(W - 1 - xi, W, range_x);
+  const float yf = pix_to_ndc(H - 1 - yi, H, range_y);
+  const float r2 = radius * radius;
+  TopK<K> q;
+  q.init();
+  int64_t beg = offsets[tile], end = offsets[tile + 1];
+  if (end > list_capacity) end = list_capacity;
+  for (int64_t base = beg; base < end; base += 256) {
+    int64_t e = base + threadIdx.x;
+    __syncthreads();
+    if (e < end) {
+      int id = lists[e];
+      float4 p = ndc4[id];
+      p.w = __int_as_float(id);
+      s_pt[threadIdx.x] = p;
+    }
+    __syncthreads();
+    int m = (int)((end - base) < 256 ? (end - base) : 256);
+    if (inside) {
+#pragma unroll 4
+      for (int j = 0; j < m; ++j) {
+        float4 p = s_pt[j];
+        float dx = p.x - xf, dy = p.y - yf;
+        float d2 = dx * dx + dy * dy;
+        if (d2 < r2) q.insert(p.z, __float_as_int(p.w), d2);
+      }
+    }
+  }
+  if (!inside) return;
+  const size_t pix = (size_t)yi * W + xi;
+  // NormWeightedCompositor: w = 1 - d2/r2, t = max(sum w, 1e-4), out = sum w*f/t
+  float t = 0.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    if (q.id[k] != 0x7fffffff) t = t + (1.0f - q.d[k] / r2);
+  t = t > 1e-4f ? t : 1e-4f;
+  float acc[3] = {0.f, 0.f, 0.f}, ones = 0.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    bool has = q.id[k] != 0x7fffffff;
+    if (idx_out) idx_out[pix * K + k] = has ? (int64_t)q.id[k] : (int64_t)-1;
+    if (zbuf_out) zbuf_out[pix * K + k] = has ? q.z[k] : -1.0f;
+    if (dist_out) dist_out[pix * K + k] = has ? q.d[k] : -1.0f;
+    if (has) {
+      float w = 1.0f - q.d[k] / r2;
+      ones = ones + w * 1.0f / t;
+      if (rgb_out) {
+        const float *f = feat + (int64_t)q.id[k] * feat_stride;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = acc[c] + w * f[c] / t;
+      }
+    }
+  }
+  if (rgb_out) {
+    if (rgb_planar) {
+      const size_t P = (size_t)H * W;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rgb_out[c * P + pix] = acc[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rgb_out[pix * 3 + c] = acc[c];
+    }
+  }
+  if (mask_out) mask_out[pix] = ones > 0.0f ? 1.0f : 0.0f;
+}
+
+static int64_t max_tiles_per_point(float radius, int H, int W) {
+  float range_x = W > H ? 2.0f * (float)W / (float)H : 2.0f;
+  float range_y = H > W ? 2.0f * (float)H / (float)W : 2.0f;
+  double wx = 2.0 * ((double)radius * W / range_x + 1.5) + 2.0;
+  double wy = 2.0 * ((double)radius * H / range_y + 1.5) + 2.0;
+  int64_t nx = (int64_t)(wx / kTile) + 2, ny = (int64_t)(wy / kTile) + 2;
+  int64_t ntx = cdiv(W, kTile), nty = cdiv(H, kTile);
+  if (nx > ntx) nx = ntx;
+  if (ny > nty) ny = nty;
+  return nx * ny;
+}
+
+struct RasterWs {
+  float4 *ndc4;
+  int32_t *tile_count, *cursor, *offsets, *lists;
+  int64_t list_capacity;
+  int64_t total_bytes;
+};
+
+static RasterWs raster_ws_layout(void *base, int64_t n, int H, int W, float radius) {
+  RasterWs w;
+  int64_t ntiles = cdiv(W, kTile) * cdiv(H, kTile);
+  char *p = reinterpret_cast<char *>(base);
+  int64_t off = 0;
+  w.ndc4 = reinterpret_cast<float4 *>(p + off);
+  off += align_up((n > 0 ? n : 1) * 16, 256);
+  w.tile_count = reinterpret_cast<int32_t *>(p + off);
+  off += align_up(ntiles * 4, 256);
+  w.cursor = reinterpret_cast<int32_t *>(p + off);
+  off += align_up(ntiles * 4, 256);
+  w.offsets = reinterpret_cast<int32_t *>(p + off);
+  off += align_up((ntiles + 1) * 4, 256);
+  w.list_capacity = (n > 0 ? n : 1) * max_tiles_per_point(radius, H, W);
+  if (w.list_capacity >= (1ll << 31)) w.list_capacity = (1ll << 31) - 1;
+  w.lists = reinterpret_cast<int32_t *>(p + off);
+  off += align_up(w.list_capacity * 4, 256);
+  w.total_bytes = off;
+  return w;
+}
+
+}  // namespace pgdvs
+
+using namespace pgdvs;
+
+PGDVS_API int64_t pgdvs_points_raster_workspace_bytes(int64_t n_points, int H, int W, float radius) {
+  if (n_points < 0 || H <= 0 || W <= 0) return -1;
+  return raster_ws_layout(nullptr, n_points, H, W, radius).total_bytes;
+}
+
+template <int K>
+static void launch_tile(dim3 grid, hipStream_t st, const RasterWs &ws, const float *feat,
+                        int64_t feat_stride, float radius, int H, int W, int ntx, int nty,
+                        int tiles_per_xcd, int64_t *idx, float *zbuf, float *dist2, float *rgb,
+                        int rgb_planar, float *mask) {
+  PGDVS_LAUNCH("raster_tile", raster_tile_kernel<K>, grid, dim3(256), 0, st, ws.ndc4, ws.offsets, ws.lists,
+                     ws.list_capacity, feat, feat_stride, radius, H, W, ntx, nty, tiles_per_xcd, idx,
+                     zbuf, dist2, rgb, rgb_planar, mask);
+}
+
+PGDVS_API int pgdvs_points_raster(const float *pts, int64_t pts_stride, const float *feat,
+                                  int64_t feat_stride, int64_t n_points,
+                                  const int64_t *n_points_dev, const float *cam_tgt, float radius,
+                                  int K, int H, int W, int64_t *idx, float *zbuf, float *dist2,
+                                  float *rgb, int rgb_planar, float *mask, void *workspace,
+                                  int64_t workspace_bytes, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), "pgdvs_points_raster: bad H/W");
+  PGDVS_REQUIRE(n_points >= 0 && n_points < (1ll << 31), "pgdvs_points_raster: bad n_points");
+  PGDVS_REQUIRE(cam_tgt && (n_points == 0 || pts) && pts_stride >= 3, "pgdvs_points_raster: bad points");
+  PGDVS_REQUIRE(!rgb || n_points == 0 || (feat && feat_stride >= 3), "pgdvs_points_raster: rgb output needs features");
+  PGDVS_REQUIRE(radius > 0.0f, "pgdvs_points_raster: radius must be > 0");
+  if (K < 1 || K > kRasterMaxK) {
+    set_error("pgdvs_points_raster: points_per_pixel must be in [1, %d]", kRasterMaxK);
+    return PGDVS_ERR_UNSUPPORTED;
+  }
+  RasterWs ws = raster_ws_layout(workspace, n_points, H, W, radius);
+  if (!workspace || workspace_bytes < ws.total_bytes) {
+    set_error("pgdvs_points_raster: workspace too small (%lld < %lld)", (long long)workspace_bytes,
+              (long long)ws.total_bytes);
+    return PGDVS_ERR_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  const int ntx = (int)cdiv(W, kTile), nty = (int)cdiv(H, kTile), ntiles = ntx * nty;
+  hipError_t e = hipMemsetAsync(ws.tile_count, 0, (size_t)((char *)ws.offsets - (char *)ws.tile_count), st);
+  if (e != hipSuccess) {
+    set_error("points_raster memset: %s", hipGetErrorString(e));
+    return PGDVS_ERR_LAUNCH;
+  }
+  if (n_points > 0) {
+    unsigned g = (unsigned)(cdiv(n_points, 256) < 4096 ? cdiv(n_points, 256) : 4096);
+    PGDVS_LAUNCH("raster_project_count", raster_project_count_kernel, dim3(g), dim3(256), 0, st, pts, pts_stride,
+                       n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.ndc4,
+                       ws.tile_count);
+  }
+  PGDVS_LAUNCH("raster_scan", raster_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_count, ntiles, ws.offsets);
+  if (n_points > 0) {
+    unsigned g = (unsigned)(cdiv(n_points, 256) < 4096 ? cdiv(n_points, 256) : 4096);
+    PGDVS_LAUNCH("raster_fill", raster_fill_kernel, dim3(g), dim3(256), 0, st, n_points, n_points_dev, cam_tgt,
+                       radius, H, W, ntx, nty, ws.ndc4, ws.offsets, ws.cursor, ws.lists,
+                       ws.list_capacity);
+  }
+  const int tiles_per_xcd = (int)cdiv(ntiles, 8);
+  dim3 grid(8 * tiles_per_xcd);
+#define PGDVS_TILE_CASE(KK)                                                                      \
+  case KK:                                                                                       \
+    launch_tile<KK>(grid, st, ws, feat, feat_stride, radius, H, W, ntx, nty, tiles_per_xcd, idx, \
+                    zbuf, dist2, rgb, rgb_planar, mask);                                         \
+    break;
+  switch (K) {
+    PGDVS_TILE_CASE(1)
+    PGDVS_TILE_CASE(2)
+    PGDVS_TILE_CASE(3)
+    PGDVS_TILE_CASE(4)
+    PGDVS_TILE_CASE(5)
+    PGDVS_TILE_CASE(6)
+    PGDVS_TILE_CASE(7)
+    PGDVS_TILE_CASE(8)
+  }
+#undef PGDVS_TILE_CASE
+  return check_launch("points_raster");
+}

@@ -1,0 +1,291 @@
+// A7: softmax splatting (forward warp), the gfx950 statement of kernel
+// `softsplat_out` (pgdvs/utils/softsplat.py:352-402) with the wrapper's pre/post
+// processing (softsplat.py:294-333) fused in, plus the renderer-level fusion
+// A6+A7+A8+A11 used by PGDVSDynamicRenderer / PGDVSRenderer.
+//
+// One thread per SOURCE PIXEL handles all channels (the reference launches one
+// thread per (channel, pixel) and re-reads the flow and re-derives the weights C
+// times).  Accumulators are planar [C][H][W] so that a wavefront of neighbouring
+// source pixels with coherent flow issues each atomic as one contiguous 256-byte
+// row segment -- the shape the memory-side f32 atomic units run at full rate on.
+// Corners whose bilinear weight is exactly zero are skipped: adding +-0 never
+// changes an accumulator, so the result is identical and the zero-flow (static)
+// majority costs one atomic per channel instead of four.
+#include "common.h"
+
+namespace pgdvs {
+
+__device__ __forceinline__ void atomic_add_f32(float *p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct SplatCorners {
+  int idx[4];   // flat destination index (y*W+x) or -1
+  float w[4];
+  bool any;
+};
+
+// corner indices + weights exactly as softsplat.py:365-401
+__device__ __forceinline__ SplatCorners splat_corners(int x, int y, float fx, float fy, int H,
+                                                      int W) {
+  SplatCorners c;
+  c.any = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c.idx[k] = -1;
+  float X = (float)x + fx;
+  float Y = (float)y + fy;
+  if (!isfinite(X) || !isfinite(Y)) return c;
+  float flx = floorf(X), fly = floorf(Y);
+  // (int) floor() of a value outside [-2, size] can only fail the bounds tests
+  if (flx < -2.0f || flx > (float)W || fly < -2.0f || fly > (float)H) return c;
+  int nwx = (int)flx, nwy = (int)fly;
+  int nex = nwx + 1, ney = nwy;
+  int swx = nwx, swy = nwy + 1;
+  int sex = nwx + 1, sey = nwy + 1;
+  c.w[0] = ((float)sex - X) * ((float)sey - Y);
+  c.w[1] = (X - (float)swx) * ((float)swy - Y);
+  c.w[2] = ((float)nex - X) * (Y - (float)ney);
+  c.w[3] = (X - (float)nwx) * (Y - (float)nwy);
+  if (nwx >= 0 && nwx < W && nwy >= 0 && nwy < H) c.idx[0] = nwy * W + nwx;
+  if (nex >= 0 && nex < W && ney >= 0 && ney < H) c.idx[1] = ney * W + nex;
+  if (swx >= 0 && swx < W && swy >= 0 && swy < H) c.idx[2] = swy * W + swx;
+  if (sex >= 0 && sex < W && sey >= 0 && sey < H) c.idx[3] = sey * W + sex;
+  c.any = c.idx[0] >= 0 || c.idx[1] >= 0 || c.idx[2] >= 0 || c.idx[3] >= 0;
+  return c;
+}
+
+__device__ __forceinline__ void splat_value(float *plane, const SplatCorners &c, float v) {
+  const bool fin = isfinite(v);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (c.idx[k] >= 0 && !(c.w[k] == 0.0f && fin)) atomic_add_f32(plane + c.idx[k], v * c.w[k]);
+  }
+}
+
+// generic op ---------------------------------------------------------------
+// mode: 0 sum, 1 avg, 2 linear, 3 soft.  acc has Cacc = C (+1 if mode != 0) planes.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+softsplat_scatter_kernel(const float *__restrict__ in, const float *__restrict__ flow,
+                         const float *__restrict__ metric, float *__restrict__ acc, int C, int H,
+                         int W) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int P = H * W;
+  if (p >= P) return;
+  int b = blockIdx.y;
+  int y = p / W, x = p - y * W;
+  const float *fl = flow + (size_t)b * 2 * P;
+  SplatCorners c = splat_corners(x, y, fl[p], fl[(size_t)P + p], H, W);
+  if (!c.any) return;
+  const int Cacc = MODE == 0 ? C : C + 1;
+  float *a = acc + (size_t)b * Cacc * P;
+  const float *src = in + (size_t)b * C * P;
+  float m = 1.0f;
+  if (MODE == 2) m = metric[(size_t)b * P + p];
+  if (MODE == 3) m = expf(metric[(size_t)b * P + p]);
+  for (int ch = 0; ch < C; ++ch) {
+    float v = src[(size_t)ch * P + p];
+    if (MODE >= 2) v = v * m;
+    splat_value(a + (size_t)ch * P, c, v);
+  }
+  if (MODE != 0) splat_value(a + (size_t)C * P, c, m);
+}
+
+// out[:, :C] = acc[:, :C] / norm(acc[:, C]) -- softsplat.py:313-330
+__global__ void __launch_bounds__(256)
+softsplat_normalize_kernel(const float *__restrict__ acc, float *__restrict__ out, int C, int H,
+                           int W, int eps) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int P = H * W;
+  if (p >= P) return;
+  int b = blockIdx.y;
+  const float *a = acc + (size_t)b * (C + 1) * P;
+  float nrm = a[(size_t)C * P + p];
+  if (eps == 0) nrm = nrm + 0.0000001f;
+  else if (eps == 1) nrm = (nrm == 0.0f) ? 1.0f : nrm;
+  else nrm = nrm < 0.0000001f ? 0.0000001f : nrm;   // clip(min): NaN stays NaN
+  float *o = out + (size_t)b * C * P;
+  for (int ch = 0; ch < C; ++ch) o[(size_t)ch * P + p] = a[(size_t)ch * P + p] / nrm;
+}
+
+// renderer-level fusion -------------------------------------------------------
+// torch.linspace(-1,1,steps)[i] as ATen computes it
+__device__ __forceinline__ float linspace_pm1(int i, int steps) {
+  if (steps == 1) return -1.0f;
+  float step = (1.0f - (-1.0f)) / (float)(steps - 1);
+  if (i < steps / 2) return -1.0f + step * (float)i;
+  return 1.0f - step * (float)(steps - 1 - i);
+}
+
+// acc planes: 0..2 rgb*e, 3 e, 4 mask*e
+__global__ void __launch_bounds__(256)
+dyn_splat_scatter_kernel(int H, int W, const float *__restrict__ rgb1,
+                         const float *__restrict__ rgb2, const float *__restrict__ flow12,
+                         const float *__restrict__ flow_1_to_tgt,
+                         const float *__restrict__ valid_mask, const float *__restrict__ noise,
+                         float alpha, float *__restrict__ acc) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int P = H * W;
+  if (p >= P) return;
+  int y = p / W, x = p - y * W;
+  SplatCorners c = splat_corners(x, y, flow_1_to_tgt[p], flow_1_to_tgt[(size_t)P + p], H, W);
+  if (!c.any) return;
+  const float m = valid_mask[p];
+  // rgb_src_1 = rgb*mask + clamp(randn,0,1)*(1-mask)   (pgdvs_renderer_dyn.py:177-182)
+  float c1[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float nz = noise ? clampf(noise[(size_t)k * P + p], 0.0f, 1.0f) : 0.0f;
+    c1[k] = rgb1[(size_t)p * 3 + k] * m + nz * (1.0f - m);
+  }
+  // backwarp rgb2 by flow12, align_corners=True (pgdvs_renderer_base.py:91-138)
+  float2 f12 = reinterpret_cast<const float2 *>(flow12)[p];
+  const float hw_x = ((float)W - 1.0f) / 2.0f, hw_y = ((float)H - 1.0f) / 2.0f;
+  float gx = linspace_pm1(x, W) + f12.x / hw_x;
+  float gy = linspace_pm1(y, H) + f12.y / hw_y;
+  float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+  float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+  bool fin = isfinite(ix) && isfinite(iy) && fabsf(ix) < 1e9f && fabsf(iy) < 1e9f;
+  float x0f = floorf(ix), y0f = floorf(iy);
+  int x0 = fin ? (int)x0f : -10, y0 = fin ? (int)y0f : -10, x1 = x0 + 1, y1 = y0 + 1;
+  float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+  float wne = (ix - (float)x0) * ((float)y1 - iy);
+  float wsw = ((float)x1 - ix) * (iy - (float)y0);
+  float wse = (ix - (float)x0) * (iy - (float)y0);
+  bool inx0 = x0 >= 0 && x0 < W, inx1 = x1 >= 0 && x1 < W;
+  bool iny0 = y0 >= 0 && y0 < H, iny1 = y1 >= 0 && y1 < H;
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float a = 0.0f;
+    if (inx0 && iny0) a = a + rgb2[((size_t)y0 * W + x0) * 3 + k] * wnw;
+    if (inx1 && iny0) a = a + rgb2[((size_t)y0 * W + x1) * 3 + k] * wne;
+    if (inx0 && iny1) a = a + rgb2[((size_t)y1 * W + x0) * 3 + k] * wsw;
+    if (inx1 && iny1) a = a + rgb2[((size_t)y1 * W + x1) * 3 + k] * wse;
+    s = s + fabsf(c1[k] - a);
+  }
+  float l1 = s / 3.0f;
+  // metric = clip(-alpha*L1, -alpha, alpha); soft mode weight exp(metric)
+  float e = expf(clampf(-alpha * l1, -alpha, alpha));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) splat_value(acc + (size_t)k * P, c, c1[k] * e);
+  splat_value(acc + (size_t)3 * P, c, e);
+  float me = m * e;
+  if (me != 0.0f) splat_value(acc + (size_t)4 * P, c, me);
+}
+
+// normalise, threshold, mask and composite (pgdvs_renderer_dyn.py:200-202,
+// pgdvs_renderer.py:169-178)
+__global__ void __launch_bounds__(256)
+dyn_splat_finish_kernel(int P, const float *__restrict__ acc, const float *__restrict__ static_rgb,
+                        float *__restrict__ dyn_rgb, float *__restrict__ dyn_mask,
+                        float *__restrict__ comb, float *__restrict__ comb_st,
+                        float *__restrict__ comb_dy) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float nrm = acc[(size_t)3 * P + p] + 0.0000001f;
+  float mk = acc[(size_t)4 * P + p] / nrm;
+  float dm = mk > 1e-3f ? 1.0f : 0.0f;
+  dyn_mask[p] = dm;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float v = (acc[(size_t)k * P + p] / nrm) * dm;
+    dyn_rgb[(size_t)k * P + p] = v;
+    if (static_rgb) {
+      float a = (1.0f - dm) * static_rgb[(size_t)k * P + p];
+      float b = dm * v;
+      if (comb_st) comb_st[(size_t)k * P + p] = a;
+      if (comb_dy) comb_dy[(size_t)k * P + p] = b;
+      if (comb) comb[(size_t)k * P + p] = a + b;
+    }
+  }
+}
+
+}  // namespace pgdvs
+
+using namespace pgdvs;
+
+PGDVS_API int64_t pgdvs_softsplat_workspace_bytes(int B, int C, int H, int W, int mode) {
+  if (mode == 0) return 256;
+  return align_up((int64_t)B * (C + 1) * H * W * (int64_t)sizeof(float), 256);
+}
+
+PGDVS_API int pgdvs_softsplat_fwd(const float *in, const float *flow, const float *metric,
+                                  float *out, int B, int C, int H, int W, int mode, int eps,
+                                  void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(in && flow && out, "pgdvs_softsplat_fwd: null pointer");
+  PGDVS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31) && B < 65536,
+                "pgdvs_softsplat_fwd: bad shape");
+  PGDVS_REQUIRE(mode >= 0 && mode <= 3 && eps >= 0 && eps <= 2, "pgdvs_softsplat_fwd: bad mode");
+  // softsplat.py:285-292
+  PGDVS_REQUIRE((mode >= 2) == (metric != nullptr),
+                "pgdvs_softsplat_fwd: metric must be given for linear/soft and absent for sum/avg");
+  hipStream_t st = as_stream(stream);
+  const int64_t P = (int64_t)H * W;
+  dim3 grid((unsigned)cdiv(P, 256), B), block(256);
+  hipError_t e;
+  if (mode == 0) {
+    e = hipMemsetAsync(out, 0, (size_t)B * C * P * sizeof(float), st);
+    if (e != hipSuccess) {
+      set_error("softsplat memset: %s", hipGetErrorString(e));
+      return PGDVS_ERR_LAUNCH;
+    }
+    PGDVS_LAUNCH("softsplat_scatter", softsplat_scatter_kernel<0>, grid, block, 0, st, in, flow, metric, out, C, H, W);
+    return check_launch("softsplat_scatter");
+  }
+  if (!workspace || workspace_bytes < pgdvs_softsplat_workspace_bytes(B, C, H, W, mode)) {
+    set_error("pgdvs_softsplat_fwd: workspace too small");
+    return PGDVS_ERR_WORKSPACE;
+  }
+  float *acc = reinterpret_cast<float *>(workspace);
+  e = hipMemsetAsync(acc, 0, (size_t)B * (C + 1) * P * sizeof(float), st);
+  if (e != hipSuccess) {
+    set_error("softsplat memset: %s", hipGetErrorString(e));
+    return PGDVS_ERR_LAUNCH;
+  }
+  if (mode == 1)
+    PGDVS_LAUNCH("softsplat_scatter", softsplat_scatter_kernel<1>, grid, block, 0, st, in, flow, metric, acc, C, H, W);
+  else if (mode == 2)
+    PGDVS_LAUNCH("softsplat_scatter", softsplat_scatter_kernel<2>, grid, block, 0, st, in, flow, metric, acc, C, H, W);
+  else
+    PGDVS_LAUNCH("softsplat_scatter", softsplat_scatter_kernel<3>, grid, block, 0, st, in, flow, metric, acc, C, H, W);
+  PGDVS_LAUNCH("softsplat_normalize", softsplat_normalize_kernel, grid, block, 0, st, acc, out, C, H, W, eps);
+  return check_launch("softsplat_fwd");
+}
+
+PGDVS_API int64_t pgdvs_dyn_splat_workspace_bytes(int H, int W) {
+  return align_up((int64_t)5 * H * W * (int64_t)sizeof(float), 256);
+}
+
+PGDVS_API int pgdvs_dyn_splat_composite(int H, int W, const float *rgb1, const float *rgb2,
+                                        const float *flow12, const float *flow_1_to_tgt,
+                                        const float *valid_dyn_mask_1, const float *noise,
+                                        float alpha, const float *static_rgb, float *render_dyn_rgb,
+                                        float *render_dyn_mask, float *combined,
+                                        float *combined_static, float *combined_dyn,
+                                        void *workspace, int64_t workspace_bytes,
+                                        pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), "pgdvs_dyn_splat_composite: bad H/W");
+  PGDVS_REQUIRE(rgb1 && rgb2 && flow12 && flow_1_to_tgt && valid_dyn_mask_1 && render_dyn_rgb &&
+                    render_dyn_mask,
+                "pgdvs_dyn_splat_composite: null pointer");
+  PGDVS_REQUIRE(alpha >= 0.0f, "pgdvs_dyn_splat_composite: alpha must be >= 0");
+  if (!workspace || workspace_bytes < pgdvs_dyn_splat_workspace_bytes(H, W)) {
+    set_error("pgdvs_dyn_splat_composite: workspace too small");
+    return PGDVS_ERR_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  const int P = H * W;
+  float *acc = reinterpret_cast<float *>(workspace);
+  hipError_t e = hipMemsetAsync(acc, 0, (size_t)5 * P * sizeof(float), st);
+  if (e != hipSuccess) {
+    set_error("dyn_splat memset: %s", hipGetErrorString(e));
+    return PGDVS_ERR_LAUNCH;
+  }
+  dim3 grid((unsigned)cdiv(P, 256)), block(256);
+  PGDVS_LAUNCH("dyn_splat_scatter", dyn_splat_scatter_kernel, grid, block, 0, st, H, W, rgb1, rgb2, flow12,
+                     flow_1_to_tgt, valid_dyn_mask_1, noise, alpha, acc);
+  PGDVS_LAUNCH("dyn_splat_finish", dyn_splat_finish_kernel, grid, block, 0, st, P, acc, static_rgb,
+                     render_dyn_rgb, render_dyn_mask, combined, combined_static, combined_dyn);
+  return check_launch("dyn_splat_composite");
+}

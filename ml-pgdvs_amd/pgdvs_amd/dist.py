@@ -1,0 +1,50 @@
+"""Multi-GPU driver pieces: target views are independent units, so a video shards
+embarrassingly across ranks (one process per GPU).  Partitioning follows the reference's
+``DistributedSampler(shuffle=False)`` use (pgdvs/engines/trainer_pgdvs.py:290-306): view
+``v`` goes to rank ``v % world`` and the tail is padded by wrap-around.  The only data-path
+collective is the gather of the final image stack to rank 0 (the reference writes PNGs per
+rank instead, pgdvs/engines/evaluator_pgdvs.py:432-440); on ROCm ``backend="nccl"`` is
+RCCL over xGMI.  With the ``gloo`` backend the same code runs on CPU tensors (tests)."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_views: int, rank: int, world: int) -> list[int]:
+    """Indices of the views rendered by ``rank`` (DistributedSampler, shuffle=False, drop_last=False)."""
+    if n_views <= 0:
+        return []
+    total = math.ceil(n_views / world) * world
+    idx = list(range(n_views))
+    pad = total - n_views
+    if pad:
+        idx += (idx * math.ceil(pad / len(idx)))[:pad]
+    return idx[rank:total:world]
+
+
+def gather_image_stack(local: torch.Tensor, n_views: int, dst: int = 0):
+    """local[n_local,3,H,W] on every rank -> on ``dst`` the stack [n_views,3,H,W] in view
+    order (wrap-around duplicates dropped), ``None`` elsewhere."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local[:n_views]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+    dist.gather(local.contiguous(), bufs, dst=dst)
+    if rank != dst:
+        return None
+    n_local = local.shape[0]
+    out = torch.empty((n_local * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        out[r::world] = bufs[r]
+    return out[:n_views]
+
+
+def reduce_metrics(values: torch.Tensor, dst: int = 0) -> torch.Tensor:
+    """One packed SUM-reduce for all scalar metrics of a step (the reference issues one
+    ``torch.distributed.reduce`` per key, pgdvs/engines/evaluator_pgdvs.py:183-186)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(values, dst=dst, op=dist.ReduceOp.SUM)
+    return values

@@ -1,0 +1,254 @@
+"""torch-tensor front end of the C ABI (include/pgdvs_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every
+function below only validates tensors, allocates outputs / scratch with
+``torch.empty`` and enqueues hand-written HIP kernels through ctypes.  Nothing in
+this module computes on the CPU; CPU tensors are rejected.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CAM_BLOCK, PgdvsHipError, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise PgdvsHipError(
+            f"{name}: tensor is on {t.device}; the MI355X path has no CPU fallback "
+            "(move the data dict to the GPU as pgdvs.engines does)"
+        )
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------------------
+def cam_prep(flat_cams: torch.Tensor) -> torch.Tensor:
+    """flat_cams[..., 34] -> camera blocks[..., 80]."""
+    fc = _req(flat_cams, torch.float32, "flat_cams")
+    assert fc.shape[-1] == 34, fc.shape
+    n = fc.numel() // 34
+    out = torch.empty(fc.shape[:-1] + (CAM_BLOCK,), dtype=torch.float32, device=fc.device)
+    check(_lib.load().pgdvs_cam_prep(_ptr(fc), n, _ptr(out), _stream()), "pgdvs_cam_prep")
+    return out
+
+
+def get_rays(cam_block: torch.Tensor, H: int, W: int, stride: int = 1):
+    cam = _req(cam_block, torch.float32, "cam_block")
+    rh, rw = (H + stride - 1) // stride, (W + stride - 1) // stride
+    n = rh * rw
+    ro = torch.empty((n, 3), dtype=torch.float32, device=cam.device)
+    rd = torch.empty((n, 3), dtype=torch.float32, device=cam.device)
+    uv = torch.empty((n, 2), dtype=torch.float32, device=cam.device)
+    check(_lib.load().pgdvs_get_rays(_ptr(cam), H, W, stride, _ptr(ro), _ptr(rd), _ptr(uv), _stream()), "pgdvs_get_rays")
+    return ro, rd, uv, (rh, rw)
+
+
+def dyn_warp(dyn_mask1, occ, use_fc, flow12, depth1, depth2, rgb1, rgb2, cam1, cam2, times):
+    H, W = dyn_mask1.shape[0], dyn_mask1.shape[1]
+    dev = dyn_mask1.device
+    m = _req(dyn_mask1, torch.float32, "dyn_mask1")
+    o = _req(occ, torch.float32, "occ") if occ is not None else None
+    args = [_req(t, torch.float32, n) for t, n in [
+        (flow12, "flow12"), (depth1, "depth1"), (depth2, "depth2"), (rgb1, "rgb1"), (rgb2, "rgb2"),
+        (cam1, "cam1"), (cam2, "cam2"), (times, "times")]]
+    mask_eff = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    valid = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    pcl = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    rgbf = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    check(_lib.load().pgdvs_dyn_warp(
+        H, W, _ptr(m), _ptr(o), int(bool(use_fc)), *[_ptr(a) for a in args],
+        _ptr(mask_eff), _ptr(valid), _ptr(pcl), _ptr(rgbf), _stream()), "pgdvs_dyn_warp")
+    return mask_eff, valid, pcl, rgbf
+
+
+def compact_u8(flags: torch.Tensor):
+    """-> (idx[int32, capacity n], count[int32, 1]) both on the device."""
+    f = _req(flags, torch.uint8, "flags").reshape(-1)
+    n = f.numel()
+    idx = torch.empty(max(n, 1), dtype=torch.int32, device=f.device)
+    cnt = torch.empty(1, dtype=torch.int32, device=f.device)
+    lib = _lib.load()
+    ws = _ws(lib.pgdvs_compact_workspace_bytes(n), f.device)
+    check(lib.pgdvs_compact_u8(_ptr(f), n, _ptr(idx), _ptr(cnt), _ptr(ws), ws.numel(), _stream()), "pgdvs_compact_u8")
+    return idx, cnt
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, cnt: torch.Tensor) -> torch.Tensor:
+    s = _req(src, torch.float32, "src")
+    width = s.shape[-1]
+    cap = idx.numel()
+    dst = torch.empty((cap, width), dtype=torch.float32, device=s.device)
+    check(_lib.load().pgdvs_gather_rows(_ptr(s), _ptr(idx), _ptr(cnt), cap, width, _ptr(dst), _stream()), "pgdvs_gather_rows")
+    return dst
+
+
+def knn_mean_dist(pts: torch.Tensor, cnt: torch.Tensor, K: int) -> torch.Tensor:
+    p = _req(pts, torch.float32, "pts").reshape(-1, 3)
+    c = _req(cnt, torch.int32, "count")
+    out = torch.empty(max(p.shape[0], 1), dtype=torch.float32, device=p.device)
+    check(_lib.load().pgdvs_knn_mean_dist(_ptr(p), _ptr(c), p.shape[0], int(K), _ptr(out), _stream()), "pgdvs_knn_mean_dist")
+    return out
+
+
+def outlier_flags(avg: torch.Tensor, cnt: torch.Tensor, std_thres: float, remove_outlier: bool):
+    a = _req(avg, torch.float32, "avg")
+    thres = torch.empty(1, dtype=torch.float32, device=a.device)
+    flag = torch.empty(max(a.numel(), 1), dtype=torch.uint8, device=a.device)
+    lib = _lib.load()
+    ws = _ws(lib.pgdvs_outlier_workspace_bytes(a.numel()), a.device)
+    check(lib.pgdvs_outlier_flags(_ptr(a), _ptr(cnt), a.numel(), float(std_thres), int(bool(remove_outlier)),
+                                  _ptr(thres), _ptr(flag), _ptr(ws), ws.numel(), _stream()), "pgdvs_outlier_flags")
+    return thres, flag
+
+
+def scatter_keep(idx, flag, cnt, P: int) -> torch.Tensor:
+    keep = torch.empty(P, dtype=torch.uint8, device=idx.device)
+    check(_lib.load().pgdvs_scatter_keep(_ptr(idx), _ptr(flag), _ptr(cnt), idx.numel(), _ptr(keep), P, _stream()), "pgdvs_scatter_keep")
+    return keep
+
+
+def project_flow_dense(cam_tgt, pcl, keep, H: int, W: int):
+    cam = _req(cam_tgt, torch.float32, "cam_tgt")
+    flow = torch.empty((2, H, W), dtype=torch.float32, device=cam.device)
+    mask = torch.empty((H, W), dtype=torch.float32, device=cam.device)
+    check(_lib.load().pgdvs_project_flow_dense(H, W, _ptr(cam), _ptr(_req(pcl, torch.float32, "pcl")),
+                                               _ptr(_req(keep, torch.uint8, "keep")), _ptr(flow), _ptr(mask), _stream()),
+          "pgdvs_project_flow_dense")
+    return flow, mask
+
+
+def project_points(cam_tgt, pts):
+    p = _req(pts, torch.float32, "pts").reshape(-1, 3)
+    uv = torch.empty((p.shape[0], 2), dtype=torch.float32, device=p.device)
+    check(_lib.load().pgdvs_project_points(_ptr(_req(cam_tgt, torch.float32, "cam_tgt")), _ptr(p), p.shape[0], _ptr(uv), _stream()),
+          "pgdvs_project_points")
+    return uv
+
+
+def backwarp_l1(rgb1, rgb2, flow):
+    a, b, f = _req(rgb1, torch.float32, "rgb1"), _req(rgb2, torch.float32, "rgb2"), _req(flow, torch.float32, "flow")
+    B, _, H, W = a.shape
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=a.device)
+    check(_lib.load().pgdvs_backwarp_l1(_ptr(a), _ptr(b), _ptr(f), _ptr(out), B, H, W, _stream()), "pgdvs_backwarp_l1")
+    return out
+
+
+_MODES = {"sum": 0, "avg": 1, "linear": 2, "soft": 3}
+_EPS = {"addeps": 0, "zeroeps": 1, "clipeps": 2}
+
+
+def softsplat_fwd(ten_in, ten_flow, ten_metric, mode: int, eps: int):
+    x = _req(ten_in, torch.float32, "tenIn")
+    f = _req(ten_flow, torch.float32, "tenFlow")
+    m = _req(ten_metric, torch.float32, "tenMetric") if ten_metric is not None else None
+    B, Cc, H, W = x.shape
+    assert f.shape == (B, 2, H, W), f.shape
+    out = torch.empty_like(x)
+    lib = _lib.load()
+    ws = _ws(lib.pgdvs_softsplat_workspace_bytes(B, Cc, H, W, mode), x.device)
+    check(lib.pgdvs_softsplat_fwd(_ptr(x), _ptr(f), _ptr(m), _ptr(out), B, Cc, H, W, mode, eps, _ptr(ws), ws.numel(), _stream()),
+          "pgdvs_softsplat_fwd")
+    return out
+
+
+def dyn_splat_composite(rgb1, rgb2, flow12, flow_1_to_tgt, valid_mask, noise, alpha, static_rgb):
+    """Returns planar (render_dyn_rgb[3,H,W], render_dyn_mask[H,W], combined, combined_static, combined_dyn)."""
+    r1 = _req(rgb1, torch.float32, "rgb1")
+    H, W = r1.shape[0], r1.shape[1]
+    dev = r1.device
+    dyn_rgb = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    dyn_mask = torch.empty((H, W), dtype=torch.float32, device=dev)
+    st = _req(static_rgb, torch.float32, "static_rgb") if static_rgb is not None else None
+    comb = torch.empty((3, 3, H, W), dtype=torch.float32, device=dev) if st is not None else None
+    nz = _req(noise, torch.float32, "noise") if noise is not None else None
+    lib = _lib.load()
+    ws = _ws(lib.pgdvs_dyn_splat_workspace_bytes(H, W), dev)
+    check(lib.pgdvs_dyn_splat_composite(
+        H, W, _ptr(r1), _ptr(_req(rgb2, torch.float32, "rgb2")), _ptr(_req(flow12, torch.float32, "flow12")),
+        _ptr(_req(flow_1_to_tgt, torch.float32, "flow_1_to_tgt")), _ptr(_req(valid_mask, torch.float32, "valid_mask")),
+        _ptr(nz), float(alpha), _ptr(st), _ptr(dyn_rgb), _ptr(dyn_mask),
+        _ptr(comb[0] if comb is not None else None), _ptr(comb[1] if comb is not None else None),
+        _ptr(comb[2] if comb is not None else None), _ptr(ws), ws.numel(), _stream()), "pgdvs_dyn_splat_composite")
+    if comb is None:
+        return dyn_rgb, dyn_mask, None, None, None
+    return dyn_rgb, dyn_mask, comb[0], comb[1], comb[2]
+
+
+def points_raster(pts, feat, cam_tgt, radius: float, K: int, H: int, W: int, *, n_points_dev=None,
+                  want_fragments: bool = False, rgb_planar: bool = False, want_rgb: bool = True):
+    """pts[N,>=3] (xyz in the first 3 columns of each row), feat[N,>=3] rows.
+    Returns dict(rgb, mask[, idx, zbuf, dist2])."""
+    p = _req(pts, torch.float32, "pts")
+    assert p.ndim == 2 and p.shape[1] >= 3, p.shape
+    n = p.shape[0]
+    dev = p.device
+    ft = _req(feat, torch.float32, "feat") if feat is not None else None
+    cam = _req(cam_tgt, torch.float32, "cam_tgt")
+    idx = torch.empty((H, W, K), dtype=torch.int64, device=dev) if want_fragments else None
+    zbuf = torch.empty((H, W, K), dtype=torch.float32, device=dev) if want_fragments else None
+    d2 = torch.empty((H, W, K), dtype=torch.float32, device=dev) if want_fragments else None
+    rgb = None
+    if want_rgb and ft is not None:
+        rgb = torch.empty((3, H, W) if rgb_planar else (H, W, 3), dtype=torch.float32, device=dev)
+    mask = torch.empty((H, W), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    ws = _ws(lib.pgdvs_points_raster_workspace_bytes(n, H, W, float(radius)), dev)
+    check(lib.pgdvs_points_raster(
+        _ptr(p), p.stride(0), _ptr(ft), ft.stride(0) if ft is not None else 0, n, _ptr(n_points_dev), _ptr(cam),
+        float(radius), int(K), H, W, _ptr(idx), _ptr(zbuf), _ptr(d2), _ptr(rgb), int(bool(rgb_planar)), _ptr(mask),
+        _ptr(ws), ws.numel(), _stream()), "pgdvs_points_raster")
+    return {"rgb": rgb, "mask": mask, "idx": idx, "zbuf": zbuf, "dist2": d2}
+
+
+def static_aggregate(rgbs, depths, dyn_masks, K3s, c2ws, capacity: int | None = None):
+    """rgbs[S,H,W,3] fp32 in [0,1]; depths[S,H,W]; dyn_masks[S,H,W] bool/uint8 (GPU tensors);
+    K3s[S,3,3], c2ws[S,4,4] float64 numpy (host).  -> (cloud[capacity,6], count[int64 dev])."""
+    r = _req(rgbs, torch.float32, "rgbs")
+    d = _req(depths, torch.float32, "depths")
+    m = _req(dyn_masks.to(torch.uint8) if dyn_masks.dtype == torch.bool else dyn_masks, torch.uint8, "dyn_masks")
+    S, H, W = d.shape
+    K3 = np.ascontiguousarray(K3s, dtype=np.float64).reshape(S, 9)
+    c2w = np.ascontiguousarray(c2ws, dtype=np.float64).reshape(S, 16)
+    cap = int(capacity) if capacity is not None else S * H * W
+    out = torch.empty((cap, 6), dtype=torch.float32, device=r.device)
+    cnt = torch.empty(1, dtype=torch.int64, device=r.device)
+    lib = _lib.load()
+    ws = _ws(lib.pgdvs_static_aggregate_workspace_bytes(H, W), r.device)
+    check(lib.pgdvs_static_aggregate(
+        _ptr(r), _ptr(d), _ptr(m), K3.ctypes.data_as(C.c_void_p), c2w.ctypes.data_as(C.c_void_p), S, H, W,
+        _ptr(out), cap, _ptr(cnt), _ptr(ws), ws.numel(), _stream()), "pgdvs_static_aggregate")
+    return out, cnt
+
+
+def combine(static_rgb, dyn_rgb, dyn_mask):
+    """[B,3,H,W], [B,3,H,W], [B,1,H,W] -> combined, combined_static, combined_dyn."""
+    st = _req(static_rgb, torch.float32, "static_rgb")
+    dy = _req(dyn_rgb, torch.float32, "dyn_rgb")
+    mk = _req(dyn_mask, torch.float32, "dyn_mask")
+    B, _, H, W = st.shape
+    outs = [torch.empty_like(st) for _ in range(3)]
+    lib = _lib.load()
+    for b in range(B):
+        check(lib.pgdvs_combine(_ptr(st[b]), _ptr(dy[b]), _ptr(mk[b]), H * W, _ptr(outs[0][b]), _ptr(outs[1][b]),
+                                _ptr(outs[2][b]), _stream()), "pgdvs_combine")
+    return outs

@@ -1,0 +1,116 @@
+"""Mirror of ``pgdvs.renderers.pgdvs_renderer.PGDVSRenderer``
+(pgdvs/renderers/pgdvs_renderer.py:26-481): same constructor, same ``forward(data,
+render_cfg, disable_tqdm, for_debug) -> dict`` contract and output keys, so
+``pgdvs.engines`` can instantiate it through Hydra by pointing ``_target_`` at this
+class."""
+import torch
+
+from .. import ops
+from ..instantiate import instantiate
+from ..models.gnt.renderer import BaseRenderer as GNTRenderer
+from .pgdvs_renderer_base import PGDVSBaseRenderer
+from .pgdvs_renderer_dyn import PGDVSDynamicRenderer
+from .st_geo_renderer import StaticGeoPointRenderer
+
+
+def disabled_train(self, mode=True):
+    """pgdvs/utils/training.py disabled_train: keep the static renderer in eval mode."""
+    return self
+
+
+class PGDVSRenderer(PGDVSBaseRenderer):
+    def __init__(self, cfg, *, render_cfg, flag_debug=False, train_static_renderer=False,
+                 softsplat_metric_abs_alpha=100.0, local_rank=0):
+        super().__init__()
+        self.cfg = cfg
+        self.flag_debug = flag_debug
+        self.static_renderer = None
+        self.refine_renderer = None
+
+        if self.cfg.static_renderer._target_ is not None:
+            self.static_renderer = instantiate(self.cfg.static_renderer)
+            if not train_static_renderer:
+                self.static_renderer = self.static_renderer.eval()
+                self.static_renderer.train = disabled_train.__get__(self.static_renderer)
+
+        self.softsplat_metric_abs_alpha = softsplat_metric_abs_alpha
+        assert self.softsplat_metric_abs_alpha >= 0, f"{self.softsplat_metric_abs_alpha}"
+        assert render_cfg.dyn_render_track_temporal in ["none", "no_tgt"], f"{render_cfg.dyn_render_track_temporal}"
+
+        self.dyn_renderer = PGDVSDynamicRenderer(
+            cfg=cfg, softsplat_metric_abs_alpha=softsplat_metric_abs_alpha,
+            proj_func=self.static_renderer.projector.compute_projections, local_rank=local_rank,
+            use_tracker=render_cfg.dyn_render_track_temporal == "no_tgt")
+
+    def forward(self, data, render_cfg={}, disable_tqdm=False, for_debug=False):
+        n_b, _, orig_h, orig_w, _ = data["rgb_src_temporal"].shape
+        ray_batch = self.prepare_ray_batch(data=data, B=n_b, H=orig_h, W=orig_w,
+                                           render_stride=render_cfg.render_stride, render_cfg=render_cfg)
+        ret_dict = {}
+        if isinstance(self.static_renderer, GNTRenderer):
+            if "rgb_gnt" in data:
+                static_rgb = data["rgb_gnt"].permute(0, 3, 1, 2)
+                ret_dict["static_coarse_rgb"] = static_rgb
+            else:
+                static_rgb, st_ret_dict = self.forward_st_gnt(data=data, ray_batch=ray_batch, render_cfg=render_cfg,
+                                                              disable_tqdm=disable_tqdm)
+                ret_dict.update(st_ret_dict)
+            if render_cfg.pure_gnt or render_cfg.pure_gnt_with_dyn_mask:
+                ret_dict["combined_rgb"] = static_rgb
+                return ret_dict
+        elif isinstance(self.static_renderer, StaticGeoPointRenderer):
+            static_rgb, st_ret_dict = self.forward_st_geo(data=data, ray_batch=ray_batch, render_cfg=render_cfg)
+            ret_dict.update(st_ret_dict)
+        else:
+            raise TypeError(type(self.static_renderer))
+
+        render_dyn_rgb, render_dyn_mask, render_dyn_info = self.dyn_renderer(
+            data, ray_batch, render_cfg, for_debug=for_debug, disable_tqdm=disable_tqdm, static_rgb=static_rgb)
+
+        ret_dict["render_dyn_rgb"] = render_dyn_rgb
+        ret_dict["render_dyn_mask"] = render_dyn_mask
+        ret_dict["render_dyn_temporal_closest_rgb"] = render_dyn_info["temporal_closest_rgb"]
+        ret_dict["render_dyn_temporal_closest_mask"] = render_dyn_info["temporal_closest_mask"]
+        ret_dict["render_dyn_temporal_track_rgb"] = render_dyn_info["temporal_track_rgb"]
+        ret_dict["render_dyn_temporal_track_mask"] = render_dyn_info["temporal_track_mask"]
+
+        # combine static and dynamic (:169-178); fused into the splat epilogue when possible
+        if "combined_rgb" in render_dyn_info:
+            combined_rgb = render_dyn_info["combined_rgb"]
+            combined_rgb_static = render_dyn_info["combined_rgb_static"]
+            combined_rgb_dyn = render_dyn_info["combined_rgb_dyn"]
+        else:
+            combined_rgb, combined_rgb_static, combined_rgb_dyn = ops.combine(static_rgb, render_dyn_rgb, render_dyn_mask)
+        ret_dict["combined_rgb"] = combined_rgb
+        ret_dict["combined_rgb_static"] = combined_rgb_static
+        ret_dict["combined_rgb_dyn"] = combined_rgb_dyn
+        return ret_dict
+
+    def forward_st_geo(self, *, data, ray_batch, render_cfg):
+        """:182-201"""
+        static_rgb, static_mask = [], []
+        counts = data.get("st_pcl_rgb_count", None)  # optional device counts [B] (int64)
+        for i_b in range(data["flat_cam_tgt"].shape[0]):
+            tmp_rgb, tmp_mask = self.static_renderer(
+                tgt_h=ray_batch["render_h"], tgt_w=ray_batch["render_w"], flat_tgt_cam=data["flat_cam_tgt"][i_b],
+                st_pcl_rgb=data["st_pcl_rgb"][i_b], render_cfg=render_cfg,
+                n_points_dev=None if counts is None else counts[i_b:i_b + 1], planar=True)
+            static_rgb.append(tmp_rgb)
+            static_mask.append(tmp_mask)
+        ret_dict = {"geo_static_rgb": torch.stack(static_rgb, 0), "geo_static_mask": torch.stack(static_mask, 0)}
+        return ret_dict["geo_static_rgb"], ret_dict
+
+    def forward_st_gnt(self, *, data, ray_batch, render_cfg, disable_tqdm=True):
+        """:203-352 -- delegates to the GNT renderer (raises until rows A13-A16 are built)."""
+        self.static_renderer(ray_batch=ray_batch)
+        raise AssertionError("unreachable")
+
+    def prepare_ray_batch(self, *, data, B, H, W, render_stride, render_cfg):
+        """:354-417.  Target rays are only materialised for the GNT network; the geometric
+        and rgb_gnt paths need just the render size."""
+        render_h = (H + render_stride - 1) // render_stride
+        render_w = (W + render_stride - 1) // render_stride
+        return {
+            "camera": data["flat_cam_tgt"], "rgb": data.get("rgb_tgt", None), "raw_h": H, "raw_w": W,
+            "render_h": render_h, "render_w": render_w, "render_stride": render_stride,
+        }

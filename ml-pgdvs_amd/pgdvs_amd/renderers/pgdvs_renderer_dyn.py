@@ -1,0 +1,160 @@
+"""Mirror of ``pgdvs.renderers.pgdvs_renderer_dyn.PGDVSDynamicRenderer``
+(pgdvs/renderers/pgdvs_renderer_dyn.py:28-724).
+
+Same constructor / forward / compute_dyn_pcl contract.  The reference compacts the
+masked pixels into variable-length point lists with boolean indexing (a host sync per
+step); here the work stays dense over [H,W] with validity flags, the compact list for
+the kNN filter is built on the device (ordered stream compaction) and no step reads a
+value back to the host.
+"""
+import torch
+
+from .. import ops
+from .pgdvs_renderer_base import PGDVSBaseRenderer
+
+
+class PGDVSDynamicRenderer(PGDVSBaseRenderer):
+    def __init__(self, *, cfg, softsplat_metric_abs_alpha=100.0, proj_func=None, local_rank=0, use_tracker=False):
+        super().__init__()
+        self.cfg = cfg
+        self.softsplat_metric_abs_alpha = softsplat_metric_abs_alpha
+        assert self.softsplat_metric_abs_alpha >= 0, f"{self.softsplat_metric_abs_alpha}"
+        self.proj_func = proj_func
+        self.tracker = None
+        self.use_tracker = use_tracker
+        if self.use_tracker:
+            # point trackers (TAPIR / CoTracker) are pretrained third-party networks that
+            # are out of scope of this build
+            raise NotImplementedError("dyn_render_track_temporal=no_tgt needs a point tracker (out of scope)")
+
+    # -- A2..A5 -------------------------------------------------------------
+    def compute_dyn_pcl(self, *, dyn_mask_1, rgb_1, depth_1, flow_12, flow_12_occ_mask, rgb_2, depth_2,
+                        cam_1, cam_2, cam_tgt, times, render_cfg, need_points=False):
+        """Dense statement of compute_dyn_pcl (:275-540).
+
+        cam_* are camera blocks (ops.cam_prep); times = device tensor (t1, t2, t_tgt).
+        Returns flow_1_to_tgt[2,H,W], valid_dyn_mask_1[H,W] and an info dict with
+        device-side compact points when requested.
+        """
+        H, W = dyn_mask_1.shape[0], dyn_mask_1.shape[1]
+        mask_eff, valid, pcl, rgbf = ops.dyn_warp(
+            dyn_mask_1, flow_12_occ_mask, render_cfg.dyn_render_use_flow_consistency, flow_12, depth_1, depth_2,
+            rgb_1, rgb_2, cam_1, cam_2, times)
+        info = {"pcl_dense": pcl, "rgb_dense": rgbf, "valid": valid}
+        # pytorch3d's kNN runs unconditionally upstream (:405-410) but its result is only
+        # observable through the outlier flags (and the tracker, not built): skip it when
+        # it cannot influence any output.
+        if render_cfg.dyn_pcl_remove_outlier:
+            idx, cnt = ops.compact_u8(valid)
+            pts = ops.gather_rows(pcl.reshape(-1, 3), idx, cnt)
+            avg = ops.knn_mean_dist(pts, cnt, render_cfg.dyn_pcl_outlier_knn)
+            thres, flag = ops.outlier_flags(avg, cnt, render_cfg.dyn_pcl_outlier_std_thres, True)
+            keep = ops.scatter_keep(idx, flag, cnt, H * W)
+            info.update(pcl_nn_dist_thres=thres, avg_nn_dist=avg, n_valid=cnt)
+        else:
+            keep = valid.reshape(-1)
+        info["keep"] = keep
+        flow_1_to_tgt, valid_mask = ops.project_flow_dense(cam_tgt, pcl, keep, H, W)
+        if need_points:
+            idx2, cnt2 = ops.compact_u8(keep)
+            info["pcl"] = ops.gather_rows(pcl.reshape(-1, 3), idx2, cnt2)
+            info["pcl_rgbs"] = ops.gather_rows(rgbf.reshape(-1, 3), idx2, cnt2)
+            info["n_pts"] = cnt2
+        return flow_1_to_tgt, valid_mask, info
+
+    def render_dyn_pcl(self, *, pcl, rgbs, n_pts, cam_tgt, H, W, render_cfg):
+        """:671-724 -- point z-buffer + norm-weighted compositing of the dynamic cloud."""
+        r = ops.points_raster(
+            pcl, rgbs, cam_tgt, render_cfg.dyn_render_pcl_pt_radius, render_cfg.dyn_render_pcl_pts_per_pixel,
+            H, W, n_points_dev=n_pts.to(torch.int64), rgb_planar=True)
+        return r["rgb"], r["mask"]
+
+    def render_dyn_mesh(self, **kw):
+        # dyn_render_type=mesh (:542-669) is a "next" row
+        raise NotImplementedError("dyn_render_type='mesh' is not built yet")
+
+    def render_with_track(self):
+        raise NotImplementedError
+
+    # -- A8 -----------------------------------------------------------------
+    def forward(self, data, ray_batch, render_cfg, for_debug=False, disable_tqdm=False, static_rgb=None):
+        """:63-257.  ``static_rgb`` [B,3,h,w] (optional) lets the splat epilogue also emit the
+        static/dynamic composite of PGDVSRenderer.forward (:169-178) in the same pass."""
+        n_b, _, orig_h, orig_w, _ = data["rgb_src_temporal"].shape
+        dev = data["rgb_src_temporal"].device
+        assert self.cfg.rgb_range == "0_1", f"{self.cfg.rgb_range}"
+        dyn_type = render_cfg.dyn_render_type
+        if dyn_type not in ("softsplat", "pcl", "mesh"):
+            raise ValueError(dyn_type)
+        if dyn_type == "mesh":
+            self.render_dyn_mesh()
+
+        cams_src = ops.cam_prep(data["flat_cam_src_temporal"])  # [B,2,80]
+        cams_tgt = ops.cam_prep(data["flat_cam_tgt"])  # [B,80]
+        times = torch.cat([data["time_src_temporal"][:, :2].float(), data["time_tgt"][:, :1].float()], dim=1).contiguous()
+
+        render_h, render_w = ray_batch["render_h"], ray_batch["render_w"]
+        same_res = (render_h == orig_h) and (render_w == orig_w)
+        fuse_static = static_rgb is not None and same_res and dyn_type == "softsplat"
+
+        noise = None
+        if dyn_type == "softsplat":
+            # torch.randn_like(rgb_src_1) upstream (:181); injectable for parity tests
+            noise = data.get("static_noise", None)
+            if noise is None:
+                noise = torch.randn((n_b, 3, orig_h, orig_w), dtype=torch.float32, device=dev)
+
+        dyn_rgbs, dyn_masks, combs = [], [], []
+        for i_b in range(n_b):
+            flow_1_to_tgt, valid_mask, info = self.compute_dyn_pcl(
+                dyn_mask_1=data["dyn_mask_src_temporal"][i_b, 0, ..., 0],
+                rgb_1=data["rgb_src_temporal"][i_b, 0], depth_1=data["depth_src_temporal"][i_b, 0, ..., 0],
+                flow_12=data["flow_fwd"][i_b], flow_12_occ_mask=data["flow_fwd_occ_mask"][i_b, ..., 0],
+                rgb_2=data["rgb_src_temporal"][i_b, 1], depth_2=data["depth_src_temporal"][i_b, 1, ..., 0],
+                cam_1=cams_src[i_b, 0], cam_2=cams_src[i_b, 1], cam_tgt=cams_tgt[i_b], times=times[i_b],
+                render_cfg=render_cfg, need_points=(dyn_type == "pcl"))
+            if dyn_type == "softsplat":
+                rgb, mask, c, cs, cd = ops.dyn_splat_composite(
+                    data["rgb_src_temporal"][i_b, 0], data["rgb_src_temporal"][i_b, 1], data["flow_fwd"][i_b],
+                    flow_1_to_tgt, valid_mask, noise[i_b], self.softsplat_metric_abs_alpha,
+                    static_rgb[i_b] if fuse_static else None)
+                if fuse_static:
+                    combs.append((c, cs, cd))
+            else:
+                rgb, mask = self.render_dyn_pcl(
+                    pcl=info["pcl"], rgbs=info["pcl_rgbs"], n_pts=info["n_pts"], cam_tgt=cams_tgt[i_b],
+                    H=orig_h, W=orig_w, render_cfg=render_cfg)
+            dyn_rgbs.append(rgb)
+            dyn_masks.append(mask[None])
+
+        render_dyn_rgb = torch.stack(dyn_rgbs, 0)  # [B,3,H,W]
+        render_dyn_mask = torch.stack(dyn_masks, 0)  # [B,1,H,W]
+
+        # no tracker: the track images are zeros, so the merge of :229-235 is the identity on
+        # the {0,1}-valued closest-frame mask
+        render_track_rgb = torch.zeros_like(render_dyn_rgb)
+        render_track_mask = torch.zeros_like(render_dyn_mask)
+        render_dyn_rgb_final, render_dyn_mask_final = render_dyn_rgb, render_dyn_mask
+
+        if not same_res:
+            render_dyn_rgb, render_dyn_mask = self.resize_rgb_mask(render_dyn_rgb, render_dyn_mask, render_h, render_w)
+            render_track_rgb, render_track_mask = self.resize_rgb_mask(render_track_rgb, render_track_mask, render_h, render_w)
+            render_dyn_rgb_final, render_dyn_mask_final = render_dyn_rgb, render_dyn_mask
+
+        info_dict = {
+            "temporal_closest_rgb": render_dyn_rgb,
+            "temporal_closest_mask": render_dyn_mask,
+            "temporal_track_rgb": render_track_rgb,
+            "temporal_track_mask": render_track_mask,
+        }
+        if fuse_static:
+            info_dict["combined_rgb"] = torch.stack([c[0] for c in combs], 0)
+            info_dict["combined_rgb_static"] = torch.stack([c[1] for c in combs], 0)
+            info_dict["combined_rgb_dyn"] = torch.stack([c[2] for c in combs], 0)
+        return render_dyn_rgb_final, render_dyn_mask_final, info_dict
+
+    def resize_rgb_mask(self, rgb, mask, render_h, render_w):
+        # :259-270 -- only taken when render_stride != 1; torch resampling (plumbing, GPU)
+        rgb = torch.nn.functional.interpolate(rgb, size=(render_h, render_w), mode="bicubic", align_corners=True, antialias=True)
+        mask = torch.nn.functional.interpolate(mask, size=(render_h, render_w), mode="nearest")
+        return rgb, mask

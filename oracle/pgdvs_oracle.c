@@ -414,13 +414,13 @@ ORC_API void orc_backwarp_l1(int H, int W, const float *rgb1, const float *rgb2,
       float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
       float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
       float x0f = floorf(ix), y0f = floorf(iy);
-      int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+      /* non-finite / huge coordinates: ATen casts to int (UB); treat as out of bounds */
+      int fin = isfinite(ix) && isfinite(iy) && fabsf(ix) < 1e9f && fabsf(iy) < 1e9f;
+      int x0 = fin ? (int)x0f : -10, y0 = fin ? (int)y0f : -10, x1 = x0 + 1, y1 = y0 + 1;
       float wnw = ((float)x1 - ix) * ((float)y1 - iy);
       float wne = (ix - (float)x0) * ((float)y1 - iy);
       float wsw = ((float)x1 - ix) * (iy - (float)y0);
       float wse = (ix - (float)x0) * (iy - (float)y0);
-      /* non-finite coordinates: ATen casts to int (UB); treat as out of bounds */
-      int fin = isfinite(ix) && isfinite(iy);
       float s = 0.0f;
       for (int k = 0; k < 3; ++k) {
         const float *pl = rgb2 + (size_t)k * P;

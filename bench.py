@@ -184,7 +184,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
 
-        sh, sw, ss = max(H // 4, 8), max(W // 4, 8), max(S // 4, 2)
+        sh, sw, ss = max(H // 2, 8), max(W // 2, 8), max(S // 2, 2)
         sv = synth.make_video(ss, sh, sw, seed=1234)
         sd = synth.make_view(sv, 0, frac=0.4, seed=5)
         c0 = time.perf_counter()

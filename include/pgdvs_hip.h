@@ -103,9 +103,14 @@ int pgdvs_gather_rows(const float *src, const int32_t *idx, const int32_t *count
 
 /* A4: statistical outlier filter = pytorch3d.ops.knn_points(X, X, K+1) + mean of the K
  * non-self squared distances (pgdvs_renderer_dyn.py:405-419, st_geo_renderer.py:37-51).
- * pts[capacity,3], *count points used (count on device); avg_out[capacity]. */
+ * pts[capacity,3], *count points used (count on device); avg_out[capacity].
+ * algo: 0 = auto, 1 = brute force (O(N^2), what pytorch3d does), 2 = exact uniform-grid
+ * search (needs K+1 <= 64).  Both return identical values.  workspace >=
+ * pgdvs_knn_workspace_bytes(capacity). */
+int64_t pgdvs_knn_workspace_bytes(int64_t capacity);
 int pgdvs_knn_mean_dist(const float *pts, const int32_t *count, int64_t capacity, int K,
-                        float *avg_out, pgdvs_stream_t stream);
+                        float *avg_out, int algo, void *workspace, int64_t workspace_bytes,
+                        pgdvs_stream_t stream);
 
 /* threshold = lower-median(avg) + unbiased-std(avg) * std_thres; flag = avg < threshold
  * (pgdvs_renderer_dyn.py:419-427).  thres_out: 1 float; flag_out[capacity] u8.

@@ -104,9 +104,23 @@ knn_mean_dist_kernel(const float *__restrict__ pts, const int32_t *__restrict__ 
     }
     best[(k + 1) * kKnnBlock + tid] = key;
   }
-  // drop column 0 (the point itself), mean over K columns; missing columns are 0
+  // drop column 0 (the point itself), mean over K columns; missing columns are 0.  Same fixed
+  // butterfly summation order as the grid kernel / CPU oracle (64 slots, offsets 32..1).
+  // The column is reused as scratch: slots [0,64) when KK <= 64, else a plain ascending sum.
   float ssum = 0.0f;
-  for (int k = 1; k < KK; ++k) ssum = ssum + (k < cnt ? best[k * kKnnBlock + tid] : 0.0f);
+  if (KK <= 64) {
+    float sl[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) sl[k] = 0.0f;
+    for (int k = 1; k < KK; ++k) sl[k] = k < cnt ? best[k * kKnnBlock + tid] : 0.0f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int i = 0; i < off; ++i) sl[i] = sl[i] + sl[i + off];
+    ssum = sl[0];
+  } else {
+    for (int k = 1; k < KK; ++k) ssum = ssum + (k < cnt ? best[k * kKnnBlock + tid] : 0.0f);
+  }
   avg_out[q] = ssum / (float)K;
 }
 
@@ -160,10 +174,21 @@ outlier_threshold_kernel(const float *__restrict__ avg, const int32_t *__restric
     __syncthreads();
     unsigned prefix = sel_prefix;
     unsigned himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
-    for (int i = tid; i < n; i += kStatBlock) {
-      unsigned u = __float_as_uint(avg[i]);
+    const int n_round = (n + kStatBlock - 1) / kStatBlock * kStatBlock;  // whole waves stay in the loop
+    for (int i = tid; i < n_round; i += kStatBlock) {
+      unsigned u = i < n ? __float_as_uint(avg[i]) : 0u;
       u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-      if ((u & himask) == (prefix & himask)) atomicAdd(&hist[(u >> shift) & 0xffu], 1u);
+      bool act = i < n && (u & himask) == (prefix & himask);
+      unsigned bin = (u >> shift) & 0xffu;
+      // neighbouring values share their leading bits: one LDS atomic per distinct bin per wave
+      unsigned long long todo = __ballot(act);
+      while (todo) {
+        int l = __builtin_ctzll(todo);
+        unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, l);
+        unsigned long long same = __ballot(act && bin == b0);
+        if ((tid & 63) == l) atomicAdd(&hist[b0], (unsigned)__popcll(same));
+        todo &= ~same;
+      }
     }
     __syncthreads();
     if (tid == 0) {
@@ -198,13 +223,27 @@ __global__ void outlier_flag_kernel(const float *__restrict__ avg, const int32_t
     flag[i] = remove_outlier ? (uint8_t)(avg[i] < t) : (uint8_t)1;
 }
 
+int64_t knn_grid_workspace_bytes(int64_t capacity);
+int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity, int K, float *avg_out,
+                       void *workspace, int64_t workspace_bytes, hipStream_t st);
+
 }  // namespace pgdvs
 
 using namespace pgdvs;
 
+PGDVS_API int64_t pgdvs_knn_workspace_bytes(int64_t capacity) {
+  return knn_grid_workspace_bytes(capacity);
+}
+
 PGDVS_API int pgdvs_knn_mean_dist(const float *pts, const int32_t *count, int64_t capacity, int K,
-                                  float *avg_out, pgdvs_stream_t stream) {
+                                  float *avg_out, int algo, void *workspace,
+                                  int64_t workspace_bytes, pgdvs_stream_t stream) {
   PGDVS_REQUIRE(pts && count && avg_out, "pgdvs_knn_mean_dist: null pointer");
+  PGDVS_REQUIRE(algo >= 0 && algo <= 2, "pgdvs_knn_mean_dist: algo must be 0, 1 or 2");
+  PGDVS_REQUIRE(algo != 2 || K + 1 <= 64, "pgdvs_knn_mean_dist: grid search needs K+1 <= 64");
+  if (capacity > 0 && K >= 1 && K + 1 <= 64 && algo != 1 && capacity < (1ll << 31))
+    return knn_grid_mean_dist(pts, count, capacity, K, avg_out, workspace, workspace_bytes,
+                              as_stream(stream));
   PGDVS_REQUIRE(K >= 1 && K + 1 <= kKnnMaxKK, "pgdvs_knn_mean_dist: K must be in [1, %d]",
                 kKnnMaxKK - 1);
   PGDVS_REQUIRE(capacity >= 0 && capacity < (1ll << 31), "pgdvs_knn_mean_dist: bad capacity");

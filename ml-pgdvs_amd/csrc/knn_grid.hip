@@ -1,0 +1,655 @@
+// A4 (fast path): EXACT k-nearest-neighbour mean distance through a uniform 3-D grid.
+//
+// pytorch3d.ops.knn_points (the reference's dependency, pgdvs_renderer_dyn.py:405-410) is a
+// brute-force O(N^2) scan.  The statistic the renderer consumes -- the mean of the K smallest
+// non-self squared distances -- only needs the K+1 smallest distance VALUES of each point,
+// which a spatial grid finds exactly: a query scans the cells of a growing cube around its
+// own cell and stops as soon as its (K+1)-th best distance is no larger than the distance to
+// the cube's nearest open face (minus a rounding margin); nothing outside the cube can then
+// change the multiset of the K+1 smallest values.  Queries that do not terminate within
+// kRingCap rings (isolated outliers) fall back to an exact scan of all points.
+//
+// One WAVEFRONT per query: the 64 lanes evaluate 64 candidates per step with coalesced
+// 16-byte loads of the cell-sorted point array; the sorted best-list lives one value per
+// lane in a register (lane k holds the k-th smallest), so an insertion is a ballot, a
+// popcount and one DPP shift -- no LDS, no per-lane divergence.  Values are summed in
+// ascending order exactly like the CPU oracle => bit-identical averages.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace pgdvs {
+
+constexpr int kGridMaxCells = 1 << 24;
+constexpr int kRingCap = 24;
+constexpr float kTargetPerCellDefault = 24.0f;
+
+struct GridParams {
+  float mn[3];
+  float h, inv_h;
+  int G[3];
+  int ncells;
+  int n;
+};
+
+__device__ __forceinline__ unsigned f2ord(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// bbox[0..2] = min (ordered-uint), bbox[3..5] = max.  Launched with few blocks: six
+// atomics per block.
+__global__ void __launch_bounds__(256)
+grid_bbox_kernel(const float *__restrict__ pts, const int32_t *__restrict__ count,
+                 unsigned *__restrict__ bbox) {
+  __shared__ float s_mn[4][3], s_mx[4][3];
+  const int n = *count;
+  float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float v = pts[(size_t)i * 3 + a];
+      if (isfinite(v)) {
+        mn[a] = fminf(mn[a], v);
+        mx[a] = fmaxf(mx[a], v);
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    for (int off = 32; off > 0; off >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_down(mn[a], off, 64));
+      mx[a] = fmaxf(mx[a], __shfl_down(mx[a], off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      s_mn[threadIdx.x >> 6][a] = mn[a];
+      s_mx[threadIdx.x >> 6][a] = mx[a];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    int a = threadIdx.x;
+    float lo = fminf(fminf(s_mn[0][a], s_mn[1][a]), fminf(s_mn[2][a], s_mn[3][a]));
+    float hi = fmaxf(fmaxf(s_mx[0][a], s_mx[1][a]), fmaxf(s_mx[2][a], s_mx[3][a]));
+    atomicMin(&bbox[a], f2ord(lo));
+    atomicMax(&bbox[3 + a], f2ord(hi));
+  }
+}
+
+// Cell size.  Pass 0 (occupied == nullptr): from the bounding box, assuming the points
+// sample a surface spanning the two largest extents.  Pass 1: rescale with the measured
+// number of occupied cells of the trial grid so that an occupied cell holds about
+// kTargetPerCell points (occupied cells of a surface grow like 1/h^2).
+__global__ void grid_params_kernel(const unsigned *__restrict__ bbox,
+                                   const int32_t *__restrict__ count,
+                                   const unsigned long long *__restrict__ sumsq,
+                                   GridParams *__restrict__ gp, float target) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int n = *count;
+  float mn[3], ext[3];
+  for (int a = 0; a < 3; ++a) {
+    float lo = ord2f(bbox[a]), hi = ord2f(bbox[3 + a]);
+    if (!(hi >= lo)) {  // no finite point
+      lo = 0.0f;
+      hi = 0.0f;
+    }
+    mn[a] = lo;
+    ext[a] = hi - lo;
+  }
+  float h;
+  if (sumsq == nullptr) {
+    float e0 = ext[0], e1 = ext[1], e2 = ext[2];
+    float big = fmaxf(e0, fmaxf(e1, e2));
+    float small = fminf(e0, fminf(e1, e2));
+    float mid = e0 + e1 + e2 - big - small;
+    float area = big * fmaxf(mid, 1e-3f * big);
+    h = sqrtf(area * target / (float)(n > 0 ? n : 1));
+  } else {
+    float per_cell = (float)((double)*sumsq / (double)(n > 0 ? n : 1));
+    if (!(per_cell >= 1.0f)) per_cell = 1.0f;
+    h = gp->h * sqrtf(target / per_cell);
+  }
+  if (!(h > 0.0f) || !isfinite(h)) h = 1.0f;
+  int G[3];
+  for (int it = 0; it < 64; ++it) {
+    long long tot = 1;
+    bool ok = true;
+    for (int a = 0; a < 3; ++a) {
+      float g = floorf(ext[a] / h) + 1.0f;
+      if (!(g < 1024.0f)) ok = false;
+      G[a] = g < 1.0f ? 1 : (g > 1024.0f ? 1024 : (int)g);
+      tot *= G[a];
+    }
+    if (ok && tot <= kGridMaxCells) break;
+    h *= 1.3f;
+  }
+  gp->h = h;
+  gp->inv_h = 1.0f / h;
+  gp->ncells = G[0] * G[1] * G[2];
+  gp->n = n;
+  for (int a = 0; a < 3; ++a) {
+    gp->mn[a] = mn[a];
+    gp->G[a] = G[a];
+  }
+}
+
+// sum of squared cell counts of the trial grid: sum(c^2)/n is the occupancy of the cell an
+// average POINT lives in (robust against many singleton outlier cells)
+__global__ void __launch_bounds__(256)
+grid_occupied_kernel(const int32_t *__restrict__ cell_count, const GridParams *__restrict__ gp,
+                     unsigned long long *__restrict__ sumsq) {
+  const int nc = gp->ncells;
+  unsigned long long c = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += gridDim.x * blockDim.x) {
+    unsigned long long v = (unsigned long long)cell_count[i];
+    c += v * v;
+  }
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(sumsq, c);
+}
+
+// zero a[0 .. gp->ncells] (device-side bound) for up to three arrays
+__global__ void __launch_bounds__(256)
+grid_zero_kernel(const GridParams *__restrict__ gp, int32_t *__restrict__ a, int32_t *__restrict__ b) {
+  const int nc = gp->ncells;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nc; i += gridDim.x * blockDim.x) {
+    a[i] = 0;
+    if (b) b[i] = 0;
+  }
+}
+
+__device__ __forceinline__ int cell_coord(float v, float mn, float inv_h, int G) {
+  float c = floorf((v - mn) * inv_h);
+  c = fminf(fmaxf(c, 0.0f), (float)(G - 1));  // NaN -> 0
+  return (int)c;
+}
+
+__global__ void __launch_bounds__(256)
+grid_count_kernel(const float *__restrict__ pts, const GridParams *__restrict__ gp,
+                  int32_t *__restrict__ cell_of, int32_t *__restrict__ cell_count) {
+  const GridParams g = *gp;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
+    int cx = cell_coord(pts[(size_t)i * 3 + 0], g.mn[0], g.inv_h, g.G[0]);
+    int cy = cell_coord(pts[(size_t)i * 3 + 1], g.mn[1], g.inv_h, g.G[1]);
+    int cz = cell_coord(pts[(size_t)i * 3 + 2], g.mn[2], g.inv_h, g.G[2]);
+    int c = (cz * g.G[1] + cy) * g.G[0] + cx;
+    cell_of[i] = c;
+    atomicAdd(&cell_count[c], 1);
+  }
+}
+
+// exclusive scan of cell_count[0 .. ncells) -> cell_start[0 .. ncells]; ncells is a device
+// value, blocks beyond it exit at once
+constexpr int kScanItems = 16;
+constexpr int kScanTile = 1024 * kScanItems;
+__global__ void __launch_bounds__(1024)
+grid_scan_blocks_kernel(const int32_t *__restrict__ in, const GridParams *__restrict__ gp,
+                        int32_t *__restrict__ block_sums) {
+  __shared__ int ws[16];
+  const int n = gp->ncells;
+  int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  int s = 0;
+  if (blockIdx.x * kScanTile < n) {
+#pragma unroll
+    for (int k = 0; k < kScanItems; k += 4) {
+      if (base + k + 3 < n) {
+        int4 v = *reinterpret_cast<const int4 *>(in + base + k);
+        s += v.x + v.y + v.z + v.w;
+      } else {
+        for (int kk = 0; kk < 4; ++kk)
+          if (base + k + kk < n) s += in[base + k + kk];
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int i = 0; i < 16; ++i) t += ws[i];
+    block_sums[blockIdx.x] = t;
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+grid_scan_sums_kernel(int32_t *__restrict__ block_sums, int nb) {
+  // nb <= 1024: one pass
+  __shared__ int ws[16];
+  int v = threadIdx.x < nb ? block_sums[threadIdx.x] : 0;
+  int x = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    int y = __shfl_up(x, off, 64);
+    if ((threadIdx.x & 63) >= off) x += y;
+  }
+  if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = x;
+  __syncthreads();
+  int wo = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wo += ws[w];
+  if (threadIdx.x < nb) block_sums[threadIdx.x] = wo + x - v;
+}
+
+__global__ void __launch_bounds__(1024)
+grid_scan_apply_kernel(const int32_t *__restrict__ in, const GridParams *__restrict__ gp,
+                       const int32_t *__restrict__ block_sums, int32_t *__restrict__ out) {
+  __shared__ int ws[16];
+  const int n = gp->ncells;
+  if (blockIdx.x * kScanTile > n) return;
+  int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  int v[kScanItems];
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = base + k < n ? in[base + k] : 0;
+    s += v[k];
+  }
+  int x = s;
+  for (int off = 1; off < 64; off <<= 1) {
+    int y = __shfl_up(x, off, 64);
+    if ((threadIdx.x & 63) >= off) x += y;
+  }
+  if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = x;
+  __syncthreads();
+  int wo = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wo += ws[w];
+  int run = block_sums[blockIdx.x] + wo + x - s;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k <= n) out[base + k] = run;  // includes out[n] = total
+    run += v[k];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+grid_fill_kernel(const float *__restrict__ pts, const GridParams *__restrict__ gp,
+                 const int32_t *__restrict__ cell_of, const int32_t *__restrict__ cell_start,
+                 int32_t *__restrict__ cursor, float4 *__restrict__ sorted) {
+  const int n = gp->n;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int c = cell_of[i];
+    int pos = cell_start[c] + atomicAdd(&cursor[c], 1);
+    sorted[pos] = make_float4(pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2],
+                              __int_as_float(i));
+  }
+}
+
+// ---- the query kernel --------------------------------------------------------
+// Sorted best-list, one value per lane (lane k = k-th smallest so far, +inf = empty).
+struct BestList {
+  float best;
+  float mx;  // wave-uniform copy of lane KK-1
+};
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// lane i <- lane i-1, lane 0 <- 0: DPP wave_shr:1 with bound_ctrl (no LDS traffic)
+__device__ __forceinline__ float wave_shift_up1_zero(float v) {
+  int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true);
+  return __int_as_float(r);
+}
+
+// Insert the candidates of one batch that beat the current K+1-th best.  The list is
+// sorted ascending, so inserting v is: every lane holding a value > v takes
+// max(left neighbour, v) -- the first such lane receives v (its left neighbour is <= v, or
+// the zero fill for lane 0; squared distances are >= 0), the others shift up by one.
+__device__ __forceinline__ void best_insert_batch(BestList &b, float d, bool valid, int KK, int lane) {
+  (void)lane;
+  unsigned long long mask = __ballot(valid && d < b.mx);
+  if (!mask) return;
+  // The filter used the threshold from before this batch; a candidate that no longer beats
+  // the (tighter) current threshold lands at a position >= K+1, which is never read.
+  while (mask) {
+    int l = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    float v = readlane_f(d, l);
+    float up = wave_shift_up1_zero(b.best);
+    float nb = fmaxf(up, v);
+    b.best = b.best > v ? nb : b.best;
+  }
+  b.mx = readlane_f(b.best, KK - 1);
+}
+
+// ascending bitonic sort of one value per lane across the wavefront
+__device__ __forceinline__ float wave_sort_asc(float v, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      float o = __shfl_xor(v, j, 64);
+      bool up = (lane & k) == 0;          // ascending block
+      bool lower = (lane & j) == 0;       // this lane keeps the smaller of the pair
+      float mn = fminf(v, o), mx = fmaxf(v, o);
+      // NaN never reaches here (distances of finite points); fminf/fmaxf keep the multiset
+      v = (up == lower) ? mn : mx;
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ float dist2(float qx, float qy, float qz, float4 p) {
+  float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+  float d = dx * dx;
+  d = d + dy * dy;
+  d = d + dz * dz;
+  return d;
+}
+
+// scan sorted[start, end): 64 candidates per lane-step, four steps of loads in flight.
+// `bound`: candidates farther than this can be ignored (+inf = no bound).
+__device__ __forceinline__ void scan_range(BestList &b, bool &first, const float4 *__restrict__ sorted,
+                                           int start, int end, float qx, float qy, float qz, int KK,
+                                           int lane, float bound = __builtin_inff()) {
+  for (int j0 = start; j0 < end; j0 += 256) {
+    float d[4];
+    bool v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int j = j0 + u * 64 + lane;
+      v[u] = j < end;
+      float4 p = v[u] ? sorted[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      d[u] = dist2(qx, qy, qz, p);
+      v[u] = v[u] && d[u] <= bound;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (j0 + u * 64 >= end) break;
+      if (first) {
+        // empty list: sort the first 64 candidates instead of 64 serial insertions
+        b.best = wave_sort_asc(v[u] ? d[u] : __builtin_inff(), lane);
+        b.mx = readlane_f(b.best, KK - 1);
+        first = false;
+      } else {
+        best_insert_batch(b, d[u], v[u], KK, lane);
+      }
+    }
+  }
+}
+
+// mean over columns 1..K of the sorted list (column 0 = the point itself is dropped;
+// columns beyond the number of points count as 0, as pytorch3d pads).  Summation order is
+// a fixed butterfly over 64 slots -- s[i] += s[i+32], s[i] += s[i+16], ... s[0] += s[1] --
+// which the CPU oracle and the brute-force kernel reproduce, so results stay bit-identical.
+__device__ __forceinline__ void knn_finish(float best, int K, int n, int lane, int orig,
+                                           float *__restrict__ avg_out) {
+  float s = (lane >= 1 && lane <= K && lane < n) ? best : 0.0f;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s = s + __shfl_down(s, off, 64);
+  if (lane == 0) avg_out[orig] = s / (float)K;
+}
+
+// Squared distance (lower bound) from coordinate q to the slab of cells [c0, c1] along one
+// axis.  The slab is widened by a rounding margin, and is unbounded on a side that touches
+// the grid boundary (boundary cells also hold the points clamped into them).
+__device__ __forceinline__ float box_axis_dist2(float q, float mn, float h, int c0, int c1, int G) {
+  float lo = c0 <= 0 ? -__builtin_inff() : mn + (float)c0 * h - 0.02f * h;
+  float hi = c1 >= G - 1 ? __builtin_inff() : mn + (float)(c1 + 1) * h + 0.02f * h;
+  float d = fmaxf(fmaxf(lo - q, q - hi), 0.0f);
+  return d * d;
+}
+
+__global__ void __launch_bounds__(256)
+grid_query_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted,
+                  const int32_t *__restrict__ cell_start, int K, float *__restrict__ avg_out,
+                  int32_t *__restrict__ stats, int ring_cap, int abl, int32_t *__restrict__ fb_count,
+                  int32_t *__restrict__ fb_list, float *__restrict__ fb_bound) {
+  const GridParams g = *gp;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int KK = K + 1;
+  // persistent waves: the grid is sized for the machine, not for the (device-side) count
+  for (int q = blockIdx.x * 4 + wave; q < g.n; q += gridDim.x * 4) {
+  const float4 qp = sorted[q];
+  const float qx = qp.x, qy = qp.y, qz = qp.z;
+  const int orig = __float_as_int(qp.w);
+  const int cx = cell_coord(qx, g.mn[0], g.inv_h, g.G[0]);
+  const int cy = cell_coord(qy, g.mn[1], g.inv_h, g.G[1]);
+  const int cz = cell_coord(qz, g.mn[2], g.inv_h, g.G[2]);
+  BestList b;
+  b.best = __builtin_inff();
+  b.mx = __builtin_inff();
+  bool first = true;
+  bool done = false;
+  int rings = 0;
+  if (abl & 1) done = true;
+  for (int r = 1; r <= ring_cap && !done; ++r) {
+    rings = r;
+    // Shell of Chebyshev radius r (r == 1: the whole 3x3x3 cube) as x-runs: the lanes look
+    // up the cell ranges of 64 (dy,dz) rows at a time, then the non-empty runs are scanned.
+    const int side = 2 * r + 1;
+    const int nrows = side * side;
+    for (int base = 0; base < nrows; base += 64) {
+      int row_id = base + lane;
+      // r == 1: visit the query's own row first so the threshold is tight before the
+      // neighbouring rows are (mostly) pruned
+      if (r == 1) row_id = row_id == 0 ? 4 : (row_id == 4 ? 0 : row_id);
+      int s0 = 0, e0 = 0, s1 = 0, e1 = 0;
+      float bd0 = 0.0f, bd1 = 0.0f;  // lower bound of the squared distance to any point of the run
+      if (row_id < nrows) {
+        int rz = (int)(((float)row_id + 0.5f) / (float)side);
+        int dz = rz - r, dy = row_id - rz * side - r;
+        int z = cz + dz, y = cy + dy;
+        if (z >= 0 && z < g.G[2] && y >= 0 && y < g.G[1]) {
+          int row = (z * g.G[1] + y) * g.G[0];
+          float byz = box_axis_dist2(qy, g.mn[1], g.h, y, y, g.G[1]) + box_axis_dist2(qz, g.mn[2], g.h, z, z, g.G[2]);
+          bool outer = r == 1 || dz == -r || dz == r || dy == -r || dy == r;
+          if (outer) {
+            int x0 = cx - r < 0 ? 0 : cx - r;
+            int x1 = cx + r >= g.G[0] ? g.G[0] - 1 : cx + r;
+            s0 = cell_start[row + x0];
+            e0 = cell_start[row + x1 + 1];
+            bd0 = byz + box_axis_dist2(qx, g.mn[0], g.h, x0, x1, g.G[0]);
+          } else {
+            if (cx - r >= 0) {
+              s0 = cell_start[row + cx - r];
+              e0 = cell_start[row + cx - r + 1];
+              bd0 = byz + box_axis_dist2(qx, g.mn[0], g.h, cx - r, cx - r, g.G[0]);
+            }
+            if (cx + r < g.G[0]) {
+              s1 = cell_start[row + cx + r];
+              e1 = cell_start[row + cx + r + 1];
+              bd1 = byz + box_axis_dist2(qx, g.mn[0], g.h, cx + r, cx + r, g.G[0]);
+            }
+          }
+        }
+      }
+      unsigned long long m0 = __ballot(e0 > s0);
+      while (m0) {
+        int l = __builtin_ctzll(m0);
+        m0 &= m0 - 1;
+        if (abl & 2) continue;
+        if (readlane_f(bd0, l) >= b.mx) continue;  // no point of this run can enter the list
+        scan_range(b, first, sorted, __builtin_amdgcn_readlane(s0, l), __builtin_amdgcn_readlane(e0, l), qx,
+                   qy, qz, KK, lane);
+      }
+      unsigned long long m1 = __ballot(e1 > s1);
+      while (m1) {
+        int l = __builtin_ctzll(m1);
+        m1 &= m1 - 1;
+        if (readlane_f(bd1, l) >= b.mx) continue;
+        scan_range(b, first, sorted, __builtin_amdgcn_readlane(s1, l), __builtin_amdgcn_readlane(e1, l), qx,
+                   qy, qz, KK, lane);
+      }
+    }
+    // distance from the query to the nearest face of the scanned cube that still has
+    // cells behind it; everything unseen is at least that far away
+    float db = __builtin_inff();
+    bool open = false;
+    const int c[3] = {cx, cy, cz};
+    const float qv[3] = {qx, qy, qz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (c[a] - r > 0) {
+        open = true;
+        db = fminf(db, qv[a] - (g.mn[a] + (float)(c[a] - r) * g.h));
+      }
+      if (c[a] + r < g.G[a] - 1) {
+        open = true;
+        db = fminf(db, (g.mn[a] + (float)(c[a] + r + 1) * g.h) - qv[a]);
+      }
+    }
+    if (!open) {
+      done = true;  // the cube covered the whole grid
+    } else {
+      float safe = db - 0.02f * g.h;
+      if (safe > 0.0f && b.mx <= safe * safe) done = true;  // mx finite => list is full
+    }
+  }
+  if (stats && lane == 0) atomicAdd(&stats[done ? (rings < 15 ? rings : 14) : 15], 1);
+  if (!done) {
+    // isolated point: handed to the cooperative exact scan (grid_fallback_kernel)
+    if (lane == 0) {
+      int slot = atomicAdd(fb_count, 1);
+      fb_list[slot] = q;
+      fb_bound[slot] = b.mx;  // the K+1-th best seen so far bounds the true one from above
+    }
+    continue;
+  }
+  knn_finish(b.best, K, g.n, lane, orig, avg_out);
+  }
+}
+
+// Exact scan of ALL points for the queries the ring search gave up on.  One 1024-thread
+// workgroup per query: each of the 16 waves scans a strided share of the points with its own
+// best-list; the lists meet in LDS and wave 0 merges them.
+__global__ void __launch_bounds__(1024)
+grid_fallback_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted, int K,
+                     const int32_t *__restrict__ fb_count, const int32_t *__restrict__ fb_list,
+                     const float *__restrict__ fb_bound, float *__restrict__ avg_out) {
+  __shared__ float s_best[16][64];
+  const int n = gp->n;
+  const int nfb = *fb_count;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int KK = K + 1;
+  for (int f = blockIdx.x; f < nfb; f += gridDim.x) {
+    const float4 qp = sorted[fb_list[f]];
+    const float bound = fb_bound[f];
+    BestList b;
+    b.best = __builtin_inff();
+    b.mx = __builtin_inff();
+    bool first = true;
+    for (int j0 = wave * 256; j0 < n; j0 += 16 * 256) {
+      int e = j0 + 256 < n ? j0 + 256 : n;
+      scan_range(b, first, sorted, j0, e, qp.x, qp.y, qp.z, KK, lane, bound);
+    }
+    __syncthreads();
+    s_best[wave][lane] = b.best;
+    __syncthreads();
+    if (wave == 0) {
+      for (int w = 1; w < 16; ++w) best_insert_batch(b, s_best[w][lane], true, KK, lane);
+      knn_finish(b.best, K, n, lane, __float_as_int(qp.w), avg_out);
+    }
+  }
+}
+
+struct GridWs {
+  unsigned *bbox;
+  unsigned long long *sumsq;
+  GridParams *gp;
+  int32_t *cell_count, *cursor, *cell_start, *block_sums, *cell_of;
+  float4 *sorted;
+  int32_t *fb_count, *fb_list;
+  float *fb_bound;
+  int32_t *stats;  // [16] ring histogram, filled only when PGDVS_KNN_STATS=1 (diagnostics)
+  int64_t total_bytes;
+};
+
+static GridWs grid_ws_layout(void *base, int64_t capacity) {
+  GridWs w;
+  char *p = reinterpret_cast<char *>(base);
+  int64_t off = 0;
+  w.bbox = reinterpret_cast<unsigned *>(p + off);
+  w.sumsq = reinterpret_cast<unsigned long long *>(p + off + 64);
+  off += 256;
+  w.gp = reinterpret_cast<GridParams *>(p + off);
+  off += 256;
+  w.cell_count = reinterpret_cast<int32_t *>(p + off);
+  off += align_up(((int64_t)kGridMaxCells + 1) * 4, 256);
+  w.cursor = reinterpret_cast<int32_t *>(p + off);
+  off += align_up(((int64_t)kGridMaxCells + 1) * 4, 256);
+  w.cell_start = reinterpret_cast<int32_t *>(p + off);
+  off += align_up(((int64_t)kGridMaxCells + 1) * 4, 256);
+  w.block_sums = reinterpret_cast<int32_t *>(p + off);
+  off += align_up((int64_t)(kGridMaxCells / kScanTile) * 4, 256);
+  w.cell_of = reinterpret_cast<int32_t *>(p + off);
+  off += align_up((capacity > 0 ? capacity : 1) * 4, 256);
+  w.sorted = reinterpret_cast<float4 *>(p + off);
+  off += align_up((capacity > 0 ? capacity : 1) * 16, 256);
+  w.stats = reinterpret_cast<int32_t *>(p + off);
+  w.fb_count = reinterpret_cast<int32_t *>(p + off + 128);
+  off += 256;
+  w.fb_list = reinterpret_cast<int32_t *>(p + off);
+  off += align_up((capacity > 0 ? capacity : 1) * 4, 256);
+  w.fb_bound = reinterpret_cast<float *>(p + off);
+  off += align_up((capacity > 0 ? capacity : 1) * 4, 256);
+  w.total_bytes = off;
+  return w;
+}
+
+int64_t knn_grid_workspace_bytes(int64_t capacity) { return grid_ws_layout(nullptr, capacity).total_bytes; }
+
+int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity, int K, float *avg_out,
+                       void *workspace, int64_t workspace_bytes, hipStream_t st) {
+  GridWs ws = grid_ws_layout(workspace, capacity);
+  if (!workspace || workspace_bytes < ws.total_bytes) {
+    set_error("knn_grid: workspace too small");
+    return PGDVS_ERR_WORKSPACE;
+  }
+  // bbox init: min <- 0xffffffff, max <- 0 in the order-preserving uint encoding
+  hipError_t e = hipMemsetAsync(ws.bbox, 0xff, 3 * sizeof(unsigned), st);
+  if (e == hipSuccess) e = hipMemsetAsync(ws.bbox + 3, 0x00, 3 * sizeof(unsigned), st);
+  if (e == hipSuccess) e = hipMemsetAsync(ws.sumsq, 0, sizeof(unsigned long long), st);
+  if (e != hipSuccess) {
+    set_error("knn_grid memset: %s", hipGetErrorString(e));
+    return PGDVS_ERR_LAUNCH;
+  }
+  unsigned gpts = (unsigned)(cdiv(capacity, 256) < 2048 ? cdiv(capacity, 256) : 2048);
+  unsigned gbb = gpts < 128 ? gpts : 128;
+  const char *etc = getenv("PGDVS_KNN_PER_CELL");  // tuning knob (any value gives exact results)
+  const float target = etc && atof(etc) >= 1.0 ? (float)atof(etc) : kTargetPerCellDefault * (float)(K + 1) / 51.0f;
+  PGDVS_LAUNCH("knn_grid_bbox", grid_bbox_kernel, dim3(gbb), dim3(256), 0, st, pts, count, ws.bbox);
+  // trial grid from the bounding box, measure the occupancy, then the final grid
+  PGDVS_LAUNCH("knn_grid_params", grid_params_kernel, dim3(1), dim3(64), 0, st, ws.bbox, count,
+               (const unsigned long long *)nullptr, ws.gp, target);
+  PGDVS_LAUNCH("knn_grid_zero", grid_zero_kernel, dim3(2048), dim3(256), 0, st, ws.gp, ws.cell_count,
+               (int32_t *)nullptr);
+  PGDVS_LAUNCH("knn_grid_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
+               ws.cell_count);
+  PGDVS_LAUNCH("knn_grid_occupied", grid_occupied_kernel, dim3(1024), dim3(256), 0, st, ws.cell_count,
+               ws.gp, ws.sumsq);
+  PGDVS_LAUNCH("knn_grid_params", grid_params_kernel, dim3(1), dim3(64), 0, st, ws.bbox, count,
+               (const unsigned long long *)ws.sumsq, ws.gp, target);
+  PGDVS_LAUNCH("knn_grid_zero", grid_zero_kernel, dim3(2048), dim3(256), 0, st, ws.gp, ws.cell_count,
+               ws.cursor);
+  PGDVS_LAUNCH("knn_grid_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
+               ws.cell_count);
+  const int nb = kGridMaxCells / kScanTile;
+  PGDVS_LAUNCH("knn_grid_scan", grid_scan_blocks_kernel, dim3(nb), dim3(1024), 0, st, ws.cell_count, ws.gp,
+               ws.block_sums);
+  PGDVS_LAUNCH("knn_grid_scan", grid_scan_sums_kernel, dim3(1), dim3(1024), 0, st, ws.block_sums, nb);
+  PGDVS_LAUNCH("knn_grid_scan", grid_scan_apply_kernel, dim3(nb), dim3(1024), 0, st, ws.cell_count, ws.gp,
+               ws.block_sums, ws.cell_start);
+  PGDVS_LAUNCH("knn_grid_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
+               ws.cell_start, ws.cursor, ws.sorted);
+  const char *env = getenv("PGDVS_KNN_STATS");
+  int32_t *stats = (env && env[0] == '1') ? ws.stats : nullptr;
+  e = hipMemsetAsync(ws.stats, 0, 256, st);  // ring histogram + fallback counter
+  if (e != hipSuccess) {
+    set_error("knn_grid memset: %s", hipGetErrorString(e));
+    return PGDVS_ERR_LAUNCH;
+  }
+  const unsigned gq = (unsigned)(cdiv(capacity, 4) < 256 * 8 ? cdiv(capacity, 4) : 256 * 8);
+  PGDVS_LAUNCH("knn_grid_query", grid_query_kernel, dim3(gq), dim3(256), 0, st, ws.gp, ws.sorted,
+               ws.cell_start, K, avg_out, stats, kRingCap, getenv("PGDVS_KNN_ABL") ? atoi(getenv("PGDVS_KNN_ABL")) : 0,
+               ws.fb_count, ws.fb_list, ws.fb_bound);
+  PGDVS_LAUNCH("knn_grid_fallback", grid_fallback_kernel, dim3(512), dim3(1024), 0, st, ws.gp, ws.sorted, K,
+               ws.fb_count, ws.fb_list, ws.fb_bound, avg_out);
+  return check_launch("knn_grid");
+}
+
+}  // namespace pgdvs

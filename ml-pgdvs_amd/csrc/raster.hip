@@ -100,6 +100,36 @@ __device__ __forceinline__ TileBox tile_box(const RasterCam &rc, float3 p, float
   return b;
 }
 
+// Wave-aggregated tile counter update.  Clouds arrive in the raster order of their source
+// frames, so the lanes of a wavefront mostly hit the same one or two tiles: group equal
+// tile ids with readfirstlane/ballot and issue ONE atomic per distinct tile instead of 64
+// same-address atomics.  Returns, for lanes with t >= 0, the slot reserved in the tile.
+__device__ __forceinline__ int wave_tile_reserve(int32_t *__restrict__ counter, int t) {
+  int slot = 0;
+  unsigned long long todo = __ballot(t >= 0);
+  const int lane = threadIdx.x & 63;
+  while (todo) {
+    int leader = __builtin_ctzll(todo);
+    int t0 = __shfl(t, leader, 64);
+    unsigned long long same = __ballot(t == t0) & todo;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&counter[t0], (int)__popcll(same));
+    base = __shfl(base, leader, 64);
+    if (t == t0 && ((todo >> lane) & 1ull))
+      slot = base + (int)__popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  return slot;
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    int o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
 __global__ void __launch_bounds__(256)
 raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_host,
                             const int64_t *__restrict__ n_dev, const float *__restrict__ cam,
@@ -107,14 +137,24 @@ raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, i
                             float4 *__restrict__ ndc4, int32_t *__restrict__ tile_count) {
   const int64_t n = n_dev ? *n_dev : n_host;
   RasterCam rc = make_raster_cam(cam, H, W);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const float *X = pts + i * pts_stride;
-    float3 p = point_to_ndc(rc, X[0], X[1], X[2]);
-    ndc4[i] = make_float4(p.x, p.y, p.z, 0.0f);
-    TileBox b = tile_box(rc, p, radius, H, W, ntx, nty);
-    for (int ty = b.ty0; ty <= b.ty1; ++ty)
-      for (int tx = b.tx0; tx <= b.tx1; ++tx) atomicAdd(&tile_count[ty * ntx + tx], 1);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n_round = (n + 63) / 64 * 64;  // keep whole wavefronts in the loop
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    TileBox b;
+    b.tx0 = 1; b.tx1 = 0; b.ty0 = 1; b.ty1 = 0;
+    if (i < n) {
+      const float *X = pts + i * pts_stride;
+      float3 p = point_to_ndc(rc, X[0], X[1], X[2]);
+      ndc4[i] = make_float4(p.x, p.y, p.z, 0.0f);
+      b = tile_box(rc, p, radius, H, W, ntx, nty);
+    }
+    int nx = wave_max_i32(b.tx1 - b.tx0 + 1), ny = wave_max_i32(b.ty1 - b.ty0 + 1);
+    for (int jy = 0; jy < ny; ++jy)
+      for (int jx = 0; jx < nx; ++jx) {
+        int tx = b.tx0 + jx, ty = b.ty0 + jy;
+        int t = (tx <= b.tx1 && ty <= b.ty1) ? ty * ntx + tx : -1;
+        wave_tile_reserve(tile_count, t);
+      }
   }
 }
 
@@ -155,16 +195,25 @@ raster_fill_kernel(int64_t n_host, const int64_t *__restrict__ n_dev,
                    int64_t list_capacity) {
   const int64_t n = n_dev ? *n_dev : n_host;
   RasterCam rc = make_raster_cam(cam, H, W);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float4 q = ndc4[i];
-    float3 p = make_float3(q.x, q.y, q.z);
-    TileBox b = tile_box(rc, p, radius, H, W, ntx, nty);
-    for (int ty = b.ty0; ty <= b.ty1; ++ty)
-      for (int tx = b.tx0; tx <= b.tx1; ++tx) {
-        int t = ty * ntx + tx;
-        int64_t pos = (int64_t)offsets[t] + atomicAdd(&cursor[t], 1);
-        if (pos < list_capacity) lists[pos] = (int32_t)i;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n_round = (n + 63) / 64 * 64;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    TileBox b;
+    b.tx0 = 1; b.tx1 = 0; b.ty0 = 1; b.ty1 = 0;
+    if (i < n) {
+      float4 q = ndc4[i];
+      b = tile_box(rc, make_float3(q.x, q.y, q.z), radius, H, W, ntx, nty);
+    }
+    int nx = wave_max_i32(b.tx1 - b.tx0 + 1), ny = wave_max_i32(b.ty1 - b.ty0 + 1);
+    for (int jy = 0; jy < ny; ++jy)
+      for (int jx = 0; jx < nx; ++jx) {
+        int tx = b.tx0 + jx, ty = b.ty0 + jy;
+        int t = (tx <= b.tx1 && ty <= b.ty1) ? ty * ntx + tx : -1;
+        int slot = wave_tile_reserve(cursor, t);
+        if (t >= 0) {
+          int64_t pos = (int64_t)offsets[t] + slot;
+          if (pos < list_capacity) lists[pos] = (int32_t)i;
+        }
       }
   }
 }

@@ -29,7 +29,8 @@ SIGNATURES = {
     "pgdvs_compact_workspace_bytes": (_i64, [_i64]),
     "pgdvs_compact_u8": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "pgdvs_gather_rows": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
-    "pgdvs_knn_mean_dist": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "pgdvs_knn_workspace_bytes": (_i64, [_i64]),
+    "pgdvs_knn_mean_dist": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _i64, _vp]),
     "pgdvs_outlier_workspace_bytes": (_i64, [_i64]),
     "pgdvs_outlier_flags": (_i, [_vp, _vp, _i64, _f, _i, _vp, _vp, _vp, _i64, _vp]),
     "pgdvs_scatter_keep": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp]),

@@ -87,6 +87,9 @@ def compact_u8(flags: torch.Tensor):
     n = f.numel()
     idx = torch.empty(max(n, 1), dtype=torch.int32, device=f.device)
     cnt = torch.empty(1, dtype=torch.int32, device=f.device)
+    if n == 0:
+        cnt.zero_()
+        return idx, cnt
     lib = _lib.load()
     ws = _ws(lib.pgdvs_compact_workspace_bytes(n), f.device)
     check(lib.pgdvs_compact_u8(_ptr(f), n, _ptr(idx), _ptr(cnt), _ptr(ws), ws.numel(), _stream()), "pgdvs_compact_u8")
@@ -102,11 +105,15 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor, cnt: torch.Tensor) -> torc
     return dst
 
 
-def knn_mean_dist(pts: torch.Tensor, cnt: torch.Tensor, K: int) -> torch.Tensor:
+def knn_mean_dist(pts: torch.Tensor, cnt: torch.Tensor, K: int, algo: int = 0) -> torch.Tensor:
+    """algo: 0 auto (grid when K+1 <= 64), 1 brute force, 2 grid."""
     p = _req(pts, torch.float32, "pts").reshape(-1, 3)
     c = _req(cnt, torch.int32, "count")
     out = torch.empty(max(p.shape[0], 1), dtype=torch.float32, device=p.device)
-    check(_lib.load().pgdvs_knn_mean_dist(_ptr(p), _ptr(c), p.shape[0], int(K), _ptr(out), _stream()), "pgdvs_knn_mean_dist")
+    lib = _lib.load()
+    ws = _ws(lib.pgdvs_knn_workspace_bytes(p.shape[0]), p.device)
+    check(lib.pgdvs_knn_mean_dist(_ptr(p), _ptr(c), p.shape[0], int(K), _ptr(out), int(algo), _ptr(ws), ws.numel(),
+                                  _stream()), "pgdvs_knn_mean_dist")
     return out
 
 

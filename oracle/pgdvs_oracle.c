@@ -324,9 +324,21 @@ ORC_API void orc_knn_mean_dist(const float *pts, int64_t N, int K, float *out) {
           best[k] = d;
         }
       }
-      /* torch.mean over K columns (cols 1..K), sequential fp32 sum */
+      /* torch.mean over K columns (cols 1..K).  torch does not specify a summation
+       * order (cascade on CPU, tree on CUDA); this restatement fixes one: a butterfly
+       * over 64 slots (s[i] += s[i+32], += s[i+16], ... ) when K+1 <= 64, which is what
+       * the HIP kernels use, else a plain ascending sum. */
       float s = 0.0f;
-      for (int k = 1; k < KK; ++k) s = s + (k < cnt ? best[k] : 0.0f);
+      if (KK <= 64) {
+        float sl[64];
+        for (int k = 0; k < 64; ++k) sl[k] = 0.0f;
+        for (int k = 1; k < KK; ++k) sl[k] = k < cnt ? best[k] : 0.0f;
+        for (int off = 32; off > 0; off >>= 1)
+          for (int k = 0; k < off; ++k) sl[k] = sl[k] + sl[k + off];
+        s = sl[0];
+      } else {
+        for (int k = 1; k < KK; ++k) s = s + (k < cnt ? best[k] : 0.0f);
+      }
       out[i] = s / (float)K;
     }
     free(best);

@@ -122,13 +122,14 @@ def test_compute_dyn_pcl_vs_oracle_and_golden(golden_dir, case):
         np.testing.assert_allclose(N(info["pcl_nn_dist_thres"])[0], o["pcl_nn_dist_thres"], rtol=1e-6)
 
 
+@pytest.mark.parametrize("algo", [1, 2])
 @pytest.mark.parametrize("n,K", [(1, 4), (5, 8), (51, 50), (300, 50), (2000, 50), (5000, 16)])
-def test_knn_mean_dist_and_threshold(n, K):
+def test_knn_mean_dist_and_threshold(n, K, algo):
     rng = np.random.default_rng(n * 131 + K)
     pts = rng.normal(size=(n, 3)).astype(np.float32)
     pts[: n // 10] = pts[n // 10: 2 * (n // 10)][: n // 10]  # duplicates -> distance ties at 0
     cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
-    avg = ops.knn_mean_dist(T(pts), cnt, K)
+    avg = ops.knn_mean_dist(T(pts), cnt, K, algo=algo)
     ref = orc.knn_mean_dist(pts, K)
     assert np.array_equal(N(avg)[:n].view(np.uint32), ref.view(np.uint32))
     thres, flag = ops.outlier_flags(avg, cnt, 0.1, True)
@@ -139,6 +140,37 @@ def test_knn_mean_dist_and_threshold(n, K):
         assert np.array_equal(N(flag)[:n].astype(bool)[margin], (ref < o_thres)[margin])
     else:
         assert np.isnan(N(thres)[0])
+
+
+@pytest.mark.parametrize("kind", ["surface", "clusters", "line", "identical"])
+def test_knn_grid_exact_on_hard_distributions(kind):
+    """the grid search must return exactly the brute-force values: surface samples with
+    flying-pixel outliers (ring expansion + fallback scan), tight clusters far apart, a
+    degenerate line, and all-identical points."""
+    rng = np.random.default_rng(sum(map(ord, kind)))
+    n, K = 12000, 50
+    if kind == "surface":
+        u = rng.uniform(-1, 1, (n, 2))
+        pts = np.stack([u[:, 0], u[:, 1], 2 + 0.3 * np.sin(3 * u[:, 0])], 1)
+        pts[:150, 2] += rng.uniform(0.2, 3.0, 150)          # outliers off the surface
+        pts[150:160] = [50.0, -30.0, 9.0]                    # far cluster smaller than K
+    elif kind == "clusters":
+        c = rng.uniform(-100, 100, (40, 3))
+        pts = c[rng.integers(0, 40, n)] + rng.normal(0, 1e-3, (n, 3))
+    elif kind == "line":
+        t = rng.uniform(0, 1, n)
+        pts = np.stack([t, 2 * t, -t], 1)
+    else:
+        pts = np.ones((n, 3))
+    pts = pts.astype(np.float32)
+    cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
+    a_grid = N(ops.knn_mean_dist(T(pts), cnt, K, algo=2))[:n]
+    ref = orc.knn_mean_dist(pts, K)
+    assert np.array_equal(a_grid.view(np.uint32), ref.view(np.uint32))
+    # capacity larger than the device-side count: trailing rows must be ignored
+    pad = np.concatenate([pts, rng.normal(size=(500, 3)).astype(np.float32)])
+    a_pad = N(ops.knn_mean_dist(T(pad), cnt, K, algo=2))[:n]
+    assert np.array_equal(a_pad.view(np.uint32), ref.view(np.uint32))
 
 
 def test_backwarp_l1(golden_dir):

@@ -125,91 +125,142 @@ knn_mean_dist_kernel(const float *__restrict__ pts, const int32_t *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
-// single-block statistics: mean / unbiased std in fp64, lower median by radix select
+// statistics for the threshold: mean / unbiased std accumulated in fp64 with a fixed
+// reduction order (deterministic), lower median by a 3-pass radix select (11+11+10 bits of
+// the order-preserving key).  Multi-block passes with block-local LDS histograms, tiny
+// single-block kernels in between to pick the bin.
 // ---------------------------------------------------------------------------
-constexpr int kStatBlock = 1024;
+constexpr int kStatBlocks = 120;
+constexpr int kStatThreads = 256;
+constexpr int kStatBins = 2048;
 
-__device__ double block_sum_f64(double v, double *scratch) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  int wave = threadIdx.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) scratch[wave] = v;
-  __syncthreads();
-  double s = 0.0;
-  for (int i = 0; i < kStatBlock / kWave; ++i) s += scratch[i];
-  return s;
+struct StatState {
+  double mean, m2;
+  unsigned prefix, rank;
+  int n;
+};
+
+__device__ __forceinline__ unsigned stat_key(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__global__ void __launch_bounds__(kStatBlock)
-outlier_threshold_kernel(const float *__restrict__ avg, const int32_t *__restrict__ count,
-                         float std_thres, float *__restrict__ thres_out) {
-  __shared__ double scratch[kStatBlock / kWave];
-  __shared__ unsigned int hist[256];
-  __shared__ unsigned int sel_prefix;
-  __shared__ unsigned int sel_rank;
+// pass: 0 -> accumulate sum(x) and histogram key bits [31:21]
+//       1 -> accumulate sum((x-mean)^2) and histogram bits [20:10] of keys matching prefix[31:21]
+//       2 -> histogram bits [9:0] of keys matching prefix[31:10]
+__global__ void __launch_bounds__(kStatThreads)
+stat_pass_kernel(const float *__restrict__ avg, const int32_t *__restrict__ count, int pass,
+                 const StatState *__restrict__ st, double *__restrict__ partials,
+                 unsigned *__restrict__ ghist) {
+  __shared__ unsigned hist[kStatBins];
+  __shared__ double wsum[kStatThreads / kWave];
   const int n = *count;
   const int tid = threadIdx.x;
-  if (n <= 0) {
-    if (tid == 0) *thres_out = __builtin_nanf("");
-    return;
+  for (int i = tid; i < kStatBins; i += kStatThreads) hist[i] = 0;
+  __syncthreads();
+  const double mean = pass == 1 ? st->mean : 0.0;
+  const unsigned prefix = pass > 0 ? st->prefix : 0u;
+  const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+  const unsigned himask = pass == 0 ? 0u : (pass == 1 ? 0xffe00000u : 0xfffffc00u);
+  const unsigned binmask = pass == 2 ? 0x3ffu : 0x7ffu;
+  double acc = 0.0;
+  const int stride = gridDim.x * kStatThreads;
+  const int n_round = (n + stride - 1) / stride * stride;  // whole waves stay in the loop
+  for (int i = blockIdx.x * kStatThreads + tid; i < n_round; i += stride) {
+    bool in = i < n;
+    float x = in ? avg[i] : 0.0f;
+    if (pass == 0) acc += in ? (double)x : 0.0;
+    if (pass == 1) {
+      double d = (double)x - mean;
+      acc += in ? d * d : 0.0;
+    }
+    unsigned u = stat_key(x);
+    bool act = in && (u & himask) == (prefix & himask);
+    unsigned bin = (u >> shift) & binmask;
+    // neighbouring values often share the bin: one LDS atomic for the whole wave then
+    unsigned long long am = __ballot(act);
+    if (am) {
+      unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, __builtin_ctzll(am));
+      unsigned long long same = __ballot(act && bin == b0);
+      if (same == am) {
+        if ((tid & 63) == (int)__builtin_ctzll(am)) atomicAdd(&hist[b0], (unsigned)__popcll(am));
+      } else if (act) {
+        atomicAdd(&hist[bin], 1u);
+      }
+    }
   }
-  double s = 0.0;
-  for (int i = tid; i < n; i += kStatBlock) s += (double)avg[i];
-  double mean = block_sum_f64(s, scratch) / (double)n;
-  double m2 = 0.0;
-  for (int i = tid; i < n; i += kStatBlock) {
-    double d = (double)avg[i] - mean;
-    m2 += d * d;
-  }
-  m2 = block_sum_f64(m2, scratch);
-  // lower median = element of rank (n-1)/2 in ascending order.  Values are >= 0 (or
-  // NaN); map float bits to an order-preserving unsigned key.
-  if (tid == 0) {
-    sel_prefix = 0;
-    sel_rank = (unsigned)((n - 1) / 2);
+  if (pass < 2) {
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((tid & 63) == 0) wsum[tid >> 6] = acc;
   }
   __syncthreads();
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int i = tid; i < 256; i += kStatBlock) hist[i] = 0;
-    __syncthreads();
-    unsigned prefix = sel_prefix;
-    unsigned himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
-    const int n_round = (n + kStatBlock - 1) / kStatBlock * kStatBlock;  // whole waves stay in the loop
-    for (int i = tid; i < n_round; i += kStatBlock) {
-      unsigned u = i < n ? __float_as_uint(avg[i]) : 0u;
-      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-      bool act = i < n && (u & himask) == (prefix & himask);
-      unsigned bin = (u >> shift) & 0xffu;
-      // neighbouring values share their leading bits: one LDS atomic per distinct bin per wave
-      unsigned long long todo = __ballot(act);
-      while (todo) {
-        int l = __builtin_ctzll(todo);
-        unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, l);
-        unsigned long long same = __ballot(act && bin == b0);
-        if ((tid & 63) == l) atomicAdd(&hist[b0], (unsigned)__popcll(same));
-        todo &= ~same;
-      }
-    }
-    __syncthreads();
-    if (tid == 0) {
-      unsigned r = sel_rank, acc = 0;
-      int b = 0;
-      for (; b < 256; ++b) {
-        if (acc + hist[b] > r) break;
-        acc += hist[b];
-      }
-      if (b > 255) b = 255;
-      sel_rank = r - acc;
-      sel_prefix = prefix | ((unsigned)b << shift);
-    }
-    __syncthreads();
+  if (pass < 2 && tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < kStatThreads / kWave; ++w) t += wsum[w];
+    partials[blockIdx.x] = t;
   }
+  for (int i = tid; i < kStatBins; i += kStatThreads)
+    if (hist[i]) atomicAdd(&ghist[pass * kStatBins + i], hist[i]);
+}
+
+// after pass p: fold the partial sums (fixed order), pick the bin holding the wanted rank
+__global__ void __launch_bounds__(256)
+stat_select_kernel(const int32_t *__restrict__ count, int pass, int nblocks,
+                   const double *__restrict__ partials, const unsigned *__restrict__ ghist,
+                   StatState *__restrict__ st, float std_thres, float *__restrict__ thres_out) {
+  __shared__ unsigned psum[256];
+  const int n = *count;
+  const int tid = threadIdx.x;
   if (tid == 0) {
-    unsigned u = sel_prefix;
-    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    float med = __uint_as_float(u);
-    float sd = n > 1 ? (float)sqrt(m2 / (double)(n - 1)) : __builtin_nanf("");
-    *thres_out = med + sd * std_thres;
+    if (pass == 0) {
+      double t = 0.0;
+      for (int b = 0; b < nblocks; ++b) t += partials[b];
+      st->mean = n > 0 ? t / (double)n : 0.0;
+      st->prefix = 0;
+      st->rank = (unsigned)(n > 0 ? (n - 1) / 2 : 0);  // torch.median: lower median
+      st->n = n;
+    } else if (pass == 1) {
+      double t = 0.0;
+      for (int b = 0; b < nblocks; ++b) t += partials[b];
+      st->m2 = t;
+    }
+  }
+  __syncthreads();
+  // 2048 bins, 8 per thread: find the bin where the running count passes rank
+  const unsigned *h = ghist + pass * kStatBins;
+  const int nb = pass == 2 ? 1024 : 2048;
+  unsigned loc[8], s = 0;
+  for (int k = 0; k < 8; ++k) {
+    loc[k] = tid * 8 + k < nb ? h[tid * 8 + k] : 0;
+    s += loc[k];
+  }
+  psum[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned r = st->rank, acc = 0;
+    int t = 0;
+    for (; t < 256; ++t) {
+      if (acc + psum[t] > r) break;
+      acc += psum[t];
+    }
+    if (t > 255) t = 255;
+    int b = t * 8;
+    for (int k = 0; k < 8; ++k, ++b) {
+      unsigned c = b < nb ? h[b] : 0;
+      if (acc + c > r) break;
+      acc += c;
+    }
+    if (b >= nb) b = nb - 1;
+    const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+    st->rank = r - acc;
+    st->prefix |= (unsigned)b << shift;
+    if (pass == 2) {
+      unsigned u = st->prefix;
+      u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+      float med = __uint_as_float(u);
+      float sd = n > 1 ? (float)sqrt(st->m2 / (double)(n - 1)) : __builtin_nanf("");
+      *thres_out = n > 0 ? med + sd * std_thres : __builtin_nanf("");
+    }
   }
 }
 
@@ -264,23 +315,39 @@ PGDVS_API int pgdvs_knn_mean_dist(const float *pts, const int32_t *count, int64_
 
 PGDVS_API int64_t pgdvs_outlier_workspace_bytes(int64_t capacity) {
   (void)capacity;
-  return 256;
+  return 256 + kStatBlocks * 8 + 3 * kStatBins * 4 + 256;
 }
 
 PGDVS_API int pgdvs_outlier_flags(const float *avg, const int32_t *count, int64_t capacity,
                                   float std_thres, int remove_outlier, float *thres_out,
                                   uint8_t *flag_out, void *workspace, int64_t workspace_bytes,
                                   pgdvs_stream_t stream) {
-  (void)workspace;
-  (void)workspace_bytes;
   PGDVS_REQUIRE(avg && count && thres_out && flag_out && capacity >= 0,
                 "pgdvs_outlier_flags: bad arguments");
-  PGDVS_LAUNCH("outlier_threshold", outlier_threshold_kernel, dim3(1), dim3(kStatBlock), 0, as_stream(stream), avg,
-                     count, std_thres, thres_out);
+  if (!workspace || workspace_bytes < pgdvs_outlier_workspace_bytes(capacity)) {
+    set_error("pgdvs_outlier_flags: workspace too small");
+    return PGDVS_ERR_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  char *p = reinterpret_cast<char *>(workspace);
+  StatState *state = reinterpret_cast<StatState *>(p);
+  double *partials = reinterpret_cast<double *>(p + 256);
+  unsigned *ghist = reinterpret_cast<unsigned *>(p + 256 + kStatBlocks * 8);
+  hipError_t e = hipMemsetAsync(ghist, 0, 3 * kStatBins * 4, st);
+  if (e != hipSuccess) {
+    set_error("outlier_flags memset: %s", hipGetErrorString(e));
+    return PGDVS_ERR_LAUNCH;
+  }
+  for (int pass = 0; pass < 3; ++pass) {
+    PGDVS_LAUNCH("outlier_stat_pass", stat_pass_kernel, dim3(kStatBlocks), dim3(kStatThreads), 0, st, avg,
+                 count, pass, state, partials, ghist);
+    PGDVS_LAUNCH("outlier_stat_select", stat_select_kernel, dim3(1), dim3(256), 0, st, count, pass,
+                 kStatBlocks, partials, ghist, state, std_thres, thres_out);
+  }
   if (capacity > 0) {
     unsigned grid = (unsigned)(cdiv(capacity, 256) < 1024 ? cdiv(capacity, 256) : 1024);
-    PGDVS_LAUNCH("outlier_flag", outlier_flag_kernel, dim3(grid), dim3(256), 0, as_stream(stream), avg, count,
-                       thres_out, remove_outlier, flag_out);
+    PGDVS_LAUNCH("outlier_flag", outlier_flag_kernel, dim3(grid), dim3(256), 0, st, avg, count,
+                 thres_out, remove_outlier, flag_out);
   }
   return check_launch("outlier_flags");
 }

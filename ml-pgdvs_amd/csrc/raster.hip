@@ -101,25 +101,44 @@ __device__ __forceinline__ TileBox tile_box(const RasterCam &rc, float3 p, float
 }
 
 // Wave-aggregated tile counter update.  Clouds arrive in the raster order of their source
-// frames, so the lanes of a wavefront mostly hit the same one or two tiles: group equal
-// tile ids with readfirstlane/ballot and issue ONE atomic per distinct tile instead of 64
-// same-address atomics.  Returns, for lanes with t >= 0, the slot reserved in the tile.
-__device__ __forceinline__ int wave_tile_reserve(int32_t *__restrict__ counter, int t) {
-  int slot = 0;
-  unsigned long long todo = __ballot(t >= 0);
+// frames, so consecutive lanes of a wavefront mostly hit the same tile: lanes form RUNS of
+// equal tile id, the first lane of each run adds the run length for all of them, and every
+// run leader is active in ONE atomic wave-instruction (the atomic units are paced per
+// instruction, not per lane).  Any order is correct -- less coherent input only means
+// shorter runs.  Returns the slot reserved for this lane (fill) or nothing (count).
+struct RunInfo {
+  int leader;   // lane index of this lane's run leader
+  int length;   // run length (valid on the leader)
+  bool is_leader;
+};
+
+__device__ __forceinline__ RunInfo wave_runs(int t) {
   const int lane = threadIdx.x & 63;
-  while (todo) {
-    int leader = __builtin_ctzll(todo);
-    int t0 = __shfl(t, leader, 64);
-    unsigned long long same = __ballot(t == t0) & todo;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&counter[t0], (int)__popcll(same));
-    base = __shfl(base, leader, 64);
-    if (t == t0 && ((todo >> lane) & 1ull))
-      slot = base + (int)__popcll(same & ((1ull << lane) - 1ull));
-    todo &= ~same;
-  }
-  return slot;
+  int prev = __shfl_up(t, 1, 64);
+  bool lead = lane == 0 || prev != t;
+  unsigned long long L = __ballot(lead);
+  RunInfo r;
+  r.is_leader = lead;
+  unsigned long long below = L & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));  // leaders at or below this lane
+  r.leader = 63 - __builtin_clzll(below);
+  unsigned long long above = lane == 63 ? 0ull : (L >> (lane + 1));  // leaders after this lane
+  r.length = above ? (int)__builtin_ctzll(above) + 1 : 64 - lane;
+  return r;
+}
+
+__device__ __forceinline__ void wave_tile_count(int32_t *__restrict__ counter, int t) {
+  RunInfo r = wave_runs(t);
+  if (r.is_leader && t >= 0)
+    __hip_atomic_fetch_add(&counter[t], r.length, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int wave_tile_reserve(int32_t *__restrict__ counter, int t) {
+  const int lane = threadIdx.x & 63;
+  RunInfo r = wave_runs(t);
+  int base = 0;
+  if (r.is_leader && t >= 0) base = atomicAdd(&counter[t], r.length);
+  base = __shfl(base, r.leader, 64);
+  return base + (lane - r.leader);
 }
 
 __device__ __forceinline__ int wave_max_i32(int v) {
@@ -153,7 +172,7 @@ raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, i
       for (int jx = 0; jx < nx; ++jx) {
         int tx = b.tx0 + jx, ty = b.ty0 + jy;
         int t = (tx <= b.tx1 && ty <= b.ty1) ? ty * ntx + tx : -1;
-        wave_tile_reserve(tile_count, t);
+        wave_tile_count(tile_count, t);
       }
   }
 }
@@ -258,12 +277,16 @@ raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ 
                    float *__restrict__ zbuf_out, float *__restrict__ dist_out,
                    float *__restrict__ rgb_out, int rgb_planar, float *__restrict__ mask_out) {
   __shared__ float4 s_pt[256];
+  __shared__ float4 s_wave[4][68];  // per-wave strip of culled points (+ padding)
   // XCD-aware mapping: blocks b, b+8, ... share an XCD -> give them a contiguous tile band
   const int ntiles = ntx * nty;
   int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= tiles_per_xcd || tile >= ntiles) return;
   const int ty = tile / ntx, tx = tile - ty * ntx;
-  const int lx = threadIdx.x & (kTile - 1), ly = threadIdx.x >> 4;
+  // a wavefront owns one 8x8 quadrant of the tile so that it can cull the staged points
+  // against its own (radius-expanded) bounds before the per-pixel tests
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
   const int xi = tx * kTile + lx, yi = ty * kTile + ly;
   const bool inside = xi < W && yi < H;
   const float range_x = W > H ? 2.0f * (float)W / (float)H : 2.0f;
@@ -271,6 +294,14 @@ raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ 
   const float xf = pix_to_ndc(W - 1 - xi, W, range_x);
   const float yf = pix_to_ndc(H - 1 - yi, H, range_y);
   const float r2 = radius * radius;
+  // quadrant bounds in NDC (pixel index is reversed: larger xi = smaller x), widened by the
+  // radius and a rounding margin
+  const int qx0 = tx * kTile + (wave & 1) * 8, qy0 = ty * kTile + (wave >> 1) * 8;
+  const float margin = radius * 1.001f + 1e-6f;
+  const float bx_hi = pix_to_ndc(W - 1 - qx0, W, range_x) + margin;
+  const float bx_lo = pix_to_ndc(W - 1 - (qx0 + 7), W, range_x) - margin;
+  const float by_hi = pix_to_ndc(H - 1 - qy0, H, range_y) + margin;
+  const float by_lo = pix_to_ndc(H - 1 - (qy0 + 7), H, range_y) - margin;
   TopK<K> q;
   q.init();
   int64_t beg = offsets[tile], end = offsets[tile + 1];
@@ -286,14 +317,29 @@ raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ 
     }
     __syncthreads();
     int m = (int)((end - base) < 256 ? (end - base) : 256);
-    if (inside) {
-#pragma unroll 4
-      for (int j = 0; j < m; ++j) {
-        float4 p = s_pt[j];
-        float dx = p.x - xf, dy = p.y - yf;
-        float d2 = dx * dx + dy * dy;
-        if (d2 < r2) q.insert(p.z, __float_as_int(p.w), d2);
+    for (int sub = 0; sub < m; sub += 64) {
+      float4 c = s_pt[(sub + lane) & 255];
+      bool hit = (sub + lane) < m && c.x >= bx_lo && c.x <= bx_hi && c.y >= by_lo && c.y <= by_hi;
+      unsigned long long mask = __ballot(hit);
+      if (!mask) continue;
+      // compact the survivors of this wave into its own LDS strip, pad to a multiple of 4
+      const int cnt = (int)__popcll(mask);
+      float4 *strip = s_wave[wave];
+      if (hit) strip[__popcll(mask & ((1ull << lane) - 1ull))] = c;
+      if (lane < 3) strip[cnt + lane] = make_float4(__builtin_inff(), __builtin_inff(), 0.f, 0.f);
+      // same wave writes and reads: LDS ops of one wave complete in order; keep the compiler
+      // from moving the reads above the writes
+      __builtin_amdgcn_wave_barrier();
+      for (int j = 0; j < cnt; j += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float4 p = strip[j + u];
+          float dx = p.x - xf, dy = p.y - yf;
+          float d2 = dx * dx + dy * dy;
+          if (inside && d2 < r2) q.insert(p.z, __float_as_int(p.w), d2);
+        }
       }
+      __builtin_amdgcn_wave_barrier();
     }
   }
   if (!inside) return;

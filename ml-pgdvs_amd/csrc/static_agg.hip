@@ -6,16 +6,16 @@
 // the static pixels that the cloud accumulated from frames < i does not already cover
 // (integer-truncated projection occupancy), so frames are processed in order; inside a
 // frame everything is data-parallel:
-//   mark    : project the accumulated cloud (fp64, as numpy does) and set occ[row,col]
-//   flags   : static && !occupied
-//   compact : ordered stream compaction -> row-major pixel order, the order numpy's
-//             boolean indexing produces (point ids matter: the rasteriser breaks z ties
-//             by id)
-//   append  : unproject the selected pixels (fp32 rays) and append (xyz,rgb) rows
+//   mark   : project the accumulated cloud (fp64, as numpy does) and stamp occ[row,col] with
+//            the frame index (no clearing between frames)
+//   count  : per-block number of selected pixels (static && not stamped)
+//   scan   : block offsets, append base, new cloud size
+//   append : ordered scatter -> row-major pixel order, the order numpy's boolean indexing
+//            produces (point ids matter: the rasteriser breaks z ties by id); unproject the
+//            selected pixels (fp32 rays) and append (xyz,rgb) rows
 // No host synchronisation: the running point count lives on the device and every
 // kernel reads it there.
 #include "common.h"
-#include "scan.h"
 
 namespace pgdvs {
 
@@ -28,7 +28,7 @@ struct ProjF64 {
 // closed bounds, astype(int) truncation)
 __global__ void __launch_bounds__(256)
 agg_mark_kernel(const float *__restrict__ cloud, const int64_t *__restrict__ count, ProjF64 pj,
-                int H, int W, uint8_t *__restrict__ occ) {
+                int H, int W, int frame, uint16_t *__restrict__ occ) {
   const int64_t n = *count;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -54,56 +54,135 @@ agg_mark_kernel(const float *__restrict__ cloud, const int64_t *__restrict__ cou
     double col = pp[0] / pp[2], row = pp[1] / pp[2];
     if (!(row >= 0.0 && row <= (double)(H - 1))) continue;
     if (!(col >= 0.0 && col <= (double)(W - 1))) continue;
-    occ[(int64_t)row * W + (int64_t)col] = 1;
+    occ[(int64_t)row * W + (int64_t)col] = (uint16_t)frame;
   }
 }
 
-__global__ void __launch_bounds__(256)
-agg_flags_kernel(const uint8_t *__restrict__ dyn_mask, const uint8_t *__restrict__ occ, int P,
-                 uint8_t *__restrict__ flags) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
+constexpr int kAggBlock = 1024;
+constexpr int kAggItems = 4;
+constexpr int kAggTile = kAggBlock * kAggItems;
+
+// selection flag of pixel p in frame `frame`: static and not covered by the accumulated
+// cloud.  occ holds the index of the last frame whose mark pass touched the pixel, so it
+// never needs clearing between frames.
+__device__ __forceinline__ bool agg_selected(const uint8_t *__restrict__ dyn_mask,
+                                             const uint16_t *__restrict__ occ, int frame, int p) {
   bool st = dyn_mask[p] == 0;
-  if (occ) st = st && occ[p] == 0;
-  flags[p] = (uint8_t)st;
+  if (frame > 0) st = st && occ[p] != (uint16_t)frame;
+  return st;
 }
 
-// tmp_pcl[tmp_st_mask] / tmp_img[tmp_st_mask] appended to the cloud (:247-251)
-__global__ void __launch_bounds__(256)
-agg_append_kernel(const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt, CamBlock cam,
-                  int W, const float *__restrict__ depth, const float *__restrict__ rgb,
-                  float *__restrict__ cloud, const int64_t *__restrict__ count, int64_t capacity) {
-  const int n = *cnt;
-  const int64_t base = *count;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-    if (base + j >= capacity) break;
-    int p = idx[j];
-    int r = p / W, c = p - r * W;
-    float u = (float)c, v = (float)r;
-    float d = depth[p];
-    float *o = cloud + (base + j) * 6;
+// per-block number of selected pixels (tmp_st_mask & ~tmp_proj_mask, :224-245)
+__global__ void __launch_bounds__(kAggBlock)
+agg_count_kernel(const uint8_t *__restrict__ dyn_mask, const uint16_t *__restrict__ occ, int frame,
+                 int P, int32_t *__restrict__ block_counts) {
+  __shared__ int wave_sums[kAggBlock / kWave];
+  int base = blockIdx.x * kAggTile + threadIdx.x * kAggItems;
+  int c = 0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float dir = cam.v[PGDVS_CAM_M + k * 3 + 0] * u;
-      dir = dir + cam.v[PGDVS_CAM_M + k * 3 + 1] * v;
-      dir = dir + cam.v[PGDVS_CAM_M + k * 3 + 2];
-      o[k] = cam.v[PGDVS_CAM_O + k] + dir * d;
-      o[3 + k] = rgb[(size_t)p * 3 + k];
-    }
+  for (int k = 0; k < kAggItems; ++k)
+    if (base + k < P) c += agg_selected(dyn_mask, occ, frame, base + k);
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int i = 0; i < kAggBlock / kWave; ++i) s += wave_sums[i];
+    block_counts[blockIdx.x] = s;
   }
 }
 
-__global__ void agg_bump_kernel(const int32_t *__restrict__ cnt, int64_t *__restrict__ count,
-                                int64_t capacity) {
-  int64_t c = *count + (int64_t)*cnt;
-  *count = c > capacity ? capacity : c;
+// exclusive scan of the block counts; publishes the append base (= current cloud size) and
+// bumps the cloud size by the number of selected pixels
+__global__ void __launch_bounds__(1024)
+agg_scan_kernel(int32_t *__restrict__ block_counts, int nb, int64_t *__restrict__ count,
+                int64_t *__restrict__ append_base, int64_t capacity) {
+  __shared__ int wave_sums[1024 / kWave];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int start = 0; start < nb; start += 1024) {
+    int i = start + threadIdx.x;
+    int v = i < nb ? block_counts[i] : 0;
+    int x = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      int y = __shfl_up(x, off, 64);
+      if ((threadIdx.x & 63) >= off) x += y;
+    }
+    int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wave_sums[wave] = x;
+    __syncthreads();
+    int wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += wave_sums[w];
+    int incl = carry + wave_off + x;
+    if (i < nb) block_counts[i] = incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int64_t base = *count;
+    *append_base = base;
+    int64_t c = base + (int64_t)carry;
+    *count = c > capacity ? capacity : c;
+  }
+}
+
+// ordered scatter: selected pixel -> its row-major rank -> unproject (fp32 rays) and append
+// (tmp_pcl[tmp_st_mask], tmp_img[tmp_st_mask] :247-251)
+__global__ void __launch_bounds__(kAggBlock)
+agg_append_kernel(const uint8_t *__restrict__ dyn_mask, const uint16_t *__restrict__ occ, int frame,
+                  int P, const int32_t *__restrict__ block_offsets, CamBlock cam, int W,
+                  const float *__restrict__ depth, const float *__restrict__ rgb,
+                  float *__restrict__ cloud, const int64_t *__restrict__ append_base,
+                  int64_t capacity) {
+  __shared__ int wave_sums[kAggBlock / kWave];
+  int base = blockIdx.x * kAggTile + threadIdx.x * kAggItems;
+  bool f[kAggItems];
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < kAggItems; ++k) {
+    f[k] = (base + k < P) && agg_selected(dyn_mask, occ, frame, base + k);
+    c += f[k];
+  }
+  int x = c;
+  for (int off = 1; off < 64; off <<= 1) {
+    int y = __shfl_up(x, off, 64);
+    if ((threadIdx.x & 63) >= off) x += y;
+  }
+  int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 63) wave_sums[wave] = x;
+  __syncthreads();
+  int wave_off = 0;
+  for (int w = 0; w < wave; ++w) wave_off += wave_sums[w];
+  int64_t pos = *append_base + block_offsets[blockIdx.x] + wave_off + x - c;
+#pragma unroll
+  for (int k = 0; k < kAggItems; ++k) {
+    if (!f[k]) continue;
+    if (pos < capacity) {
+      int p = base + k;
+      int r = p / W, col = p - r * W;
+      float u = (float)col, v = (float)r;
+      float d = depth[p];
+      float *o = cloud + pos * 6;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        float dir = cam.v[PGDVS_CAM_M + a * 3 + 0] * u;
+        dir = dir + cam.v[PGDVS_CAM_M + a * 3 + 1] * v;
+        dir = dir + cam.v[PGDVS_CAM_M + a * 3 + 2];
+        o[a] = cam.v[PGDVS_CAM_O + a] + dir * d;
+        o[3 + a] = rgb[(size_t)p * 3 + a];
+      }
+    }
+    ++pos;
+  }
 }
 
 struct AggWs {
-  uint8_t *occ, *flags;
-  int32_t *idx, *cnt;
-  void *compact_ws;
-  int64_t compact_bytes, total_bytes;
+  uint16_t *occ;
+  int32_t *block_counts;
+  int64_t *append_base;
+  int64_t total_bytes;
 };
 
 static AggWs agg_ws_layout(void *base, int H, int W) {
@@ -111,17 +190,12 @@ static AggWs agg_ws_layout(void *base, int H, int W) {
   int64_t P = (int64_t)H * W;
   char *p = reinterpret_cast<char *>(base);
   int64_t off = 0;
-  w.occ = reinterpret_cast<uint8_t *>(p + off);
-  off += align_up(P, 256);
-  w.flags = reinterpret_cast<uint8_t *>(p + off);
-  off += align_up(P, 256);
-  w.idx = reinterpret_cast<int32_t *>(p + off);
-  off += align_up(P * 4, 256);
-  w.cnt = reinterpret_cast<int32_t *>(p + off);
+  w.occ = reinterpret_cast<uint16_t *>(p + off);
+  off += align_up(P * 2, 256);
+  w.block_counts = reinterpret_cast<int32_t *>(p + off);
+  off += align_up(cdiv(P, kAggTile) * 4, 256);
+  w.append_base = reinterpret_cast<int64_t *>(p + off);
   off += 256;
-  w.compact_ws = p + off;
-  w.compact_bytes = compact_workspace_bytes(P);
-  off += w.compact_bytes;
   w.total_bytes = off;
   return w;
 }
@@ -142,7 +216,7 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
                                      int64_t workspace_bytes, pgdvs_stream_t stream) {
   PGDVS_REQUIRE(rgbs && depths && dyn_masks && K3s_host && c2ws_host && out && count_out,
                 "pgdvs_static_aggregate: null pointer");
-  PGDVS_REQUIRE(S > 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31) && capacity > 0,
+  PGDVS_REQUIRE(S > 0 && S < 65535 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31) && capacity > 0,
                 "pgdvs_static_aggregate: bad shape");
   AggWs ws = agg_ws_layout(workspace, H, W);
   if (!workspace || workspace_bytes < ws.total_bytes) {
@@ -152,10 +226,12 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
   hipStream_t st = as_stream(stream);
   const int64_t P = (int64_t)H * W;
   hipError_t e = hipMemsetAsync(count_out, 0, sizeof(int64_t), st);
+  if (e == hipSuccess) e = hipMemsetAsync(ws.occ, 0, (size_t)P * 2, st);
   if (e != hipSuccess) {
     set_error("static_aggregate memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
   }
+  const int nb = (int)cdiv(P, kAggTile);
   for (int i = 0; i < S; ++i) {
     const double *K3 = K3s_host + (size_t)i * 9;
     const double *c2w = c2ws_host + (size_t)i * 16;
@@ -179,18 +255,16 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
       return PGDVS_ERR_INVALID;
     }
     const uint8_t *mask_i = dyn_masks + (size_t)i * P;
-    if (i > 0) {
-      (void)hipMemsetAsync(ws.occ, 0, (size_t)P, st);
-      PGDVS_LAUNCH("agg_mark", agg_mark_kernel, dim3(2048), dim3(256), 0, st, out, count_out, pj, H, W,
-                         ws.occ);
-    }
-    PGDVS_LAUNCH("agg_flags", agg_flags_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, st, mask_i,
-                       i > 0 ? ws.occ : nullptr, (int)P, ws.flags);
-    int rc = compact_u8(ws.flags, P, ws.idx, ws.cnt, ws.compact_ws, ws.compact_bytes, st);
-    if (rc != PGDVS_OK) return rc;
-    PGDVS_LAUNCH("agg_append", agg_append_kernel, dim3(2048), dim3(256), 0, st, ws.idx, ws.cnt, cam, W,
-                       depths + (size_t)i * P, rgbs + (size_t)i * P * 3, out, count_out, capacity);
-    PGDVS_LAUNCH("agg_bump", agg_bump_kernel, dim3(1), dim3(1), 0, st, ws.cnt, count_out, capacity);
+    if (i > 0)
+      PGDVS_LAUNCH("agg_mark", agg_mark_kernel, dim3(2048), dim3(256), 0, st, out, count_out, pj, H, W, i,
+                   ws.occ);
+    PGDVS_LAUNCH("agg_count", agg_count_kernel, dim3(nb), dim3(kAggBlock), 0, st, mask_i, ws.occ, i, (int)P,
+                 ws.block_counts);
+    PGDVS_LAUNCH("agg_scan", agg_scan_kernel, dim3(1), dim3(1024), 0, st, ws.block_counts, nb, count_out,
+                 ws.append_base, capacity);
+    PGDVS_LAUNCH("agg_append", agg_append_kernel, dim3(nb), dim3(kAggBlock), 0, st, mask_i, ws.occ, i,
+                 (int)P, ws.block_counts, cam, W, depths + (size_t)i * P, rgbs + (size_t)i * P * 3, out,
+                 ws.append_base, capacity);
   }
   return check_launch("static_aggregate");
 }

@@ -513,20 +513,82 @@ grid_query_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ 
   }
 }
 
-// Exact scan of ALL points for the queries the ring search gave up on.  One 1024-thread
-// workgroup per query: each of the 16 waves scans a strided share of the points with its own
-// best-list; the lists meet in LDS and wave 0 merges them.
-__global__ void __launch_bounds__(1024)
+// Exact scan of ALL points for the queries the ring search gave up on, split over many
+// workgroups: work item (query f, slice s) -- a 256-thread workgroup scans slice s of the
+// point array (each of its 4 waves a strided share) and leaves the slice's 64 smallest
+// distances in global memory; grid_fallback_merge_kernel folds the kFbSlices lists.
+constexpr int kFbSlices = 16;
+constexpr int kFbMaxSliced = 16384;  // queries beyond this many use the one-workgroup scan
+
+__global__ void __launch_bounds__(256)
 grid_fallback_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted, int K,
                      const int32_t *__restrict__ fb_count, const int32_t *__restrict__ fb_list,
-                     const float *__restrict__ fb_bound, float *__restrict__ avg_out) {
+                     const float *__restrict__ fb_bound, float *__restrict__ fb_partial) {
+  __shared__ float s_best[4][64];
+  const int n = gp->n;
+  const int nfb = *fb_count;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int KK = K + 1;
+  const int slice_len = ((n + kFbSlices - 1) / kFbSlices + 255) / 256 * 256;
+  const int nsl = nfb < kFbMaxSliced ? nfb : kFbMaxSliced;
+  for (int item = blockIdx.x; item < nsl * kFbSlices; item += gridDim.x) {
+    const int f = item / kFbSlices, sl = item - f * kFbSlices;
+    const float4 qp = sorted[fb_list[f]];
+    const float bound = fb_bound[f];
+    BestList b;
+    b.best = __builtin_inff();
+    b.mx = __builtin_inff();
+    bool first = true;
+    const int s_beg = sl * slice_len;
+    const int s_end = s_beg + slice_len < n ? s_beg + slice_len : n;
+    for (int j0 = s_beg + wave * 256; j0 < s_end; j0 += 4 * 256) {
+      int e = j0 + 256 < s_end ? j0 + 256 : s_end;
+      scan_range(b, first, sorted, j0, e, qp.x, qp.y, qp.z, KK, lane, bound);
+    }
+    __syncthreads();
+    s_best[wave][lane] = b.best;
+    __syncthreads();
+    if (wave == 0) {
+      for (int w = 1; w < 4; ++w) best_insert_batch(b, s_best[w][lane], true, KK, lane);
+      fb_partial[(size_t)item * 64 + lane] = b.best;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+grid_fallback_merge_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted, int K,
+                           const int32_t *__restrict__ fb_count, const int32_t *__restrict__ fb_list,
+                           const float *__restrict__ fb_partial, float *__restrict__ avg_out) {
+  const int n = gp->n;
+  const int nfb = *fb_count;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int KK = K + 1;
+  const int nsl = nfb < kFbMaxSliced ? nfb : kFbMaxSliced;
+  for (int f = blockIdx.x * 4 + wave; f < nsl; f += gridDim.x * 4) {
+    BestList b;
+    b.best = fb_partial[((size_t)f * kFbSlices) * 64 + lane];  // slice 0 is already sorted
+    b.mx = readlane_f(b.best, KK - 1);
+    for (int sl = 1; sl < kFbSlices; ++sl)
+      best_insert_batch(b, fb_partial[((size_t)f * kFbSlices + sl) * 64 + lane], true, KK, lane);
+    knn_finish(b.best, K, n, lane, __float_as_int(sorted[fb_list[f]].w), avg_out);
+  }
+}
+
+// overflow path: more open queries than kFbMaxSliced (degenerate clouds) -- one 1024-thread
+// workgroup per query scans everything
+__global__ void __launch_bounds__(1024)
+grid_fallback_tail_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted, int K,
+                          const int32_t *__restrict__ fb_count, const int32_t *__restrict__ fb_list,
+                          const float *__restrict__ fb_bound, float *__restrict__ avg_out) {
   __shared__ float s_best[16][64];
   const int n = gp->n;
   const int nfb = *fb_count;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int KK = K + 1;
-  for (int f = blockIdx.x; f < nfb; f += gridDim.x) {
+  for (int f = kFbMaxSliced + blockIdx.x; f < nfb; f += gridDim.x) {
     const float4 qp = sorted[fb_list[f]];
     const float bound = fb_bound[f];
     BestList b;
@@ -555,6 +617,7 @@ struct GridWs {
   float4 *sorted;
   int32_t *fb_count, *fb_list;
   float *fb_bound;
+  float *fb_partial;  // [kFbMaxSliced][kFbSlices][64]
   int32_t *stats;  // [16] ring histogram, filled only when PGDVS_KNN_STATS=1 (diagnostics)
   int64_t total_bytes;
 };
@@ -587,6 +650,8 @@ static GridWs grid_ws_layout(void *base, int64_t capacity) {
   off += align_up((capacity > 0 ? capacity : 1) * 4, 256);
   w.fb_bound = reinterpret_cast<float *>(p + off);
   off += align_up((capacity > 0 ? capacity : 1) * 4, 256);
+  w.fb_partial = reinterpret_cast<float *>(p + off);
+  off += align_up((int64_t)kFbMaxSliced * kFbSlices * 64 * 4, 256);
   w.total_bytes = off;
   return w;
 }
@@ -647,8 +712,12 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   PGDVS_LAUNCH("knn_grid_query", grid_query_kernel, dim3(gq), dim3(256), 0, st, ws.gp, ws.sorted,
                ws.cell_start, K, avg_out, stats, kRingCap, getenv("PGDVS_KNN_ABL") ? atoi(getenv("PGDVS_KNN_ABL")) : 0,
                ws.fb_count, ws.fb_list, ws.fb_bound);
-  PGDVS_LAUNCH("knn_grid_fallback", grid_fallback_kernel, dim3(512), dim3(1024), 0, st, ws.gp, ws.sorted, K,
-               ws.fb_count, ws.fb_list, ws.fb_bound, avg_out);
+  PGDVS_LAUNCH("knn_grid_fallback", grid_fallback_kernel, dim3(4096), dim3(256), 0, st, ws.gp, ws.sorted, K,
+               ws.fb_count, ws.fb_list, ws.fb_bound, ws.fb_partial);
+  PGDVS_LAUNCH("knn_grid_fallback_merge", grid_fallback_merge_kernel, dim3(256), dim3(256), 0, st, ws.gp,
+               ws.sorted, K, ws.fb_count, ws.fb_list, ws.fb_partial, avg_out);
+  PGDVS_LAUNCH("knn_grid_fallback_tail", grid_fallback_tail_kernel, dim3(256), dim3(1024), 0, st, ws.gp,
+               ws.sorted, K, ws.fb_count, ws.fb_list, ws.fb_bound, avg_out);
   return check_launch("knn_grid");
 }
 

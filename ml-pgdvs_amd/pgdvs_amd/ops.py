@@ -33,6 +33,19 @@ def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def _rows(t: torch.Tensor, name: str) -> torch.Tensor:
+    """2-D fp32 GPU tensor whose rows are contiguous (row stride arbitrary): views such as
+    ``cloud[:, 3:]`` are passed to the kernels as (pointer, row stride) without a copy."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise PgdvsHipError(f"{name}: expected a GPU tensor (no CPU fallback)")
+    assert t.ndim == 2 and t.shape[1] >= 3, (name, t.shape)
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.shape[0] > 0 and t.stride(1) != 1:
+        t = t.contiguous()
+    return t
+
+
 def _ptr(t):
     return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
 
@@ -205,11 +218,10 @@ def points_raster(pts, feat, cam_tgt, radius: float, K: int, H: int, W: int, *, 
                   want_fragments: bool = False, rgb_planar: bool = False, want_rgb: bool = True):
     """pts[N,>=3] (xyz in the first 3 columns of each row), feat[N,>=3] rows.
     Returns dict(rgb, mask[, idx, zbuf, dist2])."""
-    p = _req(pts, torch.float32, "pts")
-    assert p.ndim == 2 and p.shape[1] >= 3, p.shape
+    p = _rows(pts, "pts")
     n = p.shape[0]
     dev = p.device
-    ft = _req(feat, torch.float32, "feat") if feat is not None else None
+    ft = _rows(feat, "feat") if feat is not None else None
     cam = _req(cam_tgt, torch.float32, "cam_tgt")
     idx = torch.empty((H, W, K), dtype=torch.int64, device=dev) if want_fragments else None
     zbuf = torch.empty((H, W, K), dtype=torch.float32, device=dev) if want_fragments else None
@@ -221,7 +233,8 @@ def points_raster(pts, feat, cam_tgt, radius: float, K: int, H: int, W: int, *, 
     lib = _lib.load()
     ws = _ws(lib.pgdvs_points_raster_workspace_bytes(n, H, W, float(radius)), dev)
     check(lib.pgdvs_points_raster(
-        _ptr(p), p.stride(0), _ptr(ft), ft.stride(0) if ft is not None else 0, n, _ptr(n_points_dev), _ptr(cam),
+        _ptr(p), p.stride(0) if n else 3, _ptr(ft), ft.stride(0) if (ft is not None and n) else 3, n,
+        _ptr(n_points_dev), _ptr(cam),
         float(radius), int(K), H, W, _ptr(idx), _ptr(zbuf), _ptr(d2), _ptr(rgb), int(bool(rgb_planar)), _ptr(mask),
         _ptr(ws), ws.numel(), _stream()), "pgdvs_points_raster")
     return {"rgb": rgb, "mask": mask, "idx": idx, "zbuf": zbuf, "dist2": d2}
@@ -232,7 +245,7 @@ def static_aggregate(rgbs, depths, dyn_masks, K3s, c2ws, capacity: int | None = 
     K3s[S,3,3], c2ws[S,4,4] float64 numpy (host).  -> (cloud[capacity,6], count[int64 dev])."""
     r = _req(rgbs, torch.float32, "rgbs")
     d = _req(depths, torch.float32, "depths")
-    m = _req(dyn_masks.to(torch.uint8) if dyn_masks.dtype == torch.bool else dyn_masks, torch.uint8, "dyn_masks")
+    m = _req(dyn_masks.contiguous().view(torch.uint8) if dyn_masks.dtype == torch.bool else dyn_masks, torch.uint8, "dyn_masks")
     S, H, W = d.shape
     K3 = np.ascontiguousarray(K3s, dtype=np.float64).reshape(S, 9)
     c2w = np.ascontiguousarray(c2ws, dtype=np.float64).reshape(S, 16)

@@ -96,7 +96,7 @@ def main():
     # ---------------- synthetic, seeded inputs (no datasets offline) -> resident in HBM
     video = synth.make_video(S, H, W, seed=1234)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    rgbs, depths, masks = T(video["rgbs"]), T(video["depths"]), T(video["dyn_masks"])
+    rgbs, depths, masks = T(video["rgbs"]), T(video["depths"]), T(video["dyn_masks"]).view(torch.uint8)
     K3s, c2ws = video["K3s"], video["c2ws"]
     n_views = max(1, min(args.views, S - 1))
     view_ids = [int(round(j * (S - 2) / max(n_views - 1, 1))) for j in range(n_views)]
@@ -111,8 +111,12 @@ def main():
     model = PGDVSRenderer(cfg, render_cfg=rc, softsplat_metric_abs_alpha=100.0).to(dev).eval()
     cap = S * H * W
 
+    side = torch.cuda.Stream(device=dev)
+
     def step(j):
         data = dict(views[(j + rank) % n_views])
+        # dynamic-branch geometry on a side stream, overlapping the static aggregation + raster
+        data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=side)
         cloud, cnt = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=cap)
         data["st_pcl_rgb"] = cloud[None]
         data["st_pcl_rgb_count"] = cnt

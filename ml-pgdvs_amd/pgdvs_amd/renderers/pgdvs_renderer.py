@@ -26,6 +26,7 @@ class PGDVSRenderer(PGDVSBaseRenderer):
         self.flag_debug = flag_debug
         self.static_renderer = None
         self.refine_renderer = None
+        self._side_stream = None
 
         if self.cfg.static_renderer._target_ is not None:
             self.static_renderer = instantiate(self.cfg.static_renderer)
@@ -47,6 +48,16 @@ class PGDVSRenderer(PGDVSBaseRenderer):
         ray_batch = self.prepare_ray_batch(data=data, B=n_b, H=orig_h, W=orig_w,
                                            render_stride=render_cfg.render_stride, render_cfg=render_cfg)
         ret_dict = {}
+        # The dynamic branch's geometry (unproject, flow warp, kNN filter, projection) does not
+        # depend on the static branch: enqueue it on a side HIP stream so it overlaps with the
+        # static renderer; the splat + composite joins both.  Callers may pass an already
+        # started preparation through data["_dyn_prepared"].
+        prepared = data.get("_dyn_prepared", None)
+        if prepared is None and data["rgb_src_temporal"].is_cuda and render_cfg.dyn_render_type != "mesh" \
+                and not (render_cfg.pure_gnt or render_cfg.pure_gnt_with_dyn_mask):
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=data["rgb_src_temporal"].device)
+            prepared = self.dyn_renderer.prepare(data, render_cfg, stream=self._side_stream)
         if isinstance(self.static_renderer, GNTRenderer):
             if "rgb_gnt" in data:
                 static_rgb = data["rgb_gnt"].permute(0, 3, 1, 2)
@@ -65,7 +76,8 @@ class PGDVSRenderer(PGDVSBaseRenderer):
             raise TypeError(type(self.static_renderer))
 
         render_dyn_rgb, render_dyn_mask, render_dyn_info = self.dyn_renderer(
-            data, ray_batch, render_cfg, for_debug=for_debug, disable_tqdm=disable_tqdm, static_rgb=static_rgb)
+            data, ray_batch, render_cfg, for_debug=for_debug, disable_tqdm=disable_tqdm, static_rgb=static_rgb,
+            prepared=prepared)
 
         ret_dict["render_dyn_rgb"] = render_dyn_rgb
         ret_dict["render_dyn_mask"] = render_dyn_mask

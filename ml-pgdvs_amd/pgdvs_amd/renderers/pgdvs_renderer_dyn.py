@@ -13,6 +13,25 @@ from .. import ops
 from .pgdvs_renderer_base import PGDVSBaseRenderer
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _tensors_of(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_of(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_of(v)
+
+
 class PGDVSDynamicRenderer(PGDVSBaseRenderer):
     def __init__(self, *, cfg, softsplat_metric_abs_alpha=100.0, proj_func=None, local_rank=0, use_tracker=False):
         super().__init__()
@@ -76,10 +95,40 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
     def render_with_track(self):
         raise NotImplementedError
 
+    # -- A2..A5 for a whole batch, optionally on a side stream ---------------------
+    def prepare(self, data, render_cfg, stream=None):
+        """Geometry half of forward(): camera blocks + compute_dyn_pcl for every batch item.
+        It does not depend on the static branch, so PGDVSRenderer runs it on a side HIP stream
+        while the static renderer works on the current one.  Returns an opaque dict that
+        forward(..., prepared=...) consumes; the caller must make the consuming stream wait
+        for ``prepared["stream"]`` (forward does)."""
+        cur = torch.cuda.current_stream()
+        if stream is not None:
+            stream.wait_stream(cur)
+        ctx = torch.cuda.stream(stream) if stream is not None else _NullCtx()
+        with ctx:
+            n_b = data["rgb_src_temporal"].shape[0]
+            dyn_type = render_cfg.dyn_render_type
+            cams_src = ops.cam_prep(data["flat_cam_src_temporal"])  # [B,2,80]
+            cams_tgt = ops.cam_prep(data["flat_cam_tgt"])  # [B,80]
+            times = torch.cat([data["time_src_temporal"][:, :2].float(), data["time_tgt"][:, :1].float()], dim=1).contiguous()
+            items = []
+            for i_b in range(n_b):
+                items.append(self.compute_dyn_pcl(
+                    dyn_mask_1=data["dyn_mask_src_temporal"][i_b, 0, ..., 0],
+                    rgb_1=data["rgb_src_temporal"][i_b, 0], depth_1=data["depth_src_temporal"][i_b, 0, ..., 0],
+                    flow_12=data["flow_fwd"][i_b], flow_12_occ_mask=data["flow_fwd_occ_mask"][i_b, ..., 0],
+                    rgb_2=data["rgb_src_temporal"][i_b, 1], depth_2=data["depth_src_temporal"][i_b, 1, ..., 0],
+                    cam_1=cams_src[i_b, 0], cam_2=cams_src[i_b, 1], cam_tgt=cams_tgt[i_b], times=times[i_b],
+                    render_cfg=render_cfg, need_points=(dyn_type == "pcl")))
+        return {"items": items, "cams_tgt": cams_tgt, "stream": stream}
+
     # -- A8 -----------------------------------------------------------------
-    def forward(self, data, ray_batch, render_cfg, for_debug=False, disable_tqdm=False, static_rgb=None):
+    def forward(self, data, ray_batch, render_cfg, for_debug=False, disable_tqdm=False, static_rgb=None,
+                prepared=None):
         """:63-257.  ``static_rgb`` [B,3,h,w] (optional) lets the splat epilogue also emit the
-        static/dynamic composite of PGDVSRenderer.forward (:169-178) in the same pass."""
+        static/dynamic composite of PGDVSRenderer.forward (:169-178) in the same pass.
+        ``prepared``: result of prepare() (geometry already enqueued, possibly on a side stream)."""
         n_b, _, orig_h, orig_w, _ = data["rgb_src_temporal"].shape
         dev = data["rgb_src_temporal"].device
         assert self.cfg.rgb_range == "0_1", f"{self.cfg.rgb_range}"
@@ -89,9 +138,13 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
         if dyn_type == "mesh":
             self.render_dyn_mesh()
 
-        cams_src = ops.cam_prep(data["flat_cam_src_temporal"])  # [B,2,80]
-        cams_tgt = ops.cam_prep(data["flat_cam_tgt"])  # [B,80]
-        times = torch.cat([data["time_src_temporal"][:, :2].float(), data["time_tgt"][:, :1].float()], dim=1).contiguous()
+        if prepared is None:
+            prepared = self.prepare(data, render_cfg)
+        if prepared["stream"] is not None:
+            torch.cuda.current_stream().wait_stream(prepared["stream"])
+            for t in _tensors_of(prepared):
+                t.record_stream(torch.cuda.current_stream())
+        cams_tgt = prepared["cams_tgt"]
 
         render_h, render_w = ray_batch["render_h"], ray_batch["render_w"]
         same_res = (render_h == orig_h) and (render_w == orig_w)
@@ -106,13 +159,7 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
 
         dyn_rgbs, dyn_masks, combs = [], [], []
         for i_b in range(n_b):
-            flow_1_to_tgt, valid_mask, info = self.compute_dyn_pcl(
-                dyn_mask_1=data["dyn_mask_src_temporal"][i_b, 0, ..., 0],
-                rgb_1=data["rgb_src_temporal"][i_b, 0], depth_1=data["depth_src_temporal"][i_b, 0, ..., 0],
-                flow_12=data["flow_fwd"][i_b], flow_12_occ_mask=data["flow_fwd_occ_mask"][i_b, ..., 0],
-                rgb_2=data["rgb_src_temporal"][i_b, 1], depth_2=data["depth_src_temporal"][i_b, 1, ..., 0],
-                cam_1=cams_src[i_b, 0], cam_2=cams_src[i_b, 1], cam_tgt=cams_tgt[i_b], times=times[i_b],
-                render_cfg=render_cfg, need_points=(dyn_type == "pcl"))
+            flow_1_to_tgt, valid_mask, info = prepared["items"][i_b]
             if dyn_type == "softsplat":
                 rgb, mask, c, cs, cd = ops.dyn_splat_composite(
                     data["rgb_src_temporal"][i_b, 0], data["rgb_src_temporal"][i_b, 1], data["flow_fwd"][i_b],
@@ -127,8 +174,8 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
             dyn_rgbs.append(rgb)
             dyn_masks.append(mask[None])
 
-        render_dyn_rgb = torch.stack(dyn_rgbs, 0)  # [B,3,H,W]
-        render_dyn_mask = torch.stack(dyn_masks, 0)  # [B,1,H,W]
+        render_dyn_rgb = torch.stack(dyn_rgbs, 0) if n_b > 1 else dyn_rgbs[0][None]  # [B,3,H,W]
+        render_dyn_mask = torch.stack(dyn_masks, 0) if n_b > 1 else dyn_masks[0][None]  # [B,1,H,W]
 
         # no tracker: the track images are zeros, so the merge of :229-235 is the identity on
         # the {0,1}-valued closest-frame mask
@@ -148,9 +195,10 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
             "temporal_track_mask": render_track_mask,
         }
         if fuse_static:
-            info_dict["combined_rgb"] = torch.stack([c[0] for c in combs], 0)
-            info_dict["combined_rgb_static"] = torch.stack([c[1] for c in combs], 0)
-            info_dict["combined_rgb_dyn"] = torch.stack([c[2] for c in combs], 0)
+            st = (lambda k: torch.stack([c[k] for c in combs], 0)) if n_b > 1 else (lambda k: combs[0][k][None])
+            info_dict["combined_rgb"] = st(0)
+            info_dict["combined_rgb_static"] = st(1)
+            info_dict["combined_rgb_dyn"] = st(2)
         return render_dyn_rgb_final, render_dyn_mask_final, info_dict
 
     def resize_rgb_mask(self, rgb, mask, render_h, render_w):

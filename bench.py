@@ -33,6 +33,21 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def measured_traffic(kernel, H, W, S):
+    """HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same
+    command (profiles/r01_hbm_traffic.json, made by tools/make_profile_summary.py); None when
+    the workload differs from the profiled one."""
+    f = ROOT / "profiles" / "r01_hbm_traffic.json"
+    if not f.exists() or (H, W, S) != (1080, 1920, 24):
+        return None
+    import re
+    ks = json.loads(f.read_text())["kernels"]
+    for name, v in ks.items():
+        if re.sub(r"<.*>", "", name).replace("_kernel", "") == kernel:
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +83,10 @@ def algorithmic_bytes(name, H, W, S, n_static, n_dyn, K):
         "dyn_splat_scatter": P * (12 + 8 + 8 + 4 + 12 + 4 * 12) + P * 4 * 4 + n_dyn * 4 * 4 * 5,
         "dyn_splat_finish": P * (20 + 12 + 16 + 36),
         "knn_mean_dist": n_dyn * 12 + n_dyn * 4,
+        "grid_query": n_dyn * 16 + n_dyn * 4,
+        "grid_fallback": n_dyn * 16,
+        "grid_count": n_dyn * 16, "grid_fill": n_dyn * 32, "stat_pass": n_dyn * 4,
+        "agg_count": 3 * P,
         "gather_rows": n_dyn * (4 + 12 + 12),
         "scatter_keep": n_dyn * 6,
     }
@@ -180,7 +199,7 @@ def main():
             ab = algorithmic_bytes(dom, H, W, S, n_static, n_dyn, K)
             ach = ab / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dom, H, W, S),
                         "alg_bytes_per_launch": ab, "avg_launch_ms": kernels[dom]["avg_ms"]}
 
     # ---------------- CPU baseline: the oracle (port of the reference algorithm) on host cores

@@ -339,9 +339,9 @@ PGDVS_API int pgdvs_outlier_flags(const float *avg, const int32_t *count, int64_
     return PGDVS_ERR_LAUNCH;
   }
   for (int pass = 0; pass < 3; ++pass) {
-    PGDVS_LAUNCH("outlier_stat_pass", stat_pass_kernel, dim3(kStatBlocks), dim3(kStatThreads), 0, st, avg,
+    PGDVS_LAUNCH("stat_pass", stat_pass_kernel, dim3(kStatBlocks), dim3(kStatThreads), 0, st, avg,
                  count, pass, state, partials, ghist);
-    PGDVS_LAUNCH("outlier_stat_select", stat_select_kernel, dim3(1), dim3(256), 0, st, count, pass,
+    PGDVS_LAUNCH("stat_select", stat_select_kernel, dim3(1), dim3(256), 0, st, count, pass,
                  kStatBlocks, partials, ghist, state, std_thres, thres_out);
   }
   if (capacity > 0) {

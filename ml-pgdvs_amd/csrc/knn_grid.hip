@@ -677,29 +677,29 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   unsigned gbb = gpts < 128 ? gpts : 128;
   const char *etc = getenv("PGDVS_KNN_PER_CELL");  // tuning knob (any value gives exact results)
   const float target = etc && atof(etc) >= 1.0 ? (float)atof(etc) : kTargetPerCellDefault * (float)(K + 1) / 51.0f;
-  PGDVS_LAUNCH("knn_grid_bbox", grid_bbox_kernel, dim3(gbb), dim3(256), 0, st, pts, count, ws.bbox);
+  PGDVS_LAUNCH("grid_bbox", grid_bbox_kernel, dim3(gbb), dim3(256), 0, st, pts, count, ws.bbox);
   // trial grid from the bounding box, measure the occupancy, then the final grid
-  PGDVS_LAUNCH("knn_grid_params", grid_params_kernel, dim3(1), dim3(64), 0, st, ws.bbox, count,
+  PGDVS_LAUNCH("grid_params", grid_params_kernel, dim3(1), dim3(64), 0, st, ws.bbox, count,
                (const unsigned long long *)nullptr, ws.gp, target);
-  PGDVS_LAUNCH("knn_grid_zero", grid_zero_kernel, dim3(2048), dim3(256), 0, st, ws.gp, ws.cell_count,
+  PGDVS_LAUNCH("grid_zero", grid_zero_kernel, dim3(2048), dim3(256), 0, st, ws.gp, ws.cell_count,
                (int32_t *)nullptr);
-  PGDVS_LAUNCH("knn_grid_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
+  PGDVS_LAUNCH("grid_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
                ws.cell_count);
-  PGDVS_LAUNCH("knn_grid_occupied", grid_occupied_kernel, dim3(1024), dim3(256), 0, st, ws.cell_count,
+  PGDVS_LAUNCH("grid_occupied", grid_occupied_kernel, dim3(1024), dim3(256), 0, st, ws.cell_count,
                ws.gp, ws.sumsq);
-  PGDVS_LAUNCH("knn_grid_params", grid_params_kernel, dim3(1), dim3(64), 0, st, ws.bbox, count,
+  PGDVS_LAUNCH("grid_params", grid_params_kernel, dim3(1), dim3(64), 0, st, ws.bbox, count,
                (const unsigned long long *)ws.sumsq, ws.gp, target);
-  PGDVS_LAUNCH("knn_grid_zero", grid_zero_kernel, dim3(2048), dim3(256), 0, st, ws.gp, ws.cell_count,
+  PGDVS_LAUNCH("grid_zero", grid_zero_kernel, dim3(2048), dim3(256), 0, st, ws.gp, ws.cell_count,
                ws.cursor);
-  PGDVS_LAUNCH("knn_grid_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
+  PGDVS_LAUNCH("grid_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
                ws.cell_count);
   const int nb = kGridMaxCells / kScanTile;
-  PGDVS_LAUNCH("knn_grid_scan", grid_scan_blocks_kernel, dim3(nb), dim3(1024), 0, st, ws.cell_count, ws.gp,
+  PGDVS_LAUNCH("grid_scan_blocks", grid_scan_blocks_kernel, dim3(nb), dim3(1024), 0, st, ws.cell_count, ws.gp,
                ws.block_sums);
-  PGDVS_LAUNCH("knn_grid_scan", grid_scan_sums_kernel, dim3(1), dim3(1024), 0, st, ws.block_sums, nb);
-  PGDVS_LAUNCH("knn_grid_scan", grid_scan_apply_kernel, dim3(nb), dim3(1024), 0, st, ws.cell_count, ws.gp,
+  PGDVS_LAUNCH("grid_scan_sums", grid_scan_sums_kernel, dim3(1), dim3(1024), 0, st, ws.block_sums, nb);
+  PGDVS_LAUNCH("grid_scan_apply", grid_scan_apply_kernel, dim3(nb), dim3(1024), 0, st, ws.cell_count, ws.gp,
                ws.block_sums, ws.cell_start);
-  PGDVS_LAUNCH("knn_grid_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
+  PGDVS_LAUNCH("grid_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
                ws.cell_start, ws.cursor, ws.sorted);
   const char *env = getenv("PGDVS_KNN_STATS");
   int32_t *stats = (env && env[0] == '1') ? ws.stats : nullptr;
@@ -709,14 +709,14 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
     return PGDVS_ERR_LAUNCH;
   }
   const unsigned gq = (unsigned)(cdiv(capacity, 4) < 256 * 8 ? cdiv(capacity, 4) : 256 * 8);
-  PGDVS_LAUNCH("knn_grid_query", grid_query_kernel, dim3(gq), dim3(256), 0, st, ws.gp, ws.sorted,
+  PGDVS_LAUNCH("grid_query", grid_query_kernel, dim3(gq), dim3(256), 0, st, ws.gp, ws.sorted,
                ws.cell_start, K, avg_out, stats, kRingCap, getenv("PGDVS_KNN_ABL") ? atoi(getenv("PGDVS_KNN_ABL")) : 0,
                ws.fb_count, ws.fb_list, ws.fb_bound);
-  PGDVS_LAUNCH("knn_grid_fallback", grid_fallback_kernel, dim3(4096), dim3(256), 0, st, ws.gp, ws.sorted, K,
+  PGDVS_LAUNCH("grid_fallback", grid_fallback_kernel, dim3(4096), dim3(256), 0, st, ws.gp, ws.sorted, K,
                ws.fb_count, ws.fb_list, ws.fb_bound, ws.fb_partial);
-  PGDVS_LAUNCH("knn_grid_fallback_merge", grid_fallback_merge_kernel, dim3(256), dim3(256), 0, st, ws.gp,
+  PGDVS_LAUNCH("grid_fallback_merge", grid_fallback_merge_kernel, dim3(256), dim3(256), 0, st, ws.gp,
                ws.sorted, K, ws.fb_count, ws.fb_list, ws.fb_partial, avg_out);
-  PGDVS_LAUNCH("knn_grid_fallback_tail", grid_fallback_tail_kernel, dim3(256), dim3(1024), 0, st, ws.gp,
+  PGDVS_LAUNCH("grid_fallback_tail", grid_fallback_tail_kernel, dim3(256), dim3(1024), 0, st, ws.gp,
                ws.sorted, K, ws.fb_count, ws.fb_list, ws.fb_bound, avg_out);
   return check_launch("knn_grid");
 }

@@ -93,3 +93,26 @@ def test_static_aggregation(golden_dir):
     assert st.shape == g["st_pcl_rgb"].shape  # same point set size => same occupancy decisions
     np.testing.assert_allclose(st[:, :3], g["st_pcl_rgb"][:, :3], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(st[:, 3:], g["st_pcl_rgb"][:, 3:], rtol=0, atol=1e-6)
+
+
+# ---------------------------------------------------------------- GNT rows (A13-A15)
+@pytest.mark.parametrize("tag", ["nomask", "dynmask"])
+def test_gnt_oracle_vs_reference(golden_dir, tag):
+    from oracle import gnt_oracle as G
+
+    g = _load(golden_dir, "gnt_small.npz")
+    Wt = {k[2:]: v for k, v in g.items() if k.startswith("w_")}
+    R = g["ray_o"].shape[0]
+    pts, z = G.sample_along_camera_ray(g["ray_o"], g["ray_d"], np.broadcast_to(g["depth_range"], (R, 2)), int(g["Ss"]))
+    np.testing.assert_allclose(pts, g["pts"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(z, g["z_vals"], rtol=1e-6, atol=1e-6)
+    pr = G.projector_compute(g["pts"], g["cam_tgt"], g["src_rgbs"][0], g["cams_src"], g["featmaps"],
+                             g["inv_masks"][0] if tag == "dynmask" else None)
+    assert np.array_equal(pr["mask_inbound"], g[f"{tag}_mask_inbound"])  # in-bounds / in-front tests: exact
+    assert np.array_equal(pr["mask"], g[f"{tag}_mask"])
+    np.testing.assert_allclose(pr["rgb_feat"], g[f"{tag}_rgb_feat"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(pr["ray_diff"], g[f"{tag}_ray_diff"], rtol=0, atol=5e-5)
+    out, ex = G.gnt_forward(Wt, g[f"{tag}_rgb_feat"], g[f"{tag}_ray_diff"], g[f"{tag}_mask"], g["pts"], g["ray_d"])
+    np.testing.assert_allclose(out, g[f"{tag}_out"], rtol=0, atol=1e-4)
+    for k in ex:
+        np.testing.assert_allclose(ex[k], g[f"{tag}_{k}"], rtol=0, atol=1e-4, err_msg=k)

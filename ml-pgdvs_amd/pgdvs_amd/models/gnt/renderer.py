@@ -1,24 +1,86 @@
-"""Mirror of ``pgdvs.models.gnt.renderer.BaseRenderer`` (pgdvs/models/gnt/renderer.py:21-177).
+"""Mirror of ``pgdvs.models.gnt.renderer.BaseRenderer`` (pgdvs/models/gnt/renderer.py:21-485):
+the GNT static-scene renderer -- feature extraction on all source views, then per chunk of
+rays: sampling + epipolar gathering (HIP, A13), view/ray transformer aggregation (A14) and
+the per-ray reductions (A15).  Same constructor (``model_cfg`` with a ``_target_``) and the
+same ``forward(ray_batch=..., chunk_size=..., ...)`` contract and output dictionary."""
+from collections import OrderedDict
 
-Round-1 state: the class exists so that ``static_renderer=gnt`` configurations construct
-and so that ``PGDVSRenderer`` can bind ``.projector.compute_projections``
-(pgdvs_renderer.py:78); the reference's own ``data["rgb_gnt"]`` hook
-(pgdvs_renderer.py:120-122) supplies the static image.  Running the GNT network itself
-(ResUNet features + view/ray transformer aggregation, rows A13-A16 of SURVEY.md 8a) is
-not built yet and raises.
-"""
 import torch
 
+from ... import ops
+from ...instantiate import instantiate
 from .projector import Projector
 
 
 class BaseRenderer(torch.nn.Module):
-    def __init__(self, model_cfg=None):
+    def __init__(self, *, model_cfg=None):
         super().__init__()
-        self.model_cfg = model_cfg
         self.projector = Projector()
+        self.model = None
+        if model_cfg is not None and (model_cfg.get("_target_", None) if hasattr(model_cfg, "get") else None):
+            self.model = instantiate(model_cfg)
+        elif model_cfg is not None:
+            from .model import GNTModel
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError(
-            "GNT ray-feature aggregation (A13-A16) is not built yet; pass the static image "
-            "through data['rgb_gnt'] (pgdvs_renderer.py:120-122) or use static_renderer=geo")
+            kw = {k: v for k, v in dict(model_cfg).items() if k != "_target_"}
+            self.model = GNTModel(**kw)
+
+    def forward(self, *, ray_batch, chunk_size, inv_uniform=False, n_coarse_samples_per_ray, n_fine_samples_per_ray=0,
+                flag_deterministic=False, use_dyn_mask=False, render_stride=1, ret_view_entropy=False, ret_view_std=False,
+                debug_epipolar=False, disable_tqdm=False):
+        if self.model is None:
+            raise RuntimeError("BaseRenderer was built without a model_cfg: no GNT network to run")
+        if n_fine_samples_per_ray > 0:
+            raise NotImplementedError("importance re-sampling (n_fine_samples_per_ray > 0) is not built; the benchmarks use 0")
+        if not flag_deterministic:
+            raise NotImplementedError("stochastic ray sampling is a training-time feature; PGDVS renders with flag_deterministic=True")
+        src_rgbs = ray_batch["src_rgbs"]  # [B,V,H,W,3]
+        B, V, H, W, _ = src_rgbs.shape
+        n_rays = ray_batch["ray_o"].shape[0]
+        feats = self.model.feature_net(src_rgbs.permute(0, 1, 4, 2, 3).reshape(B * V, 3, H, W))[0]
+        feats_cl = feats.permute(0, 2, 3, 1).contiguous().reshape((B, V) + tuple(feats.shape[2:]) + (feats.shape[1],))
+        cams_src = ops.cam_prep(ray_batch["src_cameras"])  # [B,V,80]
+        cams_tgt = ops.cam_prep(ray_batch["camera"])  # [B,80]
+        per_ray_range = bool(ray_batch["depth_range_per_ray"])
+        inv_masks = ray_batch["src_invalid_masks"][..., 0] if use_dyn_mask else None  # [B,V,H,W]
+        rays_per_view = n_rays // B
+        if chunk_size < 0:
+            chunk_size = n_rays
+        outs = OrderedDict()
+        for c0 in range(0, n_rays, chunk_size):
+            c1 = min(c0 + chunk_size, n_rays)
+            # a chunk may straddle batch items (true batching, renderer.py:414-485)
+            pieces = []
+            b0, b1 = c0 // rays_per_view, (c1 - 1) // rays_per_view
+            for b in range(b0, b1 + 1):
+                lo, hi = max(c0, b * rays_per_view), min(c1, (b + 1) * rays_per_view)
+                pieces.append(self._render_rays(
+                    ray_o=ray_batch["ray_o"][lo:hi], ray_d=ray_batch["ray_d"][lo:hi],
+                    depth_range=ray_batch["depth_range"][lo:hi] if per_ray_range else ray_batch["depth_range"][b:b + 1],
+                    cam_tgt=cams_tgt[b], cams_src=cams_src[b], src_rgbs=src_rgbs[b], feats_cl=feats_cl[b],
+                    inv_masks=None if inv_masks is None else inv_masks[b], n_samples=n_coarse_samples_per_ray,
+                    inv_uniform=inv_uniform, ret_view_entropy=ret_view_entropy, ret_view_std=ret_view_std))
+            for k in pieces[0]:
+                outs.setdefault(k, []).append(pieces[0][k] if len(pieces) == 1 else torch.cat([p[k] for p in pieces], 0))
+        rh = (ray_batch["raw_h"] + render_stride - 1) // render_stride
+        rw = (ray_batch["raw_w"] + render_stride - 1) // render_stride
+        coarse = OrderedDict((k, torch.cat(v, dim=0).reshape((B, rh, rw, -1))) for k, v in outs.items())
+        return OrderedDict([("outputs_coarse", coarse), ("outputs_fine", None)])
+
+    def _render_rays(self, *, ray_o, ray_d, depth_range, cam_tgt, cams_src, src_rgbs, feats_cl, inv_masks, n_samples,
+                     inv_uniform, ret_view_entropy, ret_view_std):
+        """render_rays coarse branch (:207-300) for rays of one batch item."""
+        V = src_rgbs.shape[0]
+        g = ops.gnt_gather(ray_o, ray_d, depth_range, n_samples, inv_uniform, cam_tgt, cams_src, src_rgbs, feats_cl, inv_masks)
+        out, extras = self.model.net_coarse(g["rgb_feat"], g["ray_diff"], g["mask"], g["pts"], ray_d,
+                                            ret_view_entropy=ret_view_entropy, ret_view_std=ret_view_std)
+        rgb, weights = out[:, 0:3], out[:, 3:]
+        ret = {
+            "rgb": rgb, "weights": weights, "depth": torch.sum(weights * g["z_vals"], dim=-1),
+            "inbound_cnt": torch.sum(weights * g["mask_inbound"][..., 0].sum(dim=2) / V, dim=1),
+            "dyn_cnt": torch.sum(weights * g["mask_invalid"][..., 0].sum(dim=2) / V, dim=1),
+        }
+        for k in ("view_entropy", "view_std", "view_std_normalized"):
+            if k in extras:
+                ret[k] = torch.sum(weights[..., None] * extras[k], dim=1)
+        return ret

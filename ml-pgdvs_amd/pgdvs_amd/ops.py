@@ -272,3 +272,45 @@ def combine(static_rgb, dyn_rgb, dyn_mask):
         check(lib.pgdvs_combine(_ptr(st[b]), _ptr(dy[b]), _ptr(mk[b]), H * W, _ptr(outs[0][b]), _ptr(outs[1][b]),
                                 _ptr(outs[2][b]), _stream()), "pgdvs_combine")
     return outs
+
+
+def gnt_gather(ray_o, ray_d, depth_range, n_samples: int, inv_uniform: bool, cam_tgt, cams_src, src_rgbs, featmaps_cl,
+               inv_masks=None):
+    """A13.  ray_o/ray_d[R,3], depth_range[1,2] or [R,2], cams_src[V,80], src_rgbs[V,H,W,3],
+    featmaps_cl[V,hf,wf,C], inv_masks[V,H,W] or None -> dict of [R,S,V,*] tensors."""
+    ro, rd = _req(ray_o, torch.float32, "ray_o"), _req(ray_d, torch.float32, "ray_d")
+    dr = _req(depth_range, torch.float32, "depth_range").reshape(-1, 2)
+    R, S = ro.shape[0], int(n_samples)
+    img = _req(src_rgbs, torch.float32, "src_rgbs")
+    V, H, W, _ = img.shape
+    fm = _req(featmaps_cl, torch.float32, "featmaps_cl")
+    hf, wf, Cc = fm.shape[1], fm.shape[2], fm.shape[3]
+    per_ray = dr.shape[0] != 1
+    assert dr.shape[0] in (1, R), dr.shape
+    im = _req(inv_masks, torch.float32, "inv_masks").reshape(V, H, W) if inv_masks is not None else None
+    dev = ro.device
+    e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    out = {"pts": e(R, S, 3), "z_vals": e(R, S), "rgb_feat": e(R, S, V, 3 + Cc), "ray_diff": e(R, S, V, 4),
+           "mask_inbound": e(R, S, V, 1), "mask_invalid": e(R, S, V, 1), "mask": e(R, S, V, 1)}
+    ct, cs = _req(cam_tgt, torch.float32, "cam_tgt"), _req(cams_src, torch.float32, "cams_src")
+    check(_lib.load().pgdvs_gnt_gather(
+        _ptr(ro), _ptr(rd), _ptr(dr), int(per_ray), R, S, int(bool(inv_uniform)), _ptr(ct), _ptr(cs), V, _ptr(img), H, W,
+        _ptr(fm), hf, wf, Cc, _ptr(im), _ptr(out["pts"]), _ptr(out["z_vals"]), _ptr(out["rgb_feat"]), _ptr(out["ray_diff"]),
+        _ptr(out["mask_inbound"]), _ptr(out["mask_invalid"]), _ptr(out["mask"]), _stream()), "pgdvs_gnt_gather")
+    if im is None:
+        out["mask_invalid"].zero_()
+    return out
+
+
+# ---- GNT view-transformer contraction on MFMA (csrc/gnt_view.hip) ------------------------
+def gnt_view_available(dim: int, n_views: int) -> bool:
+    """True when the fused MFMA view-layer kernel handles this shape (width 64)."""
+    lib = _lib.load()
+    return hasattr(lib, "pgdvs_gnt_view_layer") and dim == 64 and 1 <= n_views <= 64 and _GNT_VIEW_ENABLED
+
+
+_GNT_VIEW_ENABLED = True
+
+
+def gnt_view_layer(layer, q, feat, ray_diff, valid, want_stats):
+    raise NotImplementedError

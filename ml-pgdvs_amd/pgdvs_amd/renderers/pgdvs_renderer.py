@@ -113,16 +113,59 @@ class PGDVSRenderer(PGDVSBaseRenderer):
         return ret_dict["geo_static_rgb"], ret_dict
 
     def forward_st_gnt(self, *, data, ray_batch, render_cfg, disable_tqdm=True):
-        """:203-352 -- delegates to the GNT renderer (raises until rows A13-A16 are built)."""
-        self.static_renderer(ray_batch=ray_batch)
-        raise AssertionError("unreachable")
+        """:203-352 -- run the GNT static renderer and unpack its coarse outputs."""
+        if render_cfg.pure_gnt:
+            assert not render_cfg.gnt_use_dyn_mask
+            assert not render_cfg.gnt_use_masked_spatial_src
+        if render_cfg.pure_gnt_with_dyn_mask:
+            assert render_cfg.gnt_use_dyn_mask
+            assert not render_cfg.gnt_use_masked_spatial_src
+        n_src_spatial = data["rgb_src_temporal"].shape[1]  # sic: the temporal count, as upstream (:212)
+        static_ret = self.static_renderer(
+            ray_batch=ray_batch, chunk_size=render_cfg.chunk_size, inv_uniform=render_cfg.sample_inv_uniform,
+            n_coarse_samples_per_ray=render_cfg.n_coarse_samples_per_ray,
+            n_fine_samples_per_ray=render_cfg.n_fine_samples_per_ray, use_dyn_mask=render_cfg.gnt_use_dyn_mask,
+            flag_deterministic=True, render_stride=render_cfg.render_stride, ret_view_entropy=True, ret_view_std=True,
+            disable_tqdm=disable_tqdm)
+        oc = static_ret["outputs_coarse"]
+        ret = {}
+        for k in ("rgb", "depth", "view_entropy", "view_std", "view_std_normalized", "inbound_cnt"):
+            ret[f"static_coarse_{k}"] = oc[k].permute(0, 3, 1, 2)
+        ret["static_coarse_oob_mask"] = (
+            ret["static_coarse_inbound_cnt"] < (render_cfg.mask_oob_n_proj_thres / n_src_spatial)).float()
+        if render_cfg.gnt_use_dyn_mask:
+            ret["static_coarse_dyn_cnt"] = oc["dyn_cnt"].permute(0, 3, 1, 2)
+            ret["static_coarse_dyn_mask_any"] = (ret["static_coarse_dyn_cnt"] > 0.0).float()
+            ret["static_coarse_dyn_mask_all"] = (ret["static_coarse_dyn_cnt"] == 1.0).float()
+            ret["static_coarse_dyn_mask_thres"] = (
+                ret["static_coarse_dyn_cnt"] >= (render_cfg.mask_invalid_n_proj_thres / n_src_spatial)).float()
+        return ret["static_coarse_rgb"], ret
 
     def prepare_ray_batch(self, *, data, B, H, W, render_stride, render_cfg):
         """:354-417.  Target rays are only materialised for the GNT network; the geometric
         and rgb_gnt paths need just the render size."""
         render_h = (H + render_stride - 1) // render_stride
         render_w = (W + render_stride - 1) // render_stride
-        return {
+        ret = {
             "camera": data["flat_cam_tgt"], "rgb": data.get("rgb_tgt", None), "raw_h": H, "raw_w": W,
             "render_h": render_h, "render_w": render_w, "render_stride": render_stride,
         }
+        if isinstance(self.static_renderer, GNTRenderer) and "rgb_gnt" not in data:
+            tgt_K = data["flat_cam_tgt"][:, 2:18].reshape((B, 4, 4))
+            tgt_c2w = data["flat_cam_tgt"][:, 18:34].reshape((B, 4, 4))
+            ro, rd, uvs, refs, _ = self.get_batched_rays(
+                device=data["rgb_src_temporal"].device, batch_size=B, H=H, W=W, render_stride=render_stride,
+                intrinsics=tgt_K, c2w=tgt_c2w)
+            src_rgbs = data["static_rgb_src_spatial"] if render_cfg.gnt_use_masked_spatial_src else data["rgb_src_spatial"]
+            if data["depth_range"].ndim == 4:
+                depth_range = data["depth_range"][:, ::render_stride, ::render_stride, :].reshape((-1, 2))
+                per_ray = True
+            elif data["depth_range"].ndim == 2:
+                depth_range, per_ray = data["depth_range"], False
+            else:
+                raise ValueError(data["depth_range"].shape)
+            ret.update({
+                "ray_o": ro, "ray_d": rd, "batch_refs": refs, "view_uv": uvs, "depth_range": depth_range,
+                "depth_range_per_ray": per_ray, "src_rgbs": src_rgbs, "src_invalid_masks": data["dyn_mask_src_spatial"],
+                "src_cameras": data["flat_cam_src_spatial"]})
+        return ret

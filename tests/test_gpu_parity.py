@@ -395,3 +395,104 @@ def test_fullsize_properties_1080p():
     own = yy * W + xx
     dpix = (idx - own)[1:-1, 1:-1]
     assert bool(((dpix == 0) | (dpix == 1) | (dpix == W) | (dpix == W + 1)).all())
+
+
+# ---------------------------------------------------------------- GNT static renderer (A13-A16)
+def _gnt_model(golden_dir, depth=2):
+    from pgdvs_amd.models.gnt.model import GNTModel
+
+    g = _load(golden_dir, "gnt_small.npz")
+    torch.manual_seed(123)
+    m = GNTModel(netwidth=64, transformer_depth=depth).eval()
+    m.net_coarse.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w_")}, strict=True)
+    return m.to(DEV), g
+
+
+@pytest.mark.parametrize("tag", ["nomask", "dynmask"])
+def test_gnt_gather_vs_reference_and_oracle(golden_dir, tag):
+    from oracle import gnt_oracle as G
+
+    g = _load(golden_dir, "gnt_small.npz")
+    V = int(g["V"])
+    cams = ops.cam_prep(T(g["cams_src"]))
+    camt = ops.cam_prep(T(g["cam_tgt"]))
+    feat_cl = T(g["featmaps"]).permute(0, 2, 3, 1).contiguous()
+    out = ops.gnt_gather(T(g["ray_o"]), T(g["ray_d"]), T(g["depth_range"]), int(g["Ss"]), True, camt, cams,
+                         T(g["src_rgbs"][0]), feat_cl, T(g["inv_masks"][0, ..., 0]) if tag == "dynmask" else None)
+    np.testing.assert_allclose(N(out["pts"]), g["pts"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(N(out["z_vals"]), g["z_vals"], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(N(out["mask_inbound"]), g[f"{tag}_mask_inbound"])  # bound tests: exact
+    assert np.array_equal(N(out["mask"]), g[f"{tag}_mask"])
+    np.testing.assert_allclose(N(out["rgb_feat"]), g[f"{tag}_rgb_feat"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(N(out["ray_diff"]), g[f"{tag}_ray_diff"], rtol=0, atol=5e-5)
+    o = G.projector_compute(g["pts"], g["cam_tgt"], g["src_rgbs"][0], g["cams_src"], g["featmaps"],
+                            g["inv_masks"][0] if tag == "dynmask" else None)
+    np.testing.assert_allclose(N(out["rgb_feat"]), o["rgb_feat"], rtol=0, atol=2e-5)
+    assert np.array_equal(N(out["mask"]), o["mask"])
+    assert V == out["mask"].shape[2]
+
+
+@pytest.mark.parametrize("tag", ["nomask", "dynmask"])
+def test_gnt_forward_vs_reference(golden_dir, tag):
+    m, g = _gnt_model(golden_dir)
+    with torch.no_grad():
+        out, ex = m.net_coarse(T(g[f"{tag}_rgb_feat"]), T(g[f"{tag}_ray_diff"]), T(g[f"{tag}_mask"]), T(g["pts"]), T(g["ray_d"]),
+                               ret_view_entropy=True, ret_view_std=True)
+    np.testing.assert_allclose(N(out), g[f"{tag}_out"], rtol=0, atol=1e-4)
+    for k, v in ex.items():
+        np.testing.assert_allclose(N(v), g[f"{tag}_{k}"], rtol=0, atol=1e-4, err_msg=k)
+
+
+def test_gnt_renderer_end_to_end_vs_reference(golden_dir):
+    """feature net (MIOpen) + chunk loop + gather + aggregation + reductions vs BaseRenderer.forward."""
+    from pgdvs_amd.models.gnt.renderer import BaseRenderer
+
+    m, g = _gnt_model(golden_dir)
+    r = _load(golden_dir, "gnt_render.npz")
+    br = BaseRenderer(model_cfg=None)
+    br.model = m
+    br = br.to(DEV).eval()
+    H, W, stride = int(g["H"]), int(g["W"]), int(r["render_stride"])
+    camt = ops.cam_prep(T(g["cam_tgt"]))
+    ro, rd, uv, shape = ops.get_rays(camt, H, W, stride)
+    ray_batch = {"ray_o": ro, "ray_d": rd, "camera": T(g["cam_tgt"][None]), "raw_h": H, "raw_w": W,
+                 "depth_range": T(g["depth_range"]), "depth_range_per_ray": False, "src_rgbs": T(g["src_rgbs"]),
+                 "src_invalid_masks": T(g["inv_masks"]), "src_cameras": T(g["cams_src"][None])}
+    with torch.no_grad():
+        ret = br.forward(ray_batch=ray_batch, chunk_size=int(r["chunk_size"]), inv_uniform=True,
+                         n_coarse_samples_per_ray=int(g["Ss"]), use_dyn_mask=True, flag_deterministic=True,
+                         render_stride=stride, ret_view_entropy=True, ret_view_std=True)
+    for k, v in ret["outputs_coarse"].items():
+        np.testing.assert_allclose(N(v), r["out_" + k], rtol=0, atol=2e-4, err_msg=k)
+
+
+def test_pgdvs_renderer_with_gnt_static(golden_dir):
+    """PGDVSRenderer with static_renderer=gnt running the network (no rgb_gnt shortcut)."""
+    m, g = _gnt_model(golden_dir)
+    cfg = load_config(static_renderer="gnt")
+    cfg.static_renderer.model_cfg.transformer_depth = 2
+    rc = cfg.engine.engine_cfg.render_cfg
+    rc.n_coarse_samples_per_ray = int(g["Ss"])
+    rc.chunk_size = 500
+    rc.gnt_use_masked_spatial_src = False
+    rc.gnt_use_dyn_mask = True
+    model = PGDVSRenderer(cfg, render_cfg=rc).to(DEV).eval()
+    model.static_renderer.model = m
+    H, W = int(g["H"]), int(g["W"])
+    v = synth.make_video(3, H, W, seed=9)
+    d = synth.to_torch(synth.make_view(v, 0, seed=2), DEV)
+    d["flat_cam_tgt"] = T(g["cam_tgt"][None])
+    d["rgb_src_spatial"] = T(g["src_rgbs"])
+    d["dyn_mask_src_spatial"] = T(g["inv_masks"])
+    d["flat_cam_src_spatial"] = T(g["cams_src"][None])
+    d["depth_range"] = T(g["depth_range"])
+    with torch.no_grad():
+        ret = model.forward(d, render_cfg=rc)
+    for k in ("static_coarse_rgb", "static_coarse_depth", "static_coarse_view_entropy", "static_coarse_view_std",
+              "static_coarse_view_std_normalized", "static_coarse_inbound_cnt", "static_coarse_oob_mask",
+              "static_coarse_dyn_cnt", "static_coarse_dyn_mask_any", "static_coarse_dyn_mask_all",
+              "static_coarse_dyn_mask_thres", "combined_rgb", "render_dyn_rgb"):
+        assert k in ret and ret[k].shape[0] == 1 and ret[k].shape[2:] == (H, W), k
+    comb = (1 - ret["render_dyn_mask"]) * ret["static_coarse_rgb"] + ret["render_dyn_mask"] * ret["render_dyn_rgb"]
+    assert torch.allclose(ret["combined_rgb"], comb, atol=1e-6)
+    assert bool(torch.isfinite(ret["combined_rgb"]).all())

@@ -119,3 +119,30 @@ def test_gather_world_size_2_gloo(tmp_path):
         capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "GATHER_OK" in r.stdout
+
+
+def test_gnt_modules_match_reference_golden(golden_dir):
+    """Host-side GNT modules (state-dict layout, seeded init order, dense mask-driven
+    formulation of the view/ray transformers) against vectors produced by the reference."""
+    import numpy as np
+
+    from pgdvs_amd.models.gnt.model import GNTModel
+
+    g = dict(np.load(golden_dir / "gnt_small.npz"))
+    r = dict(np.load(golden_dir / "gnt_resunet.npz"))
+    torch.manual_seed(int(r["seed"]))
+    m = GNTModel(netwidth=64, transformer_depth=2).eval()
+    assert sum(p.numel() for p in m.feature_net.parameters()) == int(r["n_params"])
+    with torch.no_grad():
+        f = m.feature_net(torch.from_numpy(r["src_rgbs"][0]).permute(0, 3, 1, 2))[0].numpy()
+    np.testing.assert_allclose(f, r["feat"], rtol=0, atol=1e-5)  # same init sequence as the reference
+    sd = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w_")}
+    m.net_coarse.load_state_dict(sd, strict=True)  # checkpoint-compatible parameter names
+    T = torch.from_numpy
+    for tag in ("nomask", "dynmask"):
+        with torch.no_grad():
+            out, ex = m.net_coarse(T(g[f"{tag}_rgb_feat"]), T(g[f"{tag}_ray_diff"]), T(g[f"{tag}_mask"]), T(g["pts"]),
+                                   T(g["ray_d"]), ret_view_entropy=True, ret_view_std=True)
+        np.testing.assert_allclose(out.numpy(), g[f"{tag}_out"], rtol=0, atol=1e-5)
+        for k, v in ex.items():
+            np.testing.assert_allclose(v.numpy(), g[f"{tag}_{k}"], rtol=0, atol=1e-5, err_msg=k)

@@ -213,6 +213,19 @@ int pgdvs_gnt_gather(const float *ray_o, const float *ray_d, const float *depth_
                      float *pts, float *z_vals, float *rgb_feat, float *ray_diff,
                      float *mask_inbound, float *mask_invalid, float *mask, pgdvs_stream_t stream);
 
+/* A14 (view transformer): one fused fp32-MFMA kernel per GNT layer = Transformer2D +
+ * Attention2D of pgdvs/models/gnt/models/transformer_network.py:59-169,197-223 (width 64).
+ *   weights: pgdvs_gnt_view_weight_floats() floats, packed input-major as laid out in
+ *            csrc/gnt_view.hip (VW_* offsets); built by pgdvs_amd.ops.pack_view_layer
+ *   q_in[N,64]; feat[N,V,64] (rgbfeat_fc output); ray_diff[N,V,4]; valid[N,V] u8 (rows
+ *   without any valid view must be passed as all-valid, :124-129); q_out[N,64]
+ *   stats[N,3] (view entropy, masked std of k, normalised std; means over features) and
+ *   logit_scratch[N,V,64] are both given or both NULL. */
+int64_t pgdvs_gnt_view_weight_floats(void);
+int pgdvs_gnt_view_layer(const float *weights, const float *q_in, const float *feat,
+                         const float *ray_diff, const uint8_t *valid, int64_t N, int V, float *q_out,
+                         float *stats, float *logit_scratch, pgdvs_stream_t stream);
+
 /* A11 alone: combined = (1-m)*static + m*dyn (pgdvs_renderer.py:169-178), n elements per
  * channel, planar [3,n] with mask [n]. */
 int pgdvs_combine(const float *static_rgb, const float *dyn_rgb, const float *dyn_mask,

@@ -312,5 +312,52 @@ def gnt_view_available(dim: int, n_views: int) -> bool:
 _GNT_VIEW_ENABLED = True
 
 
+def pack_view_layer(layer) -> torch.Tensor:
+    """Pack the parameters of one view-transformer layer (Transformer2D) into the input-major
+    layout of csrc/gnt_view.hip (VW_* offsets)."""
+    a = layer.attn
+    dev = a.q_fc.weight.device
+
+    def pad_cols(w_t, cols):  # [in][out] -> [in][cols]
+        out = torch.zeros((w_t.shape[0], cols), dtype=torch.float32, device=dev)
+        out[:, : w_t.shape[1]] = w_t
+        return out
+
+    def pad_vec(b, n):
+        out = torch.zeros(n, dtype=torch.float32, device=dev)
+        out[: b.numel()] = b
+        return out
+
+    parts = [
+        layer.attn_norm.weight, layer.attn_norm.bias, a.q_fc.weight.t(), a.k_fc.weight.t(), a.v_fc.weight.t(),
+        pad_cols(a.pos_fc[0].weight.t(), 32), pad_vec(a.pos_fc[0].bias, 32), a.pos_fc[2].weight.t(), a.pos_fc[2].bias,
+        pad_cols(a.attn_fc[0].weight.t(), 32), pad_vec(a.attn_fc[0].bias, 32), a.attn_fc[2].weight.t(), a.attn_fc[2].bias,
+        a.out_fc.weight.t(), a.out_fc.bias, layer.ff_norm.weight, layer.ff_norm.bias, layer.ff.fc1.weight.t(),
+        layer.ff.fc1.bias, layer.ff.fc2.weight.t(), layer.ff.fc2.bias,
+    ]
+    packed = torch.cat([p.detach().float().contiguous().reshape(-1) for p in parts])
+    assert packed.numel() == _lib.load().pgdvs_gnt_view_weight_floats(), packed.numel()
+    return packed
+
+
 def gnt_view_layer(layer, q, feat, ray_diff, valid, want_stats):
-    raise NotImplementedError
+    """q[R,S,64], feat[R,S,V,64], ray_diff[R,S,V,4], valid[R,S,V] bool -> (q_out, stats or None)."""
+    packed = getattr(layer, "_pgdvs_packed", None)
+    if packed is None or packed.device != q.device:
+        packed = pack_view_layer(layer)
+        layer._pgdvs_packed = packed  # parameters are frozen at inference (static renderer is .eval())
+    R, S, V = feat.shape[0], feat.shape[1], feat.shape[2]
+    N = R * S
+    qi = _req(q, torch.float32, "q")
+    ft = _req(feat, torch.float32, "feat")
+    rd = _req(ray_diff, torch.float32, "ray_diff")
+    vd = _req(valid.view(torch.uint8) if valid.dtype == torch.bool else valid, torch.uint8, "valid")
+    out = torch.empty_like(qi)
+    stats = torch.empty((N, 3), dtype=torch.float32, device=q.device) if want_stats else None
+    scratch = torch.empty((N, V, 64), dtype=torch.float32, device=q.device) if want_stats else None
+    check(_lib.load().pgdvs_gnt_view_layer(_ptr(packed), _ptr(qi), _ptr(ft), _ptr(rd), _ptr(vd), N, V, _ptr(out), _ptr(stats),
+                                           _ptr(scratch), _stream()), "pgdvs_gnt_view_layer")
+    if not want_stats:
+        return out, None
+    st = stats.reshape(R, S, 3)
+    return out, (st[..., 0], st[..., 1], st[..., 2])

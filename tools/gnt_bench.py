@@ -37,3 +37,22 @@ mac_view = 4096 + 4096 + 4 * 8 + 8 * 64 + 64 * 8 + 8 * 64       # k, v, pos, att
 mac_grp = 4096 + 4096 + 2 * 64 * 256                               # q, out, FF per group
 flop = 2.0 * R * S * (V * mac_view + mac_grp)
 print(f"view layer: R={R} S={S} V={V} stats={a.stats}: {dt*1e3:.3f} ms  {flop/dt/1e12:.2f} TFLOP/s  ({flop/dt/157.3e12*100:.1f}% of fp32 MFMA peak)")
+
+# ---- full GNT forward of one chunk (all layers; ray transformer etc. still on rocBLAS/torch)
+pts = torch.randn(R, S, 3, device=dev); ray_d = torch.randn(R, 3, device=dev)
+rgb_feat = torch.randn(R, S, V, 35, device=dev); mask = valid[..., None].float()
+def full(stats):
+    with torch.no_grad():
+        return net(rgb_feat, rd, mask, pts, ray_d, ret_view_entropy=stats, ret_view_std=stats)
+for stats in (False, True):
+    full(stats); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(3): full(stats)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 3
+    tot = 2.0 * R * S * (1048064 + 84416 * V) * a.depth / 8
+    print(f"GNT forward depth={a.depth} stats={stats}: {dt*1e3:.2f} ms/chunk  {tot/dt/1e12:.2f} TFLOP/s; 1080p frame (1013 chunks) ~ {dt*1013:.1f} s")
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    full(True); torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=60))

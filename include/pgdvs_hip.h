@@ -226,6 +226,15 @@ int pgdvs_gnt_view_layer(const float *weights, const float *q_in, const float *f
                          const float *ray_diff, const uint8_t *valid, int64_t N, int V, float *q_out,
                          float *stats, float *logit_scratch, pgdvs_stream_t stream);
 
+/* A14 (ray transformer): Transformer + Attention(attn_mode="qk", 4 heads) of
+ * pgdvs/models/gnt/models/transformer_network.py:231-338 for R rays x S samples (S <= 256),
+ * width 64, fused with its feed-forward block.  weights: same packed layout as the view
+ * layer (LN1 = attn_norm, WQ/WK/WV, WO = out_fc, LN2/F1/F2 = ff_norm/ff; the view-only
+ * regions are unused).  q_out[R,S,64]; sample_weights[R,S] (nullable) = attention row of
+ * query sample 0 averaged over heads (:336). */
+int pgdvs_gnt_ray_layer(const float *weights, const float *q_in, int R, int S, float *q_out,
+                        float *sample_weights, pgdvs_stream_t stream);
+
 /* A11 alone: combined = (1-m)*static + m*dyn (pgdvs_renderer.py:169-178), n elements per
  * channel, planar [3,n] with mask [n]. */
 int pgdvs_combine(const float *static_rgb, const float *dyn_rgb, const float *dyn_mask,

@@ -55,8 +55,19 @@ constexpr int VW_LDS_BEGIN = VW_WK;
 constexpr int VW_LDS_END = VW_WO;
 constexpr int VW_LDS_FLOATS = VW_LDS_END - VW_LDS_BEGIN;
 
-__device__ __forceinline__ int feat_of(int t, int h) {
-  return (t & 3) + 8 * ((t & 15) >> 2) + 4 * h + 32 * (t >> 4);
+// feature(t,h) = featc(t) + 4*h.  The lane-dependent 4*h always goes into a per-lane BASE
+// pointer and featc(t) stays a compile-time constant, so every access is base + immediate
+// (written as one sum, the compiler merges 4*h with OR and materialises one address register
+// per element).
+__host__ __device__ constexpr int featc(int t) { return (t & 3) + 8 * ((t & 15) >> 2) + 32 * (t >> 4); }
+__device__ __forceinline__ int feat_of(int t, int h) { return featc(t) + 4 * h; }
+
+// Weight pointers are loop-invariant across the persistent tile / ray loops; left alone, LICM
+// hoists hundreds of 64-bit load addresses out of the loop and they end up in scratch.  Passing
+// the (wave-uniform) base through an empty asm per iteration keeps the address math local.
+__device__ __forceinline__ const float *opaque_uniform(const float *p) {
+  asm volatile("" : "+s"(p));
+  return p;
 }
 
 __device__ __forceinline__ floatx16 mfma(float a, float b, floatx16 c) {
@@ -66,17 +77,19 @@ __device__ __forceinline__ floatx16 mfma(float a, float b, floatx16 c) {
 // y[32] = W x (+ bias): 64 -> 64.  Wt input-major [64][64]; x, y in feature(t,h) layout.
 __device__ __forceinline__ void lin64x64(const float *__restrict__ Wt, const float *__restrict__ bias,
                                          const float (&x)[32], float (&y)[32], int i, int h) {
+  const float *wb = Wt + (4 * h) * 64 + i;
+  const float *bb = bias ? bias + 4 * h : nullptr;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     floatx16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = bias ? bias[feat_of(r + 16 * mt, h)] : 0.0f;
+    for (int r = 0; r < 16; ++r) acc[r] = bb ? bb[featc(r + 16 * mt)] : 0.0f;
 #pragma unroll
     for (int t0 = 0; t0 < 32; t0 += 8) {
       // keep at most 8 weight registers live: the scheduler must not hoist all 64 loads
       float w[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) w[u] = Wt[feat_of(t0 + u, h) * 64 + mt * 32 + i];
+      for (int u = 0; u < 8; ++u) w[u] = wb[featc(t0 + u) * 64 + mt * 32];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc = mfma(w[u], x[t0 + u], acc);
@@ -91,13 +104,15 @@ __device__ __forceinline__ void lin64x64(const float *__restrict__ Wt, const flo
 __device__ __forceinline__ void lin64x8_relu(const float *__restrict__ Wt, const float *__restrict__ bias,
                                              const float (&x)[32], float (&hid)[4], int i, int h) {
   floatx16 acc;
+  const float *wb = Wt + (4 * h) * 32 + i;
+  const float *bb = bias + 4 * h;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = r < 4 ? bias[r + 4 * h] : 0.0f;
+  for (int r = 0; r < 16; ++r) acc[r] = r < 4 ? bb[r] : 0.0f;
 #pragma unroll
   for (int t0 = 0; t0 < 32; t0 += 8) {
     float w[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) w[u] = Wt[feat_of(t0 + u, h) * 32 + i];
+    for (int u = 0; u < 8; ++u) w[u] = wb[featc(t0 + u) * 32];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc = mfma(w[u], x[t0 + u], acc);
@@ -110,13 +125,15 @@ __device__ __forceinline__ void lin64x8_relu(const float *__restrict__ Wt, const
 // y[32] = W hid + b: 8 -> 64.  Wt [8][64]
 __device__ __forceinline__ void lin8x64(const float *__restrict__ Wt, const float *__restrict__ bias,
                                         const float (&hid)[4], float (&y)[32], int i, int h) {
+  const float *wb = Wt + (4 * h) * 64 + i;
+  const float *bb = bias + 4 * h;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     floatx16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = bias[feat_of(r + 16 * mt, h)];
+    for (int r = 0; r < 16; ++r) acc[r] = bb[featc(r + 16 * mt)];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc = mfma(Wt[(t + 4 * h) * 64 + mt * 32 + i], hid[t], acc);
+    for (int t = 0; t < 4; ++t) acc = mfma(wb[t * 64 + mt * 32], hid[t], acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) y[r + 16 * mt] = acc[r];
   }
@@ -126,10 +143,12 @@ __device__ __forceinline__ void lin8x64(const float *__restrict__ Wt, const floa
 __device__ __forceinline__ void lin4x8_relu(const float *__restrict__ Wt, const float *__restrict__ bias,
                                             const float (&d2)[2], float (&hid)[4], int i, int h) {
   floatx16 acc;
+  const float *wb = Wt + h * 32 + i;
+  const float *bb = bias + 4 * h;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = r < 4 ? bias[r + 4 * h] : 0.0f;
+  for (int r = 0; r < 16; ++r) acc[r] = r < 4 ? bb[r] : 0.0f;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) acc = mfma(Wt[(2 * t + h) * 32 + i], d2[t], acc);
+  for (int t = 0; t < 2; ++t) acc = mfma(wb[2 * t * 32], d2[t], acc);
 #pragma unroll
   for (int r = 0; r < 4; ++r) hid[r] = fmaxf(acc[r], 0.0f);
 }
@@ -150,18 +169,24 @@ __device__ __forceinline__ void layer_norm64(const float (&x)[32], const float *
   }
   v += __shfl_xor(v, 32, 64);
   float rstd = 1.0f / sqrtf(v * (1.0f / 64.0f) + eps);
+  const float *gb = g + 4 * h, *bb = b + 4 * h;
 #pragma unroll
-  for (int t = 0; t < 32; ++t) {
-    int f = feat_of(t, h);
-    y[t] = (x[t] - mean) * rstd * g[f] + b[f];
-  }
+  for (int t = 0; t < 32; ++t) y[t] = (x[t] - mean) * rstd * gb[featc(t)] + bb[featc(t)];
+}
+
+__device__ __forceinline__ void store_row32(float *__restrict__ row, const float (&x)[32], int h) {
+  float *rb = row + 4 * h;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    *reinterpret_cast<float4 *>(rb + featc(c * 4)) = make_float4(x[c * 4], x[c * 4 + 1], x[c * 4 + 2], x[c * 4 + 3]);
 }
 
 __device__ __forceinline__ void load_row32(const float *__restrict__ row, float (&x)[32], int h) {
   // features feature(t,h): groups of 4 contiguous floats -> 8 x dwordx4
+  const float *rb = row + 4 * h;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    float4 v = *reinterpret_cast<const float4 *>(row + feat_of(c * 4, h));
+    float4 v = *reinterpret_cast<const float4 *>(rb + featc(c * 4));
     x[c * 4 + 0] = v.x;
     x[c * 4 + 1] = v.y;
     x[c * 4 + 2] = v.z;
@@ -171,12 +196,12 @@ __device__ __forceinline__ void load_row32(const float *__restrict__ row, float 
 
 template <bool STATS>
 __global__ void __launch_bounds__(256, 1)
-gnt_view_layer_kernel(const float *__restrict__ W, const float *__restrict__ q_in,
+gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__ q_in,
                       const float *__restrict__ feat, const float *__restrict__ ray_diff,
                       const uint8_t *__restrict__ valid, int64_t N, int V, float *__restrict__ q_out,
                       float *__restrict__ stats, float *__restrict__ logit_scratch) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [VW_LDS_FLOATS]
-  for (int k = threadIdx.x; k < VW_LDS_FLOATS; k += blockDim.x) s_w[k] = W[VW_LDS_BEGIN + k];
+  for (int k = threadIdx.x; k < VW_LDS_FLOATS; k += blockDim.x) s_w[k] = W_arg[VW_LDS_BEGIN + k];
   __syncthreads();
   const float *sWk = s_w + (VW_WK - VW_LDS_BEGIN), *sWv = s_w + (VW_WV - VW_LDS_BEGIN);
   const float *sP1 = s_w + (VW_P1 - VW_LDS_BEGIN), *sP1b = s_w + (VW_P1B - VW_LDS_BEGIN);
@@ -191,6 +216,7 @@ gnt_view_layer_kernel(const float *__restrict__ W, const float *__restrict__ q_i
     const int64_t g_raw = tile * 32 + i;
     const bool g_ok = g_raw < N;
     const int64_t g = g_ok ? g_raw : N - 1;
+    const float *W = opaque_uniform(W_arg);
     float qq[32];
     {
       float q0[32], x[32];
@@ -239,27 +265,29 @@ gnt_view_layer_kernel(const float *__restrict__ W, const float *__restrict__ q_i
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         floatx16 la, lv;
+        const float *a2b = sA2b + 4 * h, *a2w = sA2 + (4 * h) * 64 + i, *wvb = sWv + (4 * h) * 64 + i;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          la[r] = sA2b[feat_of(r + 16 * mt, h)];
+          la[r] = a2b[featc(r + 16 * mt)];
           lv[r] = 0.0f;
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) la = mfma(sA2[(t + 4 * h) * 64 + mt * 32 + i], hid[t], la);
+        for (int t = 0; t < 4; ++t) la = mfma(a2w[t * 64 + mt * 32], hid[t], la);
 #pragma unroll
         for (int t0 = 0; t0 < 32; t0 += 8) {
           float w[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) w[u] = sWv[feat_of(t0 + u, h) * 64 + mt * 32 + i];
+          for (int u = 0; u < 8; ++u) w[u] = wvb[featc(t0 + u) * 64 + mt * 32];
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < 8; ++u) lv = mfma(w[u], k[t0 + u], lv);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (STATS) {
+          float *lb = logit_scratch + row * 64 + 4 * h;
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            *reinterpret_cast<float4 *>(logit_scratch + row * 64 + feat_of(16 * mt + c * 4, h)) =
+            *reinterpret_cast<float4 *>(lb + featc(16 * mt + c * 4)) =
                 make_float4(la[c * 4], la[c * 4 + 1], la[c * 4 + 2], la[c * 4 + 3]);
         }
         if (ok) {
@@ -288,12 +316,7 @@ gnt_view_layer_kernel(const float *__restrict__ W, const float *__restrict__ q_i
 #pragma unroll
       for (int t = 0; t < 32; ++t) x1[t] += qres[t];
     }
-    if (g_ok) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-        *reinterpret_cast<float4 *>(q_out + g * 64 + feat_of(c * 4, h)) =
-            make_float4(x1[c * 4], x1[c * 4 + 1], x1[c * 4 + 2], x1[c * 4 + 3]);
-    }
+    if (g_ok) store_row32(q_out + g * 64, x1, h);
     if (STATS) {
       // entropy of the normalised attention (second sweep over the stored logits), masked
       // unbiased std of k and its normalised form; means over the 64 features
@@ -335,7 +358,7 @@ gnt_view_layer_kernel(const float *__restrict__ W, const float *__restrict__ q_i
 // q_out = F2 relu(F1 LN(x) + b1) + b2 + x  (FeedForward + ff_norm + residual, :44-55,:218-221),
 // in place on the rows written by the attention kernel.
 __global__ void __launch_bounds__(256)
-gnt_ff_kernel(const float *__restrict__ W, float *__restrict__ x_io, int64_t N) {
+gnt_ff_kernel(const float *__restrict__ W_arg, float *__restrict__ x_io, int64_t N) {
   const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
   const int wave = threadIdx.x >> 6;
   const int64_t ntiles = (N + 31) / 32;
@@ -343,24 +366,31 @@ gnt_ff_kernel(const float *__restrict__ W, float *__restrict__ x_io, int64_t N) 
     const int64_t g_raw = tile * 32 + i;
     const bool g_ok = g_raw < N;
     const int64_t g = g_ok ? g_raw : N - 1;
+    const float *W = opaque_uniform(W_arg);
     float x1[32], xn[32];
     load_row32(x_io + g * 64, x1, h);
     layer_norm64(x1, W + VW_LN2_G, W + VW_LN2_B, 1e-6f, xn, h);
     floatx16 o0, o1;
+    {
+      const float *bb = W + VW_F2B + 4 * h;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o0[r] = W[VW_F2B + feat_of(r, h)];
-      o1[r] = W[VW_F2B + feat_of(r + 16, h)];
+      for (int r = 0; r < 16; ++r) {
+        o0[r] = bb[featc(r)];
+        o1[r] = bb[featc(r + 16)];
+      }
     }
     for (int mt = 0; mt < 8; ++mt) {  // hidden features 32*mt .. 32*mt+31
       floatx16 hacc;
+      const float *b1 = W + VW_F1B + 4 * h + 32 * mt;
+      const float *f1 = W + VW_F1 + (4 * h) * 256 + mt * 32 + i;
+      const float *f2 = W + VW_F2 + (4 * h + 32 * mt) * 64 + i;  // rows = hidden features of this lane half
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hacc[r] = W[VW_F1B + (r & 3) + 8 * (r >> 2) + 4 * h + 32 * mt];
+      for (int r = 0; r < 16; ++r) hacc[r] = b1[(r & 3) + 8 * (r >> 2)];
 #pragma unroll
       for (int t0 = 0; t0 < 32; t0 += 8) {
         float w[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = W[VW_F1 + feat_of(t0 + u, h) * 256 + mt * 32 + i];
+        for (int u = 0; u < 8; ++u) w[u] = f1[featc(t0 + u) * 256];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) hacc = mfma(w[u], xn[t0 + u], hacc);
@@ -371,10 +401,9 @@ gnt_ff_kernel(const float *__restrict__ W, float *__restrict__ x_io, int64_t N) 
         float w0[4], w1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          int r = r0 + u;
-          int fin = (r & 3) + 8 * (r >> 2) + 4 * h + 32 * mt;  // hidden feature held by this lane half
-          w0[u] = W[VW_F2 + fin * 64 + i];
-          w1[u] = W[VW_F2 + fin * 64 + 32 + i];
+          const int r = r0 + u;
+          w0[u] = f2[((r & 3) + 8 * (r >> 2)) * 64];
+          w1[u] = f2[((r & 3) + 8 * (r >> 2)) * 64 + 32];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -387,14 +416,165 @@ gnt_ff_kernel(const float *__restrict__ W, float *__restrict__ x_io, int64_t N) 
       }
     }
     if (g_ok) {
+      float out[32];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        *reinterpret_cast<float4 *>(x_io + g * 64 + feat_of(c * 4, h)) =
-            make_float4(o0[c * 4] + x1[c * 4], o0[c * 4 + 1] + x1[c * 4 + 1], o0[c * 4 + 2] + x1[c * 4 + 2],
-                        o0[c * 4 + 3] + x1[c * 4 + 3]);
-        *reinterpret_cast<float4 *>(x_io + g * 64 + feat_of(16 + c * 4, h)) =
-            make_float4(o1[c * 4] + x1[16 + c * 4], o1[c * 4 + 1] + x1[16 + c * 4 + 1],
-                        o1[c * 4 + 2] + x1[16 + c * 4 + 2], o1[c * 4 + 3] + x1[16 + c * 4 + 3]);
+      for (int r = 0; r < 16; ++r) {
+        out[r] = o0[r] + x1[r];
+        out[r + 16] = o1[r] + x1[r + 16];
+      }
+      store_row32(x_io + g * 64, out, h);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Ray transformer attention (Transformer + Attention, attn_mode="qk",
+// transformer_network.py:231-338): per ray, x = LN(q); Q,K,V = W x; 4 heads x 16 dims;
+// attn = softmax(Q K^T / 4) over the S samples of the ray; y = Wo (attn V) + bo + q.
+// One workgroup per ray, one wavefront per tile of 32 query samples, same transposed MFMA
+// formulation: K ([feature][sample]) and V ([sample][feature]) of the whole ray live in LDS;
+// the 32x32 score tile of a (key tile, query tile) pair comes out of the MFMA with keys in
+// registers and the query on the lane -- exactly the B operand of the P.V product, so the
+// probabilities never leave registers either.  Also emits the head-averaged attention row of
+// query sample 0, the "learned density" the renderer uses as sample weights (:336).
+// Uses the VW_* weight offsets: LN1 = attn_norm, WQ/WK/WV, WO/WOB = out_fc (FF via gnt_ff).
+// ---------------------------------------------------------------------------------------
+constexpr int kRayVStride = 65;  // V rows padded: conflict-free per-lane row writes
+constexpr int kRaySpad = 256;    // fixed LDS geometry (S <= 256): every K/V address is base + immediate
+
+__global__ void __launch_bounds__(512)
+gnt_ray_attn_kernel(const float *__restrict__ W_arg, const float *__restrict__ q_in, int R, int S,
+                    float *__restrict__ y_out, float *__restrict__ w_out) {
+  extern __shared__ __attribute__((aligned(16))) float s_kv[];
+  const int ntile = (S + 31) / 32;
+  constexpr int Spad = kRaySpad;
+  float *Ks = s_kv;                        // [64][Spad]
+  float *Vs = s_kv + 64 * Spad;            // [Spad][kRayVStride]
+  float *s_row0 = Vs + Spad * kRayVStride;  // [8 + 64]: (m,l) per head, Q of sample 0
+  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool has_tile = wave < ntile;
+  for (int ray = blockIdx.x; ray < R; ray += gridDim.x) {
+    const float *W = opaque_uniform(W_arg);
+    const int s_raw = wave * 32 + i;
+    const int smp = s_raw < S ? s_raw : S - 1;
+    const float *xrow = q_in + ((int64_t)ray * S + smp) * 64;
+    float qv[32];
+    __syncthreads();  // previous ray's K/V fully consumed
+    if (has_tile) {
+      float x[32], xn[32];
+      load_row32(xrow, x, h);
+      layer_norm64(x, W + VW_LN1_G, W + VW_LN1_B, 1e-6f, xn, h);
+      lin64x64(W + VW_WQ, nullptr, xn, qv, i, h);
+      float kk[32];
+      lin64x64(W + VW_WK, nullptr, xn, kk, i, h);
+      float *kw = Ks + (4 * h) * Spad + wave * 32 + i;
+#pragma unroll
+      for (int t = 0; t < 32; ++t) kw[featc(t) * Spad] = kk[t];
+      lin64x64(W + VW_WV, nullptr, xn, kk, i, h);
+      float *vw = Vs + (wave * 32 + i) * kRayVStride + 4 * h;
+#pragma unroll
+      for (int t = 0; t < 32; ++t) vw[featc(t)] = kk[t];
+    }
+    __syncthreads();
+    // y = Wo (attention output) + bo accumulates head by head: each head contributes its 16
+    // features as 8 K-steps, so the attention output itself is never materialised
+    floatx16 y0, y1;
+    {
+      const float *bb = W + VW_WOB + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        y0[r] = bb[featc(r)];
+        y1[r] = bb[featc(r + 16)];
+      }
+    }
+    if (has_tile) {
+#pragma unroll
+      for (int hh = 0; hh < 4; ++hh) {
+        const int tb = 16 * (hh >> 1) + 8 * (hh & 1);  // positions of this head's 8 features
+        float m = -__builtin_inff(), l = 0.0f;
+        floatx16 O;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[r] = 0.0f;
+        for (int kt = 0; kt < ntile; ++kt) {
+          floatx16 sc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
+          const float *kr = Ks + (4 * h) * Spad + kt * 32 + i;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) sc = mfma(kr[featc(tb + u) * Spad], qv[tb + u], sc);
+          float mx = -__builtin_inff();
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            sc[r] = key < S ? sc[r] * 0.25f : -__builtin_inff();
+            mx = fmaxf(mx, sc[r]);
+          }
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          const float mn = fmaxf(m, mx);
+          const float rs = expf(m - mn);
+          float ps = 0.0f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            sc[r] = expf(sc[r] - mn);
+            ps += sc[r];
+            O[r] *= rs;
+          }
+          l = l * rs + ps;
+          m = mn;
+          const float *vr = Vs + (kt * 32 + 4 * h) * kRayVStride + (i & 15);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float a = vr[((r & 3) + 8 * (r >> 2)) * kRayVStride + 16 * hh];
+            O = mfma(i < 16 ? a : 0.0f, sc[r], O);
+          }
+        }
+        l += __shfl_xor(l, 32, 64);
+        if (wave == 0 && i == 0) {  // query sample 0: softmax statistics + its Q for the weight row
+          s_row0[hh * 2 + 0] = m;
+          s_row0[hh * 2 + 1] = l;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s_row0[8 + hh * 16 + h * 8 + u] = qv[tb + u];
+        }
+        const float inv_l = 1.0f / l;
+        const float *wo = W + VW_WO + (4 * h) * 64 + i;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float av = O[u] * inv_l;  // feature featc(tb+u) + 4h of the attention output
+          y0 = mfma(wo[featc(tb + u) * 64], av, y0);
+          y1 = mfma(wo[featc(tb + u) * 64 + 32], av, y1);
+        }
+      }
+      float xres[32];
+      load_row32(xrow, xres, h);
+      if (s_raw < S) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          xres[r] += y0[r];
+          xres[r + 16] += y1[r];
+        }
+        store_row32(y_out + ((int64_t)ray * S + s_raw) * 64, xres, h);
+      }
+    }
+    if (w_out != nullptr) {
+      // attention row of query sample 0 (head average) for all keys: one key per thread,
+      // scores recomputed on the vector ALU from K in LDS and the saved (m, l, Q) of sample 0
+      __syncthreads();
+      const int key = threadIdx.x;
+      if (key < S) {
+        float wsum = 0.0f;
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+          const int tb = 16 * (hh >> 1) + 8 * (hh & 1);
+          float sdot = 0.0f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            sdot += s_row0[8 + hh * 16 + u] * Ks[featc(tb + u) * Spad + key];
+            sdot += s_row0[8 + hh * 16 + 8 + u] * Ks[(featc(tb + u) + 4) * Spad + key];
+          }
+          wsum += expf(sdot * 0.25f - s_row0[hh * 2]) / s_row0[hh * 2 + 1];
+        }
+        w_out[(int64_t)ray * S + key] = wsum * 0.25f;  // mean over the 4 heads
       }
     }
   }
@@ -429,4 +609,29 @@ PGDVS_API int pgdvs_gnt_view_layer(const float *weights, const float *q_in, cons
   const unsigned gff = (unsigned)(cdiv(ntiles, 4) < 2048 ? cdiv(ntiles, 4) : 2048);
   PGDVS_LAUNCH("gnt_ff", gnt_ff_kernel, dim3(gff), dim3(256), 0, st, weights, q_out, N);
   return check_launch("gnt_view_layer");
+}
+
+PGDVS_API int pgdvs_gnt_ray_layer(const float *weights, const float *q_in, int R, int S, float *q_out,
+                                  float *sample_weights, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(weights && q_in && q_out, "pgdvs_gnt_ray_layer: null pointer");
+  PGDVS_REQUIRE(R >= 0 && S >= 1 && S <= 256, "pgdvs_gnt_ray_layer: samples per ray must be in [1, 256]");
+  if (R == 0) return PGDVS_OK;
+  hipStream_t st = as_stream(stream);
+  const size_t lds = (size_t)(64 * kRaySpad + kRaySpad * kRayVStride + 80) * sizeof(float);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gnt_ray_attn_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("gnt_ray_layer: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+      return PGDVS_ERR_LAUNCH;
+    }
+  }
+  const unsigned grid = (unsigned)(R < 1024 ? R : 1024);
+  PGDVS_LAUNCH("gnt_ray_attn", gnt_ray_attn_kernel, dim3(grid), dim3(512), lds, st, weights, q_in, R, S, q_out,
+               sample_weights);
+  const int64_t N = (int64_t)R * S;
+  const int64_t ntiles = cdiv(N, 32);
+  const unsigned gff = (unsigned)(cdiv(ntiles, 4) < 2048 ? cdiv(ntiles, 4) : 2048);
+  PGDVS_LAUNCH("gnt_ff", gnt_ff_kernel, dim3(gff), dim3(256), 0, st, weights, q_out, N);
+  return check_launch("gnt_ray_layer");
 }

@@ -49,6 +49,7 @@ SIGNATURES = {
                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pgdvs_gnt_view_weight_floats": (_i64, []),
     "pgdvs_gnt_view_layer": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
+    "pgdvs_gnt_ray_layer": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "pgdvs_combine": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
 }
 

@@ -135,8 +135,12 @@ class GNT(nn.Module):
 
     @staticmethod
     def _ray_layer(layer, q, want_attn):
+        from .... import ops
+
         a = layer.attn
         R, S, D = q.shape
+        if q.is_cuda and ops.gnt_ray_available(D, S, a.n_heads):
+            return ops.gnt_ray_layer(layer, q, want_attn)
         hd = D // a.n_heads
         x = layer.attn_norm(q)
         sp = lambda t: t.view(R, S, a.n_heads, hd).permute(0, 2, 1, 3)

@@ -361,3 +361,37 @@ def gnt_view_layer(layer, q, feat, ray_diff, valid, want_stats):
         return out, None
     st = stats.reshape(R, S, 3)
     return out, (st[..., 0], st[..., 1], st[..., 2])
+
+
+def pack_ray_layer(layer) -> torch.Tensor:
+    """Ray-transformer layer (Transformer) in the same packed layout; view-only regions stay 0."""
+    a = layer.attn
+    dev = a.q_fc.weight.device
+    z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+    parts = [
+        layer.attn_norm.weight, layer.attn_norm.bias, a.q_fc.weight.t(), a.k_fc.weight.t(), a.v_fc.weight.t(),
+        z(128 + 32 + 512 + 64 + 2048 + 32 + 512 + 64),
+        a.out_fc.weight.t(), a.out_fc.bias, layer.ff_norm.weight, layer.ff_norm.bias, layer.ff.fc1.weight.t(),
+        layer.ff.fc1.bias, layer.ff.fc2.weight.t(), layer.ff.fc2.bias,
+    ]
+    packed = torch.cat([p.detach().float().contiguous().reshape(-1) for p in parts])
+    assert packed.numel() == _lib.load().pgdvs_gnt_view_weight_floats(), packed.numel()
+    return packed
+
+
+def gnt_ray_available(dim: int, n_samples: int, n_heads: int) -> bool:
+    return _GNT_VIEW_ENABLED and dim == 64 and n_heads == 4 and 1 <= n_samples <= 256
+
+
+def gnt_ray_layer(layer, q, want_attn: bool):
+    """q[R,S,64] -> (q_out[R,S,64], weights[R,S] or None)."""
+    packed = getattr(layer, "_pgdvs_packed", None)
+    if packed is None or packed.device != q.device:
+        packed = pack_ray_layer(layer)
+        layer._pgdvs_packed = packed
+    qi = _req(q, torch.float32, "q")
+    R, S, _ = qi.shape
+    out = torch.empty_like(qi)
+    w = torch.empty((R, S), dtype=torch.float32, device=q.device) if want_attn else None
+    check(_lib.load().pgdvs_gnt_ray_layer(_ptr(packed), _ptr(qi), R, S, _ptr(out), _ptr(w), _stream()), "pgdvs_gnt_ray_layer")
+    return out, w

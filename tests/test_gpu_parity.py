@@ -545,3 +545,31 @@ def test_gnt_view_layer_mfma_vs_torch(V, want_stats):
             np.testing.assert_allclose(N(a), N(b), rtol=1e-3, atol=2e-5, err_msg=name)
     else:
         assert st_k is None
+
+
+@pytest.mark.parametrize("S", [1, 12, 33, 64, 256])
+def test_gnt_ray_layer_mfma_vs_torch(S):
+    """Fused ray-transformer kernel (LN, QKV, 4-head attention over the samples of a ray, out_fc,
+    residual, FF) and the sample-0 attention row against the PyTorch fp32 statement."""
+    from pgdvs_amd.models.gnt.models.transformer_network import GNT
+
+    torch.manual_seed(100 + S)
+    net = GNT(netwidth=64, transformer_depth=1).to(DEV).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.ndim == 1:
+                p.add_(torch.randn_like(p) * 0.2)
+    layer = net.view_selftrans[0]
+    R = 19
+    q = torch.randn(R, S, 64, device=DEV) * 1.5
+    with torch.no_grad():
+        out_k, w_k = GNT._ray_layer(layer, q, True)
+    ops._GNT_VIEW_ENABLED = False
+    try:
+        with torch.no_grad():
+            out_t, w_t = GNT._ray_layer(layer, q, True)
+    finally:
+        ops._GNT_VIEW_ENABLED = True
+    np.testing.assert_allclose(N(out_k), N(out_t), rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(N(w_k), N(w_t), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(N(w_k).sum(1), 1.0, rtol=1e-5)

@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel pass")
     ap.add_argument("--pts-per-pixel", type=int, default=3)
     ap.add_argument("--no-outlier", action="store_true", help="dyn_pcl_remove_outlier=false (YAML default)")
+    ap.add_argument("--gnt-rays", type=int, default=1024, help="rays of the GNT sub-benchmark chunk (0 = skip)")
     return ap.parse_args()
 
 
@@ -227,6 +228,38 @@ def main():
             "seconds": round(c1 - c0, 2),
             "value_scaled_linear_to_full": round(cpu_fps * scale, 6)}
 
+    # ---------------- GNT sub-benchmark (BASELINE configs[2]: "GNT feature aggregation on MFMA")
+    # A full 1080p / 24-view / 256-sample GNT frame is ~3.3 PFLOP (>= 20 s even at the fp32-MFMA
+    # peak), so -- as BASELINE.md section 3 prescribes -- it is reported on a ray subset as
+    # TFLOP/s and is not part of `value` (whose static image comes from the point renderer).
+    gnt = None
+    if rank == 0 and world == 1 and args.gnt_rays > 0:
+        from pgdvs_amd.models.gnt.models.transformer_network import GNT
+
+        torch.manual_seed(0)
+        net = GNT(netwidth=64, transformer_depth=8).to(dev).eval()
+        Rg, Sg, Vg = args.gnt_rays, 256, S
+        g = torch.Generator(device=dev).manual_seed(1)
+        rgb_feat = torch.randn(Rg, Sg, Vg, 35, device=dev, generator=g)
+        rd = torch.randn(Rg, Sg, Vg, 4, device=dev, generator=g)
+        mk = (torch.rand(Rg, Sg, Vg, 1, device=dev, generator=g) < 0.8).float()
+        pts = torch.randn(Rg, Sg, 3, device=dev, generator=g)
+        rdir = torch.randn(Rg, 3, device=dev, generator=g)
+        with torch.no_grad():
+            net(rgb_feat, rd, mk, pts, rdir, ret_view_entropy=True, ret_view_std=True)
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            for _ in range(3):
+                net(rgb_feat, rd, mk, pts, rdir, ret_view_entropy=True, ret_view_std=True)
+            torch.cuda.synchronize()
+        gdt = (time.perf_counter() - g0) / 3
+        gflop = 2.0 * Rg * Sg * (1048064 + 84416 * Vg)
+        gnt = {"rays": Rg, "samples_per_ray": Sg, "views": Vg, "layers": 8, "ms_per_chunk": round(gdt * 1e3, 2),
+               "tflops": round(gflop / gdt / 1e12, 2), "peak_tflops_fp32_mfma": 157.3,
+               "frac_of_peak": round(gflop / gdt / 157.3e12, 4), "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
+               "est_seconds_per_1080p_frame": round(gdt * (H * W / Rg), 1),
+               "note": "GNT.forward incl. view entropy/std side outputs; synthetic gathered features"}
+
     if rank == 0:
         frames = args.steps * world
         fps = frames / elapsed
@@ -245,7 +278,7 @@ def main():
                 "whole_view_alg_bytes": alg_total,
                 "whole_view_alg_GBps": round(alg_total * fps / 1e9 / max(world, 1), 2),
             },
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "gnt": gnt, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

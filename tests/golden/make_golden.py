@@ -316,3 +316,23 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def make_harness_golden():
+    """(pred, gt, mask) -> psnr through the reference's calculate_psnr + the evaluator's
+    quantisation expression (evaluator_pgdvs.py:70-77)."""
+    _install_stubs()
+    from pgdvs.utils.training import calculate_psnr
+
+    rng = np.random.default_rng(77)
+    H, W = 20, 30
+    pred = rng.normal(0.5, 0.4, (3, H, W)).astype(np.float32)
+    pred[0, 0, 0] = np.nan
+    gt = rng.random((3, H, W), dtype=np.float32)
+    mask = (rng.random((3, H, W)) < 0.7).astype(np.float32)
+    p = torch.nan_to_num(torch.from_numpy(pred).clamp(0.0, 1.0), nan=0.0)
+    pq = ((p * 255).byte().float() / 255.0).numpy()
+    gq = ((torch.from_numpy(gt).clamp(0, 1) * 255).byte().float() / 255.0).numpy()
+    np.savez_compressed(OUT / "harness_psnr.npz", pred=pred, gt=gt, mask=mask, pred_q=pq, gt_q=gq,
+                        psnr=calculate_psnr(pq.transpose(1, 2, 0), gq.transpose(1, 2, 0), mask.transpose(1, 2, 0)),
+                        psnr_same=calculate_psnr(gq.transpose(1, 2, 0), gq.transpose(1, 2, 0), mask.transpose(1, 2, 0)))

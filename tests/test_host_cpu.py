@@ -146,3 +146,17 @@ def test_gnt_modules_match_reference_golden(golden_dir):
         np.testing.assert_allclose(out.numpy(), g[f"{tag}_out"], rtol=0, atol=1e-5)
         for k, v in ex.items():
             np.testing.assert_allclose(v.numpy(), g[f"{tag}_{k}"], rtol=0, atol=1e-5, err_msg=k)
+
+
+def test_harness_quantisation_and_psnr_vs_reference(golden_dir):
+    import numpy as np
+
+    from pgdvs_amd.harness import masked_psnr, quantize_like_evaluator
+
+    g = dict(np.load(golden_dir / "harness_psnr.npz"))
+    pq = quantize_like_evaluator(torch.from_numpy(g["pred"]))
+    gq = quantize_like_evaluator(torch.from_numpy(g["gt"]))
+    assert np.array_equal(pq.numpy(), g["pred_q"]) and np.array_equal(gq.numpy(), g["gt_q"])
+    m = torch.from_numpy(g["mask"])
+    assert abs(masked_psnr(pq, gq, m) - float(g["psnr"])) < 1e-9
+    assert masked_psnr(gq, gq, m) == float(g["psnr_same"]) == 0

@@ -48,3 +48,33 @@ def reduce_metrics(values: torch.Tensor, dst: int = 0) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(values, dst=dst, op=dist.ReduceOp.SUM)
     return values
+
+
+class AsyncImageGather:
+    """Per-step asynchronous gather of the rendered images to ``dst``: step j's transfer (RCCL
+    over xGMI, its own stream) overlaps with the rendering of step j+1, so only the last image
+    is exposed.  ``finish()`` waits for all transfers and returns, on ``dst``, the stack
+    [n_steps * world, ...] in view order (view = step * world + rank), else None."""
+
+    def __init__(self, dst: int = 0):
+        self.dst = dst
+        self.works, self.bufs, self.keep = [], [], []
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def submit(self, img: torch.Tensor) -> None:
+        img = img.contiguous()
+        self.keep.append(img)
+        if not self.on:
+            return
+        bufs = [torch.empty_like(img) for _ in range(dist.get_world_size())] if dist.get_rank() == self.dst else None
+        self.bufs.append(bufs)
+        self.works.append(dist.gather(img, bufs, dst=self.dst, async_op=True))
+
+    def finish(self):
+        if not self.on:
+            return torch.cat(self.keep, 0) if self.keep else None
+        for w in self.works:
+            w.wait()
+        if dist.get_rank() != self.dst:
+            return None
+        return torch.cat([torch.cat(b, 0) for b in self.bufs], 0)

@@ -90,7 +90,7 @@ def test_shard_indices_matches_distributed_sampler():
 _WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.path.join(sys.argv[1], "ml-pgdvs_amd"))
-from pgdvs_amd.dist import shard_indices, gather_image_stack, reduce_metrics
+from pgdvs_amd.dist import shard_indices, gather_image_stack, reduce_metrics, AsyncImageGather
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 n_views = 5
@@ -98,6 +98,14 @@ mine = shard_indices(n_views, rank, world)
 local = torch.stack([torch.full((3, 4, 6), float(v)) for v in mine])
 out = gather_image_stack(local, n_views)
 m = reduce_metrics(torch.tensor([1.0, float(rank)]))
+ag = AsyncImageGather()
+for step in range(3):
+    ag.submit(torch.full((1, 3, 2, 2), float(step * world + rank)))
+stack = ag.finish()
+if rank == 0:
+    assert [int(stack[i, 0, 0, 0]) for i in range(3 * world)] == list(range(3 * world)), stack[:, 0, 0, 0]
+else:
+    assert stack is None
 if rank == 0:
     assert out.shape == (n_views, 3, 4, 6), out.shape
     assert [int(out[i, 0, 0, 0]) for i in range(n_views)] == list(range(n_views))

@@ -114,7 +114,8 @@ int pgdvs_knn_mean_dist(const float *pts, const int32_t *count, int64_t capacity
 
 /* threshold = lower-median(avg) + unbiased-std(avg) * std_thres; flag = avg < threshold
  * (pgdvs_renderer_dyn.py:419-427).  thres_out: 1 float; flag_out[capacity] u8.
- * remove_outlier == 0 -> all flags 1 (:453-457), threshold still produced. */
+ * remove_outlier == 0 -> all flags 1 (:453-457), threshold still produced.  flag_out[i] = 0
+ * for *count <= i < capacity. */
 int64_t pgdvs_outlier_workspace_bytes(int64_t capacity);
 int pgdvs_outlier_flags(const float *avg, const int32_t *count, int64_t capacity,
                         float std_thres, int remove_outlier, float *thres_out,
@@ -234,6 +235,48 @@ int pgdvs_gnt_view_layer(const float *weights, const float *q_in, const float *f
  * query sample 0 averaged over heads (:336). */
 int pgdvs_gnt_ray_layer(const float *weights, const float *q_in, int R, int S, float *q_out,
                         float *sample_weights, pgdvs_stream_t stream);
+
+/* A17: tracker-window point aggregation (pgdvs_renderer_dyn_track.py:98-396); tracks and
+ * visibilities are inputs.  Frames are ordered as prepare_data orders them (:599-716):
+ * [fwd2tgt tracks..., temporally-closest..., bwd2tgt tracks...].
+ *   tracks[P,N,2] (col,row), visibles[P,N] u8, frame_kind_host[N] (HOST array; 1 = temporally
+ *   closest frame, 2 = real track frame), times[N] / time_tgt[1] raw time stamps (device;
+ *   shifted to start at 0 internally as :718-721), rgbs[N,H,W,3], depths[N,H,W],
+ *   cams[N,PGDVS_CAM_BLOCK].
+ *   valid[P] u8 : invisible in every closest frame and visible in >= 2 track frames (:115-127)
+ *   pcl[P,3]    : the two visible frames nearest in time (:146-166) unprojected with the
+ *                 nearest-sampled depth (:220-253) and inter/extrapolated to time_tgt (:278-284)
+ *   rgb[P,3]    : mean of the two bilinear (align_corners=True) colour samples (:197-218,:271-276)
+ * Rows of invalid tracks are zero.  N <= 64. */
+int pgdvs_track_points(const float *tracks, const uint8_t *visibles, int64_t P, int N,
+                       const uint8_t *frame_kind_host, const float *times, const float *time_tgt,
+                       const float *rgbs, const float *depths, int H, int W, const float *cams,
+                       uint8_t *valid, float *pcl, float *rgb, pgdvs_stream_t stream);
+
+/* pytorch3d.ops.knn_points(queries, pts, K=KK) + mean over ALL KK squared distances (the
+ * track-to-base filter, :299-312; no self column).  Exact uniform-grid search over `pts`;
+ * counts on the device; KK <= 64; missing columns (fewer than KK points) count as 0.
+ * avg_out[query_capacity].  workspace >= pgdvs_knn_cross_workspace_bytes(capacity, query_capacity). */
+int64_t pgdvs_knn_cross_workspace_bytes(int64_t capacity, int64_t query_capacity);
+int pgdvs_knn_cross_mean_dist(const float *queries, const int32_t *query_count, int64_t query_capacity,
+                              const float *pts, const int32_t *count, int64_t capacity, int KK,
+                              float *avg_out, void *workspace, int64_t workspace_bytes,
+                              pgdvs_stream_t stream);
+
+/* flag[i] = avg[i] < (*thres * mult) for i < *count (:314-318, :363-371).  gate_count
+ * (nullable, device): when *gate_count == 0 ("no base cloud", :296-298) the test becomes
+ * avg[i] < *alt_thres, or passes everything if alt_thres is null.  flag_out[i] = 0 for
+ * *count <= i < capacity. */
+int pgdvs_threshold_flags(const float *avg, const int32_t *count, int64_t capacity, const float *thres,
+                          float mult, const float *alt_thres, const int32_t *gate_count,
+                          uint8_t *flag_out, pgdvs_stream_t stream);
+
+/* out = concat(a[0:*count_a], b[0:*count_b]) by rows of `width` floats, *count_out = rows
+ * written (torch.cat of :390-394).  require_a != 0: the result is empty when *count_a == 0.
+ * b may be null.  out holds capacity_a + capacity_b rows. */
+int pgdvs_concat_rows(const float *a, const int32_t *count_a, int64_t capacity_a, const float *b,
+                      const int32_t *count_b, int64_t capacity_b, int width, int require_a,
+                      float *out, int32_t *count_out, pgdvs_stream_t stream);
 
 /* A11 alone: combined = (1-m)*static + m*dyn (pgdvs_renderer.py:169-178), n elements per
  * channel, planar [3,n] with mask [n]. */

@@ -264,26 +264,28 @@ stat_select_kernel(const int32_t *__restrict__ count, int pass, int nblocks,
   }
 }
 
+// flags beyond *count (up to capacity) are cleared so the array can be compacted as a whole
 __global__ void outlier_flag_kernel(const float *__restrict__ avg, const int32_t *__restrict__ count,
-                                    const float *__restrict__ thres, int remove_outlier,
+                                    int64_t capacity, const float *__restrict__ thres, int remove_outlier,
                                     uint8_t *__restrict__ flag) {
   int64_t n = *count;
   float t = *thres;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity;
        i += (int64_t)gridDim.x * blockDim.x)
-    flag[i] = remove_outlier ? (uint8_t)(avg[i] < t) : (uint8_t)1;
+    flag[i] = i < n ? (remove_outlier ? (uint8_t)(avg[i] < t) : (uint8_t)1) : (uint8_t)0;
 }
 
-int64_t knn_grid_workspace_bytes(int64_t capacity);
+int64_t knn_grid_workspace_bytes(int64_t capacity, int64_t qcapacity);
 int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity, int K, float *avg_out,
-                       void *workspace, int64_t workspace_bytes, hipStream_t st);
+                       void *workspace, int64_t workspace_bytes, hipStream_t st, const float *qpts,
+                       const int32_t *qcount, int64_t qcapacity);
 
 }  // namespace pgdvs
 
 using namespace pgdvs;
 
 PGDVS_API int64_t pgdvs_knn_workspace_bytes(int64_t capacity) {
-  return knn_grid_workspace_bytes(capacity);
+  return knn_grid_workspace_bytes(capacity, 0);
 }
 
 PGDVS_API int pgdvs_knn_mean_dist(const float *pts, const int32_t *count, int64_t capacity, int K,
@@ -294,7 +296,7 @@ PGDVS_API int pgdvs_knn_mean_dist(const float *pts, const int32_t *count, int64_
   PGDVS_REQUIRE(algo != 2 || K + 1 <= 64, "pgdvs_knn_mean_dist: grid search needs K+1 <= 64");
   if (capacity > 0 && K >= 1 && K + 1 <= 64 && algo != 1 && capacity < (1ll << 31))
     return knn_grid_mean_dist(pts, count, capacity, K, avg_out, workspace, workspace_bytes,
-                              as_stream(stream));
+                              as_stream(stream), nullptr, nullptr, 0);
   PGDVS_REQUIRE(K >= 1 && K + 1 <= kKnnMaxKK, "pgdvs_knn_mean_dist: K must be in [1, %d]",
                 kKnnMaxKK - 1);
   PGDVS_REQUIRE(capacity >= 0 && capacity < (1ll << 31), "pgdvs_knn_mean_dist: bad capacity");
@@ -311,6 +313,23 @@ PGDVS_API int pgdvs_knn_mean_dist(const float *pts, const int32_t *count, int64_
   PGDVS_LAUNCH("knn_mean_dist", knn_mean_dist_kernel, dim3((unsigned)cdiv(capacity, kKnnBlock)),
                      dim3(kKnnBlock), lds, as_stream(stream), pts, count, K, avg_out);
   return check_launch("knn_mean_dist");
+}
+
+PGDVS_API int64_t pgdvs_knn_cross_workspace_bytes(int64_t capacity, int64_t query_capacity) {
+  return knn_grid_workspace_bytes(capacity, query_capacity);
+}
+
+PGDVS_API int pgdvs_knn_cross_mean_dist(const float *queries, const int32_t *query_count,
+                                        int64_t query_capacity, const float *pts, const int32_t *count,
+                                        int64_t capacity, int KK, float *avg_out, void *workspace,
+                                        int64_t workspace_bytes, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(queries && query_count && pts && count && avg_out, "pgdvs_knn_cross_mean_dist: null pointer");
+  PGDVS_REQUIRE(KK >= 1 && KK <= 64, "pgdvs_knn_cross_mean_dist: KK must be in [1, 64]");
+  PGDVS_REQUIRE(capacity > 0 && capacity < (1ll << 31) && query_capacity >= 0 && query_capacity < (1ll << 31),
+                "pgdvs_knn_cross_mean_dist: bad capacity");
+  if (query_capacity == 0) return PGDVS_OK;
+  return knn_grid_mean_dist(pts, count, capacity, KK - 1, avg_out, workspace, workspace_bytes,
+                            as_stream(stream), queries, query_count, query_capacity);
 }
 
 PGDVS_API int64_t pgdvs_outlier_workspace_bytes(int64_t capacity) {
@@ -347,7 +366,7 @@ PGDVS_API int pgdvs_outlier_flags(const float *avg, const int32_t *count, int64_
   if (capacity > 0) {
     unsigned grid = (unsigned)(cdiv(capacity, 256) < 1024 ? cdiv(capacity, 256) : 1024);
     PGDVS_LAUNCH("outlier_flag", outlier_flag_kernel, dim3(grid), dim3(256), 0, st, avg, count,
-                 thres_out, remove_outlier, flag_out);
+                 capacity, thres_out, remove_outlier, flag_out);
   }
   return check_launch("outlier_flags");
 }

@@ -374,12 +374,27 @@ __device__ __forceinline__ void scan_range(BestList &b, bool &first, const float
 // columns beyond the number of points count as 0, as pytorch3d pads).  Summation order is
 // a fixed butterfly over 64 slots -- s[i] += s[i+32], s[i] += s[i+16], ... s[0] += s[1] --
 // which the CPU oracle and the brute-force kernel reproduce, so results stay bit-identical.
-__device__ __forceinline__ void knn_finish(float best, int K, int n, int lane, int orig,
+//
+// Cross-set mode (queries from a second array, A17 track-to-base filter,
+// pgdvs_renderer_dyn_track.py:299-312): there is no self column, all KK columns count.
+struct QuerySrc {
+  const float *qpts;      // null: the queries are the points themselves (cell-sorted order)
+  const int32_t *qcount;
+  int first_col;          // 1: drop column 0 (self), 0: keep it
+};
+
+__device__ __forceinline__ float4 load_query(const QuerySrc &qs, const float4 *__restrict__ sorted, int q) {
+  if (qs.qpts == nullptr) return sorted[q];
+  return make_float4(qs.qpts[(size_t)q * 3], qs.qpts[(size_t)q * 3 + 1], qs.qpts[(size_t)q * 3 + 2],
+                     __int_as_float(q));
+}
+
+__device__ __forceinline__ void knn_finish(float best, int KK, int first_col, int n, int lane, int orig,
                                            float *__restrict__ avg_out) {
-  float s = (lane >= 1 && lane <= K && lane < n) ? best : 0.0f;
+  float s = (lane >= first_col && lane < KK && lane < n) ? best : 0.0f;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s = s + __shfl_down(s, off, 64);
-  if (lane == 0) avg_out[orig] = s / (float)K;
+  if (lane == 0) avg_out[orig] = s / (float)(KK - first_col);
 }
 
 // Squared distance (lower bound) from coordinate q to the slab of cells [c0, c1] along one
@@ -394,18 +409,24 @@ __device__ __forceinline__ float box_axis_dist2(float q, float mn, float h, int 
 
 __global__ void __launch_bounds__(256)
 grid_query_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted,
-                  const int32_t *__restrict__ cell_start, int K, float *__restrict__ avg_out,
+                  const int32_t *__restrict__ cell_start, int KK, QuerySrc qs, float *__restrict__ avg_out,
                   int32_t *__restrict__ stats, int ring_cap, int abl, int32_t *__restrict__ fb_count,
                   int32_t *__restrict__ fb_list, float *__restrict__ fb_bound) {
   const GridParams g = *gp;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int KK = K + 1;
+  const int nq = qs.qpts ? *qs.qcount : g.n;
   // persistent waves: the grid is sized for the machine, not for the (device-side) count
-  for (int q = blockIdx.x * 4 + wave; q < g.n; q += gridDim.x * 4) {
-  const float4 qp = sorted[q];
+  for (int q = blockIdx.x * 4 + wave; q < nq; q += gridDim.x * 4) {
+  const float4 qp = load_query(qs, sorted, q);
   const float qx = qp.x, qy = qp.y, qz = qp.z;
   const int orig = __float_as_int(qp.w);
+  if (qs.qpts && !(isfinite(qx) && isfinite(qy) && isfinite(qz))) {
+    // a non-finite query has NaN/inf distances to everything upstream: its mean fails every
+    // `< threshold` test
+    if (lane == 0) avg_out[orig] = __builtin_nanf("");
+    continue;
+  }
   const int cx = cell_coord(qx, g.mn[0], g.inv_h, g.G[0]);
   const int cy = cell_coord(qy, g.mn[1], g.inv_h, g.G[1]);
   const int cz = cell_coord(qz, g.mn[2], g.inv_h, g.G[2]);
@@ -509,7 +530,7 @@ grid_query_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ 
     }
     continue;
   }
-  knn_finish(b.best, K, g.n, lane, orig, avg_out);
+  knn_finish(b.best, KK, qs.first_col, g.n, lane, orig, avg_out);
   }
 }
 
@@ -521,20 +542,19 @@ constexpr int kFbSlices = 16;
 constexpr int kFbMaxSliced = 16384;  // queries beyond this many use the one-workgroup scan
 
 __global__ void __launch_bounds__(256)
-grid_fallback_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted, int K,
-                     const int32_t *__restrict__ fb_count, const int32_t *__restrict__ fb_list,
+grid_fallback_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted, int KK,
+                     QuerySrc qs, const int32_t *__restrict__ fb_count, const int32_t *__restrict__ fb_list,
                      const float *__restrict__ fb_bound, float *__restrict__ fb_partial) {
   __shared__ float s_best[4][64];
   const int n = gp->n;
   const int nfb = *fb_count;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int KK = K + 1;
   const int slice_len = ((n + kFbSlices - 1) / kFbSlices + 255) / 256 * 256;
   const int nsl = nfb < kFbMaxSliced ? nfb : kFbMaxSliced;
   for (int item = blockIdx.x; item < nsl * kFbSlices; item += gridDim.x) {
     const int f = item / kFbSlices, sl = item - f * kFbSlices;
-    const float4 qp = sorted[fb_list[f]];
+    const float4 qp = load_query(qs, sorted, fb_list[f]);
     const float bound = fb_bound[f];
     BestList b;
     b.best = __builtin_inff();
@@ -557,14 +577,13 @@ grid_fallback_kernel(const GridParams *__restrict__ gp, const float4 *__restrict
 }
 
 __global__ void __launch_bounds__(256)
-grid_fallback_merge_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted, int K,
-                           const int32_t *__restrict__ fb_count, const int32_t *__restrict__ fb_list,
+grid_fallback_merge_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted, int KK,
+                           QuerySrc qs, const int32_t *__restrict__ fb_count, const int32_t *__restrict__ fb_list,
                            const float *__restrict__ fb_partial, float *__restrict__ avg_out) {
   const int n = gp->n;
   const int nfb = *fb_count;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int KK = K + 1;
   const int nsl = nfb < kFbMaxSliced ? nfb : kFbMaxSliced;
   for (int f = blockIdx.x * 4 + wave; f < nsl; f += gridDim.x * 4) {
     BestList b;
@@ -572,24 +591,23 @@ grid_fallback_merge_kernel(const GridParams *__restrict__ gp, const float4 *__re
     b.mx = readlane_f(b.best, KK - 1);
     for (int sl = 1; sl < kFbSlices; ++sl)
       best_insert_batch(b, fb_partial[((size_t)f * kFbSlices + sl) * 64 + lane], true, KK, lane);
-    knn_finish(b.best, K, n, lane, __float_as_int(sorted[fb_list[f]].w), avg_out);
+    knn_finish(b.best, KK, qs.first_col, n, lane, __float_as_int(load_query(qs, sorted, fb_list[f]).w), avg_out);
   }
 }
 
 // overflow path: more open queries than kFbMaxSliced (degenerate clouds) -- one 1024-thread
 // workgroup per query scans everything
 __global__ void __launch_bounds__(1024)
-grid_fallback_tail_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted, int K,
-                          const int32_t *__restrict__ fb_count, const int32_t *__restrict__ fb_list,
+grid_fallback_tail_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted, int KK,
+                          QuerySrc qs, const int32_t *__restrict__ fb_count, const int32_t *__restrict__ fb_list,
                           const float *__restrict__ fb_bound, float *__restrict__ avg_out) {
   __shared__ float s_best[16][64];
   const int n = gp->n;
   const int nfb = *fb_count;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int KK = K + 1;
   for (int f = kFbMaxSliced + blockIdx.x; f < nfb; f += gridDim.x) {
-    const float4 qp = sorted[fb_list[f]];
+    const float4 qp = load_query(qs, sorted, fb_list[f]);
     const float bound = fb_bound[f];
     BestList b;
     b.best = __builtin_inff();
@@ -604,7 +622,7 @@ grid_fallback_tail_kernel(const GridParams *__restrict__ gp, const float4 *__res
     __syncthreads();
     if (wave == 0) {
       for (int w = 1; w < 16; ++w) best_insert_batch(b, s_best[w][lane], true, KK, lane);
-      knn_finish(b.best, K, n, lane, __float_as_int(qp.w), avg_out);
+      knn_finish(b.best, KK, qs.first_col, n, lane, __float_as_int(qp.w), avg_out);
     }
   }
 }
@@ -622,7 +640,7 @@ struct GridWs {
   int64_t total_bytes;
 };
 
-static GridWs grid_ws_layout(void *base, int64_t capacity) {
+static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   GridWs w;
   char *p = reinterpret_cast<char *>(base);
   int64_t off = 0;
@@ -646,21 +664,33 @@ static GridWs grid_ws_layout(void *base, int64_t capacity) {
   w.stats = reinterpret_cast<int32_t *>(p + off);
   w.fb_count = reinterpret_cast<int32_t *>(p + off + 128);
   off += 256;
+  const int64_t qcap = qcapacity > capacity ? qcapacity : capacity;  // queries that may fall back
   w.fb_list = reinterpret_cast<int32_t *>(p + off);
-  off += align_up((capacity > 0 ? capacity : 1) * 4, 256);
+  off += align_up((qcap > 0 ? qcap : 1) * 4, 256);
   w.fb_bound = reinterpret_cast<float *>(p + off);
-  off += align_up((capacity > 0 ? capacity : 1) * 4, 256);
+  off += align_up((qcap > 0 ? qcap : 1) * 4, 256);
   w.fb_partial = reinterpret_cast<float *>(p + off);
   off += align_up((int64_t)kFbMaxSliced * kFbSlices * 64 * 4, 256);
   w.total_bytes = off;
   return w;
 }
 
-int64_t knn_grid_workspace_bytes(int64_t capacity) { return grid_ws_layout(nullptr, capacity).total_bytes; }
+int64_t knn_grid_workspace_bytes(int64_t capacity, int64_t qcapacity) {
+  return grid_ws_layout(nullptr, capacity, qcapacity).total_bytes;
+}
 
+// qpts == nullptr: self mode (mean of columns 1..K).  Otherwise cross mode: mean of the K+1
+// smallest distances from each of the *qcount queries to the points.
 int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity, int K, float *avg_out,
-                       void *workspace, int64_t workspace_bytes, hipStream_t st) {
-  GridWs ws = grid_ws_layout(workspace, capacity);
+                       void *workspace, int64_t workspace_bytes, hipStream_t st, const float *qpts,
+                       const int32_t *qcount, int64_t qcapacity) {
+  GridWs ws = grid_ws_layout(workspace, capacity, qcapacity);
+  const int KK = K + 1;
+  QuerySrc qs;
+  qs.qpts = qpts;
+  qs.qcount = qcount;
+  qs.first_col = qpts ? 0 : 1;
+  const int64_t nq_cap = qpts ? qcapacity : capacity;
   if (!workspace || workspace_bytes < ws.total_bytes) {
     set_error("knn_grid: workspace too small");
     return PGDVS_ERR_WORKSPACE;
@@ -708,16 +738,16 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
     set_error("knn_grid memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
   }
-  const unsigned gq = (unsigned)(cdiv(capacity, 4) < 256 * 8 ? cdiv(capacity, 4) : 256 * 8);
+  const unsigned gq = (unsigned)(cdiv(nq_cap, 4) < 256 * 8 ? (cdiv(nq_cap, 4) > 0 ? cdiv(nq_cap, 4) : 1) : 256 * 8);
   PGDVS_LAUNCH("grid_query", grid_query_kernel, dim3(gq), dim3(256), 0, st, ws.gp, ws.sorted,
-               ws.cell_start, K, avg_out, stats, kRingCap, getenv("PGDVS_KNN_ABL") ? atoi(getenv("PGDVS_KNN_ABL")) : 0,
+               ws.cell_start, KK, qs, avg_out, stats, kRingCap, getenv("PGDVS_KNN_ABL") ? atoi(getenv("PGDVS_KNN_ABL")) : 0,
                ws.fb_count, ws.fb_list, ws.fb_bound);
-  PGDVS_LAUNCH("grid_fallback", grid_fallback_kernel, dim3(4096), dim3(256), 0, st, ws.gp, ws.sorted, K,
-               ws.fb_count, ws.fb_list, ws.fb_bound, ws.fb_partial);
+  PGDVS_LAUNCH("grid_fallback", grid_fallback_kernel, dim3(4096), dim3(256), 0, st, ws.gp, ws.sorted, KK,
+               qs, ws.fb_count, ws.fb_list, ws.fb_bound, ws.fb_partial);
   PGDVS_LAUNCH("grid_fallback_merge", grid_fallback_merge_kernel, dim3(256), dim3(256), 0, st, ws.gp,
-               ws.sorted, K, ws.fb_count, ws.fb_list, ws.fb_partial, avg_out);
+               ws.sorted, KK, qs, ws.fb_count, ws.fb_list, ws.fb_partial, avg_out);
   PGDVS_LAUNCH("grid_fallback_tail", grid_fallback_tail_kernel, dim3(256), dim3(1024), 0, st, ws.gp,
-               ws.sorted, K, ws.fb_count, ws.fb_list, ws.fb_bound, avg_out);
+               ws.sorted, KK, qs, ws.fb_count, ws.fb_list, ws.fb_bound, avg_out);
   return check_launch("knn_grid");
 }
 

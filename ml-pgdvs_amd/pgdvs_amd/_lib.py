@@ -50,6 +50,11 @@ SIGNATURES = {
     "pgdvs_gnt_view_weight_floats": (_i64, []),
     "pgdvs_gnt_view_layer": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "pgdvs_gnt_ray_layer": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "pgdvs_track_points": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "pgdvs_knn_cross_workspace_bytes": (_i64, [_i64, _i64]),
+    "pgdvs_knn_cross_mean_dist": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _vp, _vp, _i64, _vp]),
+    "pgdvs_threshold_flags": (_i, [_vp, _vp, _i64, _vp, _f, _vp, _vp, _vp, _vp]),
+    "pgdvs_concat_rows": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "pgdvs_combine": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
 }
 

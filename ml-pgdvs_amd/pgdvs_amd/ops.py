@@ -141,6 +141,66 @@ def outlier_flags(avg: torch.Tensor, cnt: torch.Tensor, std_thres: float, remove
     return thres, flag
 
 
+def knn_cross_mean_dist(queries: torch.Tensor, qcnt: torch.Tensor, pts: torch.Tensor, cnt: torch.Tensor, KK: int) -> torch.Tensor:
+    """mean of the KK smallest squared distances from each query to ``pts`` (all columns)."""
+    q = _req(queries, torch.float32, "queries").reshape(-1, 3)
+    p = _req(pts, torch.float32, "pts").reshape(-1, 3)
+    out = torch.empty(max(q.shape[0], 1), dtype=torch.float32, device=q.device)
+    lib = _lib.load()
+    ws = _ws(lib.pgdvs_knn_cross_workspace_bytes(p.shape[0], q.shape[0]), q.device)
+    check(lib.pgdvs_knn_cross_mean_dist(_ptr(q), _ptr(_req(qcnt, torch.int32, "query_count")), q.shape[0], _ptr(p),
+                                        _ptr(_req(cnt, torch.int32, "count")), p.shape[0], int(KK), _ptr(out), _ptr(ws),
+                                        ws.numel(), _stream()), "pgdvs_knn_cross_mean_dist")
+    return out
+
+
+def threshold_flags(avg, cnt, thres, mult: float = 1.0, alt_thres=None, gate_count=None) -> torch.Tensor:
+    a = _req(avg, torch.float32, "avg")
+    flag = torch.empty(max(a.numel(), 1), dtype=torch.uint8, device=a.device)
+    check(_lib.load().pgdvs_threshold_flags(_ptr(a), _ptr(cnt), a.numel(), _ptr(_req(thres, torch.float32, "thres")), float(mult),
+                                            _ptr(alt_thres), _ptr(gate_count), _ptr(flag), _stream()), "pgdvs_threshold_flags")
+    return flag
+
+
+def concat_rows(a, cnt_a, b=None, cnt_b=None, require_a: bool = False):
+    """[a[:cnt_a], b[:cnt_b]] with device-side counts -> (rows, count)."""
+    a = _req(a, torch.float32, "a")
+    assert a.ndim == 2
+    nb = 0
+    if b is not None:
+        b = _req(b, torch.float32, "b")
+        assert b.ndim == 2 and b.shape[1] == a.shape[1], (a.shape, b.shape)
+        nb = b.shape[0]
+    out = torch.empty((max(a.shape[0] + nb, 1), a.shape[1]), dtype=torch.float32, device=a.device)
+    cnt = torch.empty(1, dtype=torch.int32, device=a.device)
+    check(_lib.load().pgdvs_concat_rows(_ptr(a), _ptr(cnt_a), a.shape[0], _ptr(b), _ptr(cnt_b), nb, a.shape[1],
+                                        int(bool(require_a)), _ptr(out), _ptr(cnt), _stream()), "pgdvs_concat_rows")
+    return out, cnt
+
+
+def track_points(tracks, visibles, frame_kind, times, time_tgt, rgbs, depths, cams):
+    """A17 per-track validity, 3-D point at the target time and colour.
+    tracks[P,N,2], visibles[P,N] bool, frame_kind: N host ints (1 closest / 2 track frame),
+    times[N], time_tgt[1] (raw, device), rgbs[N,H,W,3], depths[N,H,W], cams[N,80]."""
+    t = _req(tracks, torch.float32, "tracks")
+    P, N = t.shape[0], t.shape[1]
+    v = visibles
+    if not v.is_cuda:
+        raise PgdvsHipError("visibles: expected a GPU tensor (no CPU fallback)")
+    v = v.contiguous().view(torch.uint8) if v.dtype == torch.bool else _req(v, torch.uint8, "visibles")
+    rg = _req(rgbs, torch.float32, "rgbs")
+    H, W = rg.shape[1], rg.shape[2]
+    kind = (C.c_uint8 * N)(*[int(k) for k in frame_kind])
+    valid = torch.empty(max(P, 1), dtype=torch.uint8, device=t.device)
+    pcl = torch.empty((max(P, 1), 3), dtype=torch.float32, device=t.device)
+    rgb = torch.empty((max(P, 1), 3), dtype=torch.float32, device=t.device)
+    check(_lib.load().pgdvs_track_points(_ptr(t), _ptr(v), P, N, C.cast(kind, C.c_void_p), _ptr(_req(times, torch.float32, "times")),
+                                         _ptr(_req(time_tgt, torch.float32, "time_tgt")), _ptr(rg),
+                                         _ptr(_req(depths, torch.float32, "depths")), H, W, _ptr(_req(cams, torch.float32, "cams")),
+                                         _ptr(valid), _ptr(pcl), _ptr(rgb), _stream()), "pgdvs_track_points")
+    return valid[:P], pcl[:P], rgb[:P]
+
+
 def scatter_keep(idx, flag, cnt, P: int) -> torch.Tensor:
     keep = torch.empty(P, dtype=torch.uint8, device=idx.device)
     check(_lib.load().pgdvs_scatter_keep(_ptr(idx), _ptr(flag), _ptr(cnt), idx.numel(), _ptr(keep), P, _stream()), "pgdvs_scatter_keep")

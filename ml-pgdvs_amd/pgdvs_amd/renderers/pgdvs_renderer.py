@@ -38,7 +38,14 @@ class PGDVSRenderer(PGDVSBaseRenderer):
         assert self.softsplat_metric_abs_alpha >= 0, f"{self.softsplat_metric_abs_alpha}"
         assert render_cfg.dyn_render_track_temporal in ["none", "no_tgt"], f"{render_cfg.dyn_render_track_temporal}"
 
-        self.dyn_renderer = PGDVSDynamicRenderer(
+        # :62-72
+        if render_cfg.dyn_render_track_temporal == "no_tgt":
+            from .pgdvs_renderer_dyn_track import PGDVSDynamicTrackRenderer
+
+            dyn_renderer_cls = PGDVSDynamicTrackRenderer
+        else:
+            dyn_renderer_cls = PGDVSDynamicRenderer
+        self.dyn_renderer = dyn_renderer_cls(
             cfg=cfg, softsplat_metric_abs_alpha=softsplat_metric_abs_alpha,
             proj_func=self.static_renderer.projector.compute_projections, local_rank=local_rank,
             use_tracker=render_cfg.dyn_render_track_temporal == "no_tgt")

@@ -42,9 +42,20 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
         self.tracker = None
         self.use_tracker = use_tracker
         if self.use_tracker:
-            # point trackers (TAPIR / CoTracker) are pretrained third-party networks that
-            # are out of scope of this build
-            raise NotImplementedError("dyn_render_track_temporal=no_tgt needs a point tracker (out of scope)")
+            # :52-61.  The point trackers (TAPIR / CoTracker) are pretrained third-party
+            # networks outside this build: any module with the reference's interface contract
+            # (``tracker(frames=[N,H,W,3], query_points=[#pt,3]) -> tracks, visibles`` and a
+            # ``query_chunk_size`` attribute) can be plugged in through cfg.tracker; without
+            # one the tracks must be supplied in the data dict (see
+            # PGDVSDynamicTrackRenderer.render_with_track).
+            tracker_cfg = getattr(self.cfg, "tracker", None)
+            if tracker_cfg is not None and getattr(tracker_cfg, "_target_", None) is not None:
+                from ..instantiate import instantiate
+
+                self.tracker = instantiate(tracker_cfg, ori_rgb_range=self.cfg.rgb_range, local_rank=local_rank)
+                if isinstance(self.tracker, torch.nn.Module):
+                    self.tracker = self.tracker.eval()
+                self.track_chunk_size = self.tracker.query_chunk_size
 
     # -- A2..A5 -------------------------------------------------------------
     def compute_dyn_pcl(self, *, dyn_mask_1, rgb_1, depth_1, flow_12, flow_12_occ_mask, rgb_2, depth_2,
@@ -63,11 +74,11 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
         # pytorch3d's kNN runs unconditionally upstream (:405-410) but its result is only
         # observable through the outlier flags (and the tracker, not built): skip it when
         # it cannot influence any output.
-        if render_cfg.dyn_pcl_remove_outlier:
+        if render_cfg.dyn_pcl_remove_outlier or self.use_tracker:  # the tracker row needs the threshold (:508)
             idx, cnt = ops.compact_u8(valid)
             pts = ops.gather_rows(pcl.reshape(-1, 3), idx, cnt)
             avg = ops.knn_mean_dist(pts, cnt, render_cfg.dyn_pcl_outlier_knn)
-            thres, flag = ops.outlier_flags(avg, cnt, render_cfg.dyn_pcl_outlier_std_thres, True)
+            thres, flag = ops.outlier_flags(avg, cnt, render_cfg.dyn_pcl_outlier_std_thres, render_cfg.dyn_pcl_remove_outlier)
             keep = ops.scatter_keep(idx, flag, cnt, H * W)
             info.update(pcl_nn_dist_thres=thres, avg_nn_dist=avg, n_valid=cnt)
         else:
@@ -92,8 +103,8 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
         # dyn_render_type=mesh (:542-669) is a "next" row
         raise NotImplementedError("dyn_render_type='mesh' is not built yet")
 
-    def render_with_track(self):
-        raise NotImplementedError
+    def render_with_track(self, *a, **kw):
+        raise NotImplementedError  # :272-273; PGDVSDynamicTrackRenderer implements it
 
     # -- A2..A5 for a whole batch, optionally on a side stream ---------------------
     def prepare(self, data, render_cfg, stream=None):
@@ -120,7 +131,7 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
                     flow_12=data["flow_fwd"][i_b], flow_12_occ_mask=data["flow_fwd_occ_mask"][i_b, ..., 0],
                     rgb_2=data["rgb_src_temporal"][i_b, 1], depth_2=data["depth_src_temporal"][i_b, 1, ..., 0],
                     cam_1=cams_src[i_b, 0], cam_2=cams_src[i_b, 1], cam_tgt=cams_tgt[i_b], times=times[i_b],
-                    render_cfg=render_cfg, need_points=(dyn_type == "pcl")))
+                    render_cfg=render_cfg, need_points=(dyn_type == "pcl" or self.use_tracker)))
         return {"items": items, "cams_tgt": cams_tgt, "stream": stream}
 
     # -- A8 -----------------------------------------------------------------
@@ -148,7 +159,7 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
 
         render_h, render_w = ray_batch["render_h"], ray_batch["render_w"]
         same_res = (render_h == orig_h) and (render_w == orig_w)
-        fuse_static = static_rgb is not None and same_res and dyn_type == "softsplat"
+        fuse_static = static_rgb is not None and same_res and dyn_type == "softsplat" and not self.use_tracker
 
         noise = None
         if dyn_type == "softsplat":
@@ -177,16 +188,32 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
         render_dyn_rgb = torch.stack(dyn_rgbs, 0) if n_b > 1 else dyn_rgbs[0][None]  # [B,3,H,W]
         render_dyn_mask = torch.stack(dyn_masks, 0) if n_b > 1 else dyn_masks[0][None]  # [B,1,H,W]
 
-        # no tracker: the track images are zeros, so the merge of :229-235 is the identity on
-        # the {0,1}-valued closest-frame mask
-        render_track_rgb = torch.zeros_like(render_dyn_rgb)
-        render_track_mask = torch.zeros_like(render_dyn_mask)
-        render_dyn_rgb_final, render_dyn_mask_final = render_dyn_rgb, render_dyn_mask
+        if self.use_tracker:
+            # :211-235 -- pixels the closest-frame rendering left empty are filled from the
+            # tracker-window cloud
+            infos = [it[2] for it in prepared["items"]]
+            base_pcl_info = {k: [inf[k] for inf in infos] for k in ("pcl", "pcl_rgbs", "pcl_nn_dist_thres", "n_pts")}
+            render_track_rgb, render_track_mask = self.render_with_track(
+                data, render_cfg=render_cfg, base_pcl_info=base_pcl_info, for_debug=for_debug, disable_tqdm=disable_tqdm,
+                cams_tgt=cams_tgt)
+            mask_for_track = ((~(render_dyn_mask > 0)) & (render_track_mask > 0)).float()
+            render_dyn_rgb_final = ops.combine(render_dyn_rgb, render_track_rgb, mask_for_track)[0]
+            render_dyn_mask_final = ((render_dyn_mask > 0) | (render_track_mask > 0)).float()
+        else:
+            # no tracker: the track images are zeros, so the merge of :229-235 is the identity on
+            # the {0,1}-valued closest-frame mask
+            render_track_rgb = torch.zeros_like(render_dyn_rgb)
+            render_track_mask = torch.zeros_like(render_dyn_mask)
+            render_dyn_rgb_final, render_dyn_mask_final = render_dyn_rgb, render_dyn_mask
 
         if not same_res:
+            if self.use_tracker:
+                render_dyn_rgb_final, render_dyn_mask_final = self.resize_rgb_mask(
+                    render_dyn_rgb_final, render_dyn_mask_final, render_h, render_w)
             render_dyn_rgb, render_dyn_mask = self.resize_rgb_mask(render_dyn_rgb, render_dyn_mask, render_h, render_w)
             render_track_rgb, render_track_mask = self.resize_rgb_mask(render_track_rgb, render_track_mask, render_h, render_w)
-            render_dyn_rgb_final, render_dyn_mask_final = render_dyn_rgb, render_dyn_mask
+            if not self.use_tracker:
+                render_dyn_rgb_final, render_dyn_mask_final = render_dyn_rgb, render_dyn_mask
 
         info_dict = {
             "temporal_closest_rgb": render_dyn_rgb,

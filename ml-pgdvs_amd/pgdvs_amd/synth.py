@@ -141,6 +141,56 @@ def make_view(video, i, frac=0.4, seed=0, with_noise=True):
     return data
 
 
+def add_track_window(data, video, i, n_side=2, seed=0, step=3, p_closest_visible=0.5):
+    """Adds the tracker-window keys (pgdvs_renderer_dyn_track.py:599-716: ``*_src_temporal_track_fwd2tgt`` /
+    ``_bwd2tgt``, ``n_actual_*``) around the view of make_view(video, i) and synthetic point
+    tracks standing in for a tracker's output: every ``step``-th dynamic pixel of the track
+    frames, moved with the disc velocity, with random visibility drop-outs.
+    Frame order of the tracks: [fwd2tgt..., i, i+1, bwd2tgt...]."""
+    S, H, W = video["depths"].shape
+    j = min(i + 1, S - 1)
+    rng = np.random.default_rng(seed + 104729 * i)
+    fwd = [f for f in range(i - n_side, i) if f >= 0]
+    bwd = [f for f in range(j + 1, j + 1 + n_side) if f < S]
+    closest = [i, j]
+
+    def pack(frames, n):
+        def pad(a):
+            a = np.asarray(a)
+            return np.concatenate([a, np.zeros((n - a.shape[0],) + a.shape[1:], a.dtype)], 0)[None]
+        fr = list(frames)
+        return {
+            "rgb": pad(video["rgbs"][fr].reshape(len(fr), H, W, 3)), "depth": pad(video["depths"][fr].reshape(len(fr), H, W)[..., None]),
+            "dyn_mask": pad(video["dyn_masks"][fr].reshape(len(fr), H, W)[..., None].astype(np.float32)),
+            "flat_cam": pad(np.stack([flat_cam(H, W, video["K3s"][f], video["c2ws"][f]) for f in fr]).reshape(len(fr), 34)
+                            if fr else np.zeros((0, 34), np.float32)),
+            "time": pad(np.array(fr, np.float32))}
+
+    for suffix, frames in (("_track_fwd2tgt", fwd), ("_track_bwd2tgt", bwd)):
+        for k, v in pack(frames, n_side).items():
+            data[f"{k}_src_temporal{suffix}"] = v
+    data["n_actual_temporal_track_fwd2tgt"] = np.array([[len(fwd)]], np.int64)
+    data["n_actual_temporal_track_bwd2tgt"] = np.array([[len(bwd)]], np.int64)
+    data["n_actual_temporal"] = np.array([[2]], np.int64)
+
+    window = fwd + closest + bwd
+    tracks, vis = [], []
+    for q in fwd + bwd:
+        rows, cols = np.nonzero(video["dyn_masks"][q])
+        rows, cols = rows[::step], cols[::step]
+        pos = np.stack([cols, rows], -1).astype(np.float64)  # (col,row)
+        tr = np.stack([pos + video["vel"] * (f - q) + rng.normal(0, 0.05, pos.shape) for f in window], 1)
+        inside = (tr[..., 0] >= 0) & (tr[..., 0] <= W - 1) & (tr[..., 1] >= 0) & (tr[..., 1] <= H - 1)
+        v = inside & (rng.random(inside.shape) < 0.85)
+        v[:, len(fwd):len(fwd) + 2] &= (rng.random((pos.shape[0], 1)) < p_closest_visible)
+        tracks.append(tr.astype(np.float32))
+        vis.append(v)
+    N = len(window)
+    data["track_tracks"] = [np.concatenate(tracks) if tracks else np.zeros((0, N, 2), np.float32)]
+    data["track_visibles"] = [np.concatenate(vis) if vis else np.zeros((0, N), bool)]
+    return data
+
+
 def to_torch(d, device):
     import torch
 
@@ -148,6 +198,8 @@ def to_torch(d, device):
     for k, v in d.items():
         if isinstance(v, np.ndarray) and v.dtype != np.float64:
             out[k] = torch.from_numpy(np.ascontiguousarray(v)).to(device)
+        elif isinstance(v, list) and v and all(isinstance(e, np.ndarray) for e in v):
+            out[k] = [torch.from_numpy(np.ascontiguousarray(e)).to(device) for e in v]
         else:
             out[k] = v
     return out

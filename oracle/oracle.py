@@ -348,11 +348,27 @@ def dyn_forward(data: dict, render_cfg: dict, static_noise=None, alpha=100.0):
         raise NotImplementedError(render_cfg["dyn_render_type"])
     track_rgb = np.zeros_like(render_dyn_rgb)
     track_mask = np.zeros_like(render_dyn_mask)
+    if render_cfg.get("dyn_render_track_temporal", "none") == "no_tgt":
+        # render_with_track (pgdvs_renderer_dyn_track.py:27-96) with supplied tracks
+        for b in range(B):
+            tracks, vis = data["track_tracks"][b], data["track_visibles"][b]
+            if tracks is None or tracks.shape[0] == 0:
+                continue
+            dft = track_prepare_data(data, b)
+            base = infos[b]
+            pcl, rgbs, tinfo = track_compute_pcl_for_tgt(
+                dft, tracks, vis, render_cfg, None if base is None else base["pcl"],
+                None if base is None else base["pcl_rgbs"], None if base is None else base["pcl_nn_dist_thres"])
+            img, msk, _ = render_points(pcl, rgbs, data["flat_cam_tgt"][b], H, W, render_cfg["dyn_render_pcl_pt_radius"],
+                                        render_cfg["dyn_render_pcl_pts_per_pixel"])
+            track_rgb[b] = img.transpose(2, 0, 1)
+            track_mask[b] = msk.transpose(2, 0, 1)
+            extra.setdefault("track_infos", []).append(tinfo)
     mask_for_track = ((~(render_dyn_mask > 0)) & (track_mask > 0)).astype(np.float32)
     final_rgb = (1 - mask_for_track) * render_dyn_rgb + mask_for_track * track_rgb
     final_mask = ((render_dyn_mask > 0) | (track_mask > 0)).astype(np.float32)
-    return final_rgb, final_mask, {"temporal_closest_rgb": render_dyn_rgb,
-                                   "temporal_closest_mask": render_dyn_mask, "infos": infos, **extra}
+    return final_rgb, final_mask, {"temporal_closest_rgb": render_dyn_rgb, "temporal_closest_mask": render_dyn_mask,
+                                   "temporal_track_rgb": track_rgb, "temporal_track_mask": track_mask, "infos": infos, **extra}
 
 
 # --------------------------------------------------------------------------
@@ -518,3 +534,86 @@ def render_view(data: dict, render_cfg: dict, static_noise=None, alpha=100.0):
     ret["combined_rgb"], ret["combined_rgb_static"], ret["combined_rgb_dyn"] = c, cs, cd
     ret["_info"] = info
     return ret
+
+
+# --------------------------------------------------------------------------
+# A17 tracker-window aggregation (pgdvs_renderer_dyn_track.py)
+# --------------------------------------------------------------------------
+def knn_cross_mean_dist(query, pts, KK) -> np.ndarray:
+    """mean of the KK smallest squared distances query -> pts (all KK columns, :299-312)."""
+    query = _f32(query).reshape(-1, 3)
+    pts = _f32(pts).reshape(-1, 3)
+    out = np.empty(query.shape[0], np.float32)
+    lib().orc_knn_cross_mean_dist(
+        _p(query, _c_float_p), ctypes.c_int64(query.shape[0]), _p(pts, _c_float_p),
+        ctypes.c_int64(pts.shape[0]), int(KK), _p(out, _c_float_p))
+    return out
+
+
+def track_prepare_data(data: dict, i_b: int) -> dict:
+    """prepare_data (:599-764) without the fixed-shape padding that only the tracker
+    networks need: frames ordered [fwd2tgt..., temporally-closest..., bwd2tgt...]."""
+    parts = {k: [] for k in ("rgb", "dyn_mask", "depth", "flat_cam", "time")}
+    kind = []
+    for suffix, nkey, kd in (("_track_fwd2tgt", "n_actual_temporal_track_fwd2tgt", 2), ("", "n_actual_temporal", 1),
+                             ("_track_bwd2tgt", "n_actual_temporal_track_bwd2tgt", 2)):
+        n = int(np.asarray(data[nkey])[i_b, 0])
+        if n <= 0:
+            continue
+        for k in parts:
+            parts[k].append(np.asarray(data[f"{k}_src_temporal{suffix}"])[i_b, :n])
+        kind += [kd] * n
+    times = np.concatenate(parts["time"]).astype(np.float32)
+    t_min = times.min()
+    return {
+        "rgbs": _f32(np.concatenate(parts["rgb"])), "dyn_masks": _f32(np.concatenate(parts["dyn_mask"])),
+        "depths": _f32(np.concatenate(parts["depth"])), "flat_cams": _f32(np.concatenate(parts["flat_cam"])),
+        "times": times - t_min, "time_tgt": np.float32(np.asarray(data["time_tgt"], np.float32)[i_b, 0] - t_min),
+        "kind": np.array(kind, np.uint8)}
+
+
+def track_points(dft: dict, tracks, vis):
+    """orc_track_points -> (valid[P] bool, pcl[P,3], rgb[P,3])."""
+    tracks = _f32(tracks)
+    P, N = tracks.shape[:2]
+    vis = np.ascontiguousarray(vis, dtype=np.uint8)
+    _, H, W, _ = dft["rgbs"].shape
+    cams = np.stack([cam_prep(fc) for fc in dft["flat_cams"]])
+    valid = np.zeros(P, np.uint8)
+    pcl = np.zeros((P, 3), np.float32)
+    rgb = np.zeros((P, 3), np.float32)
+    rgbs = _f32(dft["rgbs"])
+    depths = _f32(dft["depths"]).reshape(N, H, W)
+    kind = np.ascontiguousarray(dft["kind"], dtype=np.uint8)
+    times = _f32(dft["times"])
+    lib().orc_track_points(
+        ctypes.c_int64(P), N, H, W, _p(tracks, _c_float_p), _p(vis, _c_u8_p), _p(kind, _c_u8_p), _p(times, _c_float_p),
+        ctypes.c_float(float(dft["time_tgt"])), _p(rgbs, _c_float_p), _p(depths, _c_float_p), _p(cams, _c_float_p),
+        _p(valid, _c_u8_p), _p(pcl, _c_float_p), _p(rgb, _c_float_p))
+    return valid.astype(bool), pcl, rgb
+
+
+def track_compute_pcl_for_tgt(dft: dict, tracks, vis, render_cfg: dict, base_pcl=None, base_rgb=None, base_thres=None):
+    """compute_pcl_for_tgt (:98-396).  Returns (pcl, rgb, info)."""
+    K = int(render_cfg["dyn_pcl_outlier_knn"])
+    valid, pcl, rgb = track_points(dft, tracks, vis)
+    info = {"valid": valid, "pcl_all": pcl, "rgb_all": rgb}
+    pcl, rgb = pcl[valid], rgb[valid]
+    if pcl.shape[0] == 0:
+        return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), info
+    if base_pcl is not None and base_pcl.shape[0] > 0:
+        avg = knn_cross_mean_dist(pcl, base_pcl, K + 1)
+        keep = avg < np.float32(np.float32(base_thres) * np.float32(render_cfg["dyn_pcl_track_track2base_thres_mult"]))
+        info["avg_track2base"] = avg
+        pcl, rgb = pcl[keep], rgb[keep]
+    if pcl.shape[0] > 0:
+        avg = knn_mean_dist(pcl, K)
+        thres = np.float32(base_thres) if base_thres is not None else outlier_threshold(avg, render_cfg["dyn_pcl_outlier_std_thres"])
+        info["avg_self"] = avg
+        keep = avg < thres
+        pcl, rgb = pcl[keep], rgb[keep]
+    info["n_track"] = pcl.shape[0]
+    if base_pcl is not None and pcl.shape[0] > 0:
+        pcl = np.concatenate([pcl, _f32(base_pcl)], 0)
+        rgb = np.concatenate([rgb, _f32(base_rgb)], 0)
+    return pcl, rgb, info

@@ -2,7 +2,7 @@
  * pgdvs_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
  *
  * A plain-C restatement of the PGDVS per-target-view rendering inner loop
- * (SURVEY.md section 8a rows A1..A12).  Only tests/, __graft_entry__.smoke()
+ * (SURVEY.md section 8a rows A1..A12, A17).  Only tests/, __graft_entry__.smoke()
  * and bench.py's cpu_baseline leg may load this library; the product path
  * (ml-pgdvs_amd/) never does.
  *
@@ -16,7 +16,8 @@
  *
  * Parity pinning:
  *   - rows A1..A8, A11, A12 are pinned against golden vectors produced by
- *     importing the reference itself (tests/golden/make_golden.py).
+ *     importing the reference itself (tests/golden/make_golden.py); row A17
+ *     likewise (tests/golden/make_golden_track.py).
  *   - rows A9 (point rasteriser + norm-weighted compositor) and the kNN used
  *     by A4 restate pytorch3d 0.7.4 (un-vendored third-party dependency,
  *     README.md:38 of the reference); pytorch3d is not installable here, so
@@ -722,6 +723,148 @@ ORC_API void orc_compute_pcl(const float *cam, int H, int W, const float *depth,
         d = d + M[k * 3 + 2];
         pcl[p * 3 + k] = o[k] + d * depth[p];
       }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* A17: tracker-window aggregation                                       */
+/* (pgdvs/renderers/pgdvs_renderer_dyn_track.py:98-396).  Tracks and     */
+/* visibilities are inputs (the trackers are third-party networks).      */
+/* ------------------------------------------------------------------ */
+
+/* mean of the KK smallest squared distances from each query to the base cloud, ALL KK
+ * columns (:299-312: no self column to drop); missing columns are zero (pytorch3d pads).
+ * Same butterfly summation as orc_knn_mean_dist. */
+ORC_API void orc_knn_cross_mean_dist(const float *q, int64_t NQ, const float *pts, int64_t N,
+                                     int KK, float *out) {
+#pragma omp parallel
+  {
+    float *best = (float *)malloc(sizeof(float) * (size_t)KK);
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t i = 0; i < NQ; ++i) {
+      int cnt = 0;
+      float qx = q[i * 3], qy = q[i * 3 + 1], qz = q[i * 3 + 2];
+      for (int64_t j = 0; j < N; ++j) {
+        float dx = qx - pts[j * 3], dy = qy - pts[j * 3 + 1], dz = qz - pts[j * 3 + 2];
+        float d = dx * dx;
+        d = d + dy * dy;
+        d = d + dz * dz;
+        if (cnt < KK) {
+          int k = cnt++;
+          while (k > 0 && best[k - 1] > d) {
+            best[k] = best[k - 1];
+            --k;
+          }
+          best[k] = d;
+        } else if (d < best[KK - 1]) {
+          int k = KK - 1;
+          while (k > 0 && best[k - 1] > d) {
+            best[k] = best[k - 1];
+            --k;
+          }
+          best[k] = d;
+        }
+      }
+      float s = 0.0f;
+      if (KK <= 64) {
+        float sl[64];
+        for (int k = 0; k < 64; ++k) sl[k] = (k < KK && k < cnt) ? best[k] : 0.0f;
+        for (int off = 32; off > 0; off >>= 1)
+          for (int k = 0; k < off; ++k) sl[k] = sl[k] + sl[k + off];
+        s = sl[0];
+      } else {
+        for (int k = 0; k < KK; ++k) s = s + (k < cnt ? best[k] : 0.0f);
+      }
+      out[i] = s / (float)KK;
+    }
+    free(best);
+  }
+}
+
+/* One track point: validity (:115-127), the two visible frames closest in time to the
+ * target (:146-166; ties of |dt| resolved towards the lower frame index -- torch.argsort is
+ * not stable, so ties are unpinned), colour (bilinear, align_corners=True) and depth
+ * (nearest, align_corners=False) samples at the track position (:197-229), unprojection
+ * with c2w[:3,:3] @ inv(K) @ [u,v,1] (:231-253), the mean colour (:271-276) and the linear
+ * inter/extrapolation in time (:278-284).
+ *   tracks [P,N,2] (col,row); vis [P,N]; kind [N]: 1 = temporally-closest frame, 2 = real
+ *   track frame; rgbs [N,H,W,3]; depths [N,H,W]; cams [N,CAM_BLOCK]. */
+ORC_API void orc_track_points(int64_t P, int N, int H, int W, const float *tracks,
+                              const uint8_t *vis, const uint8_t *kind, const float *times,
+                              float time_tgt, const float *rgbs, const float *depths,
+                              const float *cams, uint8_t *valid, float *pcl, float *rgb) {
+  const float fw = (float)W, fh = (float)H;
+#pragma omp parallel for
+  for (int64_t p = 0; p < P; ++p) {
+    int seen_closest = 0, n_real = 0;
+    for (int f = 0; f < N; ++f) {
+      if (!vis[p * N + f]) continue;
+      if (kind[f] == 1) seen_closest = 1;
+      if (kind[f] == 2) ++n_real;
+    }
+    int ok = !seen_closest && n_real >= 2;
+    valid[p] = (uint8_t)ok;
+    for (int k = 0; k < 3; ++k) {
+      pcl[p * 3 + k] = 0.0f;
+      rgb[p * 3 + k] = 0.0f;
+    }
+    if (!ok) continue;
+    int f0 = -1, f1 = -1;
+    float d0 = INFINITY, d1 = INFINITY;
+    for (int f = 0; f < N; ++f) {
+      if (!vis[p * N + f]) continue;
+      float d = fabsf(times[f] - time_tgt);
+      if (d < d0) {
+        f1 = f0;
+        d1 = d0;
+        f0 = f;
+        d0 = d;
+      } else if (d < d1) {
+        f1 = f;
+        d1 = d;
+      }
+    }
+    float X[2][3], col[2][3];
+    const int fr[2] = {f0, f1};
+    for (int s = 0; s < 2; ++s) {
+      const int f = fr[s];
+      const float u = tracks[(p * N + f) * 2 + 0], v = tracks[(p * N + f) * 2 + 1];
+      const float gx = 2.0f * u / fw - 1.0f, gy = 2.0f * v / fh - 1.0f;
+      /* bilinear, align_corners=True: ((g + 1) / 2) * (size - 1) */
+      const float ix = ((gx + 1.0f) / 2.0f) * (fw - 1.0f), iy = ((gy + 1.0f) / 2.0f) * (fh - 1.0f);
+      const float x0f = floorf(ix), y0f = floorf(iy);
+      const int fin = isfinite(ix) && isfinite(iy) && fabsf(ix) < 1e9f && fabsf(iy) < 1e9f;
+      const int x0 = fin ? (int)x0f : -10, y0 = fin ? (int)y0f : -10, x1 = x0 + 1, y1 = y0 + 1;
+      const float wnw = ((float)x1 - ix) * ((float)y1 - iy), wne = (ix - (float)x0) * ((float)y1 - iy);
+      const float wsw = ((float)x1 - ix) * (iy - (float)y0), wse = (ix - (float)x0) * (iy - (float)y0);
+      const float *img = rgbs + (size_t)f * H * W * 3;
+      for (int k = 0; k < 3; ++k) {
+        float acc = 0.0f;
+        if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H) acc = acc + img[(y0 * W + x0) * 3 + k] * wnw;
+        if (x1 >= 0 && x1 < W && y0 >= 0 && y0 < H) acc = acc + img[(y0 * W + x1) * 3 + k] * wne;
+        if (x0 >= 0 && x0 < W && y1 >= 0 && y1 < H) acc = acc + img[(y1 * W + x0) * 3 + k] * wsw;
+        if (x1 >= 0 && x1 < W && y1 >= 0 && y1 < H) acc = acc + img[(y1 * W + x1) * 3 + k] * wse;
+        col[s][k] = acc;
+      }
+      /* nearest, align_corners=False: ((g + 1) * size - 1) / 2, round-half-even */
+      const float nx = nearbyintf(((gx + 1.0f) * fw - 1.0f) / 2.0f), ny = nearbyintf(((gy + 1.0f) * fh - 1.0f) / 2.0f);
+      float dsamp = 0.0f;
+      if (nx >= 0.0f && nx <= fw - 1.0f && ny >= 0.0f && ny <= fh - 1.0f)
+        dsamp = depths[(size_t)f * H * W + (int)ny * W + (int)nx];
+      const float *M = cams + (size_t)f * CAM_BLOCK + CAM_M, *o = cams + (size_t)f * CAM_BLOCK + CAM_O;
+      for (int k = 0; k < 3; ++k) {
+        float d = M[k * 3 + 0] * u;
+        d = d + M[k * 3 + 1] * v;
+        d = d + M[k * 3 + 2];
+        X[s][k] = o[k] + d * dsamp;
+      }
+    }
+    const float t0 = times[f0], t1 = times[f1];
+    const float ratio = (time_tgt - t0) / ((t1 - t0) + 1e-8f);
+    for (int k = 0; k < 3; ++k) {
+      pcl[p * 3 + k] = X[0][k] + (X[1][k] - X[0][k]) * ratio;
+      rgb[p * 3 + k] = (col[0][k] + col[1][k]) / 2.0f;
     }
   }
 }

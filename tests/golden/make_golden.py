@@ -54,6 +54,16 @@ def _install_stubs():
         return dists[None], idx[None], nn[None]
 
     sys.modules["pytorch3d.ops"].knn_points = knn_points
+    # several reference modules create a debug directory at import time
+    # (e.g. pgdvs_renderer_dyn.py:19-20); the reference tree is read-only for us
+    _mkdir = pathlib.Path.mkdir
+
+    def _guarded_mkdir(self, *a, **k):
+        if str(self).startswith(str(REF)):
+            return None
+        return _mkdir(self, *a, **k)
+
+    pathlib.Path.mkdir = _guarded_mkdir
     sys.modules["pytorch3d"].ops = sys.modules["pytorch3d.ops"]
     sys.path.insert(0, str(REF))
 

@@ -354,6 +354,121 @@ def test_dyn_pcl_render_type_vs_oracle():
     np.testing.assert_allclose(N(ret["combined_rgb"]), o["combined_rgb"], rtol=0, atol=1e-5)
 
 
+# ---------------------------------------------------------------- A17 tracker-window aggregation
+@pytest.mark.parametrize("nq,nb,KK", [(1, 1, 3), (300, 40, 51), (5000, 3000, 51), (2000, 12000, 17), (700, 9000, 64)])
+def test_knn_cross_mean_dist_vs_oracle(nq, nb, KK):
+    """queries inside, on the border of and far outside the base cloud's bounding box, duplicates
+    of base points (distance 0), fewer base points than KK (zero-padded columns)"""
+    rng = np.random.default_rng(nq * 7 + nb)
+    u = rng.uniform(-1, 1, (nb, 2))
+    base = np.stack([u[:, 0], u[:, 1], 2 + 0.3 * np.sin(3 * u[:, 0])], 1).astype(np.float32)
+    q = rng.uniform(-1.2, 1.2, (nq, 3)).astype(np.float32)
+    q[:, 2] += 2
+    q[: nq // 5] = base[rng.integers(0, nb, nq // 5)]
+    q[nq // 5: nq // 4] += np.float32(40.0)  # far outside the grid
+    qc = torch.tensor([nq], dtype=torch.int32, device=DEV)
+    bc = torch.tensor([nb], dtype=torch.int32, device=DEV)
+    ref = orc.knn_cross_mean_dist(q, base, KK)
+    got = N(ops.knn_cross_mean_dist(T(q), qc, T(base), bc, KK))[:nq]
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # capacities larger than the device counts: trailing rows are ignored
+    qpad = np.concatenate([q, rng.normal(size=(37, 3)).astype(np.float32)])
+    bpad = np.concatenate([base, rng.normal(size=(91, 3)).astype(np.float32)])
+    got = N(ops.knn_cross_mean_dist(T(qpad), qc, T(bpad), bc, KK))[:nq]
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def _track_renderer(**over):
+    from pgdvs_amd.renderers.pgdvs_renderer_dyn_track import PGDVSDynamicTrackRenderer
+
+    cfg = load_config(static_renderer="gnt")
+    rc = cfg.engine.engine_cfg.render_cfg
+    for k, v in over.items():
+        rc[k] = v
+    return PGDVSDynamicTrackRenderer(cfg=cfg, use_tracker=True).to(DEV), rc
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_track_compute_pcl_for_tgt_vs_reference_and_oracle(golden_dir, case):
+    g = _load(golden_dir, "track_pcl.npz")
+    raw = {k[5:]: v for k, v in g.items() if k.startswith("data_")}
+    rend, rc = _track_renderer(dyn_pcl_outlier_knn=int(g[f"c{case}_knn"]), dyn_pcl_track_track2base_thres_mult=50,
+                               dyn_pcl_outlier_std_thres=0.1)
+    data = {k: T(v) for k, v in raw.items()}
+    dft = rend.prepare_data(0, data, 8, DEV)
+    assert dft["idx_temporal_closest"] == list(g["dfk_idx_closest"]) and dft["idx_real_track"] == list(g["dfk_idx_real"])
+    assert np.array_equal(N(dft["time_for_track"]), g["dfk_times"]) and np.array_equal(N(dft["time_tgt"]), g["dfk_time_tgt"])
+    tracks, vis = g[f"c{case}_tracks"], g[f"c{case}_vis"]
+    # per-track stage: bit-exact against the oracle
+    odft = orc.track_prepare_data(raw, 0)
+    o_valid, o_pcl, o_rgb = orc.track_points(odft, tracks, vis)
+    valid, pcl_all, rgb_all = ops.track_points(T(tracks), T(vis), dft["frame_kind"], dft["time_for_track_raw"], dft["time_tgt_raw"],
+                                               dft["rgbs_for_track"], dft["depths_for_track"][..., 0], dft["cams_for_track"])
+    assert np.array_equal(N(valid).astype(bool), o_valid)
+    assert np.array_equal(N(pcl_all).view(np.uint32), o_pcl.view(np.uint32))
+    assert np.array_equal(N(rgb_all).view(np.uint32), o_rgb.view(np.uint32))
+    # whole row against the reference's output
+    wb = bool(g[f"c{case}_with_base"])
+    th = g[f"c{case}_base_thres"]
+    base = {"pcl": T(g[f"c{case}_base_pts"]) if wb else None, "pcl_rgbs": T(g[f"c{case}_base_rgb"]) if wb else None,
+            "pcl_nn_dist_thres": None if np.isnan(th) else T(np.array([th], np.float32))}
+    pcl, rgb = rend.compute_pcl_for_tgt(data_for_track=dft, query_pts=T(g[f"c{case}_query"]), tracks=T(tracks),
+                                        track_visibles=T(vis), render_cfg=rc, base_pcl_info=base, device=DEV)
+    assert tuple(pcl.shape) == g[f"c{case}_out_pcl"].shape  # same filter decisions
+    np.testing.assert_allclose(N(pcl), g[f"c{case}_out_pcl"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(N(rgb), g[f"c{case}_out_rgb"], rtol=0, atol=1e-6)
+    # base cloud given as a capacity-sized buffer with a device-side count
+    if wb:
+        nb = g[f"c{case}_base_pts"].shape[0]
+        junk = np.full((50, 3), 1.5, np.float32)
+        base2 = {"pcl": T(np.concatenate([g[f"c{case}_base_pts"], junk])), "pcl_rgbs": T(np.concatenate([g[f"c{case}_base_rgb"], junk])),
+                 "pcl_nn_dist_thres": base["pcl_nn_dist_thres"], "n_pts": torch.tensor([nb], dtype=torch.int32, device=DEV)}
+        pcl2, rgb2 = rend.compute_pcl_for_tgt(data_for_track=dft, query_pts=None, tracks=T(tracks), track_visibles=T(vis),
+                                              render_cfg=rc, base_pcl_info=base2, device=DEV)
+        assert torch.equal(pcl2, pcl) and torch.equal(rgb2, rgb)
+
+
+@pytest.mark.parametrize("dyn_type", ["softsplat", "pcl"])
+def test_render_with_track_end_to_end_vs_oracle(dyn_type):
+    v = synth.make_video(7, 54, 96, seed=5)
+    d = synth.make_view(v, 3, seed=1)
+    synth.add_track_window(d, v, 3, n_side=2)
+    over = dict(dyn_render_type=dyn_type, dyn_render_track_temporal="no_tgt", dyn_pcl_outlier_knn=8,
+                dyn_render_pcl_pts_per_pixel=3, dyn_render_pcl_pt_radius=0.03)
+    model, rc = _renderer("gnt", **over)
+    from pgdvs_amd.renderers.pgdvs_renderer_dyn_track import PGDVSDynamicTrackRenderer
+
+    assert isinstance(model.dyn_renderer, PGDVSDynamicTrackRenderer)
+    data = synth.to_torch(d, DEV)
+    data["rgb_gnt"] = T(v["rgbs"][:1])
+    with torch.no_grad():
+        ret = model.forward(data, render_cfg=rc)
+    od = dict(d)
+    od["rgb_gnt"] = v["rgbs"][:1]
+    o = orc.render_view(od, dict(rc), static_noise=d["static_noise"])
+    info = o["_info"]
+    assert info["temporal_track_mask"].sum() > 100  # the track cloud is actually rendered
+    assert np.array_equal(N(ret["render_dyn_temporal_track_mask"]), info["temporal_track_mask"])
+    assert np.array_equal(N(ret["render_dyn_temporal_closest_mask"]), info["temporal_closest_mask"])
+    assert np.array_equal(N(ret["render_dyn_mask"]), o["render_dyn_mask"])
+    assert o["render_dyn_mask"].sum() > info["temporal_closest_mask"].sum()  # pixels filled from the tracks
+    np.testing.assert_allclose(N(ret["render_dyn_temporal_track_rgb"]), info["temporal_track_rgb"], rtol=0, atol=1e-5)
+    for k in ["render_dyn_rgb", "combined_rgb", "combined_rgb_static", "combined_rgb_dyn"]:
+        np.testing.assert_allclose(N(ret[k]), o[k], rtol=0, atol=1e-4, err_msg=k)
+
+
+def test_track_renderer_requires_tracks_or_tracker():
+    v = synth.make_video(7, 27, 48, seed=5)
+    d = synth.make_view(v, 3, seed=1)
+    synth.add_track_window(d, v, 3, n_side=2)
+    d.pop("track_tracks")
+    model, rc = _renderer("gnt", dyn_render_track_temporal="no_tgt", dyn_pcl_outlier_knn=8)
+    data = synth.to_torch(d, DEV)
+    data["rgb_gnt"] = T(v["rgbs"][:1])
+    with pytest.raises(KeyError, match="track_tracks"):
+        model.forward(data, render_cfg=rc)
+
+
 # ---------------------------------------------------------------- full-size properties (1080p)
 def test_fullsize_properties_1080p():
     """BASELINE size: properties that need no oracle run.

@@ -116,3 +116,33 @@ def test_gnt_oracle_vs_reference(golden_dir, tag):
     np.testing.assert_allclose(out, g[f"{tag}_out"], rtol=0, atol=1e-4)
     for k in ex:
         np.testing.assert_allclose(ex[k], g[f"{tag}_{k}"], rtol=0, atol=1e-4, err_msg=k)
+
+
+# ---------------------------------------------------------------- A17 tracker-window aggregation
+def _track_case(g, c):
+    wb = bool(g[f"c{c}_with_base"])
+    th = g[f"c{c}_base_thres"]
+    rc = dict(dyn_pcl_outlier_knn=int(g[f"c{c}_knn"]), dyn_pcl_track_track2base_thres_mult=50, dyn_pcl_outlier_std_thres=0.1)
+    return rc, (g[f"c{c}_base_pts"] if wb else None), (g[f"c{c}_base_rgb"] if wb else None), (None if np.isnan(th) else th)
+
+
+def test_track_prepare_data(golden_dir):
+    g = _load(golden_dir, "track_pcl.npz")
+    dft = orc.track_prepare_data({k[5:]: v for k, v in g.items() if k.startswith("data_")}, 0)
+    assert np.array_equal(dft["times"], g["dfk_times"]) and dft["time_tgt"] == g["dfk_time_tgt"][0]
+    assert np.array_equal(np.nonzero(dft["kind"] == 1)[0], g["dfk_idx_closest"])
+    assert np.array_equal(np.nonzero(dft["kind"] == 2)[0], g["dfk_idx_real"])
+    for a, b in (("rgbs", "dfk_rgbs"), ("depths", "dfk_depths"), ("flat_cams", "dfk_cams")):
+        assert np.array_equal(dft[a], g[b])
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_track_compute_pcl_for_tgt(golden_dir, case):
+    g = _load(golden_dir, "track_pcl.npz")
+    dft = orc.track_prepare_data({k[5:]: v for k, v in g.items() if k.startswith("data_")}, 0)
+    rc, bp, br, th = _track_case(g, case)
+    pcl, rgb, _ = orc.track_compute_pcl_for_tgt(dft, g[f"c{case}_tracks"], g[f"c{case}_vis"], rc, bp, br, th)
+    # same point-set size => same validity / frame-pair / filter decisions
+    assert pcl.shape == g[f"c{case}_out_pcl"].shape
+    np.testing.assert_allclose(pcl, g[f"c{case}_out_pcl"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(rgb, g[f"c{case}_out_rgb"], rtol=0, atol=1e-6)

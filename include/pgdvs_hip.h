@@ -236,6 +236,19 @@ int pgdvs_gnt_view_layer(const float *weights, const float *q_in, const float *f
 int pgdvs_gnt_ray_layer(const float *weights, const float *q_in, int R, int S, float *q_out,
                         float *sample_weights, pgdvs_stream_t stream);
 
+/* A10, dyn_render_type = "mesh" (pgdvs_renderer_dyn.py:542-669): triangulates the kept source
+ * pixels (two triangles per pixel quad whose corners are all kept; faces touching the first
+ * kept pixel are dropped, as upstream :597 does) and renders them into the target camera
+ * with pytorch3d MeshRasterizer semantics (blur_radius 0, 1 face per pixel, perspective-
+ * correct barycentrics) + vertex colours + hard blend on black.
+ *   keep[H*W] u8 (valid_dyn_mask_1), pcl[H*W,3], rgb[H*W,3]: dense over the source frame
+ *   img_planar[3,H,W], mask[H,W] (1 where a face covers the pixel centre),
+ *   face_out[H*W] int32 (nullable): kind*H*W + source pixel of the winning face, -1 = none. */
+int64_t pgdvs_mesh_render_workspace_bytes(int H, int W);
+int pgdvs_mesh_render(const float *cam_tgt, int H, int W, const uint8_t *keep, const float *pcl,
+                      const float *rgb, float *img_planar, float *mask, int32_t *face_out,
+                      void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream);
+
 /* A17: tracker-window point aggregation (pgdvs_renderer_dyn_track.py:98-396); tracks and
  * visibilities are inputs.  Frames are ordered as prepare_data orders them (:599-716):
  * [fwd2tgt tracks..., temporally-closest..., bwd2tgt tracks...].

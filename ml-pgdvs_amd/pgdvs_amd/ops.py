@@ -300,6 +300,23 @@ def points_raster(pts, feat, cam_tgt, radius: float, K: int, H: int, W: int, *, 
     return {"rgb": rgb, "mask": mask, "idx": idx, "zbuf": zbuf, "dist2": d2}
 
 
+def mesh_render(cam_tgt, keep, pcl, rgb, H: int, W: int, want_faces: bool = False):
+    """A10 mesh variant -> dict(rgb[3,H,W], mask[H,W][, face[H,W] int32])."""
+    cam = _req(cam_tgt, torch.float32, "cam_tgt")
+    img = torch.empty((3, H, W), dtype=torch.float32, device=cam.device)
+    mask = torch.empty((H, W), dtype=torch.float32, device=cam.device)
+    face = torch.empty((H, W), dtype=torch.int32, device=cam.device) if want_faces else None
+    lib = _lib.load()
+    ws = _ws(lib.pgdvs_mesh_render_workspace_bytes(H, W), cam.device)
+    check(lib.pgdvs_mesh_render(_ptr(cam), H, W, _ptr(_req(keep, torch.uint8, "keep")), _ptr(_req(pcl, torch.float32, "pcl")),
+                                _ptr(_req(rgb, torch.float32, "rgb")), _ptr(img), _ptr(mask), _ptr(face), _ptr(ws), ws.numel(),
+                                _stream()), "pgdvs_mesh_render")
+    out = {"rgb": img, "mask": mask}
+    if want_faces:
+        out["face"] = face
+    return out
+
+
 def static_aggregate(rgbs, depths, dyn_masks, K3s, c2ws, capacity: int | None = None):
     """rgbs[S,H,W,3] fp32 in [0,1]; depths[S,H,W]; dyn_masks[S,H,W] bool/uint8 (GPU tensors);
     K3s[S,3,3], c2ws[S,4,4] float64 numpy (host).  -> (cloud[capacity,6], count[int64 dev])."""

@@ -60,7 +60,7 @@ class PGDVSRenderer(PGDVSBaseRenderer):
         # static renderer; the splat + composite joins both.  Callers may pass an already
         # started preparation through data["_dyn_prepared"].
         prepared = data.get("_dyn_prepared", None)
-        if prepared is None and data["rgb_src_temporal"].is_cuda and render_cfg.dyn_render_type != "mesh" \
+        if prepared is None and data["rgb_src_temporal"].is_cuda \
                 and not (render_cfg.pure_gnt or render_cfg.pure_gnt_with_dyn_mask):
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=data["rgb_src_temporal"].device)

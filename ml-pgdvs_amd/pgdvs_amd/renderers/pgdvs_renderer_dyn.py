@@ -99,9 +99,11 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
             H, W, n_points_dev=n_pts.to(torch.int64), rgb_planar=True)
         return r["rgb"], r["mask"]
 
-    def render_dyn_mesh(self, **kw):
-        # dyn_render_type=mesh (:542-669) is a "next" row
-        raise NotImplementedError("dyn_render_type='mesh' is not built yet")
+    def render_dyn_mesh(self, *, keep, pcl_dense, rgb_dense, cam_tgt, H, W):
+        """:542-669 -- pixel-grid triangulation of the kept source pixels, rendered with
+        pytorch3d MeshRasterizer semantics (ops.mesh_render)."""
+        r = ops.mesh_render(cam_tgt, keep, pcl_dense, rgb_dense, H, W)
+        return r["rgb"], r["mask"]
 
     def render_with_track(self, *a, **kw):
         raise NotImplementedError  # :272-273; PGDVSDynamicTrackRenderer implements it
@@ -146,9 +148,6 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
         dyn_type = render_cfg.dyn_render_type
         if dyn_type not in ("softsplat", "pcl", "mesh"):
             raise ValueError(dyn_type)
-        if dyn_type == "mesh":
-            self.render_dyn_mesh()
-
         if prepared is None:
             prepared = self.prepare(data, render_cfg)
         if prepared["stream"] is not None:
@@ -178,6 +177,9 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
                     static_rgb[i_b] if fuse_static else None)
                 if fuse_static:
                     combs.append((c, cs, cd))
+            elif dyn_type == "mesh":
+                rgb, mask = self.render_dyn_mesh(keep=info["keep"], pcl_dense=info["pcl_dense"], rgb_dense=info["rgb_dense"],
+                                                 cam_tgt=cams_tgt[i_b], H=orig_h, W=orig_w)
             else:
                 rgb, mask = self.render_dyn_pcl(
                     pcl=info["pcl"], rgbs=info["pcl_rgbs"], n_pts=info["n_pts"], cam_tgt=cams_tgt[i_b],

@@ -190,6 +190,7 @@ def compute_dyn_pcl(
         "valid": vb.reshape(H, W),
         "mask_eff": mask_eff.reshape(H, W),
         "pcl_dense": pcl.reshape(H, W, 3),
+        "rgb_dense": rgbf.reshape(H, W, 3),
         "keep": keep.reshape(H, W),
     }
 
@@ -344,6 +345,21 @@ def dyn_forward(data: dict, render_cfg: dict, static_noise=None, alpha=100.0):
         render_dyn_rgb = np.stack(rgbs).transpose(0, 3, 1, 2)
         render_dyn_mask = np.stack(masks).transpose(0, 3, 1, 2)
         extra = {}
+    elif render_cfg["dyn_render_type"] == "mesh":
+        rgbs, masks, faces = [], [], []
+        for b in range(B):
+            if infos[b] is None:
+                rgbs.append(np.zeros((H, W, 3), np.float32))
+                masks.append(np.zeros((H, W, 1), np.float32))
+                faces.append(None)
+            else:
+                img, msk, fc = mesh_render(infos[b]["keep"], infos[b]["pcl_dense"], infos[b]["rgb_dense"], data["flat_cam_tgt"][b])
+                rgbs.append(img)
+                masks.append(msk[..., None])
+                faces.append(fc)
+        render_dyn_rgb = np.stack(rgbs).transpose(0, 3, 1, 2)
+        render_dyn_mask = np.stack(masks).transpose(0, 3, 1, 2)
+        extra = {"mesh_faces": faces}
     else:
         raise NotImplementedError(render_cfg["dyn_render_type"])
     track_rgb = np.zeros_like(render_dyn_rgb)
@@ -415,6 +431,22 @@ def render_points(pts, rgbs, flat_cam_tgt, H, W, radius, K):
     ones = composite(idx, d2, radius, None)
     mask = (ones[..., :1] > 0.0).astype(np.float32)
     return img, mask, (idx, zbuf, d2)
+
+
+def mesh_render(keep, pcl_dense, rgb_dense, flat_cam_tgt):
+    """render_dyn_mesh (pgdvs_renderer_dyn.py:542-669): keep[H,W] = valid_dyn_mask_1, dense
+    vertices / colours over the source frame -> img[H,W,3], mask[H,W], face[H,W] (int64)."""
+    keep = np.ascontiguousarray(keep, dtype=np.uint8)
+    H, W = keep.shape
+    cam = cam_prep(flat_cam_tgt)
+    pcl = _f32(pcl_dense).reshape(H * W, 3)
+    rgb = _f32(rgb_dense).reshape(H * W, 3)
+    img = np.empty((H, W, 3), np.float32)
+    mask = np.empty((H, W), np.float32)
+    face = np.empty((H, W), np.int64)
+    lib().orc_mesh_render(_p(cam, _c_float_p), H, W, _p(keep, _c_u8_p), _p(pcl, _c_float_p), _p(rgb, _c_float_p),
+                          _p(img, _c_float_p), _p(mask, _c_float_p), _p(face, _c_i64_p))
+    return img, mask, face
 
 
 def static_geo_forward(st_pcl_rgb, flat_cam_tgt, H, W, render_cfg):

@@ -25,6 +25,8 @@
  *     pytorch3d/csrc/rasterize_points/rasterize_points_cpu.cpp
  *     RasterizePointsNaiveCpu, pytorch3d/csrc/compositing/
  *     norm_weighted_sum_cpu.cpp, pytorch3d/renderer/points/renderer.py).
+ *     The same holds for the mesh variant of A10 (MeshRasterizer, see
+ *     orc_mesh_render): parity UNPINNED.
  */
 #include <math.h>
 #include <stdint.h>
@@ -867,6 +869,136 @@ ORC_API void orc_track_points(int64_t P, int N, int H, int W, const float *track
       rgb[p * 3 + k] = (col[0][k] + col[1][k]) / 2.0f;
     }
   }
+}
+
+/* ------------------------------------------------------------------ */
+/* A10: dyn_render_type = "mesh" (pgdvs_renderer_dyn.py:542-669)        */
+/* Topology (:550-604): each kept source pixel (r,c) spawns the          */
+/* triangles {(r,c),(r+1,c),(r+1,c+1)} and {(r,c),(r+1,c+1),(r,c+1)};    */
+/* a face survives when its three corners are in bounds and carry a      */
+/* vertex index > 0 (sic, :597: the first kept pixel, index 0, is        */
+/* treated as "no vertex").  Face order: all first-kind faces, then all  */
+/* second-kind ones (:579-581), both in raster order of (r,c).           */
+/* Rasteriser: pytorch3d 0.7.4 MeshRasterizer with blur_radius=0,        */
+/* faces_per_pixel=1, bin_size=0 (naive path), perspective-correct       */
+/* barycentrics (PerspectiveCameras), no z clipping (znear is None),     */
+/* no back-face culling; shader = TexturesVertex interpolation +         */
+/* hard_rgb_blend on black (pgdvs/utils/pytorch3d_utils.py:50-67).       */
+/* pytorch3d is not installable here: parity UNPINNED, restated from     */
+/* pytorch3d/csrc/rasterize_meshes/rasterize_meshes.cu                   */
+/* (CheckPixelInsideFace) and csrc/utils/geometry_utils.cuh.             */
+/*   keep[P] u8, pcl[P,3], rgb[P,3] dense over the source frame;         */
+/*   out: img[H,W,3], mask[H,W], face[H,W] (kind*P + pixel, -1 = none).  */
+/* ------------------------------------------------------------------ */
+#define MESH_EPS 1e-8f
+
+static inline float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
+  return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+
+/* returns 1 and fills pz / bary when pixel centre (px,py) is strictly inside the face */
+static inline int mesh_pixel_in_face(float px, float py, const float *v0, const float *v1,
+                                     const float *v2, float *pz, float *bary) {
+  float zmax = fmaxf(fmaxf(v0[2], v1[2]), v2[2]);
+  float xmin = fminf(fminf(v0[0], v1[0]), v2[0]), xmax = fmaxf(fmaxf(v0[0], v1[0]), v2[0]);
+  float ymin = fminf(fminf(v0[1], v1[1]), v2[1]), ymax = fmaxf(fmaxf(v0[1], v1[1]), v2[1]);
+  int outside = (px > xmax) || (px < xmin) || (py > ymax) || (py < ymin);
+  float face_area = edge_fn(v0[0], v0[1], v1[0], v1[1], v2[0], v2[1]);
+  int zero_area = (face_area <= MESH_EPS) && (face_area >= -MESH_EPS);
+  if (zmax < 0.0f || outside || zero_area) return 0;
+  float area = edge_fn(v2[0], v2[1], v0[0], v0[1], v1[0], v1[1]) + MESH_EPS;
+  float b0 = edge_fn(px, py, v1[0], v1[1], v2[0], v2[1]) / area;
+  float b1 = edge_fn(px, py, v2[0], v2[1], v0[0], v0[1]) / area;
+  float b2 = edge_fn(px, py, v0[0], v0[1], v1[0], v1[1]) / area;
+  float t0 = b0 * v1[2] * v2[2];
+  float t1 = v0[2] * b1 * v2[2];
+  float t2 = v0[2] * v1[2] * b2;
+  float den = fmaxf(t0 + t1 + t2, MESH_EPS);
+  bary[0] = t0 / den;
+  bary[1] = t1 / den;
+  bary[2] = t2 / den;
+  float z = bary[0] * v0[2] + bary[1] * v1[2] + bary[2] * v2[2];
+  if (z < 0.0f) return 0;
+  if (!(bary[0] > 0.0f && bary[1] > 0.0f && bary[2] > 0.0f)) return 0;
+  *pz = z;
+  return 1;
+}
+
+/* candidate pixel index range along one axis for NDC interval [lo,hi] (superset) */
+static inline void ndc_to_pix_range(float lo, float hi, int S1, int S2, int *i0, int *i1) {
+  float range = S1 > S2 ? 2.0f * (float)S1 / (float)S2 : 2.0f;
+  float offset = range / 2.0f;
+  /* ndc(i') = -offset + (range*i' + offset)/S1 with i' = S1-1-i */
+  float a = ((lo + offset) * (float)S1 - offset) / range;
+  float b = ((hi + offset) * (float)S1 - offset) / range;
+  if (!(a >= -2.0f)) a = -2.0f;
+  if (!(b <= (float)S1 + 1.0f)) b = (float)S1 + 1.0f;
+  int ja = (int)floorf(a) - 1, jb = (int)ceilf(b) + 1;
+  if (ja < 0) ja = 0;
+  if (jb > S1 - 1) jb = S1 - 1;
+  *i0 = S1 - 1 - jb;
+  *i1 = S1 - 1 - ja;
+}
+
+ORC_API void orc_mesh_render(const float *cam, int H, int W, const uint8_t *keep,
+                             const float *pcl, const float *rgb, float *img, float *mask,
+                             int64_t *face) {
+  const int64_t P = (int64_t)H * W;
+  float *ndc = (float *)malloc(sizeof(float) * 3 * (size_t)P);
+  float *zb = (float *)malloc(sizeof(float) * (size_t)P);
+  orc_points_to_ndc(cam, H, W, pcl, P, 3, ndc);
+  int64_t first = -1;
+  for (int64_t p = 0; p < P; ++p)
+    if (keep[p]) {
+      first = p;
+      break;
+    }
+  for (int64_t p = 0; p < P; ++p) {
+    face[p] = -1;
+    zb[p] = 0.0f;
+    mask[p] = 0.0f;
+    img[p * 3] = img[p * 3 + 1] = img[p * 3 + 2] = 0.0f;
+  }
+  for (int kind = 0; kind < 2; ++kind) {
+    for (int r = 0; r + 1 < H; ++r) {
+      for (int c = 0; c + 1 < W; ++c) {
+        int64_t q0 = (int64_t)r * W + c;
+        int64_t q1 = kind == 0 ? q0 + W : q0 + W + 1;
+        int64_t q2 = kind == 0 ? q0 + W + 1 : q0 + 1;
+        if (!(keep[q0] && keep[q1] && keep[q2])) continue;
+        if (q0 == first || q1 == first || q2 == first) continue; /* vertex index 0 (:597) */
+        const float *v0 = ndc + q0 * 3, *v1 = ndc + q1 * 3, *v2 = ndc + q2 * 3;
+        float xmin = fminf(fminf(v0[0], v1[0]), v2[0]), xmax = fmaxf(fmaxf(v0[0], v1[0]), v2[0]);
+        float ymin = fminf(fminf(v0[1], v1[1]), v2[1]), ymax = fmaxf(fmaxf(v0[1], v1[1]), v2[1]);
+        if (!(xmin <= xmax && ymin <= ymax)) continue; /* NaN vertex: never inside */
+        int x0, x1, y0, y1;
+        ndc_to_pix_range(xmin, xmax, W, H, &x0, &x1);
+        ndc_to_pix_range(ymin, ymax, H, W, &y0, &y1);
+        int64_t fid = (int64_t)kind * P + q0;
+        for (int yi = y0; yi <= y1; ++yi) {
+          float yf = pix_to_ndc(H - 1 - yi, H, W);
+          for (int xi = x0; xi <= x1; ++xi) {
+            float xf = pix_to_ndc(W - 1 - xi, W, H);
+            float pz, b[3];
+            if (!mesh_pixel_in_face(xf, yf, v0, v1, v2, &pz, b)) continue;
+            int64_t t = (int64_t)yi * W + xi;
+            if (face[t] >= 0 && !(pz < zb[t] || (pz == zb[t] && fid < face[t]))) continue;
+            face[t] = fid;
+            zb[t] = pz;
+            for (int k = 0; k < 3; ++k) {
+              float a = b[0] * rgb[q0 * 3 + k];
+              a = a + b[1] * rgb[q1 * 3 + k];
+              a = a + b[2] * rgb[q2 * 3 + k];
+              img[t * 3 + k] = a;
+            }
+            mask[t] = 1.0f;
+          }
+        }
+      }
+    }
+  }
+  free(ndc);
+  free(zb);
 }
 
 ORC_API int orc_num_threads(void) {

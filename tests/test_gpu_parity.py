@@ -354,6 +354,49 @@ def test_dyn_pcl_render_type_vs_oracle():
     np.testing.assert_allclose(N(ret["combined_rgb"]), o["combined_rgb"], rtol=0, atol=1e-5)
 
 
+# ---------------------------------------------------------------- A10 mesh variant
+@pytest.mark.parametrize("H,W,noise,seed", [(54, 96, 0.0, 0), (96, 54, 0.3, 1), (64, 64, 2.0, 2)])
+def test_mesh_render_vs_oracle(H, W, noise, seed):
+    """smooth sheet, noisy sheet (stretched / overlapping triangles, z fights) and a wild cloud
+    with vertices behind the camera: winning face ids, mask and colours must match exactly"""
+    rng = np.random.default_rng(seed)
+    v = synth.make_video(2, H, W, seed=seed)
+    K3, c2w = v["K3s"][0], v["c2ws"][0]
+    cam_src = synth.flat_cam(H, W, K3, c2w)
+    pcl = orc.compute_pcl(H, W, K3, c2w, v["depths"][0] + rng.normal(0, 1, (H, W)).astype(np.float32) * noise).reshape(H, W, 3)
+    keep = (rng.random((H, W)) < 0.8) | v["dyn_masks"][0]
+    keep[0, :3] = [False, True, True]  # the first kept pixel (vertex index 0) is (0,1)
+    rgb = v["rgbs"][0]
+    cam_tgt = synth.make_view(v, 0, seed=seed)["flat_cam_tgt"][0]
+    o_img, o_mask, o_face = orc.mesh_render(keep, pcl, rgb, cam_tgt)
+    r = ops.mesh_render(ops.cam_prep(T(cam_tgt)), T(keep.astype(np.uint8)), T(pcl), T(rgb), H, W, want_faces=True)
+    assert o_mask.sum() > 0.3 * H * W * (1 if noise < 1 else 0.1)
+    assert np.array_equal(N(r["face"]).astype(np.int64), o_face)
+    assert np.array_equal(N(r["mask"]), o_mask)
+    np.testing.assert_allclose(N(r["rgb"]).transpose(1, 2, 0), o_img, rtol=0, atol=1e-6)
+    # no face may use the first kept pixel
+    first = np.flatnonzero(keep.reshape(-1))[0]
+    used = o_face[o_face >= 0] % (H * W)
+    assert not np.any(used == first)
+
+
+def test_mesh_render_type_end_to_end_vs_oracle():
+    v = synth.make_video(3, 54, 96, seed=5)
+    d = synth.make_view(v, 0, seed=1)
+    model, rc = _renderer("gnt", dyn_render_type="mesh", dyn_pcl_remove_outlier=True, dyn_pcl_outlier_knn=10)
+    data = synth.to_torch(d, DEV)
+    data["rgb_gnt"] = T(v["rgbs"][:1])
+    with torch.no_grad():
+        ret = model.forward(data, render_cfg=rc)
+    od = dict(d)
+    od["rgb_gnt"] = v["rgbs"][:1]
+    o = orc.render_view(od, dict(rc), static_noise=None)
+    assert o["render_dyn_mask"].mean() > 0.03
+    assert np.array_equal(N(ret["render_dyn_mask"]), o["render_dyn_mask"])
+    np.testing.assert_allclose(N(ret["render_dyn_rgb"]), o["render_dyn_rgb"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(N(ret["combined_rgb"]), o["combined_rgb"], rtol=0, atol=1e-5)
+
+
 # ---------------------------------------------------------------- A17 tracker-window aggregation
 @pytest.mark.parametrize("nq,nb,KK", [(1, 1, 3), (300, 40, 51), (5000, 3000, 51), (2000, 12000, 17), (700, 9000, 64)])
 def test_knn_cross_mean_dist_vs_oracle(nq, nb, KK):

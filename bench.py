@@ -14,6 +14,7 @@ frames are sharded across ranks (weak scaling: K views per rank) and the final i
 stacks are gathered to rank 0 inside the timed region.
 """
 import argparse
+import contextlib
 import ctypes
 import json
 import os
@@ -61,6 +62,8 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel pass")
     ap.add_argument("--pts-per-pixel", type=int, default=3)
     ap.add_argument("--no-outlier", action="store_true", help="dyn_pcl_remove_outlier=false (YAML default)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="independent target views rendered concurrently, each on its own pair of HIP streams")
     ap.add_argument("--gnt-rays", type=int, default=1024, help="rays of the GNT sub-benchmark chunk (0 = skip)")
     return ap.parse_args()
 
@@ -131,18 +134,32 @@ def main():
     model = PGDVSRenderer(cfg, render_cfg=rc, softsplat_metric_abs_alpha=100.0).to(dev).eval()
     cap = S * H * W
 
-    side = torch.cuda.Stream(device=dev)
+    # Views are independent (the reference shards them over ranks): `inflight` of them are kept
+    # in flight per GPU, each on its own (main, side) stream pair, so one view's launch-bound
+    # chains fill the gaps of another's.  Every view still runs the complete path.
+    n_lanes = max(1, args.inflight)
+    lanes = [(torch.cuda.Stream(device=dev) if n_lanes > 1 else None, torch.cuda.Stream(device=dev)) for _ in range(n_lanes)]
 
     def step(j):
-        data = dict(views[(j + rank) % n_views])
-        # dynamic-branch geometry on a side stream, overlapping the static aggregation + raster
-        data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=side)
-        cloud, cnt = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=cap)
-        data["st_pcl_rgb"] = cloud[None]
-        data["st_pcl_rgb_count"] = cnt
-        with torch.no_grad():
-            ret = model.forward(data, render_cfg=rc, disable_tqdm=True)
-        return ret["combined_rgb"], cnt
+        main, side = lanes[j % n_lanes]
+        if main is not None:
+            main.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
+            data = dict(views[(j + rank) % n_views])
+            # dynamic-branch geometry on a side stream, overlapping the static aggregation + raster
+            data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=side)
+            cloud, cnt = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=cap)
+            data["st_pcl_rgb"] = cloud[None]
+            data["st_pcl_rgb_count"] = cnt
+            with torch.no_grad():
+                ret = model.forward(data, render_cfg=rc, disable_tqdm=True)
+            img = ret["combined_rgb"]
+        return img, cnt, main
+
+    def join_lanes():
+        for main, _ in lanes:
+            if main is not None:
+                torch.cuda.current_stream().wait_stream(main)
 
     def barrier():
         if world > 1:
@@ -157,9 +174,11 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for j in range(n_steps):
-            img, cnt = step(j)
-            gather.submit(img)
+            img, cnt, main = step(j)
+            with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
+                gather.submit(img)
         host_enqueue[0] = time.perf_counter() - t0  # host time to enqueue everything (no sync yet)
+        join_lanes()
         gathered = gather.finish()
         torch.cuda.synchronize()
         barrier()
@@ -167,8 +186,10 @@ def main():
         lib.pgdvs_prof_enable(0)
         return t1 - t0, gathered, cnt
 
-    for j in range(args.warmup):
-        step(j)
+    ref_img = None
+    for j in range(max(args.warmup, n_lanes)):
+        img = step(j)[0]
+        ref_img = img if j == 0 else ref_img
     torch.cuda.synchronize()
 
     elapsed, gathered, cnt = timed(args.steps, profile=False)
@@ -178,6 +199,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     n_static = int(cnt.item())
+    # concurrency must not change results: the timed run's first image == the warm-up image of the same view
+    if rank == 0 and gathered is not None:
+        # (the splat accumulates with float atomics, so the comparison is to rounding, not bit-exact)
+        assert torch.allclose(gathered[0], ref_img[0], rtol=0, atol=1e-5), "in-flight views disagree with the sequential result"
     n_dyn = int(views[0]["dyn_mask_src_temporal"][0, 0].sum().item())
 
     # ---------------- per-kernel durations with HIP events on the launch stream
@@ -276,7 +301,7 @@ def main():
                 "workload": f"{W}x{H} target view, {S} source frames resident in HBM: static aggregation (A12) + "
                             f"point z-buffer raster K={K} (A9) + flow-warped dynamic splat (A1-A8, outlier filter "
                             f"{'on' if not args.no_outlier else 'off'}) + composite (A11)",
-                "height": H, "width": W, "src_frames": S, "static_points": n_static, "dyn_pixels": n_dyn,
+                "views_in_flight": n_lanes, "height": H, "width": W, "src_frames": S, "static_points": n_static, "dyn_pixels": n_dyn,
                 "parallelism": f"frames sharded over {world} GPU(s), RCCL gather of the image stack" if world > 1 else "1 GPU",
                 "whole_view_alg_bytes": alg_total,
                 "whole_view_alg_GBps": round(alg_total * fps / 1e9 / max(world, 1), 2),

@@ -192,7 +192,7 @@ int pgdvs_points_raster(const float *pts, int64_t pts_stride, const float *feat,
  *   rgbs[S,H,W,3] in [0,1]; depths[S,H,W]; dyn_masks[S,H,W] u8 (non-zero = dynamic)
  *   K3s: HOST double[S,9]; c2ws: HOST double[S,16]   (float64 numpy upstream)
  *   out[capacity,6] (xyz,rgb) in the reference's order; count_out: device int64. */
-int64_t pgdvs_static_aggregate_workspace_bytes(int H, int W);
+int64_t pgdvs_static_aggregate_workspace_bytes(int S, int H, int W, int64_t capacity);
 int pgdvs_static_aggregate(const float *rgbs, const float *depths, const uint8_t *dyn_masks,
                            const double *K3s_host, const double *c2ws_host, int S, int H, int W,
                            float *out, int64_t capacity, int64_t *count_out, void *workspace,

@@ -191,33 +191,40 @@ raster_fill_kernel(int64_t n_host, const int64_t *__restrict__ n_dev,
   }
 }
 
+// The K nearest of a pixel under pytorch3d's total order (z, id): one 64-bit key
+// (z bits << 32 | id) per entry -- z >= 0 here, so the IEEE bit pattern is monotone and a single
+// unsigned compare replaces the (z <, z ==, id <) triple.
 template <int K>
 struct TopK {
-  float z[K];
+  unsigned long long key[K];
   float d[K];
-  int id[K];
+  static constexpr unsigned long long kEmpty = ~0ull;
   __device__ __forceinline__ void init() {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      z[k] = __builtin_inff();
+      key[k] = kEmpty;
       d[k] = -1.0f;
-      id[k] = 0x7fffffff;
     }
   }
+  __device__ __forceinline__ bool has(int k) const { return key[k] != kEmpty; }
+  __device__ __forceinline__ int id(int k) const { return (int)(unsigned)(key[k] & 0xffffffffull); }
+  __device__ __forceinline__ float z(int k) const { return __uint_as_float((unsigned)(key[k] >> 32)); }
   // keep the K smallest by (z, id)
-  __device__ __forceinline__ void insert(float pz, int pid, float pd) {
-    if (!(pz < z[K - 1] || (pz == z[K - 1] && pid < id[K - 1]))) return;
-    z[K - 1] = pz;
-    id[K - 1] = pid;
+  // pz_canon: z with -0.0 already folded to +0.0 (pytorch3d keeps z == 0 points; order by id)
+  __device__ __forceinline__ void insert(float pz_canon, int pid, float pd) {
+    const unsigned long long kk = ((unsigned long long)__float_as_uint(pz_canon) << 32) | (unsigned)pid;
+    if (!(kk < key[K - 1])) return;
+    key[K - 1] = kk;
     d[K - 1] = pd;
 #pragma unroll
     for (int k = K - 1; k > 0; --k) {
-      bool sw = z[k] < z[k - 1] || (z[k] == z[k - 1] && id[k] < id[k - 1]);
-      if (sw) {
-        float tz = z[k]; z[k] = z[k - 1]; z[k - 1] = tz;
-        float td = d[k]; d[k] = d[k - 1]; d[k - 1] = td;
-        int ti = id[k]; id[k] = id[k - 1]; id[k - 1] = ti;
-      }
+      const bool sw = key[k] < key[k - 1];
+      const unsigned long long ka = key[k], kb = key[k - 1];
+      const float da = d[k], db = d[k - 1];
+      key[k] = sw ? kb : ka;
+      key[k - 1] = sw ? ka : kb;
+      d[k] = sw ? db : da;
+      d[k - 1] = sw ? da : db;
     }
   }
 };
@@ -245,7 +252,8 @@ raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ 
   const bool inside = xi < W && yi < H;
   const float range_x = W > H ? 2.0f * (float)W / (float)H : 2.0f;
   const float range_y = H > W ? 2.0f * (float)H / (float)W : 2.0f;
-  const float xf = pix_to_ndc(W - 1 - xi, W, range_x);
+  // pixels of a partial tile outside the image: NaN centre, every `d2 < r2` test fails
+  const float xf = inside ? pix_to_ndc(W - 1 - xi, W, range_x) : __builtin_nanf("");
   const float yf = pix_to_ndc(H - 1 - yi, H, range_y);
   const float r2 = radius * radius;
   // quadrant bounds in NDC (pixel index is reversed: larger xi = smaller x), widened by the
@@ -266,6 +274,7 @@ raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ 
     if (e < end) {
       int id = lists[e];
       float4 p = ndc4[id];
+      p.z = p.z + 0.0f;  // -0.0 -> +0.0 once, so that the z bits order like the values
       p.w = __int_as_float(id);
       s_pt[threadIdx.x] = p;
     }
@@ -290,7 +299,7 @@ raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ 
           float4 p = strip[j + u];
           float dx = p.x - xf, dy = p.y - yf;
           float d2 = dx * dx + dy * dy;
-          if (inside && d2 < r2) q.insert(p.z, __float_as_int(p.w), d2);
+          if (d2 < r2) q.insert(p.z, __float_as_int(p.w), d2);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -302,20 +311,20 @@ raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ 
   float t = 0.0f;
 #pragma unroll
   for (int k = 0; k < K; ++k)
-    if (q.id[k] != 0x7fffffff) t = t + (1.0f - q.d[k] / r2);
+    if (q.has(k)) t = t + (1.0f - q.d[k] / r2);
   t = t > 1e-4f ? t : 1e-4f;
   float acc[3] = {0.f, 0.f, 0.f}, ones = 0.0f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    bool has = q.id[k] != 0x7fffffff;
-    if (idx_out) idx_out[pix * K + k] = has ? (int64_t)q.id[k] : (int64_t)-1;
-    if (zbuf_out) zbuf_out[pix * K + k] = has ? q.z[k] : -1.0f;
+    bool has = q.has(k);
+    if (idx_out) idx_out[pix * K + k] = has ? (int64_t)q.id(k) : (int64_t)-1;
+    if (zbuf_out) zbuf_out[pix * K + k] = has ? q.z(k) : -1.0f;
     if (dist_out) dist_out[pix * K + k] = has ? q.d[k] : -1.0f;
     if (has) {
       float w = 1.0f - q.d[k] / r2;
       ones = ones + w * 1.0f / t;
       if (rgb_out) {
-        const float *f = feat + (int64_t)q.id[k] * feat_stride;
+        const float *f = feat + (int64_t)q.id(k) * feat_stride;
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc[c] = acc[c] + w * f[c] / t;
       }

@@ -5,16 +5,20 @@
 // Upstream this is single-threaded numpy at dataset construction.  Frame i may only add
 // the static pixels that the cloud accumulated from frames < i does not already cover
 // (integer-truncated projection occupancy), so frames are processed in order; inside a
-// frame everything is data-parallel:
+// frame everything is data-parallel.  Two launches per frame:
 //   mark   : project the accumulated cloud (fp64, as numpy does) and stamp occ[row,col] with
-//            the frame index (no clearing between frames)
-//   count  : per-block number of selected pixels (static && not stamped)
-//   scan   : block offsets, append base, new cloud size
-//   append : ordered scatter -> row-major pixel order, the order numpy's boolean indexing
-//            produces (point ids matter: the rasteriser breaks z ties by id); unproject the
-//            selected pixels (fp32 rays) and append (xyz,rgb) rows
-// No host synchronisation: the running point count lives on the device and every
-// kernel reads it there.
+//            the frame index (no clearing between frames).  Reads a packed xyz copy of the
+//            cloud (12 B/point instead of the 24 B rows); the fp64 quotients only feed a
+//            truncation and a bounds test, so they are formed with a refined reciprocal and
+//            the exact division runs only when the quotient is within rounding distance of an
+//            integer -- decisions stay identical to correctly rounded division.
+//   select : one pass over the frame's pixels that counts the selected ones (static && not
+//            stamped), turns the per-tile counts into ordered offsets inside the same launch
+//            (tagged 8-byte count granules gathered from all predecessor tiles, dynamic tile
+//            tickets for forward progress) and appends the unprojected (xyz,rgb) rows in
+//            row-major pixel order -- the order numpy's boolean indexing produces (point ids
+//            matter: the rasteriser breaks z ties by id).
+// No host synchronisation: the running point counts live on the device.
 #include "common.h"
 
 namespace pgdvs {
@@ -22,27 +26,71 @@ namespace pgdvs {
 struct ProjF64 {
   double K3[9];
   double w2c[16];
+  int affine;  // w2c's last row is exactly (0,0,0,1): vc[3] == 1 and x/vc[3] == x bit for bit
 };
+
+// Decides `q >= 0 && q <= hi` and trunc(q) for q = a / b (correctly rounded fp64 division,
+// what numpy computes) without the division in the common case: q' = a * (1/b) with a
+// Newton-refined reciprocal is within ~1e-15 relative of q; unless q' lies within 1e-13
+// relative of an integer (all decision boundaries are integers) the decisions on q' and q
+// coincide.  Otherwise fall back to the exact division.
+__device__ __forceinline__ bool trunc_div_in_range(double a, double b, int hi, int &out) {
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  double q = a * r;
+  double f = floor(q);
+  double dist = fmin(q - f, (f + 1.0) - q);
+  if (!(dist > fabs(q) * 1e-13 + 1e-290)) q = a / b;  // also taken for inf / NaN
+  if (!(q >= 0.0 && q <= (double)hi)) return false;
+  out = (int)q;
+  return true;
+}
 
 // _compute_pcl_proj_mask, nvidia_eval_pure_geo.py:257-277 (no z>0 test, no epsilon,
 // closed bounds, astype(int) truncation)
 __global__ void __launch_bounds__(256)
-agg_mark_kernel(const float *__restrict__ cloud, const int64_t *__restrict__ count, ProjF64 pj,
+agg_mark_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ count, ProjF64 pj,
                 int H, int W, int frame, uint16_t *__restrict__ occ) {
   const int64_t n = *count;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    double x = (double)cloud[i * 6 + 0], y = (double)cloud[i * 6 + 1], z = (double)cloud[i * 6 + 2];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // the whole grid is resident, so a thread walks several points: the next point's load is
+  // issued before the current point's ~80 fp64 operations
+  float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+  if (i < n) {
+    nx = xyz[i * 3 + 0];
+    ny = xyz[i * 3 + 1];
+    nz = xyz[i * 3 + 2];
+  }
+  for (; i < n; i += stride) {
+    const double x = (double)nx, y = (double)ny, z = (double)nz;
+    if (i + stride < n) {
+      nx = xyz[(i + stride) * 3 + 0];
+      ny = xyz[(i + stride) * 3 + 1];
+      nz = xyz[(i + stride) * 3 + 2];
+    }
     double vc[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 3; ++k) {
       double s = pj.w2c[k * 4 + 0] * x;
       s = s + pj.w2c[k * 4 + 1] * y;
       s = s + pj.w2c[k * 4 + 2] * z;
       s = s + pj.w2c[k * 4 + 3];
       vc[k] = s;
     }
-    double cx = vc[0] / vc[3], cy = vc[1] / vc[3], cz = vc[2] / vc[3];
+    double cx = vc[0], cy = vc[1], cz = vc[2];
+    if (!pj.affine) {
+      double s = pj.w2c[12] * x;
+      s = s + pj.w2c[13] * y;
+      s = s + pj.w2c[14] * z;
+      s = s + pj.w2c[15];
+      cx = vc[0] / s;
+      cy = vc[1] / s;
+      cz = vc[2] / s;
+    }
     double pp[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -51,151 +99,222 @@ agg_mark_kernel(const float *__restrict__ cloud, const int64_t *__restrict__ cou
       s = s + pj.K3[k * 3 + 2] * cz;
       pp[k] = s;
     }
-    double col = pp[0] / pp[2], row = pp[1] / pp[2];
-    if (!(row >= 0.0 && row <= (double)(H - 1))) continue;
-    if (!(col >= 0.0 && col <= (double)(W - 1))) continue;
-    occ[(int64_t)row * W + (int64_t)col] = (uint16_t)frame;
+    int row, col;
+    if (!trunc_div_in_range(pp[1], pp[2], H - 1, row)) continue;
+    if (!trunc_div_in_range(pp[0], pp[2], W - 1, col)) continue;
+    occ[(int64_t)row * W + col] = (uint16_t)frame;
   }
 }
 
-constexpr int kAggBlock = 1024;
-constexpr int kAggItems = 4;
-constexpr int kAggTile = kAggBlock * kAggItems;
+constexpr int kSelThreads = 256;
+constexpr int kSelItems = 16;
+constexpr int kSelTile = kSelThreads * kSelItems;
+constexpr unsigned kSelSpinLimit = 1u << 22;
 
-// selection flag of pixel p in frame `frame`: static and not covered by the accumulated
-// cloud.  occ holds the index of the last frame whose mark pass touched the pixel, so it
-// never needs clearing between frames.
-__device__ __forceinline__ bool agg_selected(const uint8_t *__restrict__ dyn_mask,
-                                             const uint16_t *__restrict__ occ, int frame, int p) {
-  bool st = dyn_mask[p] == 0;
-  if (frame > 0) st = st && occ[p] != (uint16_t)frame;
-  return st;
+// tile count granule: [63:48] frame tag, [47:46] status (unused, 1), [45:0] value
+__device__ __forceinline__ unsigned long long sel_desc(int tag, int status, long long v) {
+  return ((unsigned long long)tag << 48) | ((unsigned long long)status << 46) | (unsigned long long)v;
 }
 
-// per-block number of selected pixels (tmp_st_mask & ~tmp_proj_mask, :224-245)
-__global__ void __launch_bounds__(kAggBlock)
-agg_count_kernel(const uint8_t *__restrict__ dyn_mask, const uint16_t *__restrict__ occ, int frame,
-                 int P, int32_t *__restrict__ block_counts) {
-  __shared__ int wave_sums[kAggBlock / kWave];
-  int base = blockIdx.x * kAggTile + threadIdx.x * kAggItems;
-  int c = 0;
+struct SelArgs {
+  const uint8_t *dyn_mask;   // frame's mask [P]
+  const uint16_t *occ;       // [P]
+  const float *depth;        // frame's depth [P]
+  const float *rgb;          // frame's colours [P,3]
+  float *cloud;              // [capacity,6]
+  float *xyz;                // [capacity,3] packed copy for the mark pass
+  int64_t *cnts;             // [S+1] cloud size before each frame; cnts[S] = final
+  int64_t *count_out;
+  unsigned long long *desc;  // [tiles]
+  int32_t *ticket;           // [S]
+  int32_t *error;            // set when a look-back spin gives up
+  int64_t capacity;
+  int frame, last_frame, P, W, tiles;
+};
+
+// selection flags of 16 consecutive pixels: static and (frame 0 or) not stamped by this
+// frame's mark pass (tmp_st_mask & ~tmp_proj_mask, :224-245)
+__device__ __forceinline__ unsigned sel_flags16(const SelArgs &a, int base) {
+  unsigned flags = 0;
+  if (base + kSelItems <= a.P && ((reinterpret_cast<uintptr_t>(a.dyn_mask + base) & 15) == 0)) {
+    const uint4 m = *reinterpret_cast<const uint4 *>(a.dyn_mask + base);
+    const unsigned mw[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
-  for (int k = 0; k < kAggItems; ++k)
-    if (base + k < P) c += agg_selected(dyn_mask, occ, frame, base + k);
-  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-  if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int s = 0;
-    for (int i = 0; i < kAggBlock / kWave; ++i) s += wave_sums[i];
-    block_counts[blockIdx.x] = s;
-  }
-}
-
-// exclusive scan of the block counts; publishes the append base (= current cloud size) and
-// bumps the cloud size by the number of selected pixels
-__global__ void __launch_bounds__(1024)
-agg_scan_kernel(int32_t *__restrict__ block_counts, int nb, int64_t *__restrict__ count,
-                int64_t *__restrict__ append_base, int64_t capacity) {
-  __shared__ int wave_sums[1024 / kWave];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int start = 0; start < nb; start += 1024) {
-    int i = start + threadIdx.x;
-    int v = i < nb ? block_counts[i] : 0;
-    int x = v;
-    for (int off = 1; off < 64; off <<= 1) {
-      int y = __shfl_up(x, off, 64);
-      if ((threadIdx.x & 63) >= off) x += y;
+    for (int k = 0; k < 16; ++k) flags |= (((mw[k >> 2] >> ((k & 3) * 8)) & 0xffu) == 0u ? 1u : 0u) << k;
+    if (a.frame > 0) {
+      const uint4 o0 = *reinterpret_cast<const uint4 *>(a.occ + base);
+      const uint4 o1 = *reinterpret_cast<const uint4 *>(a.occ + base + 8);
+      const unsigned ow[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+      unsigned stamped = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        stamped |= (((ow[k >> 1] >> ((k & 1) * 16)) & 0xffffu) == (unsigned)a.frame ? 1u : 0u) << k;
+      flags &= ~stamped;
     }
-    int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 63) wave_sums[wave] = x;
-    __syncthreads();
-    int wave_off = 0;
-    for (int w = 0; w < wave; ++w) wave_off += wave_sums[w];
-    int incl = carry + wave_off + x;
-    if (i < nb) block_counts[i] = incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry = incl;
-    __syncthreads();
+  } else {
+    for (int k = 0; k < kSelItems; ++k) {
+      const int p = base + k;
+      if (p >= a.P) break;
+      bool st = a.dyn_mask[p] == 0;
+      if (a.frame > 0) st = st && a.occ[p] != (uint16_t)a.frame;
+      flags |= (st ? 1u : 0u) << k;
+    }
   }
-  if (threadIdx.x == 0) {
-    int64_t base = *count;
-    *append_base = base;
-    int64_t c = base + (int64_t)carry;
-    *count = c > capacity ? capacity : c;
-  }
+  return flags;
 }
 
-// ordered scatter: selected pixel -> its row-major rank -> unproject (fp32 rays) and append
-// (tmp_pcl[tmp_st_mask], tmp_img[tmp_st_mask] :247-251)
-__global__ void __launch_bounds__(kAggBlock)
-agg_append_kernel(const uint8_t *__restrict__ dyn_mask, const uint16_t *__restrict__ occ, int frame,
-                  int P, const int32_t *__restrict__ block_offsets, CamBlock cam, int W,
-                  const float *__restrict__ depth, const float *__restrict__ rgb,
-                  float *__restrict__ cloud, const int64_t *__restrict__ append_base,
-                  int64_t capacity) {
-  __shared__ int wave_sums[kAggBlock / kWave];
-  int base = blockIdx.x * kAggTile + threadIdx.x * kAggItems;
-  bool f[kAggItems];
-  int c = 0;
-#pragma unroll
-  for (int k = 0; k < kAggItems; ++k) {
-    f[k] = (base + k < P) && agg_selected(dyn_mask, occ, frame, base + k);
-    c += f[k];
-  }
+__global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamBlock cam) {
+  __shared__ int s_tile;
+  __shared__ int wave_sums[kSelThreads / kWave];
+  __shared__ long long s_excl;
+  __shared__ uint16_t s_list[kSelTile];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // dynamic tile id: a tile's predecessors are always owned by blocks that already run
+  // (with <= 1024 tiles the whole grid is resident and blockIdx order is as good)
+  if (tid == 0) s_tile = (a.tiles <= 1024) ? (int)blockIdx.x : atomicAdd(&a.ticket[a.frame], 1);
+  __syncthreads();
+  const int tile = s_tile;
+  const int base = tile * kSelTile + tid * kSelItems;
+  const unsigned flags = base < a.P ? sel_flags16(a, base) : 0u;
+  const int c = __popc(flags);
   int x = c;
   for (int off = 1; off < 64; off <<= 1) {
     int y = __shfl_up(x, off, 64);
-    if ((threadIdx.x & 63) >= off) x += y;
+    if (lane >= off) x += y;
   }
-  int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 63) wave_sums[wave] = x;
+  if (lane == 63) wave_sums[wave] = x;
   __syncthreads();
-  int wave_off = 0;
-  for (int w = 0; w < wave; ++w) wave_off += wave_sums[w];
-  int64_t pos = *append_base + block_offsets[blockIdx.x] + wave_off + x - c;
+  int wave_off = 0, total = 0;
 #pragma unroll
-  for (int k = 0; k < kAggItems; ++k) {
-    if (!f[k]) continue;
-    if (pos < capacity) {
-      int p = base + k;
-      int r = p / W, col = p - r * W;
-      float u = (float)col, v = (float)r;
-      float d = depth[p];
-      float *o = cloud + pos * 6;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        float dir = cam.v[PGDVS_CAM_M + a * 3 + 0] * u;
-        dir = dir + cam.v[PGDVS_CAM_M + a * 3 + 1] * v;
-        dir = dir + cam.v[PGDVS_CAM_M + a * 3 + 2];
-        o[a] = cam.v[PGDVS_CAM_O + a] + dir * d;
-        o[3 + a] = rgb[(size_t)p * 3 + a];
+  for (int w = 0; w < kSelThreads / kWave; ++w) {
+    if (w < wave) wave_off += wave_sums[w];
+    total += wave_sums[w];
+  }
+  // Ordered offsets without a second launch: every tile publishes its count as one tagged
+  // 8-byte granule, then sums the granules of ALL its predecessors (each thread polls its own
+  // few words, one visibility round trip in total -- every tile of a frame is resident at the
+  // same time, so a chained look-back would serialise instead).
+  const int tag = a.frame + 1;
+  if (tid == 0)
+    __hip_atomic_store(&a.desc[tile], sel_desc(tag, 1, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  long long part = 0;
+  for (int j = tid; j < tile; j += kSelThreads) {
+    unsigned spins = 0;
+    unsigned long long d;
+    while (true) {
+      d = __hip_atomic_load(&a.desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)(d >> 48) == tag) break;
+      if (++spins > kSelSpinLimit) {  // never expected; keeps a protocol bug from hanging the GPU
+        atomicExch(a.error, 1);
+        break;
       }
+      __builtin_amdgcn_s_sleep(1);
     }
-    ++pos;
+    part += (long long)(d & ((1ull << 46) - 1));
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+  __shared__ long long wave_part[kSelThreads / kWave];
+  if (lane == 0) wave_part[wave] = part;
+  __syncthreads();
+  if (tid == 0) {
+    long long e = 0;
+#pragma unroll
+    for (int w = 0; w < kSelThreads / kWave; ++w) e += wave_part[w];
+    s_excl = e;
+  }
+  __syncthreads();
+  const int64_t cloud_base = a.cnts[a.frame];
+  if (tile == a.tiles - 1 && tid == 0) {
+    int64_t n = cloud_base + s_excl + total;
+    n = n > a.capacity ? a.capacity : n;
+    a.cnts[a.frame + 1] = n;
+    if (a.frame == a.last_frame) *a.count_out = n;
+  }
+  // Ordered append (tmp_pcl[tmp_st_mask], tmp_img[tmp_st_mask] :247-251): the tile's selected
+  // pixels are first compacted into an LDS list (row-major rank order), then the whole block
+  // walks the list -- consecutive threads write consecutive cloud rows and every thread has
+  // several independent loads in flight, however the selected pixels cluster.
+  if (total == 0) return;
+  {
+    int slot = wave_off + x - c;
+    unsigned f = flags;
+    while (f) {
+      const int k = __builtin_ctz(f);
+      f &= f - 1;
+      s_list[slot++] = (uint16_t)(tid * kSelItems + k);
+    }
+  }
+  __syncthreads();
+  const float *__restrict__ depth = a.depth;
+  const float *__restrict__ rgb = a.rgb;
+  float *__restrict__ cloud = a.cloud;
+  float *__restrict__ xyz = a.xyz;
+  const int64_t pos0 = cloud_base + s_excl;
+  const int tile_px = tile * kSelTile;
+#pragma unroll 4
+  for (int e = tid; e < total; e += kSelThreads) {
+    const int64_t pos = pos0 + e;
+    if (pos >= a.capacity) break;
+    const int p = tile_px + (int)s_list[e];
+    const int r = p / a.W, col = p - r * a.W;
+    const float u = (float)col, v = (float)r;
+    const float d = depth[p];
+    const float c0 = rgb[(size_t)p * 3 + 0], c1 = rgb[(size_t)p * 3 + 1], c2 = rgb[(size_t)p * 3 + 2];
+    float X[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      float dir = cam.v[PGDVS_CAM_M + ax * 3 + 0] * u;
+      dir = dir + cam.v[PGDVS_CAM_M + ax * 3 + 1] * v;
+      dir = dir + cam.v[PGDVS_CAM_M + ax * 3 + 2];
+      X[ax] = cam.v[PGDVS_CAM_O + ax] + dir * d;
+    }
+    float *o = cloud + pos * 6;
+    o[0] = X[0];
+    o[1] = X[1];
+    o[2] = X[2];
+    o[3] = c0;
+    o[4] = c1;
+    o[5] = c2;
+    float *q = xyz + pos * 3;
+    q[0] = X[0];
+    q[1] = X[1];
+    q[2] = X[2];
   }
 }
 
 struct AggWs {
+  // state block zeroed once per call: cnts[S+1], ticket[S], error, desc[tiles]
+  char *state;
+  int64_t state_bytes;
+  int64_t *cnts;
+  int32_t *ticket, *error;
+  unsigned long long *desc;
   uint16_t *occ;
-  int32_t *block_counts;
-  int64_t *append_base;
+  float *xyz;
   int64_t total_bytes;
 };
 
-static AggWs agg_ws_layout(void *base, int H, int W) {
+static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   AggWs w;
-  int64_t P = (int64_t)H * W;
+  const int64_t P = (int64_t)H * W;
+  const int64_t tiles = cdiv(P, kSelTile);
   char *p = reinterpret_cast<char *>(base);
   int64_t off = 0;
+  w.state = p;
+  w.cnts = reinterpret_cast<int64_t *>(p + off);
+  off += align_up((int64_t)(S + 1) * 8, 16);
+  w.ticket = reinterpret_cast<int32_t *>(p + off);
+  off += align_up((int64_t)S * 4, 16);
+  w.error = reinterpret_cast<int32_t *>(p + off);
+  off += 16;
+  w.desc = reinterpret_cast<unsigned long long *>(p + off);
+  off += align_up(tiles * 8, 16);
+  w.state_bytes = off;
+  off = align_up(off, 256);
   w.occ = reinterpret_cast<uint16_t *>(p + off);
-  off += align_up(P * 2, 256);
-  w.block_counts = reinterpret_cast<int32_t *>(p + off);
-  off += align_up(cdiv(P, kAggTile) * 4, 256);
-  w.append_base = reinterpret_cast<int64_t *>(p + off);
-  off += 256;
+  off += align_up(P * 2 + 32, 256);
+  w.xyz = reinterpret_cast<float *>(p + off);
+  off += align_up((capacity > 0 ? capacity : 1) * 12, 256);
   w.total_bytes = off;
   return w;
 }
@@ -204,9 +323,9 @@ static AggWs agg_ws_layout(void *base, int H, int W) {
 
 using namespace pgdvs;
 
-PGDVS_API int64_t pgdvs_static_aggregate_workspace_bytes(int H, int W) {
-  if (H <= 0 || W <= 0) return -1;
-  return agg_ws_layout(nullptr, H, W).total_bytes;
+PGDVS_API int64_t pgdvs_static_aggregate_workspace_bytes(int S, int H, int W, int64_t capacity) {
+  if (S <= 0 || H <= 0 || W <= 0 || capacity <= 0) return -1;
+  return agg_ws_layout(nullptr, S, H, W, capacity).total_bytes;
 }
 
 PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
@@ -216,22 +335,23 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
                                      int64_t workspace_bytes, pgdvs_stream_t stream) {
   PGDVS_REQUIRE(rgbs && depths && dyn_masks && K3s_host && c2ws_host && out && count_out,
                 "pgdvs_static_aggregate: null pointer");
-  PGDVS_REQUIRE(S > 0 && S < 65535 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31) && capacity > 0,
+  PGDVS_REQUIRE(S > 0 && S < 65535 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31) && capacity > 0 &&
+                    capacity < (1ll << 45),
                 "pgdvs_static_aggregate: bad shape");
-  AggWs ws = agg_ws_layout(workspace, H, W);
+  AggWs ws = agg_ws_layout(workspace, S, H, W, capacity);
   if (!workspace || workspace_bytes < ws.total_bytes) {
     set_error("pgdvs_static_aggregate: workspace too small");
     return PGDVS_ERR_WORKSPACE;
   }
   hipStream_t st = as_stream(stream);
   const int64_t P = (int64_t)H * W;
-  hipError_t e = hipMemsetAsync(count_out, 0, sizeof(int64_t), st);
+  hipError_t e = hipMemsetAsync(ws.state, 0, (size_t)ws.state_bytes, st);
   if (e == hipSuccess) e = hipMemsetAsync(ws.occ, 0, (size_t)P * 2, st);
   if (e != hipSuccess) {
     set_error("static_aggregate memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
   }
-  const int nb = (int)cdiv(P, kAggTile);
+  const int tiles = (int)cdiv(P, kSelTile);
   for (int i = 0; i < S; ++i) {
     const double *K3 = K3s_host + (size_t)i * 9;
     const double *c2w = c2ws_host + (size_t)i * 16;
@@ -241,6 +361,7 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
       set_error("pgdvs_static_aggregate: singular c2w for frame %d", i);
       return PGDVS_ERR_INVALID;
     }
+    pj.affine = pj.w2c[12] == 0.0 && pj.w2c[13] == 0.0 && pj.w2c[14] == 0.0 && pj.w2c[15] == 1.0;
     // rays use K and c2w cast to fp32 (torch.FloatTensor, nvidia_eval.py:841-842)
     float flat[34];
     flat[0] = (float)H;
@@ -254,17 +375,28 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
       set_error("pgdvs_static_aggregate: singular intrinsics for frame %d", i);
       return PGDVS_ERR_INVALID;
     }
-    const uint8_t *mask_i = dyn_masks + (size_t)i * P;
     if (i > 0)
-      PGDVS_LAUNCH("agg_mark", agg_mark_kernel, dim3(2048), dim3(256), 0, st, out, count_out, pj, H, W, i,
-                   ws.occ);
-    PGDVS_LAUNCH("agg_count", agg_count_kernel, dim3(nb), dim3(kAggBlock), 0, st, mask_i, ws.occ, i, (int)P,
-                 ws.block_counts);
-    PGDVS_LAUNCH("agg_scan", agg_scan_kernel, dim3(1), dim3(1024), 0, st, ws.block_counts, nb, count_out,
-                 ws.append_base, capacity);
-    PGDVS_LAUNCH("agg_append", agg_append_kernel, dim3(nb), dim3(kAggBlock), 0, st, mask_i, ws.occ, i,
-                 (int)P, ws.block_counts, cam, W, depths + (size_t)i * P, rgbs + (size_t)i * P * 3, out,
-                 ws.append_base, capacity);
+      PGDVS_LAUNCH("agg_mark", agg_mark_kernel, dim3(2048), dim3(256), 0, st, (const float *)ws.xyz,
+                   (const int64_t *)(ws.cnts + i), pj, H, W, i, ws.occ);
+    SelArgs a;
+    a.dyn_mask = dyn_masks + (size_t)i * P;
+    a.occ = ws.occ;
+    a.depth = depths + (size_t)i * P;
+    a.rgb = rgbs + (size_t)i * P * 3;
+    a.cloud = out;
+    a.xyz = ws.xyz;
+    a.cnts = ws.cnts;
+    a.count_out = count_out;
+    a.desc = ws.desc;
+    a.ticket = ws.ticket;
+    a.error = ws.error;
+    a.capacity = capacity;
+    a.frame = i;
+    a.last_frame = S - 1;
+    a.P = (int)P;
+    a.W = W;
+    a.tiles = tiles;
+    PGDVS_LAUNCH("agg_select", agg_select_kernel, dim3(tiles), dim3(kSelThreads), 0, st, a, cam);
   }
   return check_launch("static_aggregate");
 }

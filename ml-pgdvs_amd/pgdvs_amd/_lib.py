@@ -43,7 +43,7 @@ SIGNATURES = {
     "pgdvs_dyn_splat_composite": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "pgdvs_points_raster_workspace_bytes": (_i64, [_i64, _i, _i, _f]),
     "pgdvs_points_raster": (_i, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp]),
-    "pgdvs_static_aggregate_workspace_bytes": (_i64, [_i, _i]),
+    "pgdvs_static_aggregate_workspace_bytes": (_i64, [_i, _i, _i, _i64]),
     "pgdvs_static_aggregate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _vp, _i64, _vp]),
     "pgdvs_gnt_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp,
                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -330,7 +330,7 @@ def static_aggregate(rgbs, depths, dyn_masks, K3s, c2ws, capacity: int | None = 
     out = torch.empty((cap, 6), dtype=torch.float32, device=r.device)
     cnt = torch.empty(1, dtype=torch.int64, device=r.device)
     lib = _lib.load()
-    ws = _ws(lib.pgdvs_static_aggregate_workspace_bytes(H, W), r.device)
+    ws = _ws(lib.pgdvs_static_aggregate_workspace_bytes(S, H, W, cap), r.device)
     check(lib.pgdvs_static_aggregate(
         _ptr(r), _ptr(d), _ptr(m), K3.ctypes.data_as(C.c_void_p), c2w.ctypes.data_as(C.c_void_p), S, H, W,
         _ptr(out), cap, _ptr(cnt), _ptr(ws), ws.numel(), _stream()), "pgdvs_static_aggregate")

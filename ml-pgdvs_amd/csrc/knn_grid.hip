@@ -447,7 +447,11 @@ grid_query_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ 
       int row_id = base + lane;
       // r == 1: visit the query's own row first so the threshold is tight before the
       // neighbouring rows are (mostly) pruned
-      if (r == 1) row_id = row_id == 0 ? 4 : (row_id == 4 ? 0 : row_id);
+      // r == 1: visit the rows nearest first -- own row, the two rows of the same z layer, the
+      // two rows above / below, then the four diagonal ones -- so that the threshold is tight
+      // before the farther rows are (mostly) pruned and fewer candidates are inserted only to
+      // be evicted later
+      if (r == 1) row_id = row_id < 9 ? (int)((0x862071534ull >> (row_id * 4)) & 15) : row_id;
       int s0 = 0, e0 = 0, s1 = 0, e1 = 0;
       float bd0 = 0.0f, bd1 = 0.0f;  // lower bound of the squared distance to any point of the run
       if (row_id < nrows) {

@@ -8,13 +8,17 @@ import torch
 from .. import ops
 
 
-def hwf_to_K(h, w, f):
-    """``_hwf_to_K(normalized=False)`` (pgdvs/datasets/nvidia_eval.py:1013-1019), float64."""
+def hwf_to_K(h, w, f, tgt_shape=None):
+    """``_hwf_to_K(normalized=False)`` (pgdvs/datasets/nvidia_eval.py:1013-1035), float64;
+    ``tgt_shape`` = (h, w) rescales the intrinsics to another image size."""
     K = np.eye(3)
     K[0, 0] = f
     K[1, 1] = f
     K[0, 2] = w / 2.0
     K[1, 2] = h / 2.0
+    if tgt_shape is not None:
+        K[0, :] = K[0, :] * tgt_shape[1] / w
+        K[1, :] = K[1, :] * tgt_shape[0] / h
     return K
 
 

@@ -312,6 +312,31 @@ def test_static_aggregation_vs_oracle_synth():
     assert st.shape[0] < 0.6 * 5 * 54 * 96
 
 
+def test_pure_geo_dataset_static_cloud_vs_reference(golden_dir, tmp_path):
+    """on-disk sequence -> NvidiaDynPureGeoEvaluationDataset mirror (HIP aggregation at
+    construction) vs what the reference's dataset class produced on the same tree"""
+    import sys as _sys
+
+    _sys.path.insert(0, str(golden_dir))
+    import nvidia_tree as NT
+    from pgdvs_amd.datasets.nvidia_eval import NvidiaDynPureGeoEvaluationDataset
+
+    root = NT.build_tree(tmp_path)
+    g = _load(golden_dir, "nvidia_items.npz")
+    ds = NvidiaDynPureGeoEvaluationDataset(
+        data_root=root, raw_data_dir="raw", depth_data_dir="depths", mask_data_dir="masks", flow_data_dir="flows", max_hw=-1,
+        mode="eval", scene_ids=[NT.SCENE], flow_consist_thres=1.0, device=DEV)
+    item = ds[5 * NT.N_CAMS + 5]
+    assert sorted(item.keys()) == list(g["pg_keys"])
+    st = item["st_pcl_rgb"].numpy()
+    assert st.shape == tuple(g["pg_st_pcl_rgb__shape"])  # same occupancy decisions
+    np.testing.assert_allclose(st[:64], g["pg_st_pcl_rgb_head"], rtol=1e-5, atol=1e-6)
+    a = st.astype(np.float64).reshape(-1)
+    dig = np.array([a @ np.random.default_rng(12345).random(a.size), a.sum(), a.min(), a.max()])
+    np.testing.assert_allclose(dig, g["pg_st_pcl_rgb__digest"], rtol=1e-5)
+    np.testing.assert_allclose(item["flat_cam_tgt"].numpy(), g["pg_flat_cam_tgt"], rtol=1e-6)
+
+
 # ---------------------------------------------------------------- whole view vs oracle (geo static)
 @pytest.mark.parametrize("H,W,S,rm,K", [(54, 96, 4, False, 1), (72, 128, 4, True, 3)])
 def test_render_view_geo_vs_oracle(H, W, S, rm, K):

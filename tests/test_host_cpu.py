@@ -7,6 +7,7 @@ import re
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -168,3 +169,69 @@ def test_harness_quantisation_and_psnr_vs_reference(golden_dir):
     m = torch.from_numpy(g["mask"])
     assert abs(masked_psnr(pq, gq, m) - float(g["psnr"])) < 1e-9
     assert masked_psnr(gq, gq, m) == float(g["psnr_same"]) == 0
+
+
+# ---------------------------------------------------------------- on-disk formats -> data dict (8f-3)
+def _digest(a):
+    a = np.asarray(a, np.float64).reshape(-1)
+    return np.array([a @ np.random.default_rng(12345).random(a.size), a.sum(), a.min(), a.max()])
+
+
+@pytest.fixture(scope="module")
+def nvidia_tree(tmp_path_factory):
+    import sys
+
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent / "golden"))
+    import nvidia_tree as NT
+
+    return NT, NT.build_tree(tmp_path_factory.mktemp("nvidia"))
+
+
+def test_nvidia_dataset_items_vs_reference(golden_dir, nvidia_tree):
+    """the mirror dataset, pointed at a rebuilt copy of the synthetic tree, returns what the
+    reference's NvidiaDynEvaluationDataset returned on it (tests/golden/make_golden_nvidia.py)"""
+    from pgdvs_amd.datasets.nvidia_eval import NvidiaDynEvaluationDataset, read_llff_cams
+
+    NT, root = nvidia_tree
+    g = dict(np.load(golden_dir / "nvidia_items.npz"))
+    hwf, c2w = read_llff_cams(root / "raw" / NT.SCENE / "dense" / "poses_bounds_cvd.npy")
+    assert np.array_equal(hwf, g["cam_hwf"]) and np.array_equal(c2w, g["cam_c2w"])
+    ds = NvidiaDynEvaluationDataset(
+        data_root=root, raw_data_dir="raw", depth_data_dir="depths", mask_data_dir="masks", flow_data_dir="flows", max_hw=-1,
+        mode="eval", scene_ids=[NT.SCENE], n_src_views_spatial=4, n_src_views_temporal_track_one_side=2, flow_consist_thres=1.0)
+    assert len(ds) == NT.F * NT.N_CAMS
+    for n, (f, c) in enumerate(g["items"]):
+        item = ds[int(f) * NT.N_CAMS + int(c)]
+        assert item["misc"] == {"scene_id": NT.SCENE, "tgt_frame_id": int(f), "tgt_cam_id": int(c)}
+        ref_keys = {k[len(f"i{n}_"):].split("__")[0] for k in g if k.startswith(f"i{n}_")}
+        derived = {k for k in item if k.startswith("dyn_rgb") or k.startswith("static_rgb")}
+        assert set(item.keys()) - {"scene_id", "misc"} - derived == ref_keys
+        for k in sorted(ref_keys):
+            v = item[k].numpy()
+            if k.startswith("rgb_"):
+                v = np.round(v * 255.0)
+            if f"i{n}_{k}" in g:
+                ref = g[f"i{n}_{k}"]
+                assert v.shape == ref.shape, k
+                if np.issubdtype(ref.dtype, np.integer):
+                    assert np.array_equal(v, ref), k  # frame selections, counts
+                else:
+                    np.testing.assert_allclose(v, ref, rtol=1e-6, atol=1e-7, err_msg=k)  # cameras, times, depth_range
+            else:
+                assert tuple(v.shape) == tuple(g[f"i{n}_{k}__shape"]), k
+                np.testing.assert_allclose(_digest(v), g[f"i{n}_{k}__digest"], rtol=1e-7, atol=1e-9, err_msg=k)
+        for sfx in ("spatial", "temporal", "temporal_track_fwd2tgt", "temporal_track_bwd2tgt"):
+            m = item[f"dyn_mask_src_{sfx}"]
+            assert torch.equal(item[f"dyn_rgb_src_{sfx}"], item[f"rgb_src_{sfx}"] * m)
+            assert torch.equal(item[f"static_rgb_src_{sfx}"], item[f"rgb_src_{sfx}"] * (1 - m))
+
+
+def test_nvidia_frame_selection_rules():
+    from pgdvs_amd.datasets.nvidia_eval import select_temporal_frames
+
+    s = select_temporal_frames(5, 5, 14, 2)      # inside the mono video: both neighbours
+    assert s["temporal"] == [4, 6] and s["n_actual_temporal"] == 2 and s["fwd2tgt"] == [2, 3] and s["bwd2tgt"] == [7, 8]
+    s = select_temporal_frames(0, 0, 14, 2)      # first frame: one neighbour, duplicated placeholder
+    assert s["temporal"] == [1, 1] and s["n_actual_temporal"] == 1 and s["n_actual_fwd2tgt"] == 0 and s["bwd2tgt"] == [2, 3]
+    s = select_temporal_frames(6, 2, 14, 2)      # another camera at time 6: the input frame of that instant
+    assert s["temporal"] == [6, 6] and s["n_actual_temporal"] == 1 and s["fwd2tgt"] == [4, 5] and s["bwd2tgt"] == [7, 8]

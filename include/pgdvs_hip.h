@@ -151,6 +151,13 @@ int pgdvs_softsplat_fwd(const float *in, const float *flow, const float *metric,
                         int B, int C, int H, int W, int mode, int eps, void *workspace,
                         int64_t workspace_bytes, pgdvs_stream_t stream);
 
+/* Backward of the raw splat (mode "sum"; softsplat.py:459-617, kernels softsplat_ingrad /
+ * softsplat_flowgrad): ingrad[B,C,H,W] and flowgrad[B,2,H,W] (either nullable) from
+ * outgrad[B,C,H,W].  The normalised modes differentiate through their torch pre/post-processing
+ * exactly as upstream (softsplat.py:294-333). */
+int pgdvs_softsplat_bwd(const float *in, const float *flow, const float *outgrad, float *ingrad,
+                        float *flowgrad, int B, int C, int H, int W, pgdvs_stream_t stream);
+
 /* A6+A7+A8+A11 fused for the renderer: noise-fill of static texels, metric, soft
  * splat of rgb and mask with the shared metric, threshold 1e-3, masking and the
  * final static/dynamic composite (pgdvs_renderer_dyn.py:157-202, pgdvs_renderer.py:169-178).

@@ -201,7 +201,61 @@ dyn_splat_finish_kernel(int P, const float *__restrict__ acc, const float *__res
   }
 }
 
+// Backward of the raw splat (softsplat.py:459-617): one thread per source pixel computes the
+// four corner weights and their flow derivatives once and walks the channels, producing the
+// input gradient of every channel and both flow gradients from a single read of outgrad (the
+// reference launches softsplat_ingrad over B*C*H*W and softsplat_flowgrad over B*2*H*W threads,
+// the latter re-reading every channel).  A gather: no atomics, deterministic.
+__global__ void __launch_bounds__(256)
+softsplat_bwd_kernel(const float *__restrict__ in, const float *__restrict__ flow,
+                     const float *__restrict__ outgrad, float *__restrict__ ingrad,
+                     float *__restrict__ flowgrad, int C, int H, int W) {
+  const int64_t P = (int64_t)H * W;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int n = blockIdx.y;
+  const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
+  const float X = (float)x + flow[((int64_t)n * 2 + 0) * P + p];
+  const float Y = (float)y + flow[((int64_t)n * 2 + 1) * P + p];
+  bool ok = isfinite(X) && isfinite(Y);
+  const float flx = floorf(X), fly = floorf(Y);
+  if (ok && (flx < -2.0f || flx > (float)W || fly < -2.0f || fly > (float)H)) ok = false;
+  const int nwx = ok ? (int)flx : -8, nwy = ok ? (int)fly : -8;
+  const int cx[4] = {nwx, nwx + 1, nwx, nwx + 1}, cy[4] = {nwy, nwy, nwy + 1, nwy + 1};
+  const float sex = (float)(nwx + 1), sey = (float)(nwy + 1), wx = (float)nwx, wy = (float)nwy;
+  const float w[4] = {(sex - X) * (sey - Y), (X - wx) * (sey - Y), (sex - X) * (Y - wy), (X - wx) * (Y - wy)};
+  const float dx[4] = {-1.0f * (sey - Y), +1.0f * (sey - Y), -1.0f * (Y - wy), +1.0f * (Y - wy)};
+  const float dy[4] = {(sex - X) * -1.0f, (X - wx) * -1.0f, (sex - X) * +1.0f, (X - wx) * +1.0f};
+  bool inb[4];
+  int64_t off[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    inb[k] = ok && cx[k] >= 0 && cx[k] < W && cy[k] >= 0 && cy[k] < H;
+    off[k] = inb[k] ? (int64_t)cy[k] * W + cx[k] : 0;
+  }
+  float gfx = 0.0f, gfy = 0.0f;
+  for (int ch = 0; ch < C; ++ch) {
+    const float *og = outgrad + ((int64_t)n * C + ch) * P;
+    const float v = in[((int64_t)n * C + ch) * P + p];
+    float gi = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!inb[k]) continue;
+      const float g = og[off[k]];
+      gi = gi + g * w[k];
+      gfx = gfx + g * v * dx[k];
+      gfy = gfy + g * v * dy[k];
+    }
+    if (ingrad) ingrad[((int64_t)n * C + ch) * P + p] = gi;
+  }
+  if (flowgrad) {
+    flowgrad[((int64_t)n * 2 + 0) * P + p] = gfx;
+    flowgrad[((int64_t)n * 2 + 1) * P + p] = gfy;
+  }
+}
+
 }  // namespace pgdvs
+
 
 using namespace pgdvs;
 
@@ -288,4 +342,15 @@ PGDVS_API int pgdvs_dyn_splat_composite(int H, int W, const float *rgb1, const f
   PGDVS_LAUNCH("dyn_splat_finish", dyn_splat_finish_kernel, grid, block, 0, st, P, acc, static_rgb,
                      render_dyn_rgb, render_dyn_mask, combined, combined_static, combined_dyn);
   return check_launch("dyn_splat_composite");
+}
+
+PGDVS_API int pgdvs_softsplat_bwd(const float *in, const float *flow, const float *outgrad, float *ingrad,
+                                  float *flowgrad, int B, int C, int H, int W, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(in && flow && outgrad && (ingrad || flowgrad), "pgdvs_softsplat_bwd: null pointer");
+  PGDVS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31) && B < 65536,
+                "pgdvs_softsplat_bwd: bad shape");
+  const int64_t P = (int64_t)H * W;
+  PGDVS_LAUNCH("softsplat_bwd", softsplat_bwd_kernel, dim3((unsigned)cdiv(P, 256), B), dim3(256), 0,
+               as_stream(stream), in, flow, outgrad, ingrad, flowgrad, C, H, W);
+  return check_launch("softsplat_bwd");
 }

@@ -39,6 +39,7 @@ SIGNATURES = {
     "pgdvs_backwarp_l1": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pgdvs_softsplat_workspace_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "pgdvs_softsplat_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "pgdvs_softsplat_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pgdvs_dyn_splat_workspace_bytes": (_i64, [_i, _i]),
     "pgdvs_dyn_splat_composite": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "pgdvs_points_raster_workspace_bytes": (_i64, [_i64, _i, _i, _f]),

@@ -251,6 +251,19 @@ def softsplat_fwd(ten_in, ten_flow, ten_metric, mode: int, eps: int):
     return out
 
 
+def softsplat_bwd(ten_in, ten_flow, grad_out, need_in: bool = True, need_flow: bool = True):
+    """gradients of the raw ("sum") splat wrt input and flow."""
+    i = _req(ten_in, torch.float32, "tenIn")
+    f = _req(ten_flow, torch.float32, "tenFlow")
+    g = _req(grad_out, torch.float32, "tenOutgrad")
+    B, Cc, H, W = i.shape
+    gi = torch.empty_like(i) if need_in else None
+    gf = torch.empty_like(f) if need_flow else None
+    check(_lib.load().pgdvs_softsplat_bwd(_ptr(i), _ptr(f), _ptr(g), _ptr(gi), _ptr(gf), B, Cc, H, W, _stream()),
+          "pgdvs_softsplat_bwd")
+    return gi, gf
+
+
 def dyn_splat_composite(rgb1, rgb2, flow12, flow_1_to_tgt, valid_mask, noise, alpha, static_rgb):
     """Returns planar (render_dyn_rgb[3,H,W], render_dyn_mask[H,W], combined, combined_static, combined_dyn)."""
     r1 = _req(rgb1, torch.float32, "rgb1")

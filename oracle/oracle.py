@@ -224,6 +224,17 @@ def softsplat_raw(ten_in, ten_flow) -> np.ndarray:
     return out
 
 
+def softsplat_bwd_raw(ten_in, ten_flow, grad_out):
+    """gradients of the raw splat wrt input and flow (softsplat.py:459-617)."""
+    ten_in, ten_flow, grad_out = _f32(ten_in), _f32(ten_flow), _f32(grad_out)
+    B, C, H, W = ten_in.shape
+    gi = np.empty_like(ten_in)
+    gf = np.empty_like(ten_flow)
+    lib().orc_softsplat_bwd(_p(ten_in, _c_float_p), _p(ten_flow, _c_float_p), _p(grad_out, _c_float_p), _p(gi, _c_float_p),
+                            _p(gf, _c_float_p), B, C, H, W)
+    return gi, gf
+
+
 def softsplat_corners(flow_2hw) -> np.ndarray:
     f = _f32(flow_2hw)
     _, H, W = f.shape

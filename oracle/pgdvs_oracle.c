@@ -499,6 +499,53 @@ ORC_API void orc_softsplat_fwd(const float *in, const float *flow, float *out, i
   }
 }
 
+/* softsplat backward (softsplat.py:459-617): kernels softsplat_ingrad and
+ * softsplat_flowgrad restated.  ingrad[n,c,y,x] = sum_corner outgrad[corner] * w_corner;
+ * flowgrad[n,0/1,y,x] = sum_c sum_corner outgrad[c,corner] * in[c] * d(w_corner)/d(fx|fy), in
+ * the kernels' accumulation order.  Pixels with a non-finite target get zero gradients (the
+ * kernels return early on a zero-initialised buffer).  Either output may be NULL. */
+ORC_API void orc_softsplat_bwd(const float *in, const float *flow, const float *outgrad,
+                               float *ingrad, float *flowgrad, int B, int C, int H, int W) {
+  const size_t P = (size_t)H * W;
+#pragma omp parallel for collapse(2)
+  for (int n = 0; n < B; ++n) {
+    for (int y = 0; y < H; ++y) {
+      for (int x = 0; x < W; ++x) {
+        size_t p = (size_t)y * W + x;
+        float X = (float)x + flow[((size_t)n * 2 + 0) * P + p];
+        float Y = (float)y + flow[((size_t)n * 2 + 1) * P + p];
+        float gfx = 0.0f, gfy = 0.0f;
+        int ok = isfinite(X) && isfinite(Y);
+        float flx = floorf(X), fly = floorf(Y);
+        if (ok && (flx < -2.0f || flx > (float)W || fly < -2.0f || fly > (float)H)) ok = 0; /* every corner fails the bounds test */
+        int nwx = ok ? (int)flx : -8, nwy = ok ? (int)fly : -8;
+        int cx[4] = {nwx, nwx + 1, nwx, nwx + 1}, cy[4] = {nwy, nwy, nwy + 1, nwy + 1};
+        float sex = (float)(nwx + 1), sey = (float)(nwy + 1), wx = (float)nwx, wy = (float)nwy;
+        float w[4] = {(sex - X) * (sey - Y), (X - wx) * (sey - Y), (sex - X) * (Y - wy), (X - wx) * (Y - wy)};
+        float dx[4] = {-1.0f * (sey - Y), +1.0f * (sey - Y), -1.0f * (Y - wy), +1.0f * (Y - wy)};
+        float dy[4] = {(sex - X) * -1.0f, (X - wx) * -1.0f, (sex - X) * +1.0f, (X - wx) * +1.0f};
+        for (int ch = 0; ch < C; ++ch) {
+          const float *og = outgrad + ((size_t)n * C + ch) * P;
+          float v = in[((size_t)n * C + ch) * P + p];
+          float gi = 0.0f;
+          for (int k = 0; k < 4; ++k) {
+            if (!(ok && cx[k] >= 0 && cx[k] < W && cy[k] >= 0 && cy[k] < H)) continue;
+            float g = og[(size_t)cy[k] * W + cx[k]];
+            gi = gi + g * w[k];
+            gfx = gfx + g * v * dx[k];
+            gfy = gfy + g * v * dy[k];
+          }
+          if (ingrad) ingrad[((size_t)n * C + ch) * P + p] = gi;
+        }
+        if (flowgrad) {
+          flowgrad[((size_t)n * 2 + 0) * P + p] = gfx;
+          flowgrad[((size_t)n * 2 + 1) * P + p] = gfy;
+        }
+      }
+    }
+  }
+}
+
 /* corner indices of the splat (the bit-exact integer path): idx[p,4] = flat
  * destination index y*W+x of NW,NE,SW,SE or -1 if dropped. */
 ORC_API void orc_softsplat_corners(const float *flow, int H, int W, int32_t *idx) {

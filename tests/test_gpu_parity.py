@@ -190,6 +190,34 @@ def test_softsplat_modes(golden_dir, mode):
     np.testing.assert_allclose(out, orc.softsplat(g["ten_in"], g["ten_flow"], metric, mode), rtol=2e-5, atol=2e-6)
 
 
+def test_softsplat_backward_vs_oracle_and_autograd_golden(golden_dir):
+    g = _load(golden_dir, "softsplat_bwd.npz")
+    # raw kernels: bit-exact against the oracle restatement
+    gi, gf = ops.softsplat_bwd(T(g["ten_in"]), T(g["ten_flow"]), T(g["grad_out"]))
+    o_gi, o_gf = orc.softsplat_bwd_raw(g["ten_in"], g["ten_flow"], g["grad_out"])
+    assert np.array_equal(N(gi).view(np.uint32), o_gi.view(np.uint32))
+    assert np.array_equal(N(gf).view(np.uint32), o_gf.view(np.uint32))
+    # every mode through autograd vs the reference wrapper's autograd
+    for mode in ["sum", "avg", "linear", "soft"]:
+        ti = T(g["ten_in"]).requires_grad_(True)
+        tf = T(g["ten_flow"]).requires_grad_(True)
+        tm = None
+        if mode in ("linear", "soft"):
+            tm = T(np.abs(g["ten_metric"]) + 0.1 if mode == "linear" else g["ten_metric"]).requires_grad_(True)
+        y = softsplat(ti, tf, tm, mode)
+        y.backward(T(g["grad_out"]))
+        # forward of the differentiable path == fused inference path
+        with torch.no_grad():
+            y_fused = softsplat(ti.detach(), tf.detach(), None if tm is None else tm.detach(), mode)
+        np.testing.assert_allclose(N(y), N(y_fused), rtol=0, atol=1e-5, err_msg=mode)
+        np.testing.assert_allclose(N(y), g[f"{mode}_out"], rtol=0, atol=1e-4, err_msg=mode)
+        scale = max(1.0, float(np.abs(g[f"{mode}_grad_flow"]).max()))
+        np.testing.assert_allclose(N(ti.grad), g[f"{mode}_grad_in"], rtol=0, atol=1e-4, err_msg=mode)
+        np.testing.assert_allclose(N(tf.grad), g[f"{mode}_grad_flow"], rtol=0, atol=1e-5 * scale, err_msg=mode)
+        if tm is not None:
+            np.testing.assert_allclose(N(tm.grad), g[f"{mode}_grad_metric"], rtol=0, atol=1e-4, err_msg=mode)
+
+
 def test_softsplat_argument_checks():
     x, f = torch.zeros(1, 3, 4, 4, device=DEV), torch.zeros(1, 2, 4, 4, device=DEV)
     with pytest.raises(AssertionError):

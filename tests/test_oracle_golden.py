@@ -146,3 +146,15 @@ def test_track_compute_pcl_for_tgt(golden_dir, case):
     assert pcl.shape == g[f"c{case}_out_pcl"].shape
     np.testing.assert_allclose(pcl, g[f"c{case}_out_pcl"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(rgb, g[f"c{case}_out_rgb"], rtol=0, atol=1e-6)
+
+
+# ---------------------------------------------------------------- softsplat backward (8f-4)
+def test_softsplat_backward_vs_autograd_golden(golden_dir):
+    """oracle restatement of softsplat_ingrad / softsplat_flowgrad vs torch autograd through the
+    restated forward (tests/golden/make_golden_softsplat_bwd.py); tolerance: fp32 sums of <= 12
+    products with |values| up to ~10"""
+    g = _load(golden_dir, "softsplat_bwd.npz")
+    gi, gf = orc.softsplat_bwd_raw(g["ten_in"], g["ten_flow"], g["grad_out"])
+    np.testing.assert_allclose(gi, g["sum_grad_in"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(gf, g["sum_grad_flow"], rtol=0, atol=1e-5)
+    assert np.all(gi[0, :, 0, :4] == 0) and np.all(gf[0, :, 0, :4] == 0)  # targets far outside the image

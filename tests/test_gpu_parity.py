@@ -365,6 +365,31 @@ def test_pure_geo_dataset_static_cloud_vs_reference(golden_dir, tmp_path):
     np.testing.assert_allclose(item["flat_cam_tgt"].numpy(), g["pg_flat_cam_tgt"], rtol=1e-6)
 
 
+@pytest.mark.parametrize("S,H,W", [(4, 53, 37), (3, 100, 123), (2, 1100, 2000)])
+def test_static_aggregation_shapes_vs_oracle(S, H, W):
+    """frame sizes that are not multiples of the 16-pixel vector width (unaligned mask rows of
+    later frames), a partial last tile, and > 1024 tiles (ticketed tile ids)"""
+    from pgdvs_amd.datasets.static_aggregation import aggregate_static_pcl
+
+    v = synth.make_video(S, H, W, seed=S * 7 + W)
+    st = N(aggregate_static_pcl(T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]), v["K3s"], v["c2ws"]))
+    o = orc.aggregate_static_pcl(v["rgbs"], v["depths"], v["dyn_masks"], v["K3s"], v["c2ws"])
+    assert st.shape == o.shape
+    assert np.array_equal(st.view(np.uint32), o.view(np.uint32))
+
+
+def test_static_aggregation_capacity_clamp():
+    v = synth.make_video(3, 54, 96, seed=11)
+    full, cnt = ops.static_aggregate(T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]).view(torch.uint8), v["K3s"], v["c2ws"])
+    n = int(cnt.item())
+    cap = n - 1000
+    part, cnt2 = ops.static_aggregate(T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]).view(torch.uint8), v["K3s"], v["c2ws"],
+                                      capacity=cap)
+    assert int(cnt2.item()) <= cap
+    k = min(cap, 54 * 96 // 2)  # rows appended before the clamp bit are unaffected
+    assert torch.equal(part[:k], full[:k])
+
+
 # ---------------------------------------------------------------- whole view vs oracle (geo static)
 @pytest.mark.parametrize("H,W,S,rm,K", [(54, 96, 4, False, 1), (72, 128, 4, True, 3)])
 def test_render_view_geo_vs_oracle(H, W, S, rm, K):

@@ -227,12 +227,12 @@ int pgdvs_gnt_gather(const float *ray_o, const float *ray_d, const float *depth_
  *            csrc/gnt_view.hip (VW_* offsets); built by pgdvs_amd.ops.pack_view_layer
  *   q_in[N,64]; feat[N,V,64] (rgbfeat_fc output); ray_diff[N,V,4]; valid[N,V] u8 (rows
  *   without any valid view must be passed as all-valid, :124-129); q_out[N,64]
- *   stats[N,3] (view entropy, masked std of k, normalised std; means over features) and
- *   logit_scratch[N,V,64] are both given or both NULL. */
+ *   stats[N,3] (nullable): view entropy (:497-500, evaluated online as log l - sum e a / l, within
+ *   2e-7 of the upstream expression), masked std of k, normalised std; means over features. */
 int64_t pgdvs_gnt_view_weight_floats(void);
 int pgdvs_gnt_view_layer(const float *weights, const float *q_in, const float *feat,
                          const float *ray_diff, const uint8_t *valid, int64_t N, int V, float *q_out,
-                         float *stats, float *logit_scratch, pgdvs_stream_t stream);
+                         float *stats, pgdvs_stream_t stream);
 
 /* A14 (ray transformer): Transformer + Attention(attn_mode="qk", 4 heads) of
  * pgdvs/models/gnt/models/transformer_network.py:231-338 for R rays x S samples (S <= 256),

@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256, 1)
 gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__ q_in,
                       const float *__restrict__ feat, const float *__restrict__ ray_diff,
                       const uint8_t *__restrict__ valid, int64_t N, int V, float *__restrict__ q_out,
-                      float *__restrict__ stats, float *__restrict__ logit_scratch) {
+                      float *__restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [VW_LDS_FLOATS]
   for (int k = threadIdx.x; k < VW_LDS_FLOATS; k += blockDim.x) s_w[k] = W_arg[VW_LDS_BEGIN + k];
   __syncthreads();
@@ -225,7 +225,7 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       lin64x64(W + VW_WQ, nullptr, x, qq, i, h);
     }
     float m[32], l[32], acc[32];
-    float sk[32], sk2[32], sabs[32];
+    float sk[32], sk2[32], sabs[32], ue[32];
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
       m[t] = -__builtin_inff();
@@ -235,6 +235,7 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
         sk[t] = 0.0f;
         sk2[t] = 0.0f;
         sabs[t] = 0.0f;
+        ue[t] = 0.0f;
       }
     }
     int nvalid = 0;
@@ -283,13 +284,6 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
           for (int u = 0; u < 8; ++u) lv = mfma(w[u], k[t0 + u], lv);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (STATS) {
-          float *lb = logit_scratch + row * 64 + 4 * h;
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            *reinterpret_cast<float4 *>(lb + featc(16 * mt + c * 4)) =
-                make_float4(la[c * 4], la[c * 4 + 1], la[c * 4 + 2], la[c * 4 + 3]);
-        }
         if (ok) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -297,6 +291,12 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
             float mn = fmaxf(m[t], la[r]);
             float sc = expf(m[t] - mn);  // exp(-inf) = 0 on the first valid view
             float e = expf(la[r] - mn);
+            if (STATS) {
+              // ue = sum_v exp(a_v - m) (a_v - m), carried through the running maximum: the
+              // entropy of the final softmax is log(l) - ue / l (see the epilogue)
+              const float carried = l[t] > 0.0f ? sc * (ue[t] + (m[t] - mn) * l[t]) : 0.0f;
+              ue[t] = carried + e * (la[r] - mn);
+            }
             l[t] = l[t] * sc + e;
             acc[t] = acc[t] * sc + e * (lv[r] + pos[t]);
             m[t] = mn;
@@ -318,19 +318,16 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
     }
     if (g_ok) store_row32(q_out + g * 64, x1, h);
     if (STATS) {
-      // entropy of the normalised attention (second sweep over the stored logits), masked
-      // unbiased std of k and its normalised form; means over the 64 features
+      // Entropy of the normalised attention, sum_v -p_v log(p_v + 1e-8) upstream (:497-500).
+      // With p_v = exp(a_v - m) / l:  -sum p log p = log(l) - ue / l, accumulated online above
+      // (no second sweep, no logit scratch); the 1e-8 inside the log shifts each valid view's
+      // term by -1e-8 + O(1e-16 / p_v), i.e. by less than 2e-7 in total -- far inside the
+      // fp32 noise of the upstream expression and the 1e-4 tolerance.  Then the masked
+      // unbiased std of k and its normalised form; means over the 64 features.
       float ent = 0.0f, sd = 0.0f, sdn = 0.0f;
-      for (int v = 0; v < V; ++v) {
-        const int64_t row = g * V + v;
-        if (valid[row] == 0) continue;
-        float a[32];
-        load_row32(logit_scratch + row * 64, a, h);
+      if (nvalid > 0) {
 #pragma unroll
-        for (int t = 0; t < 32; ++t) {
-          float p = expf(a[t] - m[t]) / l[t];
-          ent += -p * logf(p + 1e-8f);
-        }
+        for (int t = 0; t < 32; ++t) ent += logf(l[t]) - ue[t] / l[t] - 1e-8f * (float)nvalid;
       }
       if (nvalid > 1) {
         float n = (float)nvalid;
@@ -588,12 +585,9 @@ PGDVS_API int64_t pgdvs_gnt_view_weight_floats(void) { return VW_TOTAL; }
 
 PGDVS_API int pgdvs_gnt_view_layer(const float *weights, const float *q_in, const float *feat,
                                    const float *ray_diff, const uint8_t *valid, int64_t N, int V,
-                                   float *q_out, float *stats, float *logit_scratch,
-                                   pgdvs_stream_t stream) {
+                                   float *q_out, float *stats, pgdvs_stream_t stream) {
   PGDVS_REQUIRE(weights && q_in && feat && ray_diff && valid && q_out, "pgdvs_gnt_view_layer: null pointer");
   PGDVS_REQUIRE(N >= 0 && V >= 1, "pgdvs_gnt_view_layer: bad shape");
-  PGDVS_REQUIRE((stats == nullptr) == (logit_scratch == nullptr),
-                "pgdvs_gnt_view_layer: stats and logit_scratch go together");
   if (N == 0) return PGDVS_OK;
   const int64_t ntiles = cdiv(N, 32);
   const unsigned grid = (unsigned)(cdiv(ntiles, 4) < 256 ? cdiv(ntiles, 4) : 256);
@@ -601,10 +595,10 @@ PGDVS_API int pgdvs_gnt_view_layer(const float *weights, const float *q_in, cons
   hipStream_t st = as_stream(stream);
   if (stats) {
     PGDVS_LAUNCH("gnt_view_layer", gnt_view_layer_kernel<true>, dim3(grid), dim3(256), lds, st, weights, q_in,
-                 feat, ray_diff, valid, N, V, q_out, stats, logit_scratch);
+                 feat, ray_diff, valid, N, V, q_out, stats);
   } else {
     PGDVS_LAUNCH("gnt_view_layer", gnt_view_layer_kernel<false>, dim3(grid), dim3(256), lds, st, weights, q_in,
-                 feat, ray_diff, valid, N, V, q_out, stats, logit_scratch);
+                 feat, ray_diff, valid, N, V, q_out, stats);
   }
   const unsigned gff = (unsigned)(cdiv(ntiles, 4) < 2048 ? cdiv(ntiles, 4) : 2048);
   PGDVS_LAUNCH("gnt_ff", gnt_ff_kernel, dim3(gff), dim3(256), 0, st, weights, q_out, N);

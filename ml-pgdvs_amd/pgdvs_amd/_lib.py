@@ -49,7 +49,7 @@ SIGNATURES = {
     "pgdvs_gnt_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp,
                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pgdvs_gnt_view_weight_floats": (_i64, []),
-    "pgdvs_gnt_view_layer": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
+    "pgdvs_gnt_view_layer": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "pgdvs_gnt_ray_layer": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "pgdvs_mesh_render_workspace_bytes": (_i64, [_i, _i]),
     "pgdvs_mesh_render": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

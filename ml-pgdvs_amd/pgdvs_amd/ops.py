@@ -444,9 +444,8 @@ def gnt_view_layer(layer, q, feat, ray_diff, valid, want_stats):
     vd = _req(valid.view(torch.uint8) if valid.dtype == torch.bool else valid, torch.uint8, "valid")
     out = torch.empty_like(qi)
     stats = torch.empty((N, 3), dtype=torch.float32, device=q.device) if want_stats else None
-    scratch = torch.empty((N, V, 64), dtype=torch.float32, device=q.device) if want_stats else None
     check(_lib.load().pgdvs_gnt_view_layer(_ptr(packed), _ptr(qi), _ptr(ft), _ptr(rd), _ptr(vd), N, V, _ptr(out), _ptr(stats),
-                                           _ptr(scratch), _stream()), "pgdvs_gnt_view_layer")
+                                           _stream()), "pgdvs_gnt_view_layer")
     if not want_stats:
         return out, None
     st = stats.reshape(R, S, 3)

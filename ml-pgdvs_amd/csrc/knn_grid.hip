@@ -137,6 +137,44 @@ __global__ void grid_params_kernel(const unsigned *__restrict__ bbox,
   }
 }
 
+// Second-level grid for the queries the first level gives up on: same bounding box, cells
+// `scale` times larger (so the same number of rings reaches `scale` times farther), capped at
+// max_cells.
+__global__ void grid_params_coarse_kernel(const GridParams *__restrict__ fine, const unsigned *__restrict__ bbox,
+                                          GridParams *__restrict__ gp, float scale, int max_cells) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float ext[3];
+  for (int a = 0; a < 3; ++a) {
+    float lo = ord2f(bbox[a]), hi = ord2f(bbox[3 + a]);
+    if (!(hi >= lo)) {
+      lo = 0.0f;
+      hi = 0.0f;
+    }
+    gp->mn[a] = lo;
+    ext[a] = hi - lo;
+  }
+  float h = fine->h * scale;
+  if (!(h > 0.0f) || !isfinite(h)) h = 1.0f;
+  int G[3];
+  for (int it = 0; it < 64; ++it) {
+    long long tot = 1;
+    bool ok = true;
+    for (int a = 0; a < 3; ++a) {
+      float g = floorf(ext[a] / h) + 1.0f;
+      if (!(g < 1024.0f)) ok = false;
+      G[a] = g < 1.0f ? 1 : (g > 1024.0f ? 1024 : (int)g);
+      tot *= G[a];
+    }
+    if (ok && tot <= max_cells) break;
+    h *= 1.3f;
+  }
+  gp->h = h;
+  gp->inv_h = 1.0f / h;
+  gp->ncells = G[0] * G[1] * G[2];
+  gp->n = fine->n;
+  for (int a = 0; a < 3; ++a) gp->G[a] = G[a];
+}
+
 // sum of squared cell counts of the trial grid: sum(c^2)/n is the occupancy of the cell an
 // average POINT lives in (robust against many singleton outlier cells)
 __global__ void __launch_bounds__(256)
@@ -170,15 +208,23 @@ __device__ __forceinline__ int cell_coord(float v, float mn, float inv_h, int G)
 
 __global__ void __launch_bounds__(256)
 grid_count_kernel(const float *__restrict__ pts, const GridParams *__restrict__ gp,
-                  int32_t *__restrict__ cell_of, int32_t *__restrict__ cell_count) {
+                  int32_t *__restrict__ cell_of, int32_t *__restrict__ cell_count,
+                  const int32_t *__restrict__ gate) {
+  if (gate && *gate == 0) return;  // second-level grid: nothing fell through the first level
   const GridParams g = *gp;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
-    int cx = cell_coord(pts[(size_t)i * 3 + 0], g.mn[0], g.inv_h, g.G[0]);
-    int cy = cell_coord(pts[(size_t)i * 3 + 1], g.mn[1], g.inv_h, g.G[1]);
-    int cz = cell_coord(pts[(size_t)i * 3 + 2], g.mn[2], g.inv_h, g.G[2]);
-    int c = (cz * g.G[1] + cy) * g.G[0] + cx;
-    cell_of[i] = c;
-    atomicAdd(&cell_count[c], 1);
+  // points arrive in raster order of their source frame: neighbouring lanes mostly share a
+  // cell, so the run leaders add whole runs (one atomic instruction per wave step)
+  const int n_round = (g.n + 63) / 64 * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+    int c = -1;
+    if (i < g.n) {
+      int cx = cell_coord(pts[(size_t)i * 3 + 0], g.mn[0], g.inv_h, g.G[0]);
+      int cy = cell_coord(pts[(size_t)i * 3 + 1], g.mn[1], g.inv_h, g.G[1]);
+      int cz = cell_coord(pts[(size_t)i * 3 + 2], g.mn[2], g.inv_h, g.G[2]);
+      c = (cz * g.G[1] + cy) * g.G[0] + cx;
+      cell_of[i] = c;
+    }
+    wave_tile_count(cell_count, c);
   }
 }
 
@@ -266,13 +312,17 @@ grid_scan_apply_kernel(const int32_t *__restrict__ in, const GridParams *__restr
 __global__ void __launch_bounds__(256)
 grid_fill_kernel(const float *__restrict__ pts, const GridParams *__restrict__ gp,
                  const int32_t *__restrict__ cell_of, const int32_t *__restrict__ cell_start,
-                 int32_t *__restrict__ cursor, float4 *__restrict__ sorted) {
+                 int32_t *__restrict__ cursor, float4 *__restrict__ sorted,
+                 const int32_t *__restrict__ gate) {
+  if (gate && *gate == 0) return;
   const int n = gp->n;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    int c = cell_of[i];
-    int pos = cell_start[c] + atomicAdd(&cursor[c], 1);
-    sorted[pos] = make_float4(pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2],
-                              __int_as_float(i));
+  const int n_round = (n + 63) / 64 * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+    const int c = i < n ? cell_of[i] : -1;
+    const int slot = wave_tile_reserve(cursor, c);
+    if (i < n)
+      sorted[cell_start[c] + slot] = make_float4(pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2],
+                                                 __int_as_float(i));
   }
 }
 
@@ -381,10 +431,21 @@ struct QuerySrc {
   const float *qpts;      // null: the queries are the points themselves (cell-sorted order)
   const int32_t *qcount;
   int first_col;          // 1: drop column 0 (self), 0: keep it
+  // second-level pass: only the queries listed here (ids into qpts / qsorted) are processed, and
+  // self-queries take their position from `qsorted` (the first-level sorted array) while the
+  // grid being searched is another one
+  const int32_t *list;
+  const int32_t *list_count;
+  const float4 *qsorted;
 };
 
+__device__ __forceinline__ int query_count(const QuerySrc &qs, int n_points) {
+  return qs.list ? *qs.list_count : (qs.qpts ? *qs.qcount : n_points);
+}
+
+// q: base query id (index into qpts, or into the sorted array of self-queries)
 __device__ __forceinline__ float4 load_query(const QuerySrc &qs, const float4 *__restrict__ sorted, int q) {
-  if (qs.qpts == nullptr) return sorted[q];
+  if (qs.qpts == nullptr) return (qs.qsorted ? qs.qsorted : sorted)[q];
   return make_float4(qs.qpts[(size_t)q * 3], qs.qpts[(size_t)q * 3 + 1], qs.qpts[(size_t)q * 3 + 2],
                      __int_as_float(q));
 }
@@ -415,9 +476,10 @@ grid_query_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ 
   const GridParams g = *gp;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int nq = qs.qpts ? *qs.qcount : g.n;
+  const int nq = query_count(qs, g.n);
   // persistent waves: the grid is sized for the machine, not for the (device-side) count
-  for (int q = blockIdx.x * 4 + wave; q < nq; q += gridDim.x * 4) {
+  for (int qi = blockIdx.x * 4 + wave; qi < nq; qi += gridDim.x * 4) {
+  const int q = qs.list ? qs.list[qi] : qi;
   const float4 qp = load_query(qs, sorted, q);
   const float qx = qp.x, qy = qp.y, qz = qp.z;
   const int orig = __float_as_int(qp.w);
@@ -641,8 +703,17 @@ struct GridWs {
   float *fb_bound;
   float *fb_partial;  // [kFbMaxSliced][kFbSlices][64]
   int32_t *stats;  // [16] ring histogram, filled only when PGDVS_KNN_STATS=1 (diagnostics)
+  // second level
+  GridParams *gp2;
+  int32_t *cell_count2, *cursor2, *cell_start2, *block_sums2;
+  float4 *sorted2;
+  int32_t *fb2_count, *fb2_list;
+  float *fb2_bound;
   int64_t total_bytes;
 };
+
+constexpr int kCoarseMaxCells = 1 << 18;
+constexpr float kCoarseScale = 8.0f;
 
 static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   GridWs w;
@@ -675,6 +746,23 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   off += align_up((qcap > 0 ? qcap : 1) * 4, 256);
   w.fb_partial = reinterpret_cast<float *>(p + off);
   off += align_up((int64_t)kFbMaxSliced * kFbSlices * 64 * 4, 256);
+  w.gp2 = reinterpret_cast<GridParams *>(p + off);
+  w.fb2_count = reinterpret_cast<int32_t *>(p + off + 128);
+  off += 256;
+  w.cell_count2 = reinterpret_cast<int32_t *>(p + off);
+  off += align_up(((int64_t)kCoarseMaxCells + 1) * 4, 256);
+  w.cursor2 = reinterpret_cast<int32_t *>(p + off);
+  off += align_up(((int64_t)kCoarseMaxCells + 1) * 4, 256);
+  w.cell_start2 = reinterpret_cast<int32_t *>(p + off);
+  off += align_up(((int64_t)kCoarseMaxCells + 1) * 4, 256);
+  w.block_sums2 = reinterpret_cast<int32_t *>(p + off);
+  off += align_up((int64_t)(kGridMaxCells / kScanTile) * 4, 256);
+  w.sorted2 = reinterpret_cast<float4 *>(p + off);
+  off += align_up((capacity > 0 ? capacity : 1) * 16, 256);
+  w.fb2_list = reinterpret_cast<int32_t *>(p + off);
+  off += align_up((qcap > 0 ? qcap : 1) * 4, 256);
+  w.fb2_bound = reinterpret_cast<float *>(p + off);
+  off += align_up((qcap > 0 ? qcap : 1) * 4, 256);
   w.total_bytes = off;
   return w;
 }
@@ -694,6 +782,9 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   qs.qpts = qpts;
   qs.qcount = qcount;
   qs.first_col = qpts ? 0 : 1;
+  qs.list = nullptr;
+  qs.list_count = nullptr;
+  qs.qsorted = nullptr;
   const int64_t nq_cap = qpts ? qcapacity : capacity;
   if (!workspace || workspace_bytes < ws.total_bytes) {
     set_error("knn_grid: workspace too small");
@@ -701,8 +792,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   }
   // bbox init: min <- 0xffffffff, max <- 0 in the order-preserving uint encoding
   hipError_t e = hipMemsetAsync(ws.bbox, 0xff, 3 * sizeof(unsigned), st);
-  if (e == hipSuccess) e = hipMemsetAsync(ws.bbox + 3, 0x00, 3 * sizeof(unsigned), st);
-  if (e == hipSuccess) e = hipMemsetAsync(ws.sumsq, 0, sizeof(unsigned long long), st);
+  if (e == hipSuccess) e = hipMemsetAsync(ws.bbox + 3, 0x00, 256 - 3 * sizeof(unsigned), st);  // max, sumsq
   if (e != hipSuccess) {
     set_error("knn_grid memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
@@ -718,7 +808,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   PGDVS_LAUNCH("grid_zero", grid_zero_kernel, dim3(2048), dim3(256), 0, st, ws.gp, ws.cell_count,
                (int32_t *)nullptr);
   PGDVS_LAUNCH("grid_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
-               ws.cell_count);
+               ws.cell_count, (const int32_t *)nullptr);
   PGDVS_LAUNCH("grid_occupied", grid_occupied_kernel, dim3(1024), dim3(256), 0, st, ws.cell_count,
                ws.gp, ws.sumsq);
   PGDVS_LAUNCH("grid_params", grid_params_kernel, dim3(1), dim3(64), 0, st, ws.bbox, count,
@@ -726,7 +816,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   PGDVS_LAUNCH("grid_zero", grid_zero_kernel, dim3(2048), dim3(256), 0, st, ws.gp, ws.cell_count,
                ws.cursor);
   PGDVS_LAUNCH("grid_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
-               ws.cell_count);
+               ws.cell_count, (const int32_t *)nullptr);
   const int nb = kGridMaxCells / kScanTile;
   PGDVS_LAUNCH("grid_scan_blocks", grid_scan_blocks_kernel, dim3(nb), dim3(1024), 0, st, ws.cell_count, ws.gp,
                ws.block_sums);
@@ -734,7 +824,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   PGDVS_LAUNCH("grid_scan_apply", grid_scan_apply_kernel, dim3(nb), dim3(1024), 0, st, ws.cell_count, ws.gp,
                ws.block_sums, ws.cell_start);
   PGDVS_LAUNCH("grid_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
-               ws.cell_start, ws.cursor, ws.sorted);
+               ws.cell_start, ws.cursor, ws.sorted, (const int32_t *)nullptr);
   const char *env = getenv("PGDVS_KNN_STATS");
   int32_t *stats = (env && env[0] == '1') ? ws.stats : nullptr;
   e = hipMemsetAsync(ws.stats, 0, 256, st);  // ring histogram + fallback counter
@@ -746,12 +836,42 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   PGDVS_LAUNCH("grid_query", grid_query_kernel, dim3(gq), dim3(256), 0, st, ws.gp, ws.sorted,
                ws.cell_start, KK, qs, avg_out, stats, kRingCap, getenv("PGDVS_KNN_ABL") ? atoi(getenv("PGDVS_KNN_ABL")) : 0,
                ws.fb_count, ws.fb_list, ws.fb_bound);
+  // Second level: the queries still open after kRingCap rings (isolated points, far from
+  // everything in units of the cell size) repeat the ring search on a grid with
+  // kCoarseScale-times larger cells before anything is scanned exhaustively.  All of it is
+  // gated on the device-side count of open queries.
+  e = hipMemsetAsync(ws.fb2_count, 0, 4, st);
+  if (e != hipSuccess) {
+    set_error("knn_grid memset: %s", hipGetErrorString(e));
+    return PGDVS_ERR_LAUNCH;
+  }
+  const int nb2 = kCoarseMaxCells / kScanTile;
+  PGDVS_LAUNCH("grid2_params", grid_params_coarse_kernel, dim3(1), dim3(64), 0, st, ws.gp, ws.bbox, ws.gp2,
+               kCoarseScale, kCoarseMaxCells);
+  PGDVS_LAUNCH("grid2_zero", grid_zero_kernel, dim3(256), dim3(256), 0, st, ws.gp2, ws.cell_count2, ws.cursor2);
+  PGDVS_LAUNCH("grid2_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp2, ws.cell_of,
+               ws.cell_count2, (const int32_t *)ws.fb_count);
+  PGDVS_LAUNCH("grid2_scan", grid_scan_blocks_kernel, dim3(nb2), dim3(1024), 0, st, ws.cell_count2, ws.gp2,
+               ws.block_sums2);
+  PGDVS_LAUNCH("grid2_scan", grid_scan_sums_kernel, dim3(1), dim3(1024), 0, st, ws.block_sums2, nb2);
+  PGDVS_LAUNCH("grid2_scan", grid_scan_apply_kernel, dim3(nb2), dim3(1024), 0, st, ws.cell_count2, ws.gp2,
+               ws.block_sums2, ws.cell_start2);
+  PGDVS_LAUNCH("grid2_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp2, ws.cell_of,
+               ws.cell_start2, ws.cursor2, ws.sorted2, (const int32_t *)ws.fb_count);
+  QuerySrc qs2 = qs;
+  qs2.list = ws.fb_list;
+  qs2.list_count = ws.fb_count;
+  qs2.qsorted = ws.sorted;
+  PGDVS_LAUNCH("grid2_query", grid_query_kernel, dim3(gq < 1024 ? gq : 1024), dim3(256), 0, st, ws.gp2, ws.sorted2,
+               ws.cell_start2, KK, qs2, avg_out, (int32_t *)nullptr, kRingCap, 0, ws.fb2_count, ws.fb2_list,
+               ws.fb2_bound);
+  // exhaustive scan for what is left (rare)
   PGDVS_LAUNCH("grid_fallback", grid_fallback_kernel, dim3(4096), dim3(256), 0, st, ws.gp, ws.sorted, KK,
-               qs, ws.fb_count, ws.fb_list, ws.fb_bound, ws.fb_partial);
+               qs, ws.fb2_count, ws.fb2_list, ws.fb2_bound, ws.fb_partial);
   PGDVS_LAUNCH("grid_fallback_merge", grid_fallback_merge_kernel, dim3(256), dim3(256), 0, st, ws.gp,
-               ws.sorted, KK, qs, ws.fb_count, ws.fb_list, ws.fb_partial, avg_out);
+               ws.sorted, KK, qs, ws.fb2_count, ws.fb2_list, ws.fb_partial, avg_out);
   PGDVS_LAUNCH("grid_fallback_tail", grid_fallback_tail_kernel, dim3(256), dim3(1024), 0, st, ws.gp,
-               ws.sorted, KK, qs, ws.fb_count, ws.fb_list, ws.fb_bound, avg_out);
+               ws.sorted, KK, qs, ws.fb2_count, ws.fb2_list, ws.fb2_bound, avg_out);
   return check_launch("knn_grid");
 }
 

@@ -54,47 +54,6 @@ __device__ __forceinline__ TileBox tile_box(const RasterCam &rc, float3 p, float
   return b;
 }
 
-// Wave-aggregated tile counter update.  Clouds arrive in the raster order of their source
-// frames, so consecutive lanes of a wavefront mostly hit the same tile: lanes form RUNS of
-// equal tile id, the first lane of each run adds the run length for all of them, and every
-// run leader is active in ONE atomic wave-instruction (the atomic units are paced per
-// instruction, not per lane).  Any order is correct -- less coherent input only means
-// shorter runs.  Returns the slot reserved for this lane (fill) or nothing (count).
-struct RunInfo {
-  int leader;   // lane index of this lane's run leader
-  int length;   // run length (valid on the leader)
-  bool is_leader;
-};
-
-__device__ __forceinline__ RunInfo wave_runs(int t) {
-  const int lane = threadIdx.x & 63;
-  int prev = __shfl_up(t, 1, 64);
-  bool lead = lane == 0 || prev != t;
-  unsigned long long L = __ballot(lead);
-  RunInfo r;
-  r.is_leader = lead;
-  unsigned long long below = L & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));  // leaders at or below this lane
-  r.leader = 63 - __builtin_clzll(below);
-  unsigned long long above = lane == 63 ? 0ull : (L >> (lane + 1));  // leaders after this lane
-  r.length = above ? (int)__builtin_ctzll(above) + 1 : 64 - lane;
-  return r;
-}
-
-__device__ __forceinline__ void wave_tile_count(int32_t *__restrict__ counter, int t) {
-  RunInfo r = wave_runs(t);
-  if (r.is_leader && t >= 0)
-    __hip_atomic_fetch_add(&counter[t], r.length, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ int wave_tile_reserve(int32_t *__restrict__ counter, int t) {
-  const int lane = threadIdx.x & 63;
-  RunInfo r = wave_runs(t);
-  int base = 0;
-  if (r.is_leader && t >= 0) base = atomicAdd(&counter[t], r.length);
-  base = __shfl(base, r.leader, 64);
-  return base + (lane - r.leader);
-}
-
 __device__ __forceinline__ int wave_max_i32(int v) {
   for (int off = 32; off > 0; off >>= 1) {
     int o = __shfl_xor(v, off, 64);

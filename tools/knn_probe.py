@@ -23,6 +23,6 @@ run(); torch.cuda.synchronize()
 t=time.perf_counter(); run(); torch.cuda.synchronize(); print("ms",(time.perf_counter()-t)*1e3)
 lib.pgdvs_prof_enable(1); run(); run(); torch.cuda.synchronize(); lib.pgdvs_prof_enable(0)
 buf=C.create_string_buffer(1<<14); lib.pgdvs_prof_report(buf,len(buf)); print(buf.value.decode())
-st=ws[-256:].view(torch.int32)[:16].cpu().numpy(); print("ring hist", st)
+st=None
 gp=ws[256:256+48].cpu().numpy(); print("mn,h,inv_h", gp[:20].view(np.float32), "G,ncells,n", gp[20:40].view(np.int32))
 p=pts[:n].cpu().numpy(); print("bbox", p.min(0), p.max(0))

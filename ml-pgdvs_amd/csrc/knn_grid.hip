@@ -287,10 +287,22 @@ grid_scan_apply_kernel(const int32_t *__restrict__ in, const GridParams *__restr
   int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
   int v[kScanItems];
   int s = 0;
+  if (base + kScanItems <= n) {  // 16 contiguous ints per thread: four 16-byte loads
 #pragma unroll
-  for (int k = 0; k < kScanItems; ++k) {
-    v[k] = base + k < n ? in[base + k] : 0;
-    s += v[k];
+    for (int k = 0; k < kScanItems; k += 4) {
+      int4 q = *reinterpret_cast<const int4 *>(in + base + k);
+      v[k] = q.x;
+      v[k + 1] = q.y;
+      v[k + 2] = q.z;
+      v[k + 3] = q.w;
+      s += q.x + q.y + q.z + q.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      v[k] = base + k < n ? in[base + k] : 0;
+      s += v[k];
+    }
   }
   int x = s;
   for (int off = 1; off < 64; off <<= 1) {
@@ -302,10 +314,24 @@ grid_scan_apply_kernel(const int32_t *__restrict__ in, const GridParams *__restr
   int wo = 0;
   for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wo += ws[w];
   int run = block_sums[blockIdx.x] + wo + x - s;
+  if (base + kScanItems <= n) {
 #pragma unroll
-  for (int k = 0; k < kScanItems; ++k) {
-    if (base + k <= n) out[base + k] = run;  // includes out[n] = total
-    run += v[k];
+    for (int k = 0; k < kScanItems; k += 4) {
+      int4 q;
+      q.x = run;
+      q.y = q.x + v[k];
+      q.z = q.y + v[k + 1];
+      q.w = q.z + v[k + 2];
+      run = q.w + v[k + 3];
+      *reinterpret_cast<int4 *>(out + base + k) = q;
+    }
+    if (base + kScanItems == n) out[n] = run;  // total
+  } else {
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      if (base + k <= n) out[base + k] = run;  // includes out[n] = total
+      run += v[k];
+    }
   }
 }
 

@@ -372,7 +372,8 @@ __device__ __forceinline__ float wave_shift_up1_zero(float v) {
 // Insert the candidates of one batch that beat the current K+1-th best.  The list is
 // sorted ascending, so inserting v is: every lane holding a value > v takes
 // max(left neighbour, v) -- the first such lane receives v (its left neighbour is <= v, or
-// the zero fill for lane 0; squared distances are >= 0), the others shift up by one.
+// the zero fill for lane 0; squared distances are >= 0), the others shift up by one --
+// which is the median of (own value, left neighbour, v) on every lane.
 __device__ __forceinline__ void best_insert_batch(BestList &b, float d, bool valid, int KK, int lane) {
   (void)lane;
   unsigned long long mask = __ballot(valid && d < b.mx);
@@ -384,26 +385,71 @@ __device__ __forceinline__ void best_insert_batch(BestList &b, float d, bool val
     mask &= mask - 1;
     float v = readlane_f(d, l);
     float up = wave_shift_up1_zero(b.best);
-    float nb = fmaxf(up, v);
-    b.best = b.best > v ? nb : b.best;
+    // lanes holding a value <= v keep it (up <= best <= v: the median is best); lanes holding a
+    // larger one take max(up, v) (best is the largest of the three): one v_med3_f32
+    b.best = __builtin_amdgcn_fmed3f(b.best, up, v);
   }
   b.mx = readlane_f(b.best, KK - 1);
 }
 
+// value of lane (lane ^ J): register-to-register lane exchanges (DPP quad / row patterns, the
+// gfx950 row and half-wave swap instructions) instead of ds_bpermute, whose ~100-cycle round
+// trips through the LDS crossbar serialise the 21 dependent stages of the sort
+template <int J>
+__device__ __forceinline__ float lane_xor(float v, int lane) {
+  const int iv = __float_as_int(v);
+  if (J == 1) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+  if (J == 2) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+  if (J == 4) {
+    // banks 0,2 read lane+4 (row_shl:4), banks 1,3 read lane-4 (row_shr:4)
+    int t = __builtin_amdgcn_update_dpp(iv, iv, 0x104, 0xf, 0x5, false);
+    t = __builtin_amdgcn_update_dpp(t, iv, 0x114, 0xf, 0xa, false);
+    return __int_as_float(t);
+  }
+  if (J == 8) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0x128, 0xf, 0xf, false));  // row_ror:8
+  if (J == 16) {
+    // {rows 0,0,2,2}, {rows 1,1,3,3}
+    auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+    return __int_as_float((lane & 16) ? r[0] : r[1]);
+  }
+  // J == 32: {low half twice}, {high half twice}
+  auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+  return __int_as_float((lane & 32) ? r[0] : r[1]);
+}
+
+template <int K, int J>
+__device__ __forceinline__ float sort_step(float v, int lane) {
+  const float o = lane_xor<J>(v, lane);
+  const bool up = (lane & K) == 0;     // ascending block
+  const bool lower = (lane & J) == 0;  // this lane keeps the smaller of the pair
+  // NaN never reaches here (distances of finite points); fminf/fmaxf keep the multiset
+  const float mn = fminf(v, o), mx = fmaxf(v, o);
+  return (up == lower) ? mn : mx;
+}
+
 // ascending bitonic sort of one value per lane across the wavefront
 __device__ __forceinline__ float wave_sort_asc(float v, int lane) {
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      float o = __shfl_xor(v, j, 64);
-      bool up = (lane & k) == 0;          // ascending block
-      bool lower = (lane & j) == 0;       // this lane keeps the smaller of the pair
-      float mn = fminf(v, o), mx = fmaxf(v, o);
-      // NaN never reaches here (distances of finite points); fminf/fmaxf keep the multiset
-      v = (up == lower) ? mn : mx;
-    }
-  }
+  v = sort_step<2, 1>(v, lane);
+  v = sort_step<4, 2>(v, lane);
+  v = sort_step<4, 1>(v, lane);
+  v = sort_step<8, 4>(v, lane);
+  v = sort_step<8, 2>(v, lane);
+  v = sort_step<8, 1>(v, lane);
+  v = sort_step<16, 8>(v, lane);
+  v = sort_step<16, 4>(v, lane);
+  v = sort_step<16, 2>(v, lane);
+  v = sort_step<16, 1>(v, lane);
+  v = sort_step<32, 16>(v, lane);
+  v = sort_step<32, 8>(v, lane);
+  v = sort_step<32, 4>(v, lane);
+  v = sort_step<32, 2>(v, lane);
+  v = sort_step<32, 1>(v, lane);
+  v = sort_step<64, 32>(v, lane);
+  v = sort_step<64, 16>(v, lane);
+  v = sort_step<64, 8>(v, lane);
+  v = sort_step<64, 4>(v, lane);
+  v = sort_step<64, 2>(v, lane);
+  v = sort_step<64, 1>(v, lane);
   return v;
 }
 
@@ -898,6 +944,21 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
                ws.sorted, KK, qs, ws.fb2_count, ws.fb2_list, ws.fb_partial, avg_out);
   PGDVS_LAUNCH("grid_fallback_tail", grid_fallback_tail_kernel, dim3(256), dim3(1024), 0, st, ws.gp,
                ws.sorted, KK, qs, ws.fb2_count, ws.fb2_list, ws.fb2_bound, avg_out);
+  if (stats) {  // diagnostics only (PGDVS_KNN_STATS=1): synchronises and prints the ring histogram
+    int32_t hst[16], nfb = 0, nfb2 = 0;
+    GridParams g1, g2;
+    if (hipStreamSynchronize(st) == hipSuccess &&
+        hipMemcpy(hst, ws.stats, sizeof(hst), hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(&nfb, ws.fb_count, 4, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(&nfb2, ws.fb2_count, 4, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(&g1, ws.gp, sizeof(g1), hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(&g2, ws.gp2, sizeof(g2), hipMemcpyDeviceToHost) == hipSuccess) {
+      fprintf(stderr, "[knn_grid] n=%d h=%g G=%dx%dx%d (%d cells); level2 h=%g %dx%dx%d; rings:", g1.n, g1.h, g1.G[0],
+              g1.G[1], g1.G[2], g1.ncells, g2.h, g2.G[0], g2.G[1], g2.G[2]);
+      for (int i = 1; i < 16; ++i) fprintf(stderr, " %d", hst[i]);
+      fprintf(stderr, "; to level 2: %d, exhaustive: %d\n", nfb, nfb2);
+    }
+  }
   return check_launch("knn_grid");
 }
 

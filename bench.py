@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel pass")
     ap.add_argument("--pts-per-pixel", type=int, default=3)
     ap.add_argument("--no-outlier", action="store_true", help="dyn_pcl_remove_outlier=false (YAML default)")
-    ap.add_argument("--inflight", type=int, default=1,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="independent target views rendered concurrently, each on its own pair of HIP streams")
     ap.add_argument("--gnt-rays", type=int, default=1024, help="rays of the GNT sub-benchmark chunk (0 = skip)")
     return ap.parse_args()

@@ -7,13 +7,14 @@
 // own cell and stops as soon as its (K+1)-th best distance is no larger than the distance to
 // the cube's nearest open face (minus a rounding margin); nothing outside the cube can then
 // change the multiset of the K+1 smallest values.  Queries that do not terminate within
-// kRingCap rings (isolated outliers) fall back to an exact scan of all points.
+// kRingCap rings (isolated outliers) repeat the search on a second-level grid with
+// kCoarseScale-times larger cells; the few still open after that are scanned exhaustively.
 //
 // One WAVEFRONT per query: the 64 lanes evaluate 64 candidates per step with coalesced
 // 16-byte loads of the cell-sorted point array; the sorted best-list lives one value per
-// lane in a register (lane k holds the k-th smallest), so an insertion is a ballot, a
-// popcount and one DPP shift -- no LDS, no per-lane divergence.  Values are summed in
-// ascending order exactly like the CPU oracle => bit-identical averages.
+// lane in a register (lane k holds the k-th smallest), so an insertion is a ballot, one DPP
+// shift and one median-of-three -- no LDS, no per-lane divergence.  Values are summed in a
+// fixed order shared with the CPU oracle => bit-identical averages.
 #include <stdlib.h>
 
 #include "common.h"

@@ -792,8 +792,13 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   GridWs w;
   char *p = reinterpret_cast<char *>(base);
   int64_t off = 0;
+  // one 256-byte state block, initialised by two memsets per call: bbox min (0xff), then zeros
+  // for bbox max, sumsq, the ring histogram and the open-query counters of both levels
   w.bbox = reinterpret_cast<unsigned *>(p + off);
   w.sumsq = reinterpret_cast<unsigned long long *>(p + off + 64);
+  w.stats = reinterpret_cast<int32_t *>(p + off + 128);
+  w.fb_count = reinterpret_cast<int32_t *>(p + off + 192);
+  w.fb2_count = reinterpret_cast<int32_t *>(p + off + 196);
   off += 256;
   w.gp = reinterpret_cast<GridParams *>(p + off);
   off += 256;
@@ -809,9 +814,6 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   off += align_up((capacity > 0 ? capacity : 1) * 4, 256);
   w.sorted = reinterpret_cast<float4 *>(p + off);
   off += align_up((capacity > 0 ? capacity : 1) * 16, 256);
-  w.stats = reinterpret_cast<int32_t *>(p + off);
-  w.fb_count = reinterpret_cast<int32_t *>(p + off + 128);
-  off += 256;
   const int64_t qcap = qcapacity > capacity ? qcapacity : capacity;  // queries that may fall back
   w.fb_list = reinterpret_cast<int32_t *>(p + off);
   off += align_up((qcap > 0 ? qcap : 1) * 4, 256);
@@ -820,7 +822,6 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   w.fb_partial = reinterpret_cast<float *>(p + off);
   off += align_up((int64_t)kFbMaxSliced * kFbSlices * 64 * 4, 256);
   w.gp2 = reinterpret_cast<GridParams *>(p + off);
-  w.fb2_count = reinterpret_cast<int32_t *>(p + off + 128);
   off += 256;
   w.cell_count2 = reinterpret_cast<int32_t *>(p + off);
   off += align_up(((int64_t)kCoarseMaxCells + 1) * 4, 256);
@@ -865,7 +866,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   }
   // bbox init: min <- 0xffffffff, max <- 0 in the order-preserving uint encoding
   hipError_t e = hipMemsetAsync(ws.bbox, 0xff, 3 * sizeof(unsigned), st);
-  if (e == hipSuccess) e = hipMemsetAsync(ws.bbox + 3, 0x00, 256 - 3 * sizeof(unsigned), st);  // max, sumsq
+  if (e == hipSuccess) e = hipMemsetAsync(ws.bbox + 3, 0x00, 256 - 3 * sizeof(unsigned), st);  // max, sumsq, stats, counters
   if (e != hipSuccess) {
     set_error("knn_grid memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
@@ -900,11 +901,6 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
                ws.cell_start, ws.cursor, ws.sorted, (const int32_t *)nullptr);
   const char *env = getenv("PGDVS_KNN_STATS");
   int32_t *stats = (env && env[0] == '1') ? ws.stats : nullptr;
-  e = hipMemsetAsync(ws.stats, 0, 256, st);  // ring histogram + fallback counter
-  if (e != hipSuccess) {
-    set_error("knn_grid memset: %s", hipGetErrorString(e));
-    return PGDVS_ERR_LAUNCH;
-  }
   const unsigned gq = (unsigned)(cdiv(nq_cap, 4) < 256 * 8 ? (cdiv(nq_cap, 4) > 0 ? cdiv(nq_cap, 4) : 1) : 256 * 8);
   PGDVS_LAUNCH("grid_query", grid_query_kernel, dim3(gq), dim3(256), 0, st, ws.gp, ws.sorted,
                ws.cell_start, KK, qs, avg_out, stats, kRingCap, getenv("PGDVS_KNN_ABL") ? atoi(getenv("PGDVS_KNN_ABL")) : 0,
@@ -913,11 +909,6 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   // everything in units of the cell size) repeat the ring search on a grid with
   // kCoarseScale-times larger cells before anything is scanned exhaustively.  All of it is
   // gated on the device-side count of open queries.
-  e = hipMemsetAsync(ws.fb2_count, 0, 4, st);
-  if (e != hipSuccess) {
-    set_error("knn_grid memset: %s", hipGetErrorString(e));
-    return PGDVS_ERR_LAUNCH;
-  }
   const int nb2 = kCoarseMaxCells / kScanTile;
   PGDVS_LAUNCH("grid2_params", grid_params_coarse_kernel, dim3(1), dim3(64), 0, st, ws.gp, ws.bbox, ws.gp2,
                kCoarseScale, kCoarseMaxCells);

@@ -204,8 +204,8 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
         else:
             # no tracker: the track images are zeros, so the merge of :229-235 is the identity on
             # the {0,1}-valued closest-frame mask
-            render_track_rgb = torch.zeros_like(render_dyn_rgb)
-            render_track_mask = torch.zeros_like(render_dyn_mask)
+            render_track_rgb = self._zeros_like(render_dyn_rgb)
+            render_track_mask = self._zeros_like(render_dyn_mask)
             render_dyn_rgb_final, render_dyn_mask_final = render_dyn_rgb, render_dyn_mask
 
         if not same_res:
@@ -229,6 +229,16 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
             info_dict["combined_rgb_static"] = st(1)
             info_dict["combined_rgb_dyn"] = st(2)
         return render_dyn_rgb_final, render_dyn_mask_final, info_dict
+
+    def _zeros_like(self, t):
+        """read-only zero images of the no-tracker outputs, kept per shape instead of being
+        re-filled (33 MB at 1080p) for every view"""
+        cache = self.__dict__.setdefault("_zero_cache", {})
+        key = (tuple(t.shape), t.dtype, t.device)
+        z = cache.get(key)
+        if z is None:
+            z = cache[key] = torch.zeros_like(t)
+        return z
 
     def resize_rgb_mask(self, rgb, mask, render_h, render_w):
         # :259-270 -- only taken when render_stride != 1; torch resampling (plumbing, GPU)

@@ -544,7 +544,7 @@ __device__ __forceinline__ float box_axis_dist2(float q, float mn, float h, int 
 __global__ void __launch_bounds__(256)
 grid_query_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted,
                   const int32_t *__restrict__ cell_start, int KK, QuerySrc qs, float *__restrict__ avg_out,
-                  int32_t *__restrict__ stats, int ring_cap, int abl, int32_t *__restrict__ fb_count,
+                  int32_t *__restrict__ stats, int ring_cap, int32_t *__restrict__ fb_count,
                   int32_t *__restrict__ fb_list, float *__restrict__ fb_bound) {
   const GridParams g = *gp;
   const int lane = threadIdx.x & 63;
@@ -571,7 +571,6 @@ grid_query_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ 
   bool first = true;
   bool done = false;
   int rings = 0;
-  if (abl & 1) done = true;
   for (int r = 1; r <= ring_cap && !done; ++r) {
     rings = r;
     // Shell of Chebyshev radius r (r == 1: the whole 3x3x3 cube) as x-runs: the lanes look
@@ -621,7 +620,6 @@ grid_query_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ 
       while (m0) {
         int l = __builtin_ctzll(m0);
         m0 &= m0 - 1;
-        if (abl & 2) continue;
         if (readlane_f(bd0, l) >= b.mx) continue;  // no point of this run can enter the list
         scan_range(b, first, sorted, __builtin_amdgcn_readlane(s0, l), __builtin_amdgcn_readlane(e0, l), qx,
                    qy, qz, KK, lane);
@@ -903,7 +901,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   int32_t *stats = (env && env[0] == '1') ? ws.stats : nullptr;
   const unsigned gq = (unsigned)(cdiv(nq_cap, 4) < 256 * 8 ? (cdiv(nq_cap, 4) > 0 ? cdiv(nq_cap, 4) : 1) : 256 * 8);
   PGDVS_LAUNCH("grid_query", grid_query_kernel, dim3(gq), dim3(256), 0, st, ws.gp, ws.sorted,
-               ws.cell_start, KK, qs, avg_out, stats, kRingCap, getenv("PGDVS_KNN_ABL") ? atoi(getenv("PGDVS_KNN_ABL")) : 0,
+               ws.cell_start, KK, qs, avg_out, stats, kRingCap,
                ws.fb_count, ws.fb_list, ws.fb_bound);
   // Second level: the queries still open after kRingCap rings (isolated points, far from
   // everything in units of the cell size) repeat the ring search on a grid with
@@ -927,7 +925,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   qs2.list_count = ws.fb_count;
   qs2.qsorted = ws.sorted;
   PGDVS_LAUNCH("grid2_query", grid_query_kernel, dim3(gq < 1024 ? gq : 1024), dim3(256), 0, st, ws.gp2, ws.sorted2,
-               ws.cell_start2, KK, qs2, avg_out, (int32_t *)nullptr, kRingCap, 0, ws.fb2_count, ws.fb2_list,
+               ws.cell_start2, KK, qs2, avg_out, (int32_t *)nullptr, kRingCap, ws.fb2_count, ws.fb2_list,
                ws.fb2_bound);
   // exhaustive scan for what is left (rare)
   PGDVS_LAUNCH("grid_fallback", grid_fallback_kernel, dim3(4096), dim3(256), 0, st, ws.gp, ws.sorted, KK,

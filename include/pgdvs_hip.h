@@ -209,13 +209,15 @@ int pgdvs_static_aggregate(const float *rgbs, const float *depths, const uint8_t
 /* A13: ray sampling + Projector.compute (pgdvs/models/gnt/ray_sampler.py:59-123,
  * pgdvs/models/gnt/projector.py:41-115,117-308) for R rays x S samples x V source views.
  *   ray_o/ray_d[R,3]; depth_range[1,2] or [R,2] (depth_range_per_ray); deterministic sampling,
- *   inverse-depth uniform when inv_uniform != 0
+ *   inverse-depth uniform when inv_uniform != 0; z_samples[R,S] (nullable) = explicit sample
+ *   depths instead (the importance-resampled fine pass, ray_sampler.py:183-220)
  *   cam_tgt: camera block of the target; cams_src[V,80]; src_rgbs[V,H,W,3];
  *   featmaps_cl[V,hf,wf,C] (channels-last); inv_masks[V,H,W] (nullable: dynamic masks)
  *   outputs: pts[R,S,3] z_vals[R,S] (nullable), rgb_feat[R,S,V,3+C], ray_diff[R,S,V,4],
  *   mask_inbound / mask_invalid (nullable) / mask [R,S,V] as 0/1 floats. */
 int pgdvs_gnt_gather(const float *ray_o, const float *ray_d, const float *depth_range,
-                     int depth_range_per_ray, int R, int S, int inv_uniform, const float *cam_tgt,
+                     int depth_range_per_ray, const float *z_samples, int R, int S, int inv_uniform,
+                     const float *cam_tgt,
                      const float *cams_src, int V, const float *src_rgbs, int H, int W,
                      const float *featmaps_cl, int hf, int wf, int C, const float *inv_masks,
                      float *pts, float *z_vals, float *rgb_feat, float *ray_diff,

@@ -13,6 +13,7 @@ namespace pgdvs {
 
 struct GatherArgs {
   const float *ray_o, *ray_d, *depth_range;
+  const float *z_in;  // [R,S] explicit sample depths (fine pass) or null
   int64_t depth_range_stride;  // 0: one range for all rays, 2: per ray
   int R, S, V, inv_uniform;
   const float *cam_tgt, *cams_src;
@@ -53,7 +54,9 @@ __global__ void __launch_bounds__(256) gnt_gather_kernel(GatherArgs a) {
   const float near = a.depth_range[(int64_t)r * a.depth_range_stride + 0];
   const float far = a.depth_range[(int64_t)r * a.depth_range_stride + 1];
   float z;
-  if (a.inv_uniform) {
+  if (a.z_in) {
+    z = a.z_in[rs];
+  } else if (a.inv_uniform) {
     float start = 1.0f / near;
     float step = (1.0f / far - start) / (float)(a.S - 1);
     z = 1.0f / (start + (float)s * step);
@@ -162,8 +165,8 @@ __global__ void __launch_bounds__(256) gnt_gather_kernel(GatherArgs a) {
 using namespace pgdvs;
 
 PGDVS_API int pgdvs_gnt_gather(const float *ray_o, const float *ray_d, const float *depth_range,
-                               int depth_range_per_ray, int R, int S, int inv_uniform,
-                               const float *cam_tgt, const float *cams_src, int V,
+                               int depth_range_per_ray, const float *z_samples, int R, int S,
+                               int inv_uniform, const float *cam_tgt, const float *cams_src, int V,
                                const float *src_rgbs, int H, int W, const float *featmaps_cl, int hf,
                                int wf, int C, const float *inv_masks, float *pts, float *z_vals,
                                float *rgb_feat, float *ray_diff, float *mask_inbound,
@@ -171,7 +174,7 @@ PGDVS_API int pgdvs_gnt_gather(const float *ray_o, const float *ray_d, const flo
   PGDVS_REQUIRE(ray_o && ray_d && depth_range && cam_tgt && cams_src && src_rgbs && featmaps_cl &&
                     rgb_feat && ray_diff && mask,
                 "pgdvs_gnt_gather: null pointer");
-  PGDVS_REQUIRE(R >= 0 && S >= 2 && V >= 1 && H > 1 && W > 1 && hf > 0 && wf > 0 && C >= 0,
+  PGDVS_REQUIRE(R >= 0 && (S >= 2 || (z_samples && S >= 1)) && V >= 1 && H > 1 && W > 1 && hf > 0 && wf > 0 && C >= 0,
                 "pgdvs_gnt_gather: bad shape");
   if (R == 0) return PGDVS_OK;
   GatherArgs a;
@@ -179,6 +182,7 @@ PGDVS_API int pgdvs_gnt_gather(const float *ray_o, const float *ray_d, const flo
   a.ray_d = ray_d;
   a.depth_range = depth_range;
   a.depth_range_stride = depth_range_per_ray ? 2 : 0;
+  a.z_in = z_samples;
   a.R = R;
   a.S = S;
   a.V = V;

@@ -30,15 +30,16 @@ class BaseRenderer(torch.nn.Module):
                 debug_epipolar=False, disable_tqdm=False):
         if self.model is None:
             raise RuntimeError("BaseRenderer was built without a model_cfg: no GNT network to run")
-        if n_fine_samples_per_ray > 0:
-            raise NotImplementedError("importance re-sampling (n_fine_samples_per_ray > 0) is not built; the benchmarks use 0")
         if not flag_deterministic:
             raise NotImplementedError("stochastic ray sampling is a training-time feature; PGDVS renders with flag_deterministic=True")
         src_rgbs = ray_batch["src_rgbs"]  # [B,V,H,W,3]
         B, V, H, W, _ = src_rgbs.shape
         n_rays = ray_batch["ray_o"].shape[0]
-        feats = self.model.feature_net(src_rgbs.permute(0, 1, 4, 2, 3).reshape(B * V, 3, H, W))[0]
-        feats_cl = feats.permute(0, 2, 3, 1).contiguous().reshape((B, V) + tuple(feats.shape[2:]) + (feats.shape[1],))
+        raw_feats = self.model.feature_net(src_rgbs.permute(0, 1, 4, 2, 3).reshape(B * V, 3, H, W))  # (coarse, fine)
+        to_cl = lambda f: f.permute(0, 2, 3, 1).contiguous().reshape((B, V) + tuple(f.shape[2:]) + (f.shape[1],))  # noqa: E731
+        feats_cl = to_cl(raw_feats[0])
+        n_fine = int(n_fine_samples_per_ray)
+        feats_fine_cl = (feats_cl if raw_feats[1] is raw_feats[0] else to_cl(raw_feats[1])) if n_fine > 0 else None
         cams_src = ops.cam_prep(ray_batch["src_cameras"])  # [B,V,80]
         cams_tgt = ops.cam_prep(ray_batch["camera"])  # [B,80]
         per_ray_range = bool(ray_batch["depth_range_per_ray"])
@@ -46,7 +47,7 @@ class BaseRenderer(torch.nn.Module):
         rays_per_view = n_rays // B
         if chunk_size < 0:
             chunk_size = n_rays
-        outs = OrderedDict()
+        outs, outs_fine = OrderedDict(), OrderedDict()
         for c0 in range(0, n_rays, chunk_size):
             c1 = min(c0 + chunk_size, n_rays)
             # a chunk may straddle batch items (true batching, renderer.py:414-485)
@@ -59,28 +60,47 @@ class BaseRenderer(torch.nn.Module):
                     depth_range=ray_batch["depth_range"][lo:hi] if per_ray_range else ray_batch["depth_range"][b:b + 1],
                     cam_tgt=cams_tgt[b], cams_src=cams_src[b], src_rgbs=src_rgbs[b], feats_cl=feats_cl[b],
                     inv_masks=None if inv_masks is None else inv_masks[b], n_samples=n_coarse_samples_per_ray,
-                    inv_uniform=inv_uniform, ret_view_entropy=ret_view_entropy, ret_view_std=ret_view_std))
-            for k in pieces[0]:
-                outs.setdefault(k, []).append(pieces[0][k] if len(pieces) == 1 else torch.cat([p[k] for p in pieces], 0))
+                    inv_uniform=inv_uniform, ret_view_entropy=ret_view_entropy, ret_view_std=ret_view_std,
+                    n_fine=n_fine, feats_fine_cl=None if feats_fine_cl is None else feats_fine_cl[b]))
+            for dst, which in ((outs, 0), (outs_fine, 1)):
+                if pieces[0][which] is None:
+                    continue
+                for k in pieces[0][which]:
+                    dst.setdefault(k, []).append(
+                        pieces[0][which][k] if len(pieces) == 1 else torch.cat([p[which][k] for p in pieces], 0))
         rh = (ray_batch["raw_h"] + render_stride - 1) // render_stride
         rw = (ray_batch["raw_w"] + render_stride - 1) // render_stride
-        coarse = OrderedDict((k, torch.cat(v, dim=0).reshape((B, rh, rw, -1))) for k, v in outs.items())
-        return OrderedDict([("outputs_coarse", coarse), ("outputs_fine", None)])
+        merge = lambda d: OrderedDict((k, torch.cat(v, dim=0).reshape((B, rh, rw, -1))) for k, v in d.items())  # noqa: E731
+        return OrderedDict([("outputs_coarse", merge(outs)), ("outputs_fine", merge(outs_fine) if n_fine > 0 else None)])
 
     def _render_rays(self, *, ray_o, ray_d, depth_range, cam_tgt, cams_src, src_rgbs, feats_cl, inv_masks, n_samples,
-                     inv_uniform, ret_view_entropy, ret_view_std):
-        """render_rays coarse branch (:207-300) for rays of one batch item."""
+                     inv_uniform, ret_view_entropy, ret_view_std, n_fine=0, feats_fine_cl=None):
+        """render_rays (:207-412) for rays of one batch item -> (coarse outputs, fine outputs or None)."""
+        from .ray_sampler import sample_fine_z
+
         V = src_rgbs.shape[0]
+
+        def one_pass(net, g):
+            out, extras = net(g["rgb_feat"], g["ray_diff"], g["mask"], g["pts"], ray_d,
+                              ret_view_entropy=ret_view_entropy, ret_view_std=ret_view_std)
+            rgb, weights = out[:, 0:3], out[:, 3:]
+            ret = {
+                "rgb": rgb, "weights": weights, "depth": torch.sum(weights * g["z_vals"], dim=-1),
+                "inbound_cnt": torch.sum(weights * g["mask_inbound"][..., 0].sum(dim=2) / V, dim=1),
+                "dyn_cnt": torch.sum(weights * g["mask_invalid"][..., 0].sum(dim=2) / V, dim=1),
+            }
+            for k in ("view_entropy", "view_std", "view_std_normalized"):
+                if k in extras:
+                    ret[k] = torch.sum(weights[..., None] * extras[k], dim=1)
+            return ret
+
         g = ops.gnt_gather(ray_o, ray_d, depth_range, n_samples, inv_uniform, cam_tgt, cams_src, src_rgbs, feats_cl, inv_masks)
-        out, extras = self.model.net_coarse(g["rgb_feat"], g["ray_diff"], g["mask"], g["pts"], ray_d,
-                                            ret_view_entropy=ret_view_entropy, ret_view_std=ret_view_std)
-        rgb, weights = out[:, 0:3], out[:, 3:]
-        ret = {
-            "rgb": rgb, "weights": weights, "depth": torch.sum(weights * g["z_vals"], dim=-1),
-            "inbound_cnt": torch.sum(weights * g["mask_inbound"][..., 0].sum(dim=2) / V, dim=1),
-            "dyn_cnt": torch.sum(weights * g["mask_invalid"][..., 0].sum(dim=2) / V, dim=1),
-        }
-        for k in ("view_entropy", "view_std", "view_std_normalized"):
-            if k in extras:
-                ret[k] = torch.sum(weights[..., None] * extras[k], dim=1)
-        return ret
+        coarse = one_pass(self.model.net_coarse, g)
+        if n_fine <= 0:
+            return coarse, None
+        # importance re-sampling from the coarse weights, second pass on the fine features (:313-412)
+        z_all = sample_fine_z(inv_uniform, n_fine, True, coarse["weights"].detach().clone(), g["z_vals"])
+        gf = ops.gnt_gather(ray_o, ray_d, depth_range, z_all.shape[1], inv_uniform, cam_tgt, cams_src, src_rgbs,
+                            feats_fine_cl, inv_masks, z_samples=z_all)
+        net = self.model.net_coarse if self.model.single_net else self.model.net_fine
+        return coarse, one_pass(net, gf)

@@ -365,12 +365,16 @@ def combine(static_rgb, dyn_rgb, dyn_mask):
 
 
 def gnt_gather(ray_o, ray_d, depth_range, n_samples: int, inv_uniform: bool, cam_tgt, cams_src, src_rgbs, featmaps_cl,
-               inv_masks=None):
+               inv_masks=None, z_samples=None):
     """A13.  ray_o/ray_d[R,3], depth_range[1,2] or [R,2], cams_src[V,80], src_rgbs[V,H,W,3],
     featmaps_cl[V,hf,wf,C], inv_masks[V,H,W] or None -> dict of [R,S,V,*] tensors."""
     ro, rd = _req(ray_o, torch.float32, "ray_o"), _req(ray_d, torch.float32, "ray_d")
     dr = _req(depth_range, torch.float32, "depth_range").reshape(-1, 2)
     R, S = ro.shape[0], int(n_samples)
+    zs = None
+    if z_samples is not None:  # explicit sample depths [R,S] (fine pass)
+        zs = _req(z_samples, torch.float32, "z_samples")
+        assert tuple(zs.shape) == (R, S), (zs.shape, R, S)
     img = _req(src_rgbs, torch.float32, "src_rgbs")
     V, H, W, _ = img.shape
     fm = _req(featmaps_cl, torch.float32, "featmaps_cl")
@@ -384,7 +388,7 @@ def gnt_gather(ray_o, ray_d, depth_range, n_samples: int, inv_uniform: bool, cam
            "mask_inbound": e(R, S, V, 1), "mask_invalid": e(R, S, V, 1), "mask": e(R, S, V, 1)}
     ct, cs = _req(cam_tgt, torch.float32, "cam_tgt"), _req(cams_src, torch.float32, "cams_src")
     check(_lib.load().pgdvs_gnt_gather(
-        _ptr(ro), _ptr(rd), _ptr(dr), int(per_ray), R, S, int(bool(inv_uniform)), _ptr(ct), _ptr(cs), V, _ptr(img), H, W,
+        _ptr(ro), _ptr(rd), _ptr(dr), int(per_ray), _ptr(zs), R, S, int(bool(inv_uniform)), _ptr(ct), _ptr(cs), V, _ptr(img), H, W,
         _ptr(fm), hf, wf, Cc, _ptr(im), _ptr(out["pts"]), _ptr(out["z_vals"]), _ptr(out["rgb_feat"]), _ptr(out["ray_diff"]),
         _ptr(out["mask_inbound"]), _ptr(out["mask_invalid"]), _ptr(out["mask"]), _stream()), "pgdvs_gnt_gather")
     if im is None:

@@ -106,8 +106,16 @@ def main():
         ret = br.forward(ray_batch=ray_batch, chunk_size=37, inv_uniform=True, n_coarse_samples_per_ray=Ss,
                          n_fine_samples_per_ray=0, use_dyn_mask=True, flag_deterministic=True, render_stride=2,
                          ret_view_entropy=True, ret_view_std=True, disable_tqdm=True)
+    # importance re-sampling: 6 extra samples per ray drawn from the coarse weights, second pass
+    with torch.no_grad():
+        ret_f = br.forward(ray_batch=ray_batch, chunk_size=53, inv_uniform=True, n_coarse_samples_per_ray=Ss,
+                           n_fine_samples_per_ray=6, use_dyn_mask=True, flag_deterministic=True, render_stride=2,
+                           ret_view_entropy=True, ret_view_std=True, disable_tqdm=True)
     np.savez_compressed(OUT / "gnt_render.npz", render_stride=2, chunk_size=37,
-                        **{"out_" + k: v.numpy() for k, v in ret["outputs_coarse"].items()})
+                        **{"out_" + k: v.numpy() for k, v in ret["outputs_coarse"].items()},
+                        fine_chunk_size=53, n_fine=6,
+                        **{"fine_" + k: v.numpy() for k, v in ret_f["outputs_fine"].items()},
+                        **{"finec_" + k: v.numpy() for k, v in ret_f["outputs_coarse"].items()})
     for fn in ("gnt_small.npz", "gnt_resunet.npz", "gnt_render.npz"):
         print(f"  {fn:20s} {(OUT / fn).stat().st_size / 1024:8.1f} KiB")
 

@@ -700,6 +700,18 @@ def test_gnt_renderer_end_to_end_vs_reference(golden_dir):
                          render_stride=stride, ret_view_entropy=True, ret_view_std=True)
     for k, v in ret["outputs_coarse"].items():
         np.testing.assert_allclose(N(v), r["out_" + k], rtol=0, atol=2e-4, err_msg=k)
+    assert ret["outputs_fine"] is None
+    # importance re-sampling + second pass (outputs_fine), another chunk size
+    with torch.no_grad():
+        ret = br.forward(ray_batch=ray_batch, chunk_size=int(r["fine_chunk_size"]), inv_uniform=True,
+                         n_coarse_samples_per_ray=int(g["Ss"]), n_fine_samples_per_ray=int(r["n_fine"]), use_dyn_mask=True,
+                         flag_deterministic=True, render_stride=stride, ret_view_entropy=True, ret_view_std=True)
+    for k, v in ret["outputs_coarse"].items():
+        np.testing.assert_allclose(N(v), r["finec_" + k], rtol=0, atol=2e-4, err_msg="coarse " + k)
+    assert set(ret["outputs_fine"].keys()) == {k[5:] for k in r if k.startswith("fine_") and k not in ("fine_chunk_size",)}
+    for k, v in ret["outputs_fine"].items():
+        assert v.shape == r["fine_" + k].shape, k
+        np.testing.assert_allclose(N(v), r["fine_" + k], rtol=0, atol=3e-4, err_msg="fine " + k)
 
 
 def test_pgdvs_renderer_with_gnt_static(golden_dir):

@@ -235,3 +235,31 @@ def test_nvidia_frame_selection_rules():
     assert s["temporal"] == [1, 1] and s["n_actual_temporal"] == 1 and s["n_actual_fwd2tgt"] == 0 and s["bwd2tgt"] == [2, 3]
     s = select_temporal_frames(6, 2, 14, 2)      # another camera at time 6: the input frame of that instant
     assert s["temporal"] == [6, 6] and s["n_actual_temporal"] == 1 and s["fwd2tgt"] == [4, 5] and s["bwd2tgt"] == [7, 8]
+
+
+def test_gnt_fine_sampling_mirror_vs_torch_reference_formula():
+    """sample_pdf / sample_fine_z: deterministic inverse-CDF sampling; checked against a direct
+    numpy evaluation of the same piecewise-linear inverse (the end-to-end pin against the
+    reference's BaseRenderer fine pass is the GPU test on gnt_render.npz)"""
+    from pgdvs_amd.models.gnt.ray_sampler import sample_pdf, sample_fine_z
+
+    rng = np.random.default_rng(3)
+    R, M, Ns = 7, 10, 6
+    bins = np.sort(rng.uniform(1.0, 4.0, (R, M + 1)), axis=1).astype(np.float32)
+    w = rng.random((R, M)).astype(np.float32)
+    s = sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), Ns, det=True).numpy()
+    pdf = (w + 1e-5) / (w + 1e-5).sum(1, keepdims=True)
+    cdf = np.concatenate([np.zeros((R, 1), np.float32), np.cumsum(pdf, 1)], 1)
+    u = np.linspace(0, 1, Ns, dtype=np.float32)
+    for r in range(R):
+        for j in range(Ns):
+            above = int((u[j] >= cdf[r, :M]).sum())
+            below = max(above - 1, 0)
+            den = cdf[r, above] - cdf[r, below]
+            den = 1.0 if den < 1e-5 else den
+            exp = bins[r, below] + (u[j] - cdf[r, below]) / den * (bins[r, above] - bins[r, below])
+            assert abs(s[r, j] - exp) < 1e-5
+    z = np.sort(rng.uniform(1.0, 4.0, (R, M + 2)), axis=1).astype(np.float32)
+    zz = sample_fine_z(True, Ns, True, torch.from_numpy(rng.random((R, M + 2)).astype(np.float32)), torch.from_numpy(z)).numpy()
+    assert zz.shape == (R, M + 2 + Ns) and np.all(np.diff(zz, axis=1) >= 0)
+    assert np.all(zz.min(1) >= z.min(1) - 1e-6) and np.all(zz.max(1) <= z.max(1) + 1e-6)

@@ -230,7 +230,7 @@ def main():
     np.savez_compressed(OUT / "softsplat_modes.npz", ten_in=ten_in, ten_flow=ten_flow, ten_metric=ten_metric, **outs)
 
     # ---------------- A8 + A11: PGDVSRenderer.forward (rgb_gnt shortcut) ---
-    for name, (rm, use_fc, stride) in {"forward_a": (False, False, 1), "forward_b": (True, True, 1)}.items():
+    def _forward_case(name, rm, use_fc, stride, rng):
         H, W, B = 24, 32, 2
         data = {}
         per = [_synth_dyn_inputs(rng, H, W, same_time=(b == 1 and name == "forward_b")) for b in range(B)]
@@ -244,7 +244,7 @@ def main():
         data["flat_cam_src_temporal"] = np.stack([np.stack([p["flat_cam_1"], p["flat_cam_2"]]) for p in per])
         data["time_tgt"] = np.stack([[p["time_tgt"]] for p in per]).astype(np.float32)
         data["time_src_temporal"] = np.stack([[p["time_1"], p["time_2"]] for p in per]).astype(np.float32)
-        data["rgb_gnt"] = rng.random((B, H, W, 3), dtype=np.float32)
+        data["rgb_gnt"] = rng.random((B, -(-H // stride), -(-W // stride), 3), dtype=np.float32)
         rc = types.SimpleNamespace(
             render_stride=stride, pure_gnt=False, pure_gnt_with_dyn_mask=False, gnt_use_dyn_mask=False,
             gnt_use_masked_spatial_src=False, dyn_render_use_flow_consistency=use_fc, dyn_pcl_remove_outlier=rm,
@@ -286,8 +286,14 @@ def main():
         noise = drawn[0].contiguous()
         np.savez_compressed(
             OUT / f"{name}.npz", **{"in_" + k: v for k, v in data.items()}, static_noise=noise.numpy(),
-            remove_outlier=rm, use_flow_consistency=use_fc, outlier_knn=8, outlier_std_thres=0.1,
+            remove_outlier=rm, use_flow_consistency=use_fc, outlier_knn=8, outlier_std_thres=0.1, render_stride=stride,
             **{"out_" + k: v.numpy() for k, v in ret.items() if torch.is_tensor(v)})
+
+    _forward_case("forward_a", False, False, 1, rng)
+    _forward_case("forward_b", True, True, 1, rng)
+    # render_stride = 2: bicubic-antialias / nearest resize of the dynamic outputs (:239-248,259-270);
+    # own generator so that the fixtures above keep their values
+    _forward_case("forward_c", True, False, 2, np.random.default_rng(555))
 
     # ---------------- A12: static aggregation ------------------------------
     import tempfile

@@ -257,12 +257,15 @@ def _renderer(static="gnt", **over):
     return PGDVSRenderer(cfg, render_cfg=rc, softsplat_metric_abs_alpha=100.0).to(DEV).eval(), rc
 
 
-@pytest.mark.parametrize("name", ["forward_a.npz", "forward_b.npz"])
+@pytest.mark.parametrize("name", ["forward_a.npz", "forward_b.npz", "forward_c.npz"])
 def test_forward_vs_reference_golden(golden_dir, name):
+    """forward_c renders at render_stride 2: the dynamic outputs go through the bicubic-antialias /
+    nearest resize of pgdvs_renderer_dyn.py:239-248 before the composite"""
     g = _load(golden_dir, name)
     data = {k[3:]: T(v) for k, v in g.items() if k.startswith("in_")}
     data["static_noise"] = T(g["static_noise"])
-    model, rc = _renderer("gnt", dyn_render_use_flow_consistency=bool(g["use_flow_consistency"]),
+    model, rc = _renderer("gnt", render_stride=int(g["render_stride"]),
+                          dyn_render_use_flow_consistency=bool(g["use_flow_consistency"]),
                           dyn_pcl_remove_outlier=bool(g["remove_outlier"]), dyn_pcl_outlier_knn=int(g["outlier_knn"]),
                           dyn_pcl_outlier_std_thres=float(g["outlier_std_thres"]))
     with torch.no_grad():
@@ -475,6 +478,23 @@ def test_mesh_render_type_end_to_end_vs_oracle():
     np.testing.assert_allclose(N(ret["combined_rgb"]), o["combined_rgb"], rtol=0, atol=1e-5)
 
 
+def test_mesh_render_540p_vs_oracle():
+    """a full 960x540 frame: ~1 M candidate faces, winners / mask / colours exact"""
+    H, W = 540, 960
+    v = synth.make_video(2, H, W, seed=9)
+    d = synth.make_view(v, 0, seed=2)
+    K3, c2w = v["K3s"][0], v["c2ws"][0]
+    pcl = orc.compute_pcl(H, W, K3, c2w, v["depths"][0]).reshape(H, W, 3)
+    keep = v["dyn_masks"][0] | (np.random.default_rng(1).random((H, W)) < 0.3)
+    o_img, o_mask, o_face = orc.mesh_render(keep, pcl, v["rgbs"][0], d["flat_cam_tgt"][0])
+    r = ops.mesh_render(ops.cam_prep(T(d["flat_cam_tgt"][0])), T(keep.astype(np.uint8)), T(pcl), T(v["rgbs"][0]), H, W,
+                        want_faces=True)
+    assert o_mask.mean() > 0.1
+    assert np.array_equal(N(r["face"]).astype(np.int64), o_face)
+    assert np.array_equal(N(r["mask"]), o_mask)
+    np.testing.assert_allclose(N(r["rgb"]).transpose(1, 2, 0), o_img, rtol=0, atol=1e-6)
+
+
 # ---------------------------------------------------------------- A17 tracker-window aggregation
 @pytest.mark.parametrize("nq,nb,KK", [(1, 1, 3), (300, 40, 51), (5000, 3000, 51), (2000, 12000, 17), (700, 9000, 64)])
 def test_knn_cross_mean_dist_vs_oracle(nq, nb, KK):
@@ -576,6 +596,39 @@ def test_render_with_track_end_to_end_vs_oracle(dyn_type):
     np.testing.assert_allclose(N(ret["render_dyn_temporal_track_rgb"]), info["temporal_track_rgb"], rtol=0, atol=1e-5)
     for k in ["render_dyn_rgb", "combined_rgb", "combined_rgb_static", "combined_rgb_dyn"]:
         np.testing.assert_allclose(N(ret[k]), o[k], rtol=0, atol=1e-4, err_msg=k)
+
+
+def test_track_points_large_vs_oracle():
+    """~60 k tracks over an 8-frame window at 270x480: per-track stage bit-exact, whole row same
+    point set as the oracle"""
+    v = synth.make_video(9, 270, 480, seed=4)
+    d = synth.make_view(v, 4, seed=1)
+    synth.add_track_window(d, v, 4, n_side=3, step=1)
+    rend, rc = _track_renderer(dyn_pcl_outlier_knn=20)
+    data = synth.to_torch(d, DEV)
+    dft = rend.prepare_data(0, data, 8, DEV)
+    tracks, vis = d["track_tracks"][0], d["track_visibles"][0]
+    assert tracks.shape[0] > 40000
+    odft = orc.track_prepare_data(d, 0)
+    o_valid, o_pcl, o_rgb = orc.track_points(odft, tracks, vis)
+    valid, pcl_all, rgb_all = ops.track_points(T(tracks), T(vis), dft["frame_kind"], dft["time_for_track_raw"], dft["time_tgt_raw"],
+                                               dft["rgbs_for_track"], dft["depths_for_track"][..., 0], dft["cams_for_track"])
+    assert np.array_equal(N(valid).astype(bool), o_valid) and o_valid.sum() > 5000
+    assert np.array_equal(N(pcl_all).view(np.uint32), o_pcl.view(np.uint32))
+    assert np.array_equal(N(rgb_all).view(np.uint32), o_rgb.view(np.uint32))
+    base = orc.compute_dyn_pcl(
+        dyn_mask_1=d["dyn_mask_src_temporal"][0, 0], rgb_1=d["rgb_src_temporal"][0, 0], depth_1=d["depth_src_temporal"][0, 0],
+        flow_12=d["flow_fwd"][0], flow_12_occ_mask=d["flow_fwd_occ_mask"][0], rgb_2=d["rgb_src_temporal"][0, 1],
+        depth_2=d["depth_src_temporal"][0, 1], flat_cam_1=d["flat_cam_src_temporal"][0, 0],
+        flat_cam_2=d["flat_cam_src_temporal"][0, 1], flat_cam_tgt=d["flat_cam_tgt"][0], time_1=float(d["time_src_temporal"][0, 0]),
+        time_2=float(d["time_src_temporal"][0, 1]), time_tgt=float(d["time_tgt"][0, 0]), dyn_pcl_outlier_knn=20)
+    o_pcl2, o_rgb2, _ = orc.track_compute_pcl_for_tgt(odft, tracks, vis, dict(rc), base["pcl"], base["pcl_rgbs"], base["pcl_nn_dist_thres"])
+    binfo = {"pcl": T(base["pcl"]), "pcl_rgbs": T(base["pcl_rgbs"]), "pcl_nn_dist_thres": T(np.array([base["pcl_nn_dist_thres"]], np.float32))}
+    pcl2, rgb2 = rend.compute_pcl_for_tgt(data_for_track=dft, query_pts=None, tracks=T(tracks), track_visibles=T(vis),
+                                          render_cfg=rc, base_pcl_info=binfo, device=DEV)
+    assert tuple(pcl2.shape) == o_pcl2.shape and o_pcl2.shape[0] > base["pcl"].shape[0]
+    assert np.array_equal(N(pcl2).view(np.uint32), o_pcl2.view(np.uint32))
+    assert np.array_equal(N(rgb2).view(np.uint32), o_rgb2.view(np.uint32))
 
 
 def test_track_renderer_requires_tracks_or_tracker():

@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-outlier", action="store_true", help="dyn_pcl_remove_outlier=false (YAML default)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent target views rendered concurrently, each on its own pair of HIP streams")
+    ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
+                    help="eager: enqueue every kernel of every view from Python; graph: replay one captured HIP graph "
+                         "per lane; auto: eager unless the host turns out to be the bottleneck during warm-up")
     ap.add_argument("--gnt-rays", type=int, default=1024, help="rays of the GNT sub-benchmark chunk (0 = skip)")
     return ap.parse_args()
 
@@ -140,26 +143,64 @@ def main():
     n_lanes = max(1, args.inflight)
     lanes = [(torch.cuda.Stream(device=dev) if n_lanes > 1 else None, torch.cuda.Stream(device=dev)) for _ in range(n_lanes)]
 
-    def step(j):
+    def render_view(data, side):
+        """the whole per-view path: A12 + A9 on the current stream, A1-A5 on `side`, A6-A8 + A11"""
+        data = dict(data)
+        # dynamic-branch geometry on a side stream, overlapping the static aggregation + raster
+        data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=side)
+        cloud, cnt = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=cap)
+        data["st_pcl_rgb"] = cloud[None]
+        data["st_pcl_rgb_count"] = cnt
+        with torch.no_grad():
+            ret = model.forward(data, render_cfg=rc, disable_tqdm=True)
+        return ret["combined_rgb"], cnt
+
+    def step_eager(j):
         main, side = lanes[j % n_lanes]
         if main is not None:
             main.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
-            data = dict(views[(j + rank) % n_views])
-            # dynamic-branch geometry on a side stream, overlapping the static aggregation + raster
-            data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=side)
-            cloud, cnt = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=cap)
-            data["st_pcl_rgb"] = cloud[None]
-            data["st_pcl_rgb_count"] = cnt
-            with torch.no_grad():
-                ret = model.forward(data, render_cfg=rc, disable_tqdm=True)
-            img = ret["combined_rgb"]
+            img, cnt = render_view(views[(j + rank) % n_views], side)
         return img, cnt, main
+
+    # One captured HIP graph per lane (pgdvs_amd.runtime.GraphedRender): per view the host copies
+    # the view's inputs into the graph's static buffers and launches the graph instead of
+    # enqueuing ~170 kernels; any capture problem falls back to the eager path.
+    graphs, graph_note = None, "eager launches"
+
+    def build_graphs():
+        nonlocal graphs, graph_note
+        try:
+            from pgdvs_amd.runtime import GraphedRender
+
+            graphs = [GraphedRender(lambda d, side=side: render_view(d, side), views[0],
+                                    stream=main if main is not None else torch.cuda.Stream(device=dev))
+                      for main, side in lanes]
+            graph_note = "one HIP graph per lane, replayed per view"
+        except Exception as e:  # noqa: BLE001 -- report and measure eagerly
+            graphs, graph_note = None, f"eager launches (graph capture failed: {type(e).__name__}: {e})"
+            torch.cuda.synchronize()
+
+    if args.launch == "graph":
+        build_graphs()
+
+    def step_graph(j):
+        g = graphs[j % n_lanes]
+        g.stream.wait_stream(torch.cuda.current_stream())
+        img, cnt = g(views[(j + rank) % n_views])
+        with torch.cuda.stream(g.stream):
+            img = img.clone()  # the graph's output buffer is overwritten by its next replay
+        return img, cnt, g.stream
+
+    def step(j, eager=False):
+        return step_eager(j) if (graphs is None or eager) else step_graph(j)
 
     def join_lanes():
         for main, _ in lanes:
             if main is not None:
                 torch.cuda.current_stream().wait_stream(main)
+        for g in graphs or []:
+            torch.cuda.current_stream().wait_stream(g.stream)
 
     def barrier():
         if world > 1:
@@ -174,7 +215,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for j in range(n_steps):
-            img, cnt, main = step(j)
+            img, cnt, main = step(j, eager=profile)  # per-kernel HIP events need real launches
             with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
                 gather.submit(img)
         host_enqueue[0] = time.perf_counter() - t0  # host time to enqueue everything (no sync yet)
@@ -190,7 +231,35 @@ def main():
     for j in range(max(args.warmup, n_lanes)):
         img = step(j)[0]
         ref_img = img if j == 0 else ref_img
+    join_lanes()
     torch.cuda.synchronize()
+    if args.launch == "auto":
+        # is the host keeping up?  enqueue a few views eagerly and compare the time the host needs
+        # to issue them with the time the GPU needs to run them; a busy host (shared box) can
+        # take several times its usual 0.7 ms per view, and then graph replay is the faster path
+        n_try = 2 * n_lanes
+        t0 = time.perf_counter()
+        for j in range(n_try):
+            step_eager(j)
+        t_host = time.perf_counter() - t0
+        join_lanes()
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        host_bound = t_host > 0.8 * t_all
+        if world > 1:  # every rank must take the same path (collectives inside the timed loop)
+            flag = torch.tensor([1.0 if host_bound else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            host_bound = bool(flag.item() > 0)
+        if host_bound:
+            build_graphs()
+            if graphs is not None:
+                graph_note += f" (auto: host enqueue {t_host / n_try * 1e3:.2f} ms/view of {t_all / n_try * 1e3:.2f} ms)"
+                for j in range(n_lanes):
+                    step(j)
+                join_lanes()
+                torch.cuda.synchronize()
+        else:
+            graph_note = f"eager launches (auto: host enqueue {t_host / n_try * 1e3:.2f} ms/view of {t_all / n_try * 1e3:.2f} ms)"
 
     elapsed, gathered, cnt = timed(args.steps, profile=False)
     host_ms = host_enqueue[0] / args.steps * 1e3
@@ -327,7 +396,7 @@ def main():
                 "workload": f"{W}x{H} target view, {S} source frames resident in HBM: static aggregation (A12) + "
                             f"point z-buffer raster K={K} (A9) + flow-warped dynamic splat (A1-A8, outlier filter "
                             f"{'on' if not args.no_outlier else 'off'}) + composite (A11)",
-                "views_in_flight": n_lanes, "height": H, "width": W, "src_frames": S, "static_points": n_static, "dyn_pixels": n_dyn,
+                "views_in_flight": n_lanes, "launch": graph_note, "height": H, "width": W, "src_frames": S, "static_points": n_static, "dyn_pixels": n_dyn,
                 "parallelism": f"frames sharded over {world} GPU(s), RCCL gather of the image stack" if world > 1 else "1 GPU",
                 "whole_view_alg_bytes": alg_total,
                 "whole_view_alg_GBps": round(alg_total * fps / 1e9 / max(world, 1), 2),

@@ -152,8 +152,9 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
             prepared = self.prepare(data, render_cfg)
         if prepared["stream"] is not None:
             torch.cuda.current_stream().wait_stream(prepared["stream"])
-            for t in _tensors_of(prepared):
-                t.record_stream(torch.cuda.current_stream())
+            if not torch.cuda.is_current_stream_capturing():  # (a captured graph owns its memory pool)
+                for t in _tensors_of(prepared):
+                    t.record_stream(torch.cuda.current_stream())
         cams_tgt = prepared["cams_tgt"]
 
         render_h, render_w = ray_batch["render_h"], ray_batch["render_w"]

@@ -239,13 +239,28 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       }
     }
     int nvalid = 0;
+    // one wavefront per SIMD: nothing else hides the latency of the per-view feature rows, so the
+    // next view's row, validity flag and direction are requested before this view's ~180 MFMAs
+    float f_nx[32], d_nx[2];
+    uint8_t ok_nx;
+    load_row32(feat + (g * V) * 64, f_nx, h);
+    ok_nx = valid[g * V];
+    d_nx[0] = ray_diff[(g * V) * 4 + h];
+    d_nx[1] = ray_diff[(g * V) * 4 + 2 + h];
     for (int v = 0; v < V; ++v) {
       const int64_t row = g * V + v;
       float f[32], k[32];
-      load_row32(feat + row * 64, f, h);
+#pragma unroll
+      for (int t = 0; t < 32; ++t) f[t] = f_nx[t];
+      const bool ok = ok_nx != 0;
+      float d2[2] = {d_nx[0], d_nx[1]};
+      if (v + 1 < V) {
+        load_row32(feat + (row + 1) * 64, f_nx, h);
+        ok_nx = valid[row + 1];
+        d_nx[0] = ray_diff[(row + 1) * 4 + h];
+        d_nx[1] = ray_diff[(row + 1) * 4 + 2 + h];
+      }
       lin64x64(sWk, nullptr, f, k, i, h);
-      const bool ok = valid[row] != 0;
-      float d2[2] = {ray_diff[row * 4 + h], ray_diff[row * 4 + 2 + h]};
       float hid[4], pos[32], a[32];
       lin4x8_relu(sP1, sP1b, d2, hid, i, h);
       lin8x64(sP2, sP2b, hid, pos, i, h);

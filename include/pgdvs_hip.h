@@ -13,7 +13,9 @@
  *   - every pointer is a DEVICE pointer unless the parameter is documented "host";
  *   - all buffers are caller-allocated, contiguous, fp32 unless stated otherwise;
  *   - `stream` is a hipStream_t (NULL = default stream); every call only enqueues
- *     work on it and never synchronises or allocates;
+ *     work on it and never synchronises or allocates (one diagnostics switch does
+ *     synchronise: PGDVS_KNN_STATS=1 in the environment makes the kNN print its ring
+ *     histogram to stderr);
  *   - return value: 0 on success, negative pgdvs_status on error, message via
  *     pgdvs_last_error() (thread-local);
  *   - no global mutable state; re-entrant per stream.
@@ -105,8 +107,8 @@ int pgdvs_gather_rows(const float *src, const int32_t *idx, const int32_t *count
  * non-self squared distances (pgdvs_renderer_dyn.py:405-419, st_geo_renderer.py:37-51).
  * pts[capacity,3], *count points used (count on device); avg_out[capacity].
  * algo: 0 = auto, 1 = brute force (O(N^2), what pytorch3d does), 2 = exact uniform-grid
- * search (needs K+1 <= 64).  Both return identical values.  workspace >=
- * pgdvs_knn_workspace_bytes(capacity). */
+ * search (needs K+1 <= 64; two grid levels, then an exhaustive scan for what is still open).
+ * Both return identical values.  workspace >= pgdvs_knn_workspace_bytes(capacity). */
 int64_t pgdvs_knn_workspace_bytes(int64_t capacity);
 int pgdvs_knn_mean_dist(const float *pts, const int32_t *count, int64_t capacity, int K,
                         float *avg_out, int algo, void *workspace, int64_t workspace_bytes,

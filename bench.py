@@ -78,8 +78,7 @@ def algorithmic_bytes(name, H, W, S, n_static, n_dyn, K):
     avg_acc = n_static * 0.5 if S > 1 else 0  # mean accumulated-cloud size seen by agg_mark
     table = {
         "agg_mark": 12 * (n_static * (S - 1) / max(S, 1)) if S > 1 else 0,  # xyz of the accumulated cloud (upper bound: final size)
-        "agg_flags": 2 * P + P,
-        "agg_append": (n_static / S) * (4 + 12 + 24 + 4),
+        "agg_select": 3 * P + (n_static / S) * (4 + 12 + 24 + 12),  # mask + occupancy; depth, rgb -> cloud row + xyz copy
         "compact_count": P,
         "compact_scatter": P + 4 * P * 0.5,
         "raster_project_count": n_static * (12 + 16),
@@ -93,7 +92,6 @@ def algorithmic_bytes(name, H, W, S, n_static, n_dyn, K):
         "grid_query": n_dyn * 16 + n_dyn * 4,
         "grid_fallback": n_dyn * 16,
         "grid_count": n_dyn * 16, "grid_fill": n_dyn * 32, "stat_pass": n_dyn * 4,
-        "agg_count": 3 * P,
         "gather_rows": n_dyn * (4 + 12 + 12),
         "scatter_keep": n_dyn * 6,
     }
@@ -155,8 +153,8 @@ def main():
             ret = model.forward(data, render_cfg=rc, disable_tqdm=True)
         return ret["combined_rgb"], cnt
 
-    def step_eager(j):
-        main, side = lanes[j % n_lanes]
+    def step_eager(j, lane=None):
+        main, side = lanes[(j % n_lanes) if lane is None else lane]
         if main is not None:
             main.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
@@ -192,8 +190,8 @@ def main():
             img = img.clone()  # the graph's output buffer is overwritten by its next replay
         return img, cnt, g.stream
 
-    def step(j, eager=False):
-        return step_eager(j) if (graphs is None or eager) else step_graph(j)
+    def step(j, eager=False, lane=None):
+        return step_eager(j, lane) if (graphs is None or eager) else step_graph(j)
 
     def join_lanes():
         for main, _ in lanes:
@@ -215,7 +213,9 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for j in range(n_steps):
-            img, cnt, main = step(j, eager=profile)  # per-kernel HIP events need real launches
+            # per-kernel HIP events need real launches; one view at a time, so that a kernel's
+            # duration is its own and not the queueing behind the other lanes' kernels
+            img, cnt, main = step(j, eager=profile, lane=0 if profile else None)
             with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
                 gather.submit(img)
         host_enqueue[0] = time.perf_counter() - t0  # host time to enqueue everything (no sync yet)

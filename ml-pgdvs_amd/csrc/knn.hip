@@ -203,68 +203,73 @@ stat_pass_kernel(const float *__restrict__ avg, const int32_t *__restrict__ coun
     if (hist[i]) atomicAdd(&ghist[pass * kStatBins + i], hist[i]);
 }
 
-// after pass p: fold the partial sums (fixed order), pick the bin holding the wanted rank
+// after pass p: fold the partial sums (fixed tree order), pick the bin holding the wanted rank.
+// One 256-thread block, everything in parallel: the kernel sits on the critical chain of the
+// dynamic branch three times per view.
 __global__ void __launch_bounds__(256)
 stat_select_kernel(const int32_t *__restrict__ count, int pass, int nblocks,
                    const double *__restrict__ partials, const unsigned *__restrict__ ghist,
                    StatState *__restrict__ st, float std_thres, float *__restrict__ thres_out) {
-  __shared__ unsigned psum[256];
+  __shared__ unsigned wtot[4];
+  __shared__ double dsum[4];
   const int n = *count;
-  const int tid = threadIdx.x;
-  if (tid == 0) {
-    if (pass == 0) {
-      double t = 0.0;
-      for (int b = 0; b < nblocks; ++b) t += partials[b];
-      st->mean = n > 0 ? t / (double)n : 0.0;
-      st->prefix = 0;
-      st->rank = (unsigned)(n > 0 ? (n - 1) / 2 : 0);  // torch.median: lower median
-      st->n = n;
-    } else if (pass == 1) {
-      double t = 0.0;
-      for (int b = 0; b < nblocks; ++b) t += partials[b];
-      st->m2 = t;
-    }
-  }
-  __syncthreads();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned rank_in = pass == 0 ? (unsigned)(n > 0 ? (n - 1) / 2 : 0) : st->rank;  // torch.median: lower median
+  const unsigned prefix_in = pass == 0 ? 0u : st->prefix;
+  const double m2_in = st->m2;
+  // sum of the per-block partials (nblocks <= 256), fixed shuffle tree
+  double t = (pass < 2 && tid < nblocks) ? partials[tid] : 0.0;
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  if (lane == 0) dsum[wave] = t;
   // 2048 bins, 8 per thread: find the bin where the running count passes rank
   const unsigned *h = ghist + pass * kStatBins;
   const int nb = pass == 2 ? 1024 : 2048;
   unsigned loc[8], s = 0;
+#pragma unroll
   for (int k = 0; k < 8; ++k) {
     loc[k] = tid * 8 + k < nb ? h[tid * 8 + k] : 0;
     s += loc[k];
   }
-  psum[tid] = s;
+  unsigned x = s;
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wtot[wave] = x;
   __syncthreads();
-  if (tid == 0) {
-    unsigned r = st->rank, acc = 0;
-    int t = 0;
-    for (; t < 256; ++t) {
-      if (acc + psum[t] > r) break;
-      acc += psum[t];
+  unsigned before = x - s;  // counts in the bins of the threads before this one
+  for (int w = 0; w < wave; ++w) before += wtot[w];
+  const double total = (dsum[0] + dsum[1]) + (dsum[2] + dsum[3]);
+  const unsigned all = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+  // the thread whose 8 bins contain the rank (the last thread takes it if the histogram is short)
+  const bool owner = (before <= rank_in && rank_in < before + s) || (tid == 255 && rank_in >= all);
+  if (owner) {
+    unsigned acc = before;
+    int k = 0;
+    for (; k < 7; ++k) {
+      if (acc + loc[k] > rank_in) break;
+      acc += loc[k];
     }
-    if (t > 255) t = 255;
-    int b = t * 8;
-    for (int k = 0; k < 8; ++k, ++b) {
-      unsigned c = b < nb ? h[b] : 0;
-      if (acc + c > r) break;
-      acc += c;
-    }
-    if (b >= nb) b = nb - 1;
+    int bsel = tid * 8 + k;
+    if (bsel >= nb) bsel = nb - 1;
     const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
-    st->rank = r - acc;
-    st->prefix |= (unsigned)b << shift;
-    if (pass == 2) {
-      unsigned u = st->prefix;
-      u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    const unsigned prefix = prefix_in | ((unsigned)bsel << shift);
+    st->rank = rank_in - acc;
+    st->prefix = prefix;
+    if (pass == 0) {
+      st->mean = n > 0 ? total / (double)n : 0.0;
+      st->n = n;
+    } else if (pass == 1) {
+      st->m2 = total;
+    } else {
+      unsigned u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
       float med = __uint_as_float(u);
-      float sd = n > 1 ? (float)sqrt(st->m2 / (double)(n - 1)) : __builtin_nanf("");
+      float sd = n > 1 ? (float)sqrt(m2_in / (double)(n - 1)) : __builtin_nanf("");
       *thres_out = n > 0 ? med + sd * std_thres : __builtin_nanf("");
     }
   }
 }
 
-// flags beyond *count (up to capacity) are cleared so the array can be compacted as a whole
 __global__ void outlier_flag_kernel(const float *__restrict__ avg, const int32_t *__restrict__ count,
                                     int64_t capacity, const float *__restrict__ thres, int remove_outlier,
                                     uint8_t *__restrict__ flag) {

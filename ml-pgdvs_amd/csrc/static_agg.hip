@@ -251,15 +251,33 @@ __global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamB
   float *__restrict__ xyz = a.xyz;
   const int64_t pos0 = cloud_base + s_excl;
   const int tile_px = tile * kSelTile;
+  const float inv_w = 1.0f / (float)a.W;
 #pragma unroll 4
   for (int e = tid; e < total; e += kSelThreads) {
     const int64_t pos = pos0 + e;
     if (pos >= a.capacity) break;
     const int p = tile_px + (int)s_list[e];
-    const int r = p / a.W, col = p - r * a.W;
+    // row / column of the pixel: float reciprocal + one correction step (exact for P < 2^24),
+    // integer division otherwise
+    int r, col;
+    if (a.P < (1 << 24)) {
+      r = (int)(((float)p + 0.5f) * inv_w);
+      col = p - r * a.W;
+      if (col < 0) {
+        --r;
+        col += a.W;
+      } else if (col >= a.W) {
+        ++r;
+        col -= a.W;
+      }
+    } else {
+      r = p / a.W;
+      col = p - r * a.W;
+    }
     const float u = (float)col, v = (float)r;
     const float d = depth[p];
-    const float c0 = rgb[(size_t)p * 3 + 0], c1 = rgb[(size_t)p * 3 + 1], c2 = rgb[(size_t)p * 3 + 2];
+    struct f3 { float x, y, z; };  // 12-byte loads / stores in one instruction
+    const f3 c = *reinterpret_cast<const f3 *>(rgb + (size_t)p * 3);
     float X[3];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
@@ -268,17 +286,16 @@ __global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamB
       dir = dir + cam.v[PGDVS_CAM_M + ax * 3 + 2];
       X[ax] = cam.v[PGDVS_CAM_O + ax] + dir * d;
     }
-    float *o = cloud + pos * 6;
-    o[0] = X[0];
-    o[1] = X[1];
-    o[2] = X[2];
-    o[3] = c0;
-    o[4] = c1;
-    o[5] = c2;
-    float *q = xyz + pos * 3;
-    q[0] = X[0];
-    q[1] = X[1];
-    q[2] = X[2];
+    // a cloud row is 24 bytes at an 8-byte aligned address: three 8-byte stores
+    float2 *o = reinterpret_cast<float2 *>(cloud + pos * 6);
+    o[0] = make_float2(X[0], X[1]);
+    o[1] = make_float2(X[2], c.x);
+    o[2] = make_float2(c.y, c.z);
+    f3 xq;
+    xq.x = X[0];
+    xq.y = X[1];
+    xq.z = X[2];
+    *reinterpret_cast<f3 *>(xyz + pos * 3) = xq;
   }
 }
 

@@ -20,6 +20,11 @@ OUT = pathlib.Path(__file__).resolve().parent
 ITEMS = [(5, 5), (0, 0), (13, 1), (6, 2), (0, 3), (13, 7)]  # (frame, camera); camera == frame % 12: inside the mono video
 
 
+MONO_KW = dict(n_src_views_spatial=3, n_src_views_temporal_track_one_side=2, vis_center_time=4, n_render_frames=16,
+               vis_time_interval=3, vis_bt_max_disp=8, flow_consist_thres=1.0)
+MONO_ITEMS = [0, 5, 9, 15]
+
+
 def _cv2_stub():
     cv2 = types.ModuleType("cv2")
     cv2.INTER_NEAREST, cv2.INTER_AREA = 0, 3
@@ -92,6 +97,35 @@ def main():
         out["pg_flat_cam_tgt"] = _to_np(item["flat_cam_tgt"])
     np.savez_compressed(OUT / "nvidia_items.npz", items=np.array(ITEMS), **out)
     print(f"  nvidia_items.npz {(OUT / 'nvidia_items.npz').stat().st_size / 1024:.1f} KiB, keys {len(out)}")
+
+    # ---- monocular-video visualisation dataset (bullet-time camera path between the input poses)
+    if not hasattr(np, "mat"):  # the reference's quaternion helper predates NumPy 2 (geometry.py:123)
+        np.mat = np.asmatrix
+    import pgdvs.datasets.mono_vis as MV
+
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        NT.build_mono_tree(td)
+        ds = MV.MonoVisualizationDataset(data_root=td, max_hw=-1, mode="vis", scene_ids=[NT.MONO_SCENE], **MONO_KW)
+        out["n_items"] = len(ds)
+        out["all_tgt_c2w"] = np.stack([e[4] for e in ds.valid_fs])
+        out["all_tgt_time"] = np.array([e[2] for e in ds.valid_fs])
+        for n, idx in enumerate(MONO_ITEMS):
+            item = ds[idx]
+            for k, v in item.items():
+                if k in ("scene_id", "misc") or k.startswith("dyn_rgb") or k.startswith("static_rgb"):
+                    continue
+                v = _to_np(v)
+                if k.startswith("rgb_"):
+                    v = np.round(v * 255.0).astype(np.uint8)
+                elif "mask" in k:
+                    v = v.astype(np.uint8)
+                if v.size > 2048:
+                    out[f"i{n}_{k}__shape"], out[f"i{n}_{k}__digest"] = np.array(v.shape), digest(v)
+                else:
+                    out[f"i{n}_{k}"] = v
+    np.savez_compressed(OUT / "mono_items.npz", items=np.array(MONO_ITEMS), **out)
+    print(f"  mono_items.npz {(OUT / 'mono_items.npz').stat().st_size / 1024:.1f} KiB, keys {len(out)}")
 
 
 if __name__ == "__main__":

@@ -84,3 +84,42 @@ def build_tree(root, seed=20240607):
                     cd = rng.normal(0, 0.6, (H, W, 2)).astype(np.float32)
                     np.savez(fdir / f"{a:05d}_{b:05d}.npz", flow=flow, coord_diff=cd)
     return root
+
+
+# ---------------------------------------------------------------------------- monocular video layout
+MONO_SCENE = "my_video"
+MH, MW, MF = 40, 56, 10
+
+
+def build_mono_tree(root, seed=424242):
+    """The layout the reference's preprocessing writes for an in-the-wild monocular video and
+    ``MonoVisualizationDataset`` reads (pgdvs/datasets/mono_vis.py:96-118,262-275,684-738):
+      <scene>/rgbs/<name>.png, poses/<name>.npz {K[4,4], c2w[4,4]}, depths/<name>.npz {depth[H,W]},
+      masks/final/<name>_final.png, flows/interval_k/<a>_<b>.npz {flow, coord_diff}"""
+    root = pathlib.Path(root)
+    rng = np.random.default_rng(seed)
+    sd = root / MONO_SCENE
+    for d in ("rgbs", "poses", "depths", "masks/final"):
+        (sd / d).mkdir(parents=True)
+    yy, xx = np.mgrid[0:MH, 0:MW].astype(np.float32)
+    names = [f"{i:05d}" for i in range(MF)]
+    for i, nm in enumerate(names):
+        img = np.stack([127 + 100 * np.sin(xx / 6 + i), 127 + 100 * np.cos(yy / 9 + 0.4 * i), 25.0 * ((xx + 2 * yy + i) % 10)], -1)
+        PIL.Image.fromarray(np.clip(img + rng.integers(-3, 4, img.shape), 0, 255).astype(np.uint8)).save(sd / "rgbs" / f"{nm}.png")
+        K = np.eye(4)
+        K[0, 0] = K[1, 1] = 0.9 * MW + 0.3 * i
+        K[0, 2], K[1, 2] = MW / 2.0, MH / 2.0
+        np.savez(sd / "poses" / f"{nm}.npz", K=K, c2w=_pose(3.0 * i - 12, 1.1 * i, [0.07 * i, 0.01 * i * i, 0.02 * i]))
+        depth = (1.5 + 0.5 * np.sin(xx / MW * 3 + 0.5 * i) + 0.3 * np.cos(yy / MH * 4)).astype(np.float32)
+        np.savez(sd / "depths" / f"{nm}.npz", depth=depth)
+        dyn = ((xx - MW * (0.3 + 0.03 * i)) ** 2 + (yy - MH * 0.5) ** 2) < (0.2 * MW) ** 2
+        PIL.Image.fromarray(dyn).save(sd / "masks" / "final" / f"{nm}_final.png")
+    for k in (1, 2):
+        fdir = sd / "flows" / f"interval_{k}"
+        fdir.mkdir(parents=True)
+        for a in range(MF):
+            for b in (a - k, a + k):
+                if 0 <= b < MF:
+                    np.savez(fdir / f"{names[a]}_{names[b]}.npz", flow=rng.normal(0, 1.5, (MH, MW, 2)).astype(np.float32),
+                             coord_diff=rng.normal(0, 0.6, (MH, MW, 2)).astype(np.float32))
+    return root

@@ -50,10 +50,6 @@ constexpr int VW_F1B = VW_F1 + 16384;             // [256]
 constexpr int VW_F2 = VW_F1B + 256;               // [256 in][64 out]
 constexpr int VW_F2B = VW_F2 + 16384;             // [64]
 constexpr int VW_TOTAL = VW_F2B + 64;
-// the per-view hot weights are staged in LDS
-constexpr int VW_LDS_BEGIN = VW_WK;
-constexpr int VW_LDS_END = VW_WO;
-constexpr int VW_LDS_FLOATS = VW_LDS_END - VW_LDS_BEGIN;
 
 // feature(t,h) = featc(t) + 4*h.  The lane-dependent 4*h always goes into a per-lane BASE
 // pointer and featc(t) stays a compile-time constant, so every access is base + immediate
@@ -194,41 +190,252 @@ __device__ __forceinline__ void load_row32(const float *__restrict__ row, float 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// View transformer kernel.  Tiles of 16 (ray,sample) groups per wavefront on the 16x16x4 MFMA:
+// lane = j + 16*hq (group j of the tile, quarter hq), and a lane keeps, for its group, the 16
+// features F(t,hq) = 16*(t>>2) + 4*hq + (t&3), t = 0..15 -- the accumulator layout of
+// v_mfma_f32_16x16x4_f32 (row = 4*hq + r of output tile mt <-> t = 4*mt + r), which again is
+// the B-operand layout of the next product (K-step (c,r) <-> t = 4*c + r, k index = hq).
+// Half the per-lane state of a 32-group tile: every running quantity of the softmax and of the
+// side statistics stays in the 256 architectural VGPRs (the vector ALU cannot read AGPRs), and
+// two wavefronts fit per SIMD, so one wavefront's exp / accumulate work runs in the shadow of
+// the other's matrix instructions.  The 64 -> 8 -> 64 MLPs also waste less padding (M = 16).
+// ---------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWStride = 68, kA1Stride = 36;  // padded LDS rows of Wk / Wv and A1
+// offsets inside the unpadded tail of the LDS image (same order as the packed weights)
+constexpr int kSmP1B = VW_P1B - VW_P1, kSmP2 = VW_P2 - VW_P1, kSmP2B = VW_P2B - VW_P1;
+constexpr int kSmA1B = VW_A1 - VW_P1;  // A1 itself lives in the padded region
+constexpr int kSmA2 = kSmA1B + (VW_A2 - VW_A1B), kSmA2B = kSmA1B + (VW_A2B - VW_A1B);
+constexpr int kSmallFloats = kSmA1B + (VW_WO - VW_A1B);
+constexpr int kViewLdsFloats = 2 * 64 * kWStride + 64 * kA1Stride + kSmallFloats;
+
+constexpr float kLog2e = 1.4426950408889634f;
+// The softmax over views keeps a per-feature reference logit m and rescales the running sums
+// only when a new logit exceeds it by more than this gap (always on the first valid view,
+// where m = -inf): exp(a - m) <= e^16 cannot overflow, and softmax is shift-invariant, so a
+// stale reference changes nothing but the rounding.  The common case is then one v_exp_f32
+// and two fused multiply-adds per (feature, view) instead of two library expf calls.
+constexpr float kRescaleGap = 16.0f;
+
+__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
+
+__device__ __forceinline__ floatx4 mfma16(float a, float b, floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void load_row16(const float *__restrict__ row, float (&x)[16], int hq) {
+  const float *rb = row + 4 * hq;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float4 v = *reinterpret_cast<const float4 *>(rb + 16 * c);
+    x[4 * c + 0] = v.x;
+    x[4 * c + 1] = v.y;
+    x[4 * c + 2] = v.z;
+    x[4 * c + 3] = v.w;
+  }
+}
+
+__device__ __forceinline__ void store_row16(float *__restrict__ row, const float (&x)[16], int hq) {
+  float *rb = row + 4 * hq;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    *reinterpret_cast<float4 *>(rb + 16 * c) = make_float4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+}
+
+__device__ __forceinline__ float quad_sum(float s) {  // over the four lanes j, j+16, j+32, j+48
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  return s;
+}
+
+__device__ __forceinline__ void layer_norm64q(const float (&x)[16], const float *__restrict__ g,
+                                              const float *__restrict__ b, float eps, float (&y)[16], int hq) {
+  float s = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) s += x[t];
+  const float mean = quad_sum(s) * (1.0f / 64.0f);
+  float v = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const float d = x[t] - mean;
+    v += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(quad_sum(v) * (1.0f / 64.0f) + eps);
+  float gg[16], bb[16];
+  load_row16(g, gg, hq);
+  load_row16(b, bb, hq);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) y[t] = (x[t] - mean) * rstd * gg[t] + bb[t];
+}
+
+// weights of K-steps 2q, 2q+1 of a 64 -> 64 product for the four output tiles; wb is the
+// lane's base Wt + (4*hq)*STRIDE + i, so every address is base + immediate
+template <int STRIDE>
+__device__ __forceinline__ void ldq8(float (&w)[8], const float *__restrict__ wb, int q) {
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int s = 2 * q + s2;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) w[4 * s2 + mt] = wb[(16 * (s >> 2) + (s & 3)) * STRIDE + 16 * mt];
+  }
+}
+
+__device__ __forceinline__ void mmq8(floatx4 (&acc)[4], const float (&w)[8], const float (&x)[16], int q) {
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(w[4 * s2 + mt], x[2 * q + s2], acc[mt]);
+}
+
+// acc[mt] += W x for the four 16-row output tiles of a 64 -> 64 product.  `w` holds the
+// weights of K-steps 0,1 on entry; while 8 MFMAs run, the next 8 weights are on their way, and
+// the last chunk covers `next(w)`, the first weights of whatever product follows.
+template <int STRIDE, class Next>
+__device__ __forceinline__ void chain64q(floatx4 (&acc)[4], const float *__restrict__ wb, const float (&x)[16],
+                                         float (&w)[8], Next &&next) {
+  float w2[8];
+#pragma unroll
+  for (int q = 0; q < 8; q += 2) {
+    ldq8<STRIDE>(w2, wb, q + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mmq8(acc, w, x, q);
+    __builtin_amdgcn_sched_barrier(0);
+    if (q + 2 < 8)
+      ldq8<STRIDE>(w, wb, q + 2);
+    else
+      next(w);
+    __builtin_amdgcn_sched_barrier(0);
+    mmq8(acc, w2, x, q + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// 64 -> 16 (8 used): one output tile; the 16 K-steps alternate between two accumulators
+template <int STRIDE>
+__device__ __forceinline__ void ldn8(float (&w)[8], const float *__restrict__ wb, int q) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int s = 8 * q + u;
+    w[u] = wb[(16 * (s >> 2) + (s & 3)) * STRIDE];
+  }
+}
+
+template <class Next>
+__device__ __forceinline__ floatx4 chain64n(const float *__restrict__ wb, const float (&x)[16], float (&w)[8],
+                                            Next &&next) {
+  floatx4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  float w2[8];
+  ldn8<kA1Stride>(w2, wb, 1);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < 8; u += 2) {
+    c0 = mfma16(w[u], x[u], c0);
+    c1 = mfma16(w[u + 1], x[u + 1], c1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  next(w);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < 8; u += 2) {
+    c0 = mfma16(w2[u], x[8 + u], c0);
+    c1 = mfma16(w2[u + 1], x[9 + u], c1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  return c0 + c1;
+}
+
+// The 8 hidden units of a 64 -> 8 -> 64 MLP leave the first layer in lanes hq = 0,1 (unit
+// 4*hq + r in register r; hq = 2,3 hold the M padding).  Moving the lower half-wave's odd
+// registers into the upper half-wave packs them into two full K = 4 steps:
+// step u, lane (j,hq) <-> hidden unit 4*(hq&1) + (hq>>1) + 2*u.
+__device__ __forceinline__ void pack_hidden(const float (&hid)[4], float (&hk)[2]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(hid[2 * u]), __float_as_int(hid[2 * u + 1]), false, false);
+    hk[u] = __int_as_float(r[0]);
+  }
+}
+
 template <bool STATS>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, 2)
 gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__ q_in,
                       const float *__restrict__ feat, const float *__restrict__ ray_diff,
                       const uint8_t *__restrict__ valid, int64_t N, int V, float *__restrict__ q_out,
                       float *__restrict__ stats) {
-  extern __shared__ __attribute__((aligned(16))) float s_w[];  // [VW_LDS_FLOATS]
-  for (int k = threadIdx.x; k < VW_LDS_FLOATS; k += blockDim.x) s_w[k] = W_arg[VW_LDS_BEGIN + k];
+  // LDS image of the per-view weights.  The rows of the three big matrices are padded by 4
+  // floats: the two quarters that share a ds_read_b32 lane group read input rows 4 apart, and
+  // 4 * 68 (4 * 36) = 16 mod 32 puts them on opposite halves of the 32 banks (unpadded they
+  // collide 2-way on every weight read).
+  extern __shared__ __attribute__((aligned(16))) float s_w[];  // [kViewLdsFloats]
+  float *s_wk = s_w, *s_wv = s_wk + 64 * kWStride, *s_a1 = s_wv + 64 * kWStride, *s_small = s_a1 + 64 * kA1Stride;
+  for (int k = threadIdx.x; k < 4096; k += blockDim.x) {
+    s_wk[(k >> 6) * kWStride + (k & 63)] = W_arg[VW_WK + k];
+    s_wv[(k >> 6) * kWStride + (k & 63)] = W_arg[VW_WV + k];
+  }
+  for (int k = threadIdx.x; k < 2048; k += blockDim.x) s_a1[(k >> 5) * kA1Stride + (k & 31)] = W_arg[VW_A1 + k];
+  // s_small: P1 [4][32], P1B [32], P2 [8][64], P2B [64], A1B [32], A2 [8][64], A2B [64]
+  for (int k = threadIdx.x; k < kSmallFloats; k += blockDim.x) {
+    const int src = k < kSmA1B ? VW_P1 + k : VW_A1B + (k - kSmA1B);
+    s_small[k] = W_arg[src];
+  }
   __syncthreads();
-  const float *sWk = s_w + (VW_WK - VW_LDS_BEGIN), *sWv = s_w + (VW_WV - VW_LDS_BEGIN);
-  const float *sP1 = s_w + (VW_P1 - VW_LDS_BEGIN), *sP1b = s_w + (VW_P1B - VW_LDS_BEGIN);
-  const float *sP2 = s_w + (VW_P2 - VW_LDS_BEGIN), *sP2b = s_w + (VW_P2B - VW_LDS_BEGIN);
-  const float *sA1 = s_w + (VW_A1 - VW_LDS_BEGIN), *sA1b = s_w + (VW_A1B - VW_LDS_BEGIN);
-  const float *sA2 = s_w + (VW_A2 - VW_LDS_BEGIN), *sA2b = s_w + (VW_A2B - VW_LDS_BEGIN);
-
-  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, i = lane & 15, hq = lane >> 4;
   const int wave = threadIdx.x >> 6;
-  const int64_t ntiles = (N + 31) / 32;
+  // per-lane bases of the A operands: input row 4*hq (+ 16*c + r), output column i (+ 16*mt)
+  const float *wk = s_wk + (4 * hq) * kWStride + i;
+  const float *wv = s_wv + (4 * hq) * kWStride + i;
+  const float *wa1 = s_a1 + (4 * hq) * kA1Stride + i;
+  const float *sP1 = s_small, *sP1b = s_small + kSmP1B, *sP2 = s_small + kSmP2, *sP2b = s_small + kSmP2B;
+  const float *sA1b = s_small + kSmA1B, *sA2 = s_small + kSmA2, *sA2b = s_small + kSmA2B;
+  // the small MLPs' weights are loop invariants of a lane
+  const int hu = 4 * (hq & 1) + (hq >> 1);  // packed hidden unit of K-step 0 (see pack_hidden)
+  float p2w[2][4], a2w[2][4], p1b[4], a1b[4];
+  const float p1w = sP1[hq * 32 + i];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      p2w[u][mt] = sP2[(hu + 2 * u) * 64 + 16 * mt + i];
+      a2w[u][mt] = sA2[(hu + 2 * u) * 64 + 16 * mt + i];
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    p1b[r] = sP1b[4 * hq + r];
+    a1b[r] = sA1b[4 * hq + r];
+  }
+
+  const int64_t ntiles = (N + 15) / 16;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
-    const int64_t g_raw = tile * 32 + i;
+    const int64_t g_raw = tile * 16 + i;
     const bool g_ok = g_raw < N;
     const int64_t g = g_ok ? g_raw : N - 1;
     const float *W = opaque_uniform(W_arg);
-    float qq[32];
+    float w[8];
+    // q' = Wq LN(q) enters every view as (pos - q'): c1 = P2b - q' is the accumulator the
+    // positional MLP's second layer starts from, so pq = pos - q' costs nothing; then
+    // a = k + pq, and the value product starts from pq as well: sum_v attn (vv + pos - q'),
+    // to which q' is added back once in the epilogue (the attention weights sum to one).
+    float c1[16];
     {
-      float q0[32], x[32];
-      load_row32(q_in + g * 64, q0, h);
-      layer_norm64(q0, W + VW_LN1_G, W + VW_LN1_B, 1e-6f, x, h);
-      lin64x64(W + VW_WQ, nullptr, x, qq, i, h);
-    }
-    float m[32], l[32], acc[32];
-    float sk[32], sk2[32], sabs[32], ue[32];
+      float q0[16], x[16];
+      load_row16(q_in + g * 64, q0, hq);
+      layer_norm64q(q0, W + VW_LN1_G, W + VW_LN1_B, 1e-6f, x, hq);
+      const float *wq = W + VW_WQ + (4 * hq) * 64 + i;
+      floatx4 qq[4] = {};
+      ldq8<64>(w, wq, 0);
+      chain64q<64>(qq, wq, x, w, [&](float (&d)[8]) { ldq8<kWStride>(d, wk, 0); });
+      float b[16];
+      load_row16(sP2b, b, hq);
 #pragma unroll
-    for (int t = 0; t < 32; ++t) {
-      m[t] = -__builtin_inff();
+      for (int t = 0; t < 16; ++t) c1[t] = b[t] - qq[t >> 2][t & 3];
+    }
+    float m[16], l[16], acc[16];
+    float sk[16], sk2[16], sabs[16], ue[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      m[t] = 0.0f;
       l[t] = 0.0f;
       acc[t] = 0.0f;
       if (STATS) {
@@ -239,99 +446,138 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       }
     }
     int nvalid = 0;
-    // one wavefront per SIMD: nothing else hides the latency of the per-view feature rows, so the
-    // next view's row, validity flag and direction are requested before this view's ~180 MFMAs
-    float f_nx[32], d_nx[2];
+    float f_nx[16], d_nx;
     uint8_t ok_nx;
-    load_row32(feat + (g * V) * 64, f_nx, h);
+    load_row16(feat + (g * V) * 64, f_nx, hq);
     ok_nx = valid[g * V];
-    d_nx[0] = ray_diff[(g * V) * 4 + h];
-    d_nx[1] = ray_diff[(g * V) * 4 + 2 + h];
+    d_nx = ray_diff[(g * V) * 4 + hq];
     for (int v = 0; v < V; ++v) {
       const int64_t row = g * V + v;
-      float f[32], k[32];
-#pragma unroll
-      for (int t = 0; t < 32; ++t) f[t] = f_nx[t];
+      float k[16];
       const bool ok = ok_nx != 0;
-      float d2[2] = {d_nx[0], d_nx[1]};
-      if (v + 1 < V) {
-        load_row32(feat + (row + 1) * 64, f_nx, h);
-        ok_nx = valid[row + 1];
-        d_nx[0] = ray_diff[(row + 1) * 4 + h];
-        d_nx[1] = ray_diff[(row + 1) * 4 + 2 + h];
+      const float dv = d_nx;
+      {  // k = Wk f
+        floatx4 c[4] = {};
+        chain64q<kWStride>(c, wk, f_nx, w, [&](float (&d)[8]) { ldn8<kA1Stride>(d, wa1, 0); });
+#pragma unroll
+        for (int t = 0; t < 16; ++t) k[t] = c[t >> 2][t & 3];
       }
-      lin64x64(sWk, nullptr, f, k, i, h);
-      float hid[4], pos[32], a[32];
-      lin4x8_relu(sP1, sP1b, d2, hid, i, h);
-      lin8x64(sP2, sP2b, hid, pos, i, h);
+      // the next view's row, validity flag and direction are requested as soon as this view's
+      // row has been consumed: ~100 MFMAs (x2 wavefronts per SIMD) cover the HBM latency
+      if (v + 1 < V) {
+        load_row16(feat + (row + 1) * 64, f_nx, hq);
+        ok_nx = valid[row + 1];
+        d_nx = ray_diff[(row + 1) * 4 + hq];
+      }
+      float a[16], hid[4], hk[2];
+      floatx4 pq[4];
+      {  // pq = P2 relu(P1 d + b) + b - q'   (4 -> 8 -> 64)
+        floatx4 c = {0.0f, 0.0f, 0.0f, 0.0f};
+        c = mfma16(p1w, dv, c);
 #pragma unroll
-      for (int t = 0; t < 32; ++t) a[t] = k[t] - qq[t] + pos[t];
-      lin64x8_relu(sA1, sA1b, a, hid, i, h);
+        for (int r = 0; r < 4; ++r) hid[r] = fmaxf(c[r] + p1b[r], 0.0f);
+        pack_hidden(hid, hk);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pq[mt][r] = c1[4 * mt + r];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) pq[mt] = mfma16(p2w[u][mt], hk[u], pq[mt]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) a[t] = k[t] + pq[t >> 2][t & 3];
+      {  // hidden layer of the attention MLP (64 -> 8, M padded to 16)
+        const floatx4 c = chain64n(wa1, a, w, [&](float (&d)[8]) { ldq8<kWStride>(d, wv, 0); });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hid[r] = fmaxf(c[r] + a1b[r], 0.0f);
+        pack_hidden(hid, hk);
+      }
       if (STATS && ok) {
-        ++nvalid;
 #pragma unroll
-        for (int t = 0; t < 32; ++t) {
+        for (int t = 0; t < 16; ++t) {
           sk[t] += k[t];
-          sk2[t] += k[t] * k[t];
+          sk2[t] = __builtin_fmaf(k[t], k[t], sk2[t]);
           sabs[t] += fabsf(k[t]);
         }
       }
-      // logits and values are produced 16 features (one M-tile) at a time and folded into the
-      // online softmax right away, which keeps the live register set small
+      floatx4 lv[4];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        floatx16 la, lv;
-        const float *a2b = sA2b + 4 * h, *a2w = sA2 + (4 * h) * 64 + i, *wvb = sWv + (4 * h) * 64 + i;
+      for (int mt = 0; mt < 4; ++mt) lv[mt] = pq[mt];
+      chain64q<kWStride>(lv, wv, k, w, [&](float (&d)[8]) { ldq8<kWStride>(d, wk, 0); });
+      float x[16];  // logits, then logits relative to the reference m
+      {
+        floatx4 la[4];
+        float b[16];
+        load_row16(sA2b, b, hq);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          la[r] = a2b[featc(r + 16 * mt)];
-          lv[r] = 0.0f;
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) la[mt][r] = b[4 * mt + r];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) la[mt] = mfma16(a2w[u][mt], hk[u], la[mt]);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) la = mfma(a2w[t * 64 + mt * 32], hid[t], la);
+        for (int t = 0; t < 16; ++t) x[t] = la[t >> 2][t & 3];
+      }
+      const bool first = ok && nvalid == 0;
+      if (__builtin_amdgcn_ballot_w64(first) != 0) {
+        // a group's first valid view defines the reference: x = 0, e = 1 below
 #pragma unroll
-        for (int t0 = 0; t0 < 32; t0 += 8) {
-          float w[8];
+        for (int t = 0; t < 16; ++t) m[t] = first ? x[t] : m[t];
+      }
+      nvalid += ok ? 1 : 0;
+      float xmax = -__builtin_inff();
 #pragma unroll
-          for (int u = 0; u < 8; ++u) w[u] = wvb[featc(t0 + u) * 64 + mt * 32];
-          __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < 16; ++t) {
+        x[t] -= m[t];
+        xmax = fmaxf(xmax, x[t]);
+      }
+      if (__builtin_amdgcn_ballot_w64(ok && xmax > kRescaleGap) != 0) {
+        // (rare) move the reference up by d = max(x, 0): every running sum scales by exp(-d).
+        // ue = sum_v exp(a_v - m) (a_v - m) follows the change of reference as
+        // exp(-d) (ue - d l); the entropy of the final softmax is log(l) - ue / l (epilogue).
 #pragma unroll
-          for (int u = 0; u < 8; ++u) lv = mfma(w[u], k[t0 + u], lv);
-          __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 16; ++t) {
+          const float d = ok ? fmaxf(x[t], 0.0f) : 0.0f;
+          const float sc = exp_fast(-d);
+          if (STATS) ue[t] = sc * (ue[t] - d * l[t]);
+          l[t] *= sc;
+          acc[t] *= sc;
+          m[t] += d;
+          x[t] -= d;
         }
-        if (ok) {
+      }
+      if (ok) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int t = r + 16 * mt;
-            float mn = fmaxf(m[t], la[r]);
-            float sc = expf(m[t] - mn);  // exp(-inf) = 0 on the first valid view
-            float e = expf(la[r] - mn);
-            if (STATS) {
-              // ue = sum_v exp(a_v - m) (a_v - m), carried through the running maximum: the
-              // entropy of the final softmax is log(l) - ue / l (see the epilogue)
-              const float carried = l[t] > 0.0f ? sc * (ue[t] + (m[t] - mn) * l[t]) : 0.0f;
-              ue[t] = carried + e * (la[r] - mn);
-            }
-            l[t] = l[t] * sc + e;
-            acc[t] = acc[t] * sc + e * (lv[r] + pos[t]);
-            m[t] = mn;
-          }
+        for (int t = 0; t < 16; ++t) {
+          const float e = exp_fast(x[t]);
+          if (STATS) ue[t] = __builtin_fmaf(e, x[t], ue[t]);
+          l[t] += e;
+          acc[t] = __builtin_fmaf(e, lv[t >> 2][t & 3], acc[t]);
         }
       }
     }
-    // x = Wo (acc / l) + bo + q ;  q_out = FF(LN(x)) + x
-    float x1[32];
+    // x = Wo (acc / l + q') + bo + q ;  q_out = FF(LN(x)) + x
+    float x1[16];
     {
-      float xa[32];
+      float xa[16], b[16];
+      load_row16(sP2b, b, hq);
 #pragma unroll
-      for (int t = 0; t < 32; ++t) xa[t] = acc[t] / l[t];
-      lin64x64(W + VW_WO, W + VW_WOB, xa, x1, i, h);
-      float qres[32];
-      load_row32(q_in + g * 64, qres, h);
+      for (int t = 0; t < 16; ++t) xa[t] = acc[t] / l[t] + (b[t] - c1[t]);
+      const float *wo = W + VW_WO + (4 * hq) * 64 + i;
+      floatx4 o[4];
+      load_row16(W + VW_WOB, b, hq);
 #pragma unroll
-      for (int t = 0; t < 32; ++t) x1[t] += qres[t];
+      for (int t = 0; t < 16; ++t) o[t >> 2][t & 3] = b[t];
+      ldq8<64>(w, wo, 0);
+      chain64q<64>(o, wo, xa, w, [&](float (&d)[8]) {});
+      float qres[16];
+      load_row16(q_in + g * 64, qres, hq);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) x1[t] = o[t >> 2][t & 3] + qres[t];
     }
-    if (g_ok) store_row32(q_out + g * 64, x1, h);
+    if (g_ok) store_row16(q_out + g * 64, x1, hq);
     if (STATS) {
       // Entropy of the normalised attention, sum_v -p_v log(p_v + 1e-8) upstream (:497-500).
       // With p_v = exp(a_v - m) / l:  -sum p log p = log(l) - ue / l, accumulated online above
@@ -342,23 +588,23 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       float ent = 0.0f, sd = 0.0f, sdn = 0.0f;
       if (nvalid > 0) {
 #pragma unroll
-        for (int t = 0; t < 32; ++t) ent += logf(l[t]) - ue[t] / l[t] - 1e-8f * (float)nvalid;
+        for (int t = 0; t < 16; ++t) ent += logf(l[t]) - ue[t] / l[t] - 1e-8f * (float)nvalid;
       }
       if (nvalid > 1) {
-        float n = (float)nvalid;
+        const float n = (float)nvalid;
 #pragma unroll
-        for (int t = 0; t < 32; ++t) {
-          float mean = sk[t] / n;
-          float var = (sk2[t] - n * mean * mean) / (n - 1.0f);
-          float s = sqrtf(fmaxf(var, 0.0f));
-          sd += s;
-          sdn += s / (sabs[t] / n + 1e-6f);
+        for (int t = 0; t < 16; ++t) {
+          const float mean = sk[t] / n;
+          const float var = (sk2[t] - n * mean * mean) / (n - 1.0f);
+          const float sdev = sqrtf(fmaxf(var, 0.0f));
+          sd += sdev;
+          sdn += sdev / (sabs[t] / n + 1e-6f);
         }
       }
-      ent += __shfl_xor(ent, 32, 64);
-      sd += __shfl_xor(sd, 32, 64);
-      sdn += __shfl_xor(sdn, 32, 64);
-      if (g_ok && h == 0) {
+      ent = quad_sum(ent);
+      sd = quad_sum(sd);
+      sdn = quad_sum(sdn);
+      if (g_ok && hq == 0) {
         stats[g * 3 + 0] = ent * (1.0f / 64.0f);
         stats[g * 3 + 1] = sd * (1.0f / 64.0f);
         stats[g * 3 + 2] = sdn * (1.0f / 64.0f);
@@ -604,9 +850,10 @@ PGDVS_API int pgdvs_gnt_view_layer(const float *weights, const float *q_in, cons
   PGDVS_REQUIRE(weights && q_in && feat && ray_diff && valid && q_out, "pgdvs_gnt_view_layer: null pointer");
   PGDVS_REQUIRE(N >= 0 && V >= 1, "pgdvs_gnt_view_layer: bad shape");
   if (N == 0) return PGDVS_OK;
+  const int64_t vtiles = cdiv(N, 16);
+  const unsigned grid = (unsigned)(cdiv(vtiles, 4) < 512 ? cdiv(vtiles, 4) : 512);
   const int64_t ntiles = cdiv(N, 32);
-  const unsigned grid = (unsigned)(cdiv(ntiles, 4) < 256 ? cdiv(ntiles, 4) : 256);
-  const size_t lds = (size_t)VW_LDS_FLOATS * sizeof(float);
+  const size_t lds = (size_t)kViewLdsFloats * sizeof(float);
   hipStream_t st = as_stream(stream);
   if (stats) {
     PGDVS_LAUNCH("gnt_view_layer", gnt_view_layer_kernel<true>, dim3(grid), dim3(256), lds, st, weights, q_in,

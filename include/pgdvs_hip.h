@@ -225,6 +225,19 @@ int pgdvs_gnt_gather(const float *ray_o, const float *ray_d, const float *depth_
                      float *pts, float *z_vals, float *rgb_feat, float *ray_diff,
                      float *mask_inbound, float *mask_invalid, float *mask, pgdvs_stream_t stream);
 
+/* A14 (entry of GNT.forward, pgdvs/models/gnt/models/transformer_network.py:455-474):
+ * feat = rgbfeat_fc(rgb_feat) (Linear(3+C,64) -> ReLU -> Linear(64,64)) on the fp32 MFMA, fused
+ * with the reductions over the source views that follow it upstream.
+ *   weights: pgdvs_gnt_embed_weight_floats(Cin) floats = W1 input-major [4*ceil(Cin/4)][64]
+ *            (rows >= Cin zero), b1[64], W2 input-major [64][64], b2[64]
+ *            (pgdvs_amd.ops.pack_embed); Cin = 3 + C must be in (32, 36]
+ *   rgb_feat[N,V,Cin] -> feat[N,V,64]; q0[N,64] = max over the V views (:458);
+ *   stats[N,2] (nullable) = mean over features of the unbiased std over views and of
+ *   std / (mean |feat| + 1e-6) (:464-472; all views, no mask). */
+int64_t pgdvs_gnt_embed_weight_floats(int Cin);
+int pgdvs_gnt_embed(const float *weights, const float *rgb_feat, int64_t N, int V, int Cin,
+                    float *feat, float *q0, float *stats, pgdvs_stream_t stream);
+
 /* A14 (view transformer): one fused fp32-MFMA kernel per GNT layer = Transformer2D +
  * Attention2D of pgdvs/models/gnt/models/transformer_network.py:59-169,197-223 (width 64).
  *   weights: pgdvs_gnt_view_weight_floats() floats, packed input-major as laid out in

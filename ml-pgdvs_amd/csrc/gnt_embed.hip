@@ -1,0 +1,170 @@
+// A14 (entry of GNT.forward, pgdvs/models/gnt/models/transformer_network.py:455-474):
+//   feat = rgbfeat_fc(rgb_feat)              (Linear(3+C, 64) -> ReLU -> Linear(64, 64))
+//   q0   = max over the source views of feat
+//   view_std_list[0] = mean_f std_v(feat),  view_std_normalized_list[0] = mean_f std / (mean_v |feat| + 1e-6)
+// One pass: a wavefront owns 16 (ray,sample) groups and walks their V source views; both
+// layers run on the 16x16x4 fp32 MFMA (layout: gnt_mfma.h), the feature row is written once
+// and the per-group maximum / moments are carried in registers, so the [N,V,64] tensor is
+// never re-read for the reductions (upstream: two GEMMs, a ReLU, a max, two std passes and a
+// mean-abs over a 1.6 GB tensor at 1080p chunk sizes).
+#include "gnt_mfma.h"
+
+namespace pgdvs {
+
+constexpr int kEmbStride = 68;  // padded LDS rows (see gnt_view.hip: 4 * 68 = 16 mod 32 banks)
+
+// packed weights (floats): W1t [4*KS in (zero padded)][64 out], b1 [64], W2t [64 in][64 out], b2 [64]
+template <int KS>
+__global__ void __launch_bounds__(256, 2)
+gnt_embed_kernel(const float *__restrict__ W_arg, const float *__restrict__ rgb_feat, int64_t N, int V, int Cin,
+                 float *__restrict__ feat, float *__restrict__ q0, float *__restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];
+  float *s_w1 = s_w, *s_w2 = s_w + 4 * KS * kEmbStride;
+  const float *b1g = W_arg + 4 * KS * 64, *w2g = b1g + 64, *b2g = w2g + 4096;
+  for (int k = threadIdx.x; k < 4 * KS * 64; k += blockDim.x) s_w1[(k >> 6) * kEmbStride + (k & 63)] = W_arg[k];
+  for (int k = threadIdx.x; k < 4096; k += blockDim.x) s_w2[(k >> 6) * kEmbStride + (k & 63)] = w2g[k];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, i = lane & 15, hq = lane >> 4;
+  const int wave = threadIdx.x >> 6;
+  // layer 1 takes the raw row as B operand: K-step s <-> input channel 4*s + hq
+  const float *w1 = s_w1 + hq * kEmbStride + i;
+  // layer 2 takes layer 1's accumulators: K-step (c,r) <-> hidden unit 16*c + 4*hq + r
+  const float *w2 = s_w2 + (4 * hq) * kEmbStride + i;
+  float b1[16], b2[16];
+  load_row16(b1g, b1, hq);
+  load_row16(b2g, b2, hq);
+
+  const int64_t ntiles = (N + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t g_raw = tile * 16 + i;
+    const bool g_ok = g_raw < N;
+    const int64_t g = g_ok ? g_raw : N - 1;
+    float qmax[16], f0[16], s1[16], s2[16], sa[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      qmax[t] = -__builtin_inff();
+      f0[t] = 0.0f;
+      s1[t] = 0.0f;
+      s2[t] = 0.0f;
+      sa[t] = 0.0f;
+    }
+    float x_nx[KS];
+    {
+      const float *row = rgb_feat + (g * V) * Cin;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) x_nx[s] = 4 * s + hq < Cin ? row[4 * s + hq] : 0.0f;
+    }
+    float w[8];
+    ldq8<kEmbStride>(w, w2, 0);
+    for (int v = 0; v < V; ++v) {
+      const int64_t r = g * V + v;
+      float x[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) x[s] = x_nx[s];
+      if (v + 1 < V) {
+        const float *row = rgb_feat + (r + 1) * Cin;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) x_nx[s] = 4 * s + hq < Cin ? row[4 * s + hq] : 0.0f;
+      }
+      // hidden = relu(W1 x + b1)
+      floatx4 hacc[4];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) hacc[t >> 2][t & 3] = b1[t];
+      {
+        float wa[4], wb[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) wa[mt] = w1[16 * mt];
+#pragma unroll
+        for (int s = 0; s < KS; s += 2) {
+          if (s + 1 < KS) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) wb[mt] = w1[(4 * (s + 1)) * kEmbStride + 16 * mt];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) hacc[mt] = mfma16(wa[mt], x[s], hacc[mt]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 2 < KS) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) wa[mt] = w1[(4 * (s + 2)) * kEmbStride + 16 * mt];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 1 < KS) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) hacc[mt] = mfma16(wb[mt], x[s + 1], hacc[mt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      float hid[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) hid[t] = fmaxf(hacc[t >> 2][t & 3], 0.0f);
+      // feat = W2 hidden + b2
+      floatx4 o[4];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) o[t >> 2][t & 3] = b2[t];
+      chain64q<kEmbStride>(o, w2, hid, w, [&](float (&d)[8]) { ldq8<kEmbStride>(d, w2, 0); });
+      float f[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) f[t] = o[t >> 2][t & 3];
+      if (g_ok) store_row16(feat + r * 64, f, hq);
+      // running maximum and moments over the views (all of them: the mask plays no part here);
+      // the moments are taken about the first view's value, which keeps the one-pass variance
+      // as accurate as the two-pass form for features whose spread is small against their mean
+      if (v == 0) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) f0[t] = f[t];
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        qmax[t] = fmaxf(qmax[t], f[t]);
+        if (stats != nullptr) {
+          const float d = f[t] - f0[t];
+          s1[t] += d;
+          s2[t] = __builtin_fmaf(d, d, s2[t]);
+          sa[t] += fabsf(f[t]);
+        }
+      }
+    }
+    if (g_ok) store_row16(q0 + g * 64, qmax, hq);
+    if (stats != nullptr) {
+      const float n = (float)V;
+      float sd = 0.0f, sdn = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        // torch.std (unbiased): NaN for a single view, like upstream
+        const float var = (s2[t] - s1[t] * s1[t] / n) / (n - 1.0f);
+        const float sdev = sqrtf(fmaxf(var, 0.0f));
+        sd += sdev;
+        sdn += sdev / (sa[t] / n + 1e-6f);
+      }
+      sd = quad_sum(sd);
+      sdn = quad_sum(sdn);
+      if (g_ok && hq == 0) {
+        stats[g * 2 + 0] = V > 1 ? sd * (1.0f / 64.0f) : __builtin_nanf("");
+        stats[g * 2 + 1] = V > 1 ? sdn * (1.0f / 64.0f) : __builtin_nanf("");
+      }
+    }
+  }
+}
+
+}  // namespace pgdvs
+
+using namespace pgdvs;
+
+PGDVS_API int64_t pgdvs_gnt_embed_weight_floats(int Cin) { return (int64_t)((Cin + 3) / 4) * 4 * 64 + 64 + 4096 + 64; }
+
+PGDVS_API int pgdvs_gnt_embed(const float *weights, const float *rgb_feat, int64_t N, int V, int Cin, float *feat,
+                              float *q0, float *stats, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(weights && rgb_feat && feat && q0, "pgdvs_gnt_embed: null pointer");
+  PGDVS_REQUIRE(N >= 0 && V >= 1, "pgdvs_gnt_embed: bad shape");
+  PGDVS_REQUIRE(Cin > 32 && Cin <= 36, "pgdvs_gnt_embed: %d input channels (built for 3 + 32 feature channels)", Cin);
+  if (N == 0) return PGDVS_OK;
+  constexpr int KS = 9;
+  const int64_t tiles = cdiv(N, 16);
+  const unsigned grid = (unsigned)(cdiv(tiles, 4) < 512 ? cdiv(tiles, 4) : 512);
+  const size_t lds = (size_t)(4 * KS + 64) * kEmbStride * sizeof(float);
+  PGDVS_LAUNCH("gnt_embed", gnt_embed_kernel<KS>, dim3(grid), dim3(256), lds, as_stream(stream), weights, rgb_feat, N,
+               V, Cin, feat, q0, stats);
+  return check_launch("gnt_embed");
+}

@@ -1,0 +1,95 @@
+// Shared pieces of the GNT kernels that run on the 16x16x4 fp32 MFMA (gnt_view.hip,
+// gnt_embed.hip).  Tiles of 16 rows per wavefront: lane = j + 16*hq (row j of the tile,
+// quarter hq), and a lane keeps, for its row, the 16 features
+//   F(t,hq) = 16*(t>>2) + 4*hq + (t&3),  t = 0..15
+// -- the accumulator layout of v_mfma_f32_16x16x4_f32 (row = 4*hq + r of output tile mt
+// <-> t = 4*mt + r), which is also the B-operand layout of the next product (K-step (c,r)
+// <-> t = 4*c + r, k index = hq): chained layers never leave registers.
+#pragma once
+#include "common.h"
+
+namespace pgdvs {
+
+// Weight pointers are loop-invariant across the persistent tile / ray loops; left alone, LICM
+// hoists hundreds of 64-bit load addresses out of the loop and they end up in scratch.  Passing
+// the (wave-uniform) base through an empty asm per iteration keeps the address math local.
+__device__ __forceinline__ const float *opaque_uniform(const float *p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+
+__device__ __forceinline__ floatx4 mfma16(float a, float b, floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void load_row16(const float *__restrict__ row, float (&x)[16], int hq) {
+  const float *rb = row + 4 * hq;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float4 v = *reinterpret_cast<const float4 *>(rb + 16 * c);
+    x[4 * c + 0] = v.x;
+    x[4 * c + 1] = v.y;
+    x[4 * c + 2] = v.z;
+    x[4 * c + 3] = v.w;
+  }
+}
+
+__device__ __forceinline__ void store_row16(float *__restrict__ row, const float (&x)[16], int hq) {
+  float *rb = row + 4 * hq;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    *reinterpret_cast<float4 *>(rb + 16 * c) = make_float4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+}
+
+__device__ __forceinline__ float quad_sum(float s) {  // over the four lanes j, j+16, j+32, j+48
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  return s;
+}
+
+// weights of K-steps 2q, 2q+1 of a 64 -> 64 product for the four output tiles; wb is the
+// lane's base Wt + (4*hq)*STRIDE + i, so every address is base + immediate
+template <int STRIDE>
+__device__ __forceinline__ void ldq8(float (&w)[8], const float *__restrict__ wb, int q) {
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int s = 2 * q + s2;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) w[4 * s2 + mt] = wb[(16 * (s >> 2) + (s & 3)) * STRIDE + 16 * mt];
+  }
+}
+
+__device__ __forceinline__ void mmq8(floatx4 (&acc)[4], const float (&w)[8], const float (&x)[16], int q) {
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(w[4 * s2 + mt], x[2 * q + s2], acc[mt]);
+}
+
+// acc[mt] += W x for the four 16-row output tiles of a 64 -> 64 product.  `w` holds the
+// weights of K-steps 0,1 on entry; while 8 MFMAs run, the next 8 weights are on their way, and
+// the last chunk covers `next(w)`, the first weights of whatever product follows.
+template <int STRIDE, class Next>
+__device__ __forceinline__ void chain64q(floatx4 (&acc)[4], const float *__restrict__ wb, const float (&x)[16],
+                                         float (&w)[8], Next &&next) {
+  float w2[8];
+#pragma unroll
+  for (int q = 0; q < 8; q += 2) {
+    ldq8<STRIDE>(w2, wb, q + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mmq8(acc, w, x, q);
+    __builtin_amdgcn_sched_barrier(0);
+    if (q + 2 < 8)
+      ldq8<STRIDE>(w, wb, q + 2);
+    else
+      next(w);
+    __builtin_amdgcn_sched_barrier(0);
+    mmq8(acc, w2, x, q + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+}  // namespace pgdvs

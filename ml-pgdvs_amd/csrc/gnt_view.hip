@@ -22,6 +22,7 @@
 // f32-input MFMA (exact fp32 products, fp32 accumulate): TF32 is off in the reference
 // (pgdvs/run.py:21-24) and outputs must agree to 1e-4.
 #include "common.h"
+#include "gnt_mfma.h"
 
 namespace pgdvs {
 
@@ -57,14 +58,6 @@ constexpr int VW_TOTAL = VW_F2B + 64;
 // per element).
 __host__ __device__ constexpr int featc(int t) { return (t & 3) + 8 * ((t & 15) >> 2) + 32 * (t >> 4); }
 __device__ __forceinline__ int feat_of(int t, int h) { return featc(t) + 4 * h; }
-
-// Weight pointers are loop-invariant across the persistent tile / ray loops; left alone, LICM
-// hoists hundreds of 64-bit load addresses out of the loop and they end up in scratch.  Passing
-// the (wave-uniform) base through an empty asm per iteration keeps the address math local.
-__device__ __forceinline__ const float *opaque_uniform(const float *p) {
-  asm volatile("" : "+s"(p));
-  return p;
-}
 
 __device__ __forceinline__ floatx16 mfma(float a, float b, floatx16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -201,8 +194,6 @@ __device__ __forceinline__ void load_row32(const float *__restrict__ row, float 
 // two wavefronts fit per SIMD, so one wavefront's exp / accumulate work runs in the shadow of
 // the other's matrix instructions.  The 64 -> 8 -> 64 MLPs also waste less padding (M = 16).
 // ---------------------------------------------------------------------------------------
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
 constexpr int kWStride = 68, kA1Stride = 36;  // padded LDS rows of Wk / Wv and A1
 // offsets inside the unpadded tail of the LDS image (same order as the packed weights)
 constexpr int kSmP1B = VW_P1B - VW_P1, kSmP2 = VW_P2 - VW_P1, kSmP2B = VW_P2B - VW_P1;
@@ -220,35 +211,6 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kRescaleGap = 16.0f;
 
 __device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
-
-__device__ __forceinline__ floatx4 mfma16(float a, float b, floatx4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ void load_row16(const float *__restrict__ row, float (&x)[16], int hq) {
-  const float *rb = row + 4 * hq;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float4 v = *reinterpret_cast<const float4 *>(rb + 16 * c);
-    x[4 * c + 0] = v.x;
-    x[4 * c + 1] = v.y;
-    x[4 * c + 2] = v.z;
-    x[4 * c + 3] = v.w;
-  }
-}
-
-__device__ __forceinline__ void store_row16(float *__restrict__ row, const float (&x)[16], int hq) {
-  float *rb = row + 4 * hq;
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-    *reinterpret_cast<float4 *>(rb + 16 * c) = make_float4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
-}
-
-__device__ __forceinline__ float quad_sum(float s) {  // over the four lanes j, j+16, j+32, j+48
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  return s;
-}
 
 __device__ __forceinline__ void layer_norm64q(const float (&x)[16], const float *__restrict__ g,
                                               const float *__restrict__ b, float eps, float (&y)[16], int hq) {
@@ -268,48 +230,6 @@ __device__ __forceinline__ void layer_norm64q(const float (&x)[16], const float 
   load_row16(b, bb, hq);
 #pragma unroll
   for (int t = 0; t < 16; ++t) y[t] = (x[t] - mean) * rstd * gg[t] + bb[t];
-}
-
-// weights of K-steps 2q, 2q+1 of a 64 -> 64 product for the four output tiles; wb is the
-// lane's base Wt + (4*hq)*STRIDE + i, so every address is base + immediate
-template <int STRIDE>
-__device__ __forceinline__ void ldq8(float (&w)[8], const float *__restrict__ wb, int q) {
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-    const int s = 2 * q + s2;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) w[4 * s2 + mt] = wb[(16 * (s >> 2) + (s & 3)) * STRIDE + 16 * mt];
-  }
-}
-
-__device__ __forceinline__ void mmq8(floatx4 (&acc)[4], const float (&w)[8], const float (&x)[16], int q) {
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(w[4 * s2 + mt], x[2 * q + s2], acc[mt]);
-}
-
-// acc[mt] += W x for the four 16-row output tiles of a 64 -> 64 product.  `w` holds the
-// weights of K-steps 0,1 on entry; while 8 MFMAs run, the next 8 weights are on their way, and
-// the last chunk covers `next(w)`, the first weights of whatever product follows.
-template <int STRIDE, class Next>
-__device__ __forceinline__ void chain64q(floatx4 (&acc)[4], const float *__restrict__ wb, const float (&x)[16],
-                                         float (&w)[8], Next &&next) {
-  float w2[8];
-#pragma unroll
-  for (int q = 0; q < 8; q += 2) {
-    ldq8<STRIDE>(w2, wb, q + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mmq8(acc, w, x, q);
-    __builtin_amdgcn_sched_barrier(0);
-    if (q + 2 < 8)
-      ldq8<STRIDE>(w, wb, q + 2);
-    else
-      next(w);
-    __builtin_amdgcn_sched_barrier(0);
-    mmq8(acc, w2, x, q + 1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
 }
 
 // 64 -> 16 (8 used): one output tile; the 16 K-steps alternate between two accumulators
@@ -615,12 +535,22 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
 
 // q_out = F2 relu(F1 LN(x) + b1) + b2 + x  (FeedForward + ff_norm + residual, :44-55,:218-221),
 // in place on the rows written by the attention kernel.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512, 1)
 gnt_ff_kernel(const float *__restrict__ W_arg, float *__restrict__ x_io, int64_t N) {
+  // both weight matrices (128 KB) live in LDS for the lifetime of the (persistent) workgroup:
+  // read from global memory every 32-row tile would pull them through L2 8192 times per
+  // launch at 1024 rays x 256 samples.  ds_read_b32 serves each 32-lane half in one cycle
+  // (consecutive columns), so no padding is needed.
+  extern __shared__ __attribute__((aligned(16))) float s_ff[];  // F1 [64][256], F2 [256][64]
+  for (int k = threadIdx.x * 4; k < 2 * 16384; k += blockDim.x * 4) {
+    const int src = k < 16384 ? VW_F1 + k : VW_F2 + (k - 16384);
+    *reinterpret_cast<float4 *>(s_ff + k) = *reinterpret_cast<const float4 *>(W_arg + src);
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-  const int wave = threadIdx.x >> 6;
+  const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   const int64_t ntiles = (N + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  for (int64_t tile = (int64_t)blockIdx.x * nwave + wave; tile < ntiles; tile += (int64_t)gridDim.x * nwave) {
     const int64_t g_raw = tile * 32 + i;
     const bool g_ok = g_raw < N;
     const int64_t g = g_ok ? g_raw : N - 1;
@@ -637,41 +567,78 @@ gnt_ff_kernel(const float *__restrict__ W_arg, float *__restrict__ x_io, int64_t
         o1[r] = bb[featc(r + 16)];
       }
     }
-    for (int mt = 0; mt < 8; ++mt) {  // hidden features 32*mt .. 32*mt+31
-      floatx16 hacc;
-      const float *b1 = W + VW_F1B + 4 * h + 32 * mt;
-      const float *f1 = W + VW_F1 + (4 * h) * 256 + mt * 32 + i;
-      const float *f2 = W + VW_F2 + (4 * h + 32 * mt) * 64 + i;  // rows = hidden features of this lane half
+    // Hidden features are produced 32 at a time (tile mt) and consumed right away by the second
+    // layer.  The first-layer chain of tile mt+1 is interleaved with the second-layer MFMAs of
+    // tile mt: independent accumulators alternate in the matrix pipe, and each chunk's weights
+    // (8 + 8 floats) are requested one chunk ahead.
+    const float *f1 = s_ff + (4 * h) * 256 + i;
+    const float *f2 = s_ff + 16384 + (4 * h) * 64 + i;  // rows = hidden features of this lane half
+    const float *b1 = W + VW_F1B + 4 * h;
+    auto ld_f1 = [&](float (&w)[8], int mt, int c) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hacc[r] = b1[(r & 3) + 8 * (r >> 2)];
+      for (int u = 0; u < 8; ++u) w[u] = f1[featc(8 * c + u) * 256 + 32 * mt];
+    };
+    auto ld_f2 = [&](float (&w)[8], int mt, int c) {
 #pragma unroll
-      for (int t0 = 0; t0 < 32; t0 += 8) {
-        float w[8];
+      for (int u = 0; u < 4; ++u) {
+        const int r = 4 * c + u;
+        w[u] = f2[(32 * mt + (r & 3) + 8 * (r >> 2)) * 64];
+        w[4 + u] = f2[(32 * mt + (r & 3) + 8 * (r >> 2)) * 64 + 32];
+      }
+    };
+    floatx16 hcur;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = f1[featc(t0 + u) * 256];
+    for (int r = 0; r < 16; ++r) hcur[r] = b1[(r & 3) + 8 * (r >> 2)];
+    {
+      float wa[8], wb[8];
+      ld_f1(wa, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 4; c += 2) {
+        ld_f1(wb, 0, c + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) hacc = mfma(w[u], xn[t0 + u], hacc);
+        for (int u = 0; u < 8; ++u) hcur = mfma(wa[u], xn[8 * c + u], hcur);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < 4) ld_f1(wa, 0, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) hcur = mfma(wb[u], xn[8 * (c + 1) + u], hcur);
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
+    float pa[8], qa[8], pb[8], qb[8];
+    ld_f1(pa, 1, 0);
+    ld_f2(qa, 0, 0);
 #pragma unroll
-      for (int r0 = 0; r0 < 16; r0 += 4) {
-        float w0[4], w1[4];
+    for (int mt = 0; mt < 8; ++mt) {
+      floatx16 hnext;
+      if (mt < 7) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int r = r0 + u;
-          w0[u] = f2[((r & 3) + 8 * (r >> 2)) * 64];
-          w1[u] = f2[((r & 3) + 8 * (r >> 2)) * 64 + 32];
-        }
+        for (int r = 0; r < 16; ++r) hnext[r] = b1[32 * (mt + 1) + (r & 3) + 8 * (r >> 2)];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float(&p)[8] = (c & 1) ? pb : pa;
+        float(&q)[8] = (c & 1) ? qb : qa;
+        float(&pn)[8] = (c & 1) ? pa : pb;
+        float(&qn)[8] = (c & 1) ? qa : qb;
+        // next chunk: same tile pair, or chunk 0 of the next pair
+        const int nmt = c < 3 ? mt : mt + 1, nc = c < 3 ? c + 1 : 0;
+        if (nmt < 7) ld_f1(pn, nmt + 1, nc);
+        if (nmt < 8) ld_f2(qn, nmt, nc);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          float hv = fmaxf(hacc[r0 + u], 0.0f);
-          o0 = mfma(w0[u], hv, o0);
-          o1 = mfma(w1[u], hv, o1);
+        for (int u = 0; u < 8; ++u) {
+          if (mt < 7) hnext = mfma(p[u], xn[8 * c + u], hnext);
+          if (u < 4) {
+            const float hv = fmaxf(hcur[4 * c + u], 0.0f);
+            o0 = mfma(q[u], hv, o0);
+            o1 = mfma(q[4 + u], hv, o1);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (mt < 7) hcur = hnext;
     }
     if (g_ok) {
       float out[32];
@@ -689,129 +656,156 @@ gnt_ff_kernel(const float *__restrict__ W_arg, float *__restrict__ x_io, int64_t
 // Ray transformer attention (Transformer + Attention, attn_mode="qk",
 // transformer_network.py:231-338): per ray, x = LN(q); Q,K,V = W x; 4 heads x 16 dims;
 // attn = softmax(Q K^T / 4) over the S samples of the ray; y = Wo (attn V) + bo + q.
-// One workgroup per ray, one wavefront per tile of 32 query samples, same transposed MFMA
-// formulation: K ([feature][sample]) and V ([sample][feature]) of the whole ray live in LDS;
-// the 32x32 score tile of a (key tile, query tile) pair comes out of the MFMA with keys in
-// registers and the query on the lane -- exactly the B operand of the P.V product, so the
-// probabilities never leave registers either.  Also emits the head-averaged attention row of
-// query sample 0, the "learned density" the renderer uses as sample weights (:336).
+// One workgroup per ray, one wavefront per tile of 16 query samples, 16x16x4 MFMA (layout:
+// gnt_mfma.h).  A head is 16 features = exactly one M tile, so neither the score product
+// (keys x dims) nor the P.V product (dims x keys) carries padding.  K ([feature][sample]) and
+// V ([sample][feature]) of the whole ray live in LDS; the 16x16 score tile leaves the MFMA with
+// 4 keys per lane and the query on the lane -- the B operand of the P.V product, so the
+// probabilities never leave registers.  Q is pre-scaled by log2(e)/4: probabilities are
+// exp2(score - m) with a per-query reference m that is only moved when a score exceeds it by
+// kRayGap (see kRescaleGap above).  Also emits the head-averaged attention row of query
+// sample 0, the "learned density" the renderer uses as sample weights (:336).
 // Uses the VW_* weight offsets: LN1 = attn_norm, WQ/WK/WV, WO/WOB = out_fc (FF via gnt_ff).
 // ---------------------------------------------------------------------------------------
-constexpr int kRayVStride = 65;  // V rows padded: conflict-free per-lane row writes
-constexpr int kRaySpad = 256;    // fixed LDS geometry (S <= 256): every K/V address is base + immediate
+constexpr int kRayKStride = 260;  // K rows [feature][sample] padded: 4 * 260 = 16 mod 32 banks
+constexpr int kRayVStride = 68;   // V rows [sample][feature] padded likewise
+constexpr int kRaySmax = 256;
+constexpr float kRayGap = 20.0f;  // in log2 units
+constexpr int kRayLdsFloats = 64 * kRayKStride + kRaySmax * kRayVStride + 8 + 64;
 
-__global__ void __launch_bounds__(512)
+__device__ __forceinline__ float quad_max(float v, int lane) {  // over the lanes j, j+16, j+32, j+48
+  const int iv = __float_as_int(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+  v = fmaxf(v, __int_as_float((lane & 16) ? a[0] : a[1]));
+  const int iw = __float_as_int(v);
+  const auto b = __builtin_amdgcn_permlane32_swap(iw, iw, false, false);
+  return fmaxf(v, __int_as_float((lane & 32) ? b[0] : b[1]));
+}
+
+__global__ void __launch_bounds__(1024)
 gnt_ray_attn_kernel(const float *__restrict__ W_arg, const float *__restrict__ q_in, int R, int S,
                     float *__restrict__ y_out, float *__restrict__ w_out) {
   extern __shared__ __attribute__((aligned(16))) float s_kv[];
-  const int ntile = (S + 31) / 32;
-  constexpr int Spad = kRaySpad;
-  float *Ks = s_kv;                        // [64][Spad]
-  float *Vs = s_kv + 64 * Spad;            // [Spad][kRayVStride]
-  float *s_row0 = Vs + Spad * kRayVStride;  // [8 + 64]: (m,l) per head, Q of sample 0
-  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  float *Ks = s_kv;                              // [64][kRayKStride]
+  float *Vs = s_kv + 64 * kRayKStride;           // [kRaySmax][kRayVStride]
+  float *s_row0 = Vs + kRaySmax * kRayVStride;   // [8 + 64]: (m,l) per head, scaled Q of sample 0
+  const int ntile = (S + 15) / 16;
+  const int lane = threadIdx.x & 63, i = lane & 15, hq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const bool has_tile = wave < ntile;
   for (int ray = blockIdx.x; ray < R; ray += gridDim.x) {
     const float *W = opaque_uniform(W_arg);
-    const int s_raw = wave * 32 + i;
-    const int smp = s_raw < S ? s_raw : S - 1;
+    const int s_raw = wave * 16 + i;
+    const int smp = s_raw < S ? s_raw : S - 1;  // lanes past the end recompute the last sample: finite K/V
     const float *xrow = q_in + ((int64_t)ray * S + smp) * 64;
-    float qv[32];
+    float qv[16];
     __syncthreads();  // previous ray's K/V fully consumed
     if (has_tile) {
-      float x[32], xn[32];
-      load_row32(xrow, x, h);
-      layer_norm64(x, W + VW_LN1_G, W + VW_LN1_B, 1e-6f, xn, h);
-      lin64x64(W + VW_WQ, nullptr, xn, qv, i, h);
-      float kk[32];
-      lin64x64(W + VW_WK, nullptr, xn, kk, i, h);
-      float *kw = Ks + (4 * h) * Spad + wave * 32 + i;
+      float x[16], xn[16], w[8];
+      load_row16(xrow, x, hq);
+      layer_norm64q(x, W + VW_LN1_G, W + VW_LN1_B, 1e-6f, xn, hq);
+      const float *wq = W + VW_WQ + (4 * hq) * 64 + i, *wk = W + VW_WK + (4 * hq) * 64 + i;
+      const float *wv = W + VW_WV + (4 * hq) * 64 + i;
+      floatx4 c[4] = {};
+      ldq8<64>(w, wq, 0);
+      chain64q<64>(c, wq, xn, w, [&](float (&d)[8]) { ldq8<64>(d, wk, 0); });
 #pragma unroll
-      for (int t = 0; t < 32; ++t) kw[featc(t) * Spad] = kk[t];
-      lin64x64(W + VW_WV, nullptr, xn, kk, i, h);
-      float *vw = Vs + (wave * 32 + i) * kRayVStride + 4 * h;
+      for (int t = 0; t < 16; ++t) {
+        qv[t] = c[t >> 2][t & 3] * (0.25f * kLog2e);
+        c[t >> 2][t & 3] = 0.0f;
+      }
+      chain64q<64>(c, wk, xn, w, [&](float (&d)[8]) { ldq8<64>(d, wv, 0); });
+      float *kw = Ks + (4 * hq) * kRayKStride + wave * 16 + i;
 #pragma unroll
-      for (int t = 0; t < 32; ++t) vw[featc(t)] = kk[t];
+      for (int t = 0; t < 16; ++t) {
+        kw[(16 * (t >> 2) + (t & 3)) * kRayKStride] = c[t >> 2][t & 3];
+        c[t >> 2][t & 3] = 0.0f;
+      }
+      chain64q<64>(c, wv, xn, w, [&](float (&d)[8]) {});
+      float vv[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) vv[t] = c[t >> 2][t & 3];
+      store_row16(Vs + (wave * 16 + i) * kRayVStride, vv, hq);
     }
     __syncthreads();
-    // y = Wo (attention output) + bo accumulates head by head: each head contributes its 16
-    // features as 8 K-steps, so the attention output itself is never materialised
-    floatx16 y0, y1;
-    {
-      const float *bb = W + VW_WOB + 4 * h;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        y0[r] = bb[featc(r)];
-        y1[r] = bb[featc(r + 16)];
-      }
-    }
     if (has_tile) {
+      // y = Wo (attention output) + bo accumulates head by head: each head contributes its 16
+      // features as 4 K-steps, so the attention output itself is never materialised
+      floatx4 y[4];
+      {
+        float b[16];
+        load_row16(W + VW_WOB, b, hq);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) y[t >> 2][t & 3] = b[t];
+      }
+      const float *wo = W + VW_WO + (4 * hq) * 64 + i;
 #pragma unroll
       for (int hh = 0; hh < 4; ++hh) {
-        const int tb = 16 * (hh >> 1) + 8 * (hh & 1);  // positions of this head's 8 features
-        float m = -__builtin_inff(), l = 0.0f;
-        floatx16 O;
+        const float *kr = Ks + (16 * hh + 4 * hq) * kRayKStride + i;  // + r * stride + 16 * kt
+        const float *vr = Vs + (4 * hq) * kRayVStride + 16 * hh + i;  // + (16 * kt + r) * stride
+        float m = 0.0f, l = 0.0f;
+        floatx4 O = {0.0f, 0.0f, 0.0f, 0.0f};
+        float ka[4], va[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) O[r] = 0.0f;
+        for (int r = 0; r < 4; ++r) ka[r] = kr[r * kRayKStride];
         for (int kt = 0; kt < ntile; ++kt) {
-          floatx16 sc;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
-          const float *kr = Ks + (4 * h) * Spad + kt * 32 + i;
+          for (int r = 0; r < 4; ++r) va[r] = vr[(16 * kt + r) * kRayVStride];
+          floatx4 sc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-          for (int u = 0; u < 8; ++u) sc = mfma(kr[featc(tb + u) * Spad], qv[tb + u], sc);
-          float mx = -__builtin_inff();
+          for (int r = 0; r < 4; ++r) sc = mfma16(ka[r], qv[4 * hh + r], sc);
+          if (kt + 1 < ntile) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            sc[r] = key < S ? sc[r] * 0.25f : -__builtin_inff();
-            mx = fmaxf(mx, sc[r]);
+            for (int r = 0; r < 4; ++r) ka[r] = kr[r * kRayKStride + 16 * (kt + 1)];
           }
-          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-          const float mn = fmaxf(m, mx);
-          const float rs = expf(m - mn);
-          float ps = 0.0f;
+          float x[4], xmax = -__builtin_inff();
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            sc[r] = expf(sc[r] - mn);
-            ps += sc[r];
-            O[r] *= rs;
+          for (int r = 0; r < 4; ++r) {
+            const int key = 16 * kt + 4 * hq + r;
+            x[r] = key < S ? sc[r] : -__builtin_inff();
+            xmax = fmaxf(xmax, x[r]);
           }
-          l = l * rs + ps;
-          m = mn;
-          const float *vr = Vs + (kt * 32 + 4 * h) * kRayVStride + (i & 15);
+          if (kt == 0) {
+            m = quad_max(xmax, lane);  // key 0 is always valid: finite
+          } else if (__builtin_amdgcn_ballot_w64(xmax - m > kRayGap) != 0) {
+            const float mn = fmaxf(m, quad_max(xmax, lane));
+            const float f = __builtin_amdgcn_exp2f(m - mn);
+            l *= f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float a = vr[((r & 3) + 8 * (r >> 2)) * kRayVStride + 16 * hh];
-            O = mfma(i < 16 ? a : 0.0f, sc[r], O);
+            for (int r = 0; r < 4; ++r) O[r] *= f;
+            m = mn;
           }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            x[r] = __builtin_amdgcn_exp2f(x[r] - m);
+            l += x[r];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) O = mfma16(va[r], x[r], O);
         }
-        l += __shfl_xor(l, 32, 64);
-        if (wave == 0 && i == 0) {  // query sample 0: softmax statistics + its Q for the weight row
-          s_row0[hh * 2 + 0] = m;
-          s_row0[hh * 2 + 1] = l;
+        l = quad_sum(l);
+        if (wave == 0 && i == 0) {  // query sample 0: softmax statistics + its scaled Q for the weight row
+          if (hq == 0) {
+            s_row0[hh * 2 + 0] = m;
+            s_row0[hh * 2 + 1] = l;
+          }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) s_row0[8 + hh * 16 + h * 8 + u] = qv[tb + u];
+          for (int r = 0; r < 4; ++r) s_row0[8 + hh * 16 + 4 * hq + r] = qv[4 * hh + r];
         }
         const float inv_l = 1.0f / l;
-        const float *wo = W + VW_WO + (4 * h) * 64 + i;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float av = O[u] * inv_l;  // feature featc(tb+u) + 4h of the attention output
-          y0 = mfma(wo[featc(tb + u) * 64], av, y0);
-          y1 = mfma(wo[featc(tb + u) * 64 + 32], av, y1);
+        for (int r = 0; r < 4; ++r) {
+          const float av = O[r] * inv_l;  // feature 16*hh + 4*hq + r of the attention output
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) y[mt] = mfma16(wo[(16 * hh + r) * 64 + 16 * mt], av, y[mt]);
         }
       }
-      float xres[32];
-      load_row32(xrow, xres, h);
+      float xres[16];
+      load_row16(xrow, xres, hq);
       if (s_raw < S) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          xres[r] += y0[r];
-          xres[r + 16] += y1[r];
-        }
-        store_row32(y_out + ((int64_t)ray * S + s_raw) * 64, xres, h);
+        for (int t = 0; t < 16; ++t) xres[t] += y[t >> 2][t & 3];
+        store_row16(y_out + ((int64_t)ray * S + s_raw) * 64, xres, hq);
       }
     }
     if (w_out != nullptr) {
@@ -823,14 +817,10 @@ gnt_ray_attn_kernel(const float *__restrict__ W_arg, const float *__restrict__ q
         float wsum = 0.0f;
 #pragma unroll
         for (int hh = 0; hh < 4; ++hh) {
-          const int tb = 16 * (hh >> 1) + 8 * (hh & 1);
           float sdot = 0.0f;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            sdot += s_row0[8 + hh * 16 + u] * Ks[featc(tb + u) * Spad + key];
-            sdot += s_row0[8 + hh * 16 + 8 + u] * Ks[(featc(tb + u) + 4) * Spad + key];
-          }
-          wsum += expf(sdot * 0.25f - s_row0[hh * 2]) / s_row0[hh * 2 + 1];
+          for (int d = 0; d < 16; ++d) sdot += s_row0[8 + hh * 16 + d] * Ks[(16 * hh + d) * kRayKStride + key];
+          wsum += __builtin_amdgcn_exp2f(sdot - s_row0[hh * 2]) / s_row0[hh * 2 + 1];
         }
         w_out[(int64_t)ray * S + key] = wsum * 0.25f;  // mean over the 4 heads
       }
@@ -844,6 +834,25 @@ using namespace pgdvs;
 
 PGDVS_API int64_t pgdvs_gnt_view_weight_floats(void) { return VW_TOTAL; }
 
+// feed-forward block in place on x[N,64]: one persistent 8-wave workgroup per CU
+static int launch_ff(const float *weights, float *x, int64_t N, hipStream_t st) {
+  constexpr size_t lds = 2 * 16384 * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gnt_ff_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("gnt_ff: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+      return PGDVS_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  const int64_t ntiles = cdiv(N, 32);
+  const unsigned grid = (unsigned)(cdiv(ntiles, 8) < 256 ? cdiv(ntiles, 8) : 256);
+  PGDVS_LAUNCH("gnt_ff", gnt_ff_kernel, dim3(grid), dim3(512), lds, st, weights, x, N);
+  return PGDVS_OK;
+}
+
 PGDVS_API int pgdvs_gnt_view_layer(const float *weights, const float *q_in, const float *feat,
                                    const float *ray_diff, const uint8_t *valid, int64_t N, int V,
                                    float *q_out, float *stats, pgdvs_stream_t stream) {
@@ -852,7 +861,6 @@ PGDVS_API int pgdvs_gnt_view_layer(const float *weights, const float *q_in, cons
   if (N == 0) return PGDVS_OK;
   const int64_t vtiles = cdiv(N, 16);
   const unsigned grid = (unsigned)(cdiv(vtiles, 4) < 512 ? cdiv(vtiles, 4) : 512);
-  const int64_t ntiles = cdiv(N, 32);
   const size_t lds = (size_t)kViewLdsFloats * sizeof(float);
   hipStream_t st = as_stream(stream);
   if (stats) {
@@ -862,8 +870,7 @@ PGDVS_API int pgdvs_gnt_view_layer(const float *weights, const float *q_in, cons
     PGDVS_LAUNCH("gnt_view_layer", gnt_view_layer_kernel<false>, dim3(grid), dim3(256), lds, st, weights, q_in,
                  feat, ray_diff, valid, N, V, q_out, stats);
   }
-  const unsigned gff = (unsigned)(cdiv(ntiles, 4) < 2048 ? cdiv(ntiles, 4) : 2048);
-  PGDVS_LAUNCH("gnt_ff", gnt_ff_kernel, dim3(gff), dim3(256), 0, st, weights, q_out, N);
+  if (launch_ff(weights, q_out, N, st) != PGDVS_OK) return PGDVS_ERR_LAUNCH;
   return check_launch("gnt_view_layer");
 }
 
@@ -873,21 +880,21 @@ PGDVS_API int pgdvs_gnt_ray_layer(const float *weights, const float *q_in, int R
   PGDVS_REQUIRE(R >= 0 && S >= 1 && S <= 256, "pgdvs_gnt_ray_layer: samples per ray must be in [1, 256]");
   if (R == 0) return PGDVS_OK;
   hipStream_t st = as_stream(stream);
-  const size_t lds = (size_t)(64 * kRaySpad + kRaySpad * kRayVStride + 80) * sizeof(float);
-  if (lds > 64 * 1024) {
+  const size_t lds = (size_t)kRayLdsFloats * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gnt_ray_attn_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       set_error("gnt_ray_layer: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
       return PGDVS_ERR_LAUNCH;
     }
+    configured = true;
   }
   const unsigned grid = (unsigned)(R < 1024 ? R : 1024);
-  PGDVS_LAUNCH("gnt_ray_attn", gnt_ray_attn_kernel, dim3(grid), dim3(512), lds, st, weights, q_in, R, S, q_out,
+  PGDVS_LAUNCH("gnt_ray_attn", gnt_ray_attn_kernel, dim3(grid), dim3(1024), lds, st, weights, q_in, R, S, q_out,
                sample_weights);
   const int64_t N = (int64_t)R * S;
-  const int64_t ntiles = cdiv(N, 32);
-  const unsigned gff = (unsigned)(cdiv(ntiles, 4) < 2048 ? cdiv(ntiles, 4) : 2048);
-  PGDVS_LAUNCH("gnt_ff", gnt_ff_kernel, dim3(gff), dim3(256), 0, st, weights, q_out, N);
+  if (launch_ff(weights, q_out, N, st) != PGDVS_OK) return PGDVS_ERR_LAUNCH;
   return check_launch("gnt_ray_layer");
 }

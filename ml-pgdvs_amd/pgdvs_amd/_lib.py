@@ -48,6 +48,8 @@ SIGNATURES = {
     "pgdvs_static_aggregate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _vp, _i64, _vp]),
     "pgdvs_gnt_gather": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp,
                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pgdvs_gnt_embed_weight_floats": (_i64, [_i]),
+    "pgdvs_gnt_embed": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "pgdvs_gnt_view_weight_floats": (_i64, []),
     "pgdvs_gnt_view_layer": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "pgdvs_gnt_ray_layer": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),

@@ -156,8 +156,14 @@ class GNT(nn.Module):
         viewdirs = ray_d / torch.norm(ray_d, dim=-1, keepdim=True)
         input_views = _posenc(viewdirs.float(), self.view_freqs, self.max_log2)[:, None].expand(pts.shape[0], pts.shape[1], -1)
         input_pts = _posenc(pts.float(), self.pos_freqs, self.max_log2)
-        feat = self.rgbfeat_fc(rgb_feat)
-        q = feat.max(dim=2)[0]
+        from .... import ops
+
+        fused = rgb_feat.is_cuda and ops.gnt_embed_available(self.rgbfeat_fc, rgb_feat.shape[-1])
+        if fused:
+            feat, q, std0 = ops.gnt_embed(self.rgbfeat_fc, rgb_feat, ret_view_std)
+        else:
+            feat = self.rgbfeat_fc(rgb_feat)
+            q = feat.max(dim=2)[0]
         V = feat.shape[2]
         valid = mask[..., 0] != 0
         cnt = valid.sum(-1)
@@ -166,7 +172,10 @@ class GNT(nn.Module):
         cnt = torch.where(empty, torch.full_like(cnt, V), cnt)
         want_stats = ret_view_entropy or ret_view_std
         ents, stds, stdns = [], [], []
-        if ret_view_std:
+        if ret_view_std and fused:
+            stds.append(std0[0])
+            stdns.append(std0[1])
+        elif ret_view_std:
             s0 = torch.std(feat, dim=2)
             stds.append(s0.mean(-1))
             stdns.append((s0 / (feat.abs().mean(2) + TINY_NUMBER)).mean(-1))

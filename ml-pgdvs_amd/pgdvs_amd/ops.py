@@ -456,6 +456,44 @@ def gnt_view_layer(layer, q, feat, ray_diff, valid, want_stats):
     return out, (st[..., 0], st[..., 1], st[..., 2])
 
 
+def gnt_embed_available(mlp, cin: int) -> bool:
+    """True when the fused rgbfeat_fc kernel handles this network (3+32 channels -> 64 -> 64)."""
+    return (_GNT_VIEW_ENABLED and 32 < cin <= 36 and mlp[0].out_features == 64 and mlp[2].out_features == 64
+            and mlp[0].in_features == cin)
+
+
+def pack_embed(mlp) -> torch.Tensor:
+    """rgbfeat_fc (Linear -> ReLU -> Linear) in the input-major layout of csrc/gnt_embed.hip."""
+    cin = mlp[0].in_features
+    rows = (cin + 3) // 4 * 4
+    w1 = torch.zeros((rows, 64), dtype=torch.float32, device=mlp[0].weight.device)
+    w1[:cin] = mlp[0].weight.detach().float().t()
+    parts = [w1, mlp[0].bias, mlp[2].weight.t(), mlp[2].bias]
+    packed = torch.cat([p.detach().float().contiguous().reshape(-1) for p in parts])
+    assert packed.numel() == _lib.load().pgdvs_gnt_embed_weight_floats(cin), packed.numel()
+    return packed
+
+
+def gnt_embed(mlp, rgb_feat, want_std: bool):
+    """rgb_feat[R,S,V,Cin] -> feat[R,S,V,64], q0[R,S,64], (std[R,S], std_normalized[R,S]) or None."""
+    packed = getattr(mlp, "_pgdvs_packed", None)
+    if packed is None or packed.device != rgb_feat.device:
+        packed = pack_embed(mlp)
+        mlp._pgdvs_packed = packed
+    x = _req(rgb_feat, torch.float32, "rgb_feat")
+    R, S, V, cin = x.shape
+    N = R * S
+    feat = torch.empty((R, S, V, 64), dtype=torch.float32, device=x.device)
+    q0 = torch.empty((R, S, 64), dtype=torch.float32, device=x.device)
+    stats = torch.empty((N, 2), dtype=torch.float32, device=x.device) if want_std else None
+    check(_lib.load().pgdvs_gnt_embed(_ptr(packed), _ptr(x), N, V, cin, _ptr(feat), _ptr(q0), _ptr(stats), _stream()),
+          "pgdvs_gnt_embed")
+    if not want_std:
+        return feat, q0, None
+    st = stats.reshape(R, S, 2)
+    return feat, q0, (st[..., 0], st[..., 1])
+
+
 def pack_ray_layer(layer) -> torch.Tensor:
     """Ray-transformer layer (Transformer) in the same packed layout; view-only regions stay 0."""
     a = layer.attn

@@ -881,6 +881,78 @@ def test_gnt_view_layer_mfma_vs_torch(V, want_stats):
         assert st_k is None
 
 
+def test_gnt_view_layer_wide_logit_range():
+    """view logits tens of units apart: the running softmax has to move its reference logit
+    (the rare rescaling branch of the kernel) and still agree with torch's softmax"""
+    from pgdvs_amd.models.gnt.models.transformer_network import GNT
+
+    torch.manual_seed(99)
+    net = GNT(netwidth=64, transformer_depth=1).to(DEV).eval()
+    layer = net.view_crosstrans[0]
+    with torch.no_grad():
+        layer.attn.attn_fc[2].weight.mul_(60.0)
+        layer.attn.attn_fc[2].bias.add_(torch.randn_like(layer.attn.attn_fc[2].bias) * 5.0)
+    R, S, V = 23, 11, 12
+    q = torch.randn(R, S, 64, device=DEV)
+    feat = torch.randn(R, S, V, 64, device=DEV) * 2.0
+    rd = torch.randn(R, S, V, 4, device=DEV)
+    valid = torch.rand(R, S, V, device=DEV) < 0.7
+    cnt = valid.sum(-1)
+    empty = cnt == 0
+    valid = valid | empty[..., None]
+    cnt = torch.where(empty, torch.full_like(cnt, V), cnt)
+    with torch.no_grad():
+        out_k, st_k = net._view_layer(layer, q, feat, rd, valid, cnt, True)
+        a = layer.attn
+        k = a.k_fc(feat)
+        logits = a.attn_fc(k - a.q_fc(layer.attn_norm(q))[:, :, None] + a.pos_fc(rd))
+        spread = (logits.amax(2) - logits.amin(2)).max().item()
+    assert spread > 40.0, spread  # the inputs do exercise the branch
+    ops._GNT_VIEW_ENABLED = False
+    try:
+        with torch.no_grad():
+            out_t, st_t = net._view_layer(layer, q, feat, rd, valid, cnt, True)
+    finally:
+        ops._GNT_VIEW_ENABLED = True
+    np.testing.assert_allclose(N(out_k), N(out_t), rtol=2e-4, atol=5e-5)
+    for a_, b_, name in zip(st_k, st_t, ("entropy", "std", "std_norm")):
+        np.testing.assert_allclose(N(a_), N(b_), rtol=1e-3, atol=5e-5, err_msg=name)
+
+
+@pytest.mark.parametrize("V", [1, 5, 24])
+def test_gnt_embed_mfma_vs_torch(V):
+    """rgbfeat_fc + max / std over the views in one MFMA kernel against the torch statements"""
+    import ctypes
+
+    from pgdvs_amd import _lib
+    from pgdvs_amd.models.gnt.models.transformer_network import GNT
+
+    torch.manual_seed(31 + V)
+    net = GNT(netwidth=64, transformer_depth=1).to(DEV).eval()
+    R, S = 29, 13  # N = 377: not a multiple of the 16-group tile
+    x = torch.randn(R, S, V, 35, device=DEV)
+    x[..., 3:] += 4.0  # features with a mean far above their spread: the one-pass variance must cope
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(4096)
+    lib.pgdvs_prof_report(buf, len(buf))
+    lib.pgdvs_prof_enable(1)
+    with torch.no_grad():
+        feat, q0, st = ops.gnt_embed(net.rgbfeat_fc, x, True)
+    lib.pgdvs_prof_enable(0)
+    lib.pgdvs_prof_report(buf, len(buf))
+    assert b"gnt_embed" in buf.value
+    with torch.no_grad():
+        ref = net.rgbfeat_fc(x)
+        s0 = torch.std(ref, dim=2)
+        ref_std, ref_stdn = s0.mean(-1), (s0 / (ref.abs().mean(2) + 1e-6)).mean(-1)
+    np.testing.assert_allclose(N(feat), N(ref), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(N(q0), N(ref.max(dim=2)[0]), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(N(st[0]), N(ref_std), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(N(st[1]), N(ref_stdn), rtol=1e-4, atol=1e-5)
+    feat2, q02, none = ops.gnt_embed(net.rgbfeat_fc, x, False)
+    assert none is None and torch.equal(feat2, feat) and torch.equal(q02, q0)
+
+
 @pytest.mark.parametrize("S", [1, 12, 33, 64, 256])
 def test_gnt_ray_layer_mfma_vs_torch(S):
     """Fused ray-transformer kernel (LN, QKV, 4-head attention over the samples of a ray, out_fc,

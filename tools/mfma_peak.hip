@@ -1,0 +1,55 @@
+// Sustained fp32-MFMA rate of the device (calibration for the roofline fraction of the GNT kernels):
+// register-only loops of v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32, W waves per SIMD.
+// build+run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__global__ void k32(float *out, int iters) {
+  floatx16 a0 = {}, a1 = {}, a2 = {}, a3 = {};
+  float x = threadIdx.x * 1e-3f, y = 1.0f + blockIdx.x * 1e-6f;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a3, 0, 0, 0);
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
+}
+__global__ void k16(float *out, int iters) {
+  floatx4 a0 = {}, a1 = {}, a2 = {}, a3 = {};
+  float x = threadIdx.x * 1e-3f, y = 1.0f + blockIdx.x * 1e-6f;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a3, 0, 0, 0);
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
+}
+int main() {
+  float *out;
+  hipMalloc(&out, 256 * 1024 * 4 * sizeof(float));
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int wpb : {256, 512, 1024}) {          // 1, 2, 4 waves per SIMD (one block per CU)
+    for (int which = 0; which < 2; ++which) {
+      for (int iters : {20000, 200000}) {      // ~1 ms and ~10 ms+ launches: does the clock hold?
+        if (which == 0) k32<<<256, wpb>>>(out, 100); else k16<<<256, wpb>>>(out, 100);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        if (which == 0) k32<<<256, wpb>>>(out, iters); else k16<<<256, wpb>>>(out, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        double flop = 256.0 * (wpb / 64) * iters * 4.0 * (which == 0 ? 2.0 * 32 * 32 * 2 : 2.0 * 16 * 16 * 4);
+        printf("%s waves/SIMD=%d iters=%d: %.3f ms  %.1f TFLOP/s\n", which == 0 ? "32x32x2 " : "16x16x4 ", wpb / 256, iters, ms,
+               flop / ms / 1e9);
+      }
+    }
+  }
+  return 0;
+}

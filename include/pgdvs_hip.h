@@ -238,6 +238,17 @@ int64_t pgdvs_gnt_embed_weight_floats(int Cin);
 int pgdvs_gnt_embed(const float *weights, const float *rgb_feat, int64_t N, int V, int Cin,
                     float *feat, float *q0, float *stats, pgdvs_stream_t stream);
 
+/* A14, positional re-embedding of the even layers (transformer_network.py:482-486):
+ * q <- q_fc(cat(q, posenc(pts), posenc(viewdir))) with q_fc = Linear(64+P+P',64) -> ReLU ->
+ * Linear(64,64).  The caller forms the position part T[N,*] = posenc(pts) W1[:,64:64+P]^T and the
+ * direction part tv[R,*] = posenc(viewdir) W1[:,64+P:]^T + b1 (row strides in floats, multiples
+ * of 4, so that the slices of all even layers can share one GEMM); the kernel computes
+ * q_out = W2 relu(W1[:, :64] q + T[g] + tv[g / S]) + b2.
+ *   weights: W1[:, :64] input-major [64][64], W2 input-major [64][64], b2[64]. */
+int pgdvs_gnt_posfc(const float *weights, const float *q_in, const float *T, int64_t t_stride,
+                    const float *tv, int64_t tv_stride, int64_t N, int S, float *q_out,
+                    pgdvs_stream_t stream);
+
 /* A14 (view transformer): one fused fp32-MFMA kernel per GNT layer = Transformer2D +
  * Attention2D of pgdvs/models/gnt/models/transformer_network.py:59-169,197-223 (width 64).
  *   weights: pgdvs_gnt_view_weight_floats() floats, packed input-major as laid out in

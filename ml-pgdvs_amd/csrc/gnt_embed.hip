@@ -168,3 +168,76 @@ PGDVS_API int pgdvs_gnt_embed(const float *weights, const float *rgb_feat, int64
                V, Cin, feat, q0, stats);
   return check_launch("gnt_embed");
 }
+
+// ---------------------------------------------------------------------------------------
+// Positional re-embedding of the even layers (transformer_network.py:482-486):
+//   q <- q_fc(cat(q, posenc(pts), posenc(viewdir))),  q_fc = Linear(64+P+P', 64) -> ReLU -> Linear(64, 64)
+// The first layer is linear in the three concatenated blocks, so its position part
+// T = W1[:, 64:64+P] posenc(pts) (one GEMM for all even layers at once) and its direction part
+// tv = W1[:, 64+P:] posenc(viewdir) + b1 (per ray) are formed once per forward pass by the
+// caller; this kernel does  q <- W2 relu(W1[:, :64] q + T + tv) + b2  per row on the MFMA,
+// without materialising the concatenation.
+//   weights (floats): W1q input-major [64][64], W2 input-major [64][64], b2 [64]
+// ---------------------------------------------------------------------------------------
+namespace pgdvs {
+
+__global__ void __launch_bounds__(256, 2)
+gnt_posfc_kernel(const float *__restrict__ W_arg, const float *__restrict__ q_in, const float *__restrict__ T,
+                 int64_t t_stride, const float *__restrict__ tv, int64_t tv_stride, int64_t N, int S,
+                 float *__restrict__ q_out) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];
+  float *s_w1 = s_w, *s_w2 = s_w + 64 * kEmbStride;
+  for (int k = threadIdx.x; k < 4096; k += blockDim.x) {
+    s_w1[(k >> 6) * kEmbStride + (k & 63)] = W_arg[k];
+    s_w2[(k >> 6) * kEmbStride + (k & 63)] = W_arg[4096 + k];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, i = lane & 15, hq = lane >> 4;
+  const int wave = threadIdx.x >> 6;
+  const float *w1 = s_w1 + (4 * hq) * kEmbStride + i, *w2 = s_w2 + (4 * hq) * kEmbStride + i;
+  float b2[16];
+  load_row16(W_arg + 8192, b2, hq);
+  const int64_t ntiles = (N + 15) / 16;
+  float w[8];
+  ldq8<kEmbStride>(w, w1, 0);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t g_raw = tile * 16 + i;
+    const bool g_ok = g_raw < N;
+    const int64_t g = g_ok ? g_raw : N - 1;
+    float x[16], t[16], u[16];
+    load_row16(q_in + g * 64, x, hq);
+    load_row16(T + g * t_stride, t, hq);
+    load_row16(tv + (g / S) * tv_stride, u, hq);
+    floatx4 c[4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c[k >> 2][k & 3] = t[k] + u[k];
+    chain64q<kEmbStride>(c, w1, x, w, [&](float (&d)[8]) { ldq8<kEmbStride>(d, w2, 0); });
+    float hid[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      hid[k] = fmaxf(c[k >> 2][k & 3], 0.0f);
+      c[k >> 2][k & 3] = b2[k];
+    }
+    chain64q<kEmbStride>(c, w2, hid, w, [&](float (&d)[8]) { ldq8<kEmbStride>(d, w1, 0); });
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = c[k >> 2][k & 3];
+    if (g_ok) store_row16(q_out + g * 64, x, hq);
+  }
+}
+
+}  // namespace pgdvs
+
+PGDVS_API int pgdvs_gnt_posfc(const float *weights, const float *q_in, const float *T, int64_t t_stride,
+                              const float *tv, int64_t tv_stride, int64_t N, int S, float *q_out,
+                              pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(weights && q_in && T && tv && q_out, "pgdvs_gnt_posfc: null pointer");
+  PGDVS_REQUIRE(N >= 0 && S >= 1 && t_stride >= 64 && tv_stride >= 64 && t_stride % 4 == 0 && tv_stride % 4 == 0,
+                "pgdvs_gnt_posfc: bad shape");
+  if (N == 0) return PGDVS_OK;
+  const int64_t tiles = cdiv(N, 16);
+  const unsigned grid = (unsigned)(cdiv(tiles, 4) < 512 ? cdiv(tiles, 4) : 512);
+  const size_t lds = (size_t)2 * 64 * kEmbStride * sizeof(float);
+  PGDVS_LAUNCH("gnt_posfc", gnt_posfc_kernel, dim3(grid), dim3(256), lds, as_stream(stream), weights, q_in, T, t_stride,
+               tv, tv_stride, N, S, q_out);
+  return check_launch("gnt_posfc");
+}

@@ -745,18 +745,30 @@ gnt_ray_attn_kernel(const float *__restrict__ W_arg, const float *__restrict__ q
         const float *vr = Vs + (4 * hq) * kRayVStride + 16 * hh + i;  // + (16 * kt + r) * stride
         float m = 0.0f, l = 0.0f;
         floatx4 O = {0.0f, 0.0f, 0.0f, 0.0f};
+        // the score tile of key tile kt+1 is issued before the softmax of tile kt: the matrix
+        // pipe works on it while the vector ALU exponentiates, and its K operands were
+        // requested one tile earlier still
         float ka[4], va[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ka[r] = kr[r * kRayKStride];
+        floatx4 sc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc = mfma16(ka[r], qv[4 * hh + r], sc);
+        if (1 < ntile) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ka[r] = kr[r * kRayKStride + 16];
+        }
         for (int kt = 0; kt < ntile; ++kt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) va[r] = vr[(16 * kt + r) * kRayVStride];
-          floatx4 sc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sc = mfma16(ka[r], qv[4 * hh + r], sc);
+          floatx4 sn = {0.0f, 0.0f, 0.0f, 0.0f};
           if (kt + 1 < ntile) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ka[r] = kr[r * kRayKStride + 16 * (kt + 1)];
+            for (int r = 0; r < 4; ++r) sn = mfma16(ka[r], qv[4 * hh + r], sn);
+            if (kt + 2 < ntile) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) ka[r] = kr[r * kRayKStride + 16 * (kt + 2)];
+            }
           }
           float x[4], xmax = -__builtin_inff();
 #pragma unroll
@@ -782,6 +794,7 @@ gnt_ray_attn_kernel(const float *__restrict__ W_arg, const float *__restrict__ q
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) O = mfma16(va[r], x[r], O);
+          sc = sn;
         }
         l = quad_sum(l);
         if (wave == 0 && i == 0) {  // query sample 0: softmax statistics + its scaled Q for the weight row

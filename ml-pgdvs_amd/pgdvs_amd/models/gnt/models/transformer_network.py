@@ -180,10 +180,13 @@ class GNT(nn.Module):
             stds.append(s0.mean(-1))
             stdns.append((s0 / (feat.abs().mean(2) + TINY_NUMBER)).mean(-1))
         attn = None
+        posfc = None
+        if rgb_feat.is_cuda and ops.gnt_posfc_available(self.q_fcs, q.shape[-1]):
+            posfc = ops.GntPosFc(self.q_fcs, input_pts, input_views[:, 0])
         for i, (vl, qfc, rl) in enumerate(zip(self.view_crosstrans, self.q_fcs, self.view_selftrans)):
             q, stats = self._view_layer(vl, q, feat, ray_diff, valid, cnt, want_stats)
             if i % 2 == 0:
-                q = qfc(torch.cat((q, input_pts, input_views), dim=-1))
+                q = posfc(i, q) if posfc is not None else qfc(torch.cat((q, input_pts, input_views), dim=-1))
             q, attn = self._ray_layer(rl, q, self.ret_alpha)
             if want_stats:
                 ents.append(stats[0])

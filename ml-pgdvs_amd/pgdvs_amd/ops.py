@@ -494,6 +494,49 @@ def gnt_embed(mlp, rgb_feat, want_std: bool):
     return feat, q0, (st[..., 0], st[..., 1])
 
 
+def gnt_posfc_available(q_fcs, dim: int) -> bool:
+    mlps = [m for m in q_fcs if not isinstance(m, torch.nn.Identity)]
+    return (_GNT_VIEW_ENABLED and dim == 64 and len(mlps) > 0
+            and all(m[0].out_features == 64 and m[2].in_features == 64 and m[2].out_features == 64 for m in mlps))
+
+
+class GntPosFc:
+    """Per-forward state of the even layers' positional re-embedding (csrc/gnt_embed.hip,
+    pgdvs_gnt_posfc): the position / direction parts of every q_fc's first layer come from one
+    GEMM each, the per-row part runs in the MFMA kernel."""
+
+    def __init__(self, q_fcs, pe_pts, pe_view):
+        """pe_pts[R,S,P], pe_view[R,P']"""
+        self.ids = [i for i, m in enumerate(q_fcs) if not isinstance(m, torch.nn.Identity)]
+        mlps = [q_fcs[i] for i in self.ids]
+        P, Pv = pe_pts.shape[-1], pe_view.shape[-1]
+        cache = getattr(q_fcs, "_pgdvs_packed", None)
+        if cache is None or cache[0].device != pe_pts.device:
+            wp = torch.cat([m[0].weight.detach().float()[:, 64:64 + P] for m in mlps], 0).t().contiguous()  # [P, 64 L]
+            wv = torch.cat([m[0].weight.detach().float()[:, 64 + P:64 + P + Pv] for m in mlps], 0).t().contiguous()
+            b1 = torch.cat([m[0].bias.detach().float() for m in mlps], 0)
+            packed = [torch.cat([m[0].weight.detach().float()[:, :64].t().contiguous().reshape(-1),
+                                 m[2].weight.detach().float().t().contiguous().reshape(-1),
+                                 m[2].bias.detach().float()]) for m in mlps]
+            cache = (wp, wv, b1, packed)
+            q_fcs._pgdvs_packed = cache  # parameters are frozen at inference
+        wp, wv, b1, self.packed = cache
+        R, S = pe_pts.shape[0], pe_pts.shape[1]
+        self.R, self.S = R, S
+        self.T = pe_pts.reshape(R * S, P).float() @ wp        # [N, 64 L]
+        self.tv = torch.addmm(b1, pe_view.float(), wv)        # [R, 64 L]
+
+    def __call__(self, layer_index, q):
+        k = self.ids.index(layer_index)
+        qi = _req(q, torch.float32, "q")
+        out = torch.empty_like(qi)
+        N = self.R * self.S
+        check(_lib.load().pgdvs_gnt_posfc(_ptr(self.packed[k]), _ptr(qi), self.T.data_ptr() + 256 * k, self.T.shape[1],
+                                          self.tv.data_ptr() + 256 * k, self.tv.shape[1], N, self.S, _ptr(out), _stream()),
+              "pgdvs_gnt_posfc")
+        return out
+
+
 def pack_ray_layer(layer) -> torch.Tensor:
     """Ray-transformer layer (Transformer) in the same packed layout; view-only regions stay 0."""
     a = layer.attn

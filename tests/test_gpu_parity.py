@@ -953,6 +953,27 @@ def test_gnt_embed_mfma_vs_torch(V):
     assert none is None and torch.equal(feat2, feat) and torch.equal(q02, q0)
 
 
+def test_gnt_posfc_mfma_vs_torch():
+    """even layers' q_fc(cat(q, posenc(pts), posenc(dir))) split into GEMM parts + the MFMA row
+    kernel against the concatenated torch statement"""
+    from pgdvs_amd.models.gnt.models.transformer_network import GNT, _posenc
+
+    torch.manual_seed(5)
+    net = GNT(netwidth=64, transformer_depth=4).to(DEV).eval()
+    R, S = 21, 19
+    q = torch.randn(R, S, 64, device=DEV)
+    pts = torch.randn(R, S, 3, device=DEV)
+    dirs = torch.nn.functional.normalize(torch.randn(R, 3, device=DEV), dim=-1)
+    pe_p = _posenc(pts, net.pos_freqs, net.max_log2)
+    pe_v = _posenc(dirs, net.view_freqs, net.max_log2)
+    with torch.no_grad():
+        fused = ops.GntPosFc(net.q_fcs, pe_p, pe_v)
+        for i in (0, 2):
+            out = fused(i, q)
+            ref = net.q_fcs[i](torch.cat((q, pe_p, pe_v[:, None].expand(R, S, -1)), dim=-1))
+            np.testing.assert_allclose(N(out), N(ref), rtol=1e-4, atol=3e-5)
+
+
 @pytest.mark.parametrize("S", [1, 12, 33, 64, 256])
 def test_gnt_ray_layer_mfma_vs_torch(S):
     """Fused ray-transformer kernel (LN, QKV, 4-head attention over the samples of a ray, out_fc,

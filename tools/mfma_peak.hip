@@ -28,6 +28,57 @@ __global__ void k16(float *out, int iters) {
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
 }
+// does vector-ALU work run in the shadow of the matrix pipe?  NV independent v_fma per 4 MFMAs
+// (4 x 32 = 128 matrix cycles); same wave (W = 1) or spread over W waves per SIMD
+template <int OP>
+__device__ __forceinline__ float vop(float a, float y, float x) {
+  if (OP == 0) return __builtin_fmaf(a, y, x);                                          // v_fma_f32
+  if (OP == 1) return fmaxf(a, y) ;                                                      // v_max_f32 (chain kept alive below)
+  if (OP == 2) return __builtin_amdgcn_exp2f(a);                                         // v_exp_f32 (transcendental)
+  if (OP == 3) return __int_as_float((__float_as_int(a) + __float_as_int(y)) ^ 0x5a5a);  // integer add + xor (2 ops)
+  return __int_as_float(__float_as_int(a) > 7 ? __float_as_int(y) : __float_as_int(x)); // v_cmp + v_cndmask (2 ops)
+}
+template <int NV, int OP = 0>
+__global__ void kmix(float *out, int iters) {
+  floatx4 a0 = {}, a1 = {}, a2 = {}, a3 = {};
+  float x = threadIdx.x * 1e-3f, y = 1.0f + blockIdx.x * 1e-6f;
+  float v[8];
+  for (int k = 0; k < 8; ++k) v[k] = x + k;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NV / 4; ++k) v[k % 8] = vop<OP>(v[k % 8], y, x);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a1, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NV / 4; ++k) v[(k + 2) % 8] = vop<OP>(v[(k + 2) % 8], y, x);
+    a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a2, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NV / 4; ++k) v[(k + 4) % 8] = vop<OP>(v[(k + 4) % 8], y, x);
+    a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a3, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NV / 4; ++k) v[(k + 6) % 8] = vop<OP>(v[(k + 6) % 8], y, x);
+  }
+  float sv = 0;
+  for (int k = 0; k < 8; ++k) sv += v[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3] + sv;
+}
+template <int NV, int OP = 0>
+void run_mix(float *out, hipEvent_t e0, hipEvent_t e1) {
+  for (int wpb : {256, 512, 1024}) {
+    const int iters = 100000;
+    kmix<NV, OP><<<256, wpb>>>(out, 100);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    kmix<NV, OP><<<256, wpb>>>(out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    double cyc = ms * 1e-3 * 2.4e9 / ((double)iters * (wpb / 256));
+    printf("mix op=%d NV=%2d valu per 4 mfma (128 matrix cycles), waves/SIMD=%d: %.1f cycles per iteration-wave @2.4GHz\n", OP, NV, wpb / 256, cyc);
+  }
+}
+
 int main() {
   float *out;
   hipMalloc(&out, 256 * 1024 * 4 * sizeof(float));
@@ -51,5 +102,15 @@ int main() {
       }
     }
   }
+  run_mix<0>(out, e0, e1);
+  run_mix<8>(out, e0, e1);
+  run_mix<16>(out, e0, e1);
+  run_mix<24>(out, e0, e1);
+  run_mix<32>(out, e0, e1);
+  run_mix<48>(out, e0, e1);
+  run_mix<16, 1>(out, e0, e1);
+  run_mix<16, 2>(out, e0, e1);
+  run_mix<16, 3>(out, e0, e1);
+  run_mix<16, 4>(out, e0, e1);
   return 0;
 }

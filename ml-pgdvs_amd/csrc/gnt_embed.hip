@@ -21,8 +21,8 @@ gnt_embed_kernel(const float *__restrict__ W_arg, const float *__restrict__ rgb_
   extern __shared__ __attribute__((aligned(16))) float s_w[];
   float *s_w1 = s_w, *s_w2 = s_w + 4 * KS * kEmbStride;
   const float *b1g = W_arg + 4 * KS * 64, *w2g = b1g + 64, *b2g = w2g + 4096;
-  for (int k = threadIdx.x; k < 4 * KS * 64; k += blockDim.x) s_w1[(k >> 6) * kEmbStride + (k & 63)] = W_arg[k];
-  for (int k = threadIdx.x; k < 4096; k += blockDim.x) s_w2[(k >> 6) * kEmbStride + (k & 63)] = w2g[k];
+  stage_f4<4 * KS * 16, 256>(W_arg, s_w1, [](int q) { return (q >> 4) * kEmbStride + 4 * (q & 15); });
+  stage_f4<1024, 256>(w2g, s_w2, [](int q) { return (q >> 4) * kEmbStride + 4 * (q & 15); });
   __syncthreads();
   const int lane = threadIdx.x & 63, i = lane & 15, hq = lane >> 4;
   const int wave = threadIdx.x >> 6;
@@ -187,10 +187,8 @@ gnt_posfc_kernel(const float *__restrict__ W_arg, const float *__restrict__ q_in
                  float *__restrict__ q_out) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];
   float *s_w1 = s_w, *s_w2 = s_w + 64 * kEmbStride;
-  for (int k = threadIdx.x; k < 4096; k += blockDim.x) {
-    s_w1[(k >> 6) * kEmbStride + (k & 63)] = W_arg[k];
-    s_w2[(k >> 6) * kEmbStride + (k & 63)] = W_arg[4096 + k];
-  }
+  stage_f4<1024, 256>(W_arg, s_w1, [](int q) { return (q >> 4) * kEmbStride + 4 * (q & 15); });
+  stage_f4<1024, 256>(W_arg + 4096, s_w2, [](int q) { return (q >> 4) * kEmbStride + 4 * (q & 15); });
   __syncthreads();
   const int lane = threadIdx.x & 63, i = lane & 15, hq = lane >> 4;
   const int wave = threadIdx.x >> 6;

@@ -20,6 +20,26 @@ __device__ __forceinline__ const float *opaque_uniform(const float *p) {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// Weight staging global -> LDS for a workgroup of NT threads: NF4 float4's, every load issued
+// before the first store (a load / wait / store loop pays the L2 latency once per iteration:
+// 16 round trips for the 128 KB of the feed-forward block).  dst_of maps a float4 index to
+// its float offset in LDS (row re-striding).
+template <int NF4, int NT, class DstOf>
+__device__ __forceinline__ void stage_f4(const float *__restrict__ src, float *__restrict__ dst, DstOf dst_of) {
+  constexpr int IT = (NF4 + NT - 1) / NT;
+  float4 v[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int q = (int)threadIdx.x + it * NT;
+    if (NF4 % NT == 0 || q < NF4) v[it] = reinterpret_cast<const float4 *>(src)[q];
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int q = (int)threadIdx.x + it * NT;
+    if (NF4 % NT == 0 || q < NF4) *reinterpret_cast<float4 *>(dst + dst_of(q)) = v[it];
+  }
+}
+
 
 __device__ __forceinline__ floatx4 mfma16(float a, float b, floatx4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

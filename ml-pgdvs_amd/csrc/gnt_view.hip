@@ -290,16 +290,12 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
   // collide 2-way on every weight read).
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [kViewLdsFloats]
   float *s_wk = s_w, *s_wv = s_wk + 64 * kWStride, *s_a1 = s_wv + 64 * kWStride, *s_small = s_a1 + 64 * kA1Stride;
-  for (int k = threadIdx.x; k < 4096; k += blockDim.x) {
-    s_wk[(k >> 6) * kWStride + (k & 63)] = W_arg[VW_WK + k];
-    s_wv[(k >> 6) * kWStride + (k & 63)] = W_arg[VW_WV + k];
-  }
-  for (int k = threadIdx.x; k < 2048; k += blockDim.x) s_a1[(k >> 5) * kA1Stride + (k & 31)] = W_arg[VW_A1 + k];
+  stage_f4<1024, 256>(W_arg + VW_WK, s_wk, [](int q) { return (q >> 4) * kWStride + 4 * (q & 15); });
+  stage_f4<1024, 256>(W_arg + VW_WV, s_wv, [](int q) { return (q >> 4) * kWStride + 4 * (q & 15); });
+  stage_f4<512, 256>(W_arg + VW_A1, s_a1, [](int q) { return (q >> 3) * kA1Stride + 4 * (q & 7); });
   // s_small: P1 [4][32], P1B [32], P2 [8][64], P2B [64], A1B [32], A2 [8][64], A2B [64]
-  for (int k = threadIdx.x; k < kSmallFloats; k += blockDim.x) {
-    const int src = k < kSmA1B ? VW_P1 + k : VW_A1B + (k - kSmA1B);
-    s_small[k] = W_arg[src];
-  }
+  stage_f4<kSmA1B / 4, 256>(W_arg + VW_P1, s_small, [](int q) { return 4 * q; });
+  stage_f4<(kSmallFloats - kSmA1B) / 4, 256>(W_arg + VW_A1B, s_small + kSmA1B, [](int q) { return 4 * q; });
   __syncthreads();
   const int lane = threadIdx.x & 63, i = lane & 15, hq = lane >> 4;
   const int wave = threadIdx.x >> 6;
@@ -542,25 +538,41 @@ gnt_ff_kernel(const float *__restrict__ W_arg, float *__restrict__ x_io, int64_t
   // launch at 1024 rays x 256 samples.  ds_read_b32 serves each 32-lane half in one cycle
   // (consecutive columns), so no padding is needed.
   extern __shared__ __attribute__((aligned(16))) float s_ff[];  // F1 [64][256], F2 [256][64]
-  for (int k = threadIdx.x * 4; k < 2 * 16384; k += blockDim.x * 4) {
-    const int src = k < 16384 ? VW_F1 + k : VW_F2 + (k - 16384);
-    *reinterpret_cast<float4 *>(s_ff + k) = *reinterpret_cast<const float4 *>(W_arg + src);
-  }
+  stage_f4<4096, 512>(W_arg + VW_F1, s_ff, [](int q) { return 4 * q; });
+  stage_f4<4096, 512>(W_arg + VW_F2, s_ff + 16384, [](int q) { return 4 * q; });
+  // the biases as well: a global load in front of an accumulator chain costs an L2 round trip
+  // that the one-chunk-ahead weight pipeline cannot cover          [F1B 256 | F2B 64 | LN2 128]
+  stage_f4<64, 512>(W_arg + VW_F1B, s_ff + 32768, [](int q) { return 4 * q; });
+  stage_f4<16, 512>(W_arg + VW_F2B, s_ff + 32768 + 256, [](int q) { return 4 * q; });
+  stage_f4<32, 512>(W_arg + VW_LN2_G, s_ff + 32768 + 320, [](int q) { return 4 * q; });  // gamma[64], beta[64]
   __syncthreads();
   const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
   const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   const int64_t ntiles = (N + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * nwave + wave; tile < ntiles; tile += (int64_t)gridDim.x * nwave) {
+  // the next tile's rows are requested before this tile's 512 MFMAs (nothing else covers the HBM
+  // latency: the vector ALU and the fp32 matrix pipe do not run concurrently)
+  const int64_t tstep = (int64_t)gridDim.x * nwave;
+  float x_nx[32];
+  {
+    const int64_t t0 = (int64_t)blockIdx.x * nwave + wave;
+    const int64_t g0 = t0 * 32 + i;
+    if (t0 < ntiles) load_row32(x_io + (g0 < N ? g0 : N - 1) * 64, x_nx, h);
+  }
+  for (int64_t tile = (int64_t)blockIdx.x * nwave + wave; tile < ntiles; tile += tstep) {
     const int64_t g_raw = tile * 32 + i;
     const bool g_ok = g_raw < N;
     const int64_t g = g_ok ? g_raw : N - 1;
-    const float *W = opaque_uniform(W_arg);
     float x1[32], xn[32];
-    load_row32(x_io + g * 64, x1, h);
-    layer_norm64(x1, W + VW_LN2_G, W + VW_LN2_B, 1e-6f, xn, h);
+#pragma unroll
+    for (int t = 0; t < 32; ++t) x1[t] = x_nx[t];
+    if (tile + tstep < ntiles) {
+      const int64_t gn = (tile + tstep) * 32 + i;
+      load_row32(x_io + (gn < N ? gn : N - 1) * 64, x_nx, h);
+    }
+    layer_norm64(x1, s_ff + 32768 + 320, s_ff + 32768 + 384, 1e-6f, xn, h);
     floatx16 o0, o1;
     {
-      const float *bb = W + VW_F2B + 4 * h;
+      const float *bb = s_ff + 32768 + 256 + 4 * h;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         o0[r] = bb[featc(r)];
@@ -573,7 +585,7 @@ gnt_ff_kernel(const float *__restrict__ W_arg, float *__restrict__ x_io, int64_t
     // (8 + 8 floats) are requested one chunk ahead.
     const float *f1 = s_ff + (4 * h) * 256 + i;
     const float *f2 = s_ff + 16384 + (4 * h) * 64 + i;  // rows = hidden features of this lane half
-    const float *b1 = W + VW_F1B + 4 * h;
+    const float *b1 = s_ff + 32768 + 4 * h;
     auto ld_f1 = [&](float (&w)[8], int mt, int c) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) w[u] = f1[featc(8 * c + u) * 256 + 32 * mt];
@@ -849,7 +861,7 @@ PGDVS_API int64_t pgdvs_gnt_view_weight_floats(void) { return VW_TOTAL; }
 
 // feed-forward block in place on x[N,64]: one persistent 8-wave workgroup per CU
 static int launch_ff(const float *weights, float *x, int64_t N, hipStream_t st) {
-  constexpr size_t lds = 2 * 16384 * sizeof(float);
+  constexpr size_t lds = (2 * 16384 + 256 + 64 + 128) * sizeof(float);
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gnt_ff_kernel),

@@ -30,6 +30,98 @@ __global__ void k16(float *out, int iters) {
 }
 // does vector-ALU work run in the shadow of the matrix pipe?  NV independent v_fma per 4 MFMAs
 // (4 x 32 = 128 matrix cycles); same wave (W = 1) or spread over W waves per SIMD
+// dependent accumulation chains: NA independent accumulators, round-robin (NA = 1: every MFMA
+// waits for its predecessor's result)
+template <int NA, bool BIG>
+__global__ void kchain(float *out, int iters) {
+  floatx16 a[4] = {};
+  floatx4 b[4] = {};
+  float x = threadIdx.x * 1e-3f, y = 1.0f + blockIdx.x * 1e-6f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (BIG) a[k % NA] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a[k % NA], 0, 0, 0);
+      else b[k % NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, b[k % NA], 0, 0, 0);
+    }
+  }
+  float r = 0;
+  for (int k = 0; k < 4; ++k) r += a[k][0] + b[k][1];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <int NA, bool BIG>
+void run_chain(float *out, hipEvent_t e0, hipEvent_t e1) {
+  for (int wpb : {256, 512, 1024}) {
+    const int iters = 50000;
+    kchain<NA, BIG><<<256, wpb>>>(out, 100);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    kchain<NA, BIG><<<256, wpb>>>(out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    double cyc = ms * 1e-3 * 2.4e9 / ((double)iters * 8 * (wpb / 256));
+    printf("chain %s accumulators=%d waves/SIMD=%d: %.1f cycles per MFMA (pipe: %d)\n", BIG ? "32x32x2" : "16x16x4", NA, wpb / 256, cyc, BIG ? 64 : 32);
+  }
+}
+
+// MFMAs whose A operand arrives from LDS (one ds_read_b32 per MFMA, double-buffered in chunks
+// of 8 like the GNT kernels): does the feed cost matrix-pipe cycles?
+template <bool BIG>
+__global__ void klds(float *out, int iters) {
+  __shared__ float lds[16384];
+  for (int k = threadIdx.x; k < 16384; k += blockDim.x) lds[k] = k * 1e-6f;
+  __syncthreads();
+  floatx16 a[2] = {};
+  floatx4 b[4] = {};
+  float y = 1.0f + blockIdx.x * 1e-6f;
+  const float *wb = lds + (threadIdx.x & 63);
+  float w0[8], w1[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) w0[u] = wb[u * 64];
+  for (int i = 0; i < iters; ++i) {
+    const float *wi = wb + (i & 15) * 1024;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w1[u] = wi[512 + u * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (BIG) a[u & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[u], y, a[u & 1], 0, 0, 0);
+      else b[u & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[u], y, b[u & 3], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w0[u] = wi[u * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (BIG) a[u & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[u], y, a[u & 1], 0, 0, 0);
+      else b[u & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[u], y, b[u & 3], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float r = 0;
+  for (int k = 0; k < 2; ++k) r += a[k][0];
+  for (int k = 0; k < 4; ++k) r += b[k][1];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <bool BIG>
+void run_lds(float *out, hipEvent_t e0, hipEvent_t e1) {
+  for (int wpb : {256, 512, 1024}) {
+    const int iters = 30000;
+    klds<BIG><<<256, wpb>>>(out, 100);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    klds<BIG><<<256, wpb>>>(out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    double cyc = ms * 1e-3 * 2.4e9 / ((double)iters * 16 * (wpb / 256));
+    printf("lds-fed %s waves/SIMD=%d: %.1f cycles per MFMA (pipe: %d)\n", BIG ? "32x32x2" : "16x16x4", wpb / 256, cyc, BIG ? 64 : 32);
+  }
+}
+
 template <int OP>
 __device__ __forceinline__ float vop(float a, float y, float x) {
   if (OP == 0) return __builtin_fmaf(a, y, x);                                          // v_fma_f32
@@ -102,6 +194,13 @@ int main() {
       }
     }
   }
+  run_chain<1, true>(out, e0, e1);
+  run_chain<2, true>(out, e0, e1);
+  run_chain<1, false>(out, e0, e1);
+  run_chain<2, false>(out, e0, e1);
+  run_chain<4, false>(out, e0, e1);
+  run_lds<true>(out, e0, e1);
+  run_lds<false>(out, e0, e1);
   run_mix<0>(out, e0, e1);
   run_mix<8>(out, e0, e1);
   run_mix<16>(out, e0, e1);

@@ -683,7 +683,8 @@ constexpr int kRayKStride = 260;  // K rows [feature][sample] padded: 4 * 260 = 
 constexpr int kRayVStride = 68;   // V rows [sample][feature] padded likewise
 constexpr int kRaySmax = 256;
 constexpr float kRayGap = 20.0f;  // in log2 units
-constexpr int kRayLdsFloats = 64 * kRayKStride + kRaySmax * kRayVStride + 8 + 64;
+constexpr int kRayWStride = 68;   // the projection matrix staged in LDS, rows padded likewise
+constexpr int kRayLdsFloats = 64 * kRayKStride + kRaySmax * kRayVStride + 72 + 192 + 64 * kRayWStride;
 
 __device__ __forceinline__ float quad_max(float v, int lane) {  // over the lanes j, j+16, j+32, j+48
   const int iv = __float_as_int(v);
@@ -701,56 +702,87 @@ gnt_ray_attn_kernel(const float *__restrict__ W_arg, const float *__restrict__ q
   float *Ks = s_kv;                              // [64][kRayKStride]
   float *Vs = s_kv + 64 * kRayKStride;           // [kRaySmax][kRayVStride]
   float *s_row0 = Vs + kRaySmax * kRayVStride;   // [8 + 64]: (m,l) per head, scaled Q of sample 0
+  float *s_par = s_row0 + 72;                    // LN gamma[64], beta[64], out_fc bias[64]
+  float *s_wst = s_par + 192;                    // [64][kRayWStride]: the projection matrix in use
   const int ntile = (S + 15) / 16;
   const int lane = threadIdx.x & 63, i = lane & 15, hq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const bool has_tile = wave < ntile;
+  // The four 64x64 matrices take turns in one LDS buffer: every thread carries one float4 of the
+  // NEXT matrix in registers (requested a whole product earlier, so the L2 latency is long
+  // gone) and drops it into the buffer between two barriers.  Read straight from global memory
+  // by each of the 16 wavefronts, the weights cost an L2 round trip per 8-MFMA chunk.
+  const int stage_dst = ((int)threadIdx.x >> 4) * kRayWStride + 4 * ((int)threadIdx.x & 15);
+  auto fetch = [&](int off) { return reinterpret_cast<const float4 *>(W_arg + off)[threadIdx.x]; };
+  if (threadIdx.x < 32) reinterpret_cast<float4 *>(s_par)[threadIdx.x] = reinterpret_cast<const float4 *>(W_arg + VW_LN1_G)[threadIdx.x];
+  if (threadIdx.x < 16) reinterpret_cast<float4 *>(s_par + 128)[threadIdx.x] = reinterpret_cast<const float4 *>(W_arg + VW_WOB)[threadIdx.x];
+  const float *wst = s_wst + (4 * hq) * kRayWStride + i;
+  float4 pf = fetch(VW_WQ);
   for (int ray = blockIdx.x; ray < R; ray += gridDim.x) {
-    const float *W = opaque_uniform(W_arg);
     const int s_raw = wave * 16 + i;
     const int smp = s_raw < S ? s_raw : S - 1;  // lanes past the end recompute the last sample: finite K/V
     const float *xrow = q_in + ((int64_t)ray * S + smp) * 64;
-    float qv[16];
-    __syncthreads();  // previous ray's K/V fully consumed
+    float qv[16], xn[16], w[8];
+    __syncthreads();  // previous ray: K/V and the weight buffer (Wo) fully consumed
+    *reinterpret_cast<float4 *>(s_wst + stage_dst) = pf;  // Wq
+    pf = fetch(VW_WK);
     if (has_tile) {
-      float x[16], xn[16], w[8];
+      float x[16];
       load_row16(xrow, x, hq);
-      layer_norm64q(x, W + VW_LN1_G, W + VW_LN1_B, 1e-6f, xn, hq);
-      const float *wq = W + VW_WQ + (4 * hq) * 64 + i, *wk = W + VW_WK + (4 * hq) * 64 + i;
-      const float *wv = W + VW_WV + (4 * hq) * 64 + i;
-      floatx4 c[4] = {};
-      ldq8<64>(w, wq, 0);
-      chain64q<64>(c, wq, xn, w, [&](float (&d)[8]) { ldq8<64>(d, wk, 0); });
+      layer_norm64q(x, s_par, s_par + 64, 1e-6f, xn, hq);
+    }
+    __syncthreads();
+    floatx4 c[4] = {};
+    if (has_tile) {
+      ldq8<kRayWStride>(w, wst, 0);
+      chain64q<kRayWStride>(c, wst, xn, w, [&](float (&d)[8]) {});
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         qv[t] = c[t >> 2][t & 3] * (0.25f * kLog2e);
         c[t >> 2][t & 3] = 0.0f;
       }
-      chain64q<64>(c, wk, xn, w, [&](float (&d)[8]) { ldq8<64>(d, wv, 0); });
+    }
+    __syncthreads();
+    *reinterpret_cast<float4 *>(s_wst + stage_dst) = pf;  // Wk
+    pf = fetch(VW_WV);
+    __syncthreads();
+    if (has_tile) {
+      ldq8<kRayWStride>(w, wst, 0);
+      chain64q<kRayWStride>(c, wst, xn, w, [&](float (&d)[8]) {});
       float *kw = Ks + (4 * hq) * kRayKStride + wave * 16 + i;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         kw[(16 * (t >> 2) + (t & 3)) * kRayKStride] = c[t >> 2][t & 3];
         c[t >> 2][t & 3] = 0.0f;
       }
-      chain64q<64>(c, wv, xn, w, [&](float (&d)[8]) {});
+    }
+    __syncthreads();
+    *reinterpret_cast<float4 *>(s_wst + stage_dst) = pf;  // Wv
+    pf = fetch(VW_WO);
+    __syncthreads();
+    if (has_tile) {
+      ldq8<kRayWStride>(w, wst, 0);
+      chain64q<kRayWStride>(c, wst, xn, w, [&](float (&d)[8]) {});
       float vv[16];
 #pragma unroll
       for (int t = 0; t < 16; ++t) vv[t] = c[t >> 2][t & 3];
       store_row16(Vs + (wave * 16 + i) * kRayVStride, vv, hq);
     }
     __syncthreads();
+    *reinterpret_cast<float4 *>(s_wst + stage_dst) = pf;  // Wo
+    pf = fetch(VW_WQ);
+    __syncthreads();  // K, V of the whole ray and Wo in place
     if (has_tile) {
       // y = Wo (attention output) + bo accumulates head by head: each head contributes its 16
       // features as 4 K-steps, so the attention output itself is never materialised
       floatx4 y[4];
       {
         float b[16];
-        load_row16(W + VW_WOB, b, hq);
+        load_row16(s_par + 128, b, hq);
 #pragma unroll
         for (int t = 0; t < 16; ++t) y[t >> 2][t & 3] = b[t];
       }
-      const float *wo = W + VW_WO + (4 * hq) * 64 + i;
+      const float *wo = wst;
 #pragma unroll
       for (int hh = 0; hh < 4; ++hh) {
         const float *kr = Ks + (16 * hh + 4 * hq) * kRayKStride + i;  // + r * stride + 16 * kt
@@ -822,7 +854,7 @@ gnt_ray_attn_kernel(const float *__restrict__ W_arg, const float *__restrict__ q
         for (int r = 0; r < 4; ++r) {
           const float av = O[r] * inv_l;  // feature 16*hh + 4*hq + r of the attention output
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) y[mt] = mfma16(wo[(16 * hh + r) * 64 + 16 * mt], av, y[mt]);
+          for (int mt = 0; mt < 4; ++mt) y[mt] = mfma16(wo[(16 * hh + r) * kRayWStride + 16 * mt], av, y[mt]);
         }
       }
       float xres[16];

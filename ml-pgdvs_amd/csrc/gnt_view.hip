@@ -200,7 +200,7 @@ constexpr int kSmP1B = VW_P1B - VW_P1, kSmP2 = VW_P2 - VW_P1, kSmP2B = VW_P2B - 
 constexpr int kSmA1B = VW_A1 - VW_P1;  // A1 itself lives in the padded region
 constexpr int kSmA2 = kSmA1B + (VW_A2 - VW_A1B), kSmA2B = kSmA1B + (VW_A2B - VW_A1B);
 constexpr int kSmallFloats = kSmA1B + (VW_WO - VW_A1B);
-constexpr int kViewLdsFloats = 2 * 64 * kWStride + 64 * kA1Stride + kSmallFloats;
+constexpr int kViewLdsFloats = 4 * 64 * kWStride + 64 * kA1Stride + kSmallFloats + 192;
 
 constexpr float kLog2e = 1.4426950408889634f;
 // The softmax over views keeps a per-feature reference logit m and rescales the running sums
@@ -279,7 +279,7 @@ __device__ __forceinline__ void pack_hidden(const float (&hid)[4], float (&hk)[2
 }
 
 template <bool STATS>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(512, 1)
 gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__ q_in,
                       const float *__restrict__ feat, const float *__restrict__ ray_diff,
                       const uint8_t *__restrict__ valid, int64_t N, int V, float *__restrict__ q_out,
@@ -290,16 +290,25 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
   // collide 2-way on every weight read).
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [kViewLdsFloats]
   float *s_wk = s_w, *s_wv = s_wk + 64 * kWStride, *s_a1 = s_wv + 64 * kWStride, *s_small = s_a1 + 64 * kA1Stride;
-  stage_f4<1024, 256>(W_arg + VW_WK, s_wk, [](int q) { return (q >> 4) * kWStride + 4 * (q & 15); });
-  stage_f4<1024, 256>(W_arg + VW_WV, s_wv, [](int q) { return (q >> 4) * kWStride + 4 * (q & 15); });
-  stage_f4<512, 256>(W_arg + VW_A1, s_a1, [](int q) { return (q >> 3) * kA1Stride + 4 * (q & 7); });
+  float *s_wq = s_small + kSmallFloats, *s_wo = s_wq + 64 * kWStride, *s_par = s_wo + 64 * kWStride;
+  constexpr auto row68 = [](int q) { return (q >> 4) * kWStride + 4 * (q & 15); };
+  stage_f4<1024, 512>(W_arg + VW_WK, s_wk, row68);
+  stage_f4<1024, 512>(W_arg + VW_WV, s_wv, row68);
+  stage_f4<512, 512>(W_arg + VW_A1, s_a1, [](int q) { return (q >> 3) * kA1Stride + 4 * (q & 7); });
   // s_small: P1 [4][32], P1B [32], P2 [8][64], P2B [64], A1B [32], A2 [8][64], A2B [64]
-  stage_f4<kSmA1B / 4, 256>(W_arg + VW_P1, s_small, [](int q) { return 4 * q; });
-  stage_f4<(kSmallFloats - kSmA1B) / 4, 256>(W_arg + VW_A1B, s_small + kSmA1B, [](int q) { return 4 * q; });
+  stage_f4<kSmA1B / 4, 512>(W_arg + VW_P1, s_small, [](int q) { return 4 * q; });
+  stage_f4<(kSmallFloats - kSmA1B) / 4, 512>(W_arg + VW_A1B, s_small + kSmA1B, [](int q) { return 4 * q; });
+  // the per-tile pieces too (q_fc, out_fc, LayerNorm, out_fc bias): from global memory they
+  // cost an L2 round trip per 8-MFMA chunk of a tile's prologue and epilogue
+  stage_f4<1024, 512>(W_arg + VW_WQ, s_wq, row68);
+  stage_f4<1024, 512>(W_arg + VW_WO, s_wo, row68);
+  stage_f4<32, 512>(W_arg + VW_LN1_G, s_par, [](int q) { return 4 * q; });        // gamma[64], beta[64]
+  stage_f4<16, 512>(W_arg + VW_WOB, s_par + 128, [](int q) { return 4 * q; });    // out_fc bias[64]
   __syncthreads();
   const int lane = threadIdx.x & 63, i = lane & 15, hq = lane >> 4;
   const int wave = threadIdx.x >> 6;
   // per-lane bases of the A operands: input row 4*hq (+ 16*c + r), output column i (+ 16*mt)
+  const float *wq = s_wq + (4 * hq) * kWStride + i, *wo = s_wo + (4 * hq) * kWStride + i;
   const float *wk = s_wk + (4 * hq) * kWStride + i;
   const float *wv = s_wv + (4 * hq) * kWStride + i;
   const float *wa1 = s_a1 + (4 * hq) * kA1Stride + i;
@@ -323,12 +332,17 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
   }
 
   const int64_t ntiles = (N + 15) / 16;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
     const int64_t g_raw = tile * 16 + i;
     const bool g_ok = g_raw < N;
     const int64_t g = g_ok ? g_raw : N - 1;
-    const float *W = opaque_uniform(W_arg);
     float w[8];
+    // the first view's row, validity flag and direction travel while q' is being formed
+    float f_nx[16], d_nx;
+    uint8_t ok_nx;
+    load_row16(feat + (g * V) * 64, f_nx, hq);
+    ok_nx = valid[g * V];
+    d_nx = ray_diff[(g * V) * 4 + hq];
     // q' = Wq LN(q) enters every view as (pos - q'): c1 = P2b - q' is the accumulator the
     // positional MLP's second layer starts from, so pq = pos - q' costs nothing; then
     // a = k + pq, and the value product starts from pq as well: sum_v attn (vv + pos - q'),
@@ -337,11 +351,10 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
     {
       float q0[16], x[16];
       load_row16(q_in + g * 64, q0, hq);
-      layer_norm64q(q0, W + VW_LN1_G, W + VW_LN1_B, 1e-6f, x, hq);
-      const float *wq = W + VW_WQ + (4 * hq) * 64 + i;
+      layer_norm64q(q0, s_par, s_par + 64, 1e-6f, x, hq);
       floatx4 qq[4] = {};
-      ldq8<64>(w, wq, 0);
-      chain64q<64>(qq, wq, x, w, [&](float (&d)[8]) { ldq8<kWStride>(d, wk, 0); });
+      ldq8<kWStride>(w, wq, 0);
+      chain64q<kWStride>(qq, wq, x, w, [&](float (&d)[8]) { ldq8<kWStride>(d, wk, 0); });
       float b[16];
       load_row16(sP2b, b, hq);
 #pragma unroll
@@ -362,11 +375,6 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       }
     }
     int nvalid = 0;
-    float f_nx[16], d_nx;
-    uint8_t ok_nx;
-    load_row16(feat + (g * V) * 64, f_nx, hq);
-    ok_nx = valid[g * V];
-    d_nx = ray_diff[(g * V) * 4 + hq];
     for (int v = 0; v < V; ++v) {
       const int64_t row = g * V + v;
       float k[16];
@@ -477,19 +485,18 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
     // x = Wo (acc / l + q') + bo + q ;  q_out = FF(LN(x)) + x
     float x1[16];
     {
+      float qres[16];
+      load_row16(q_in + g * 64, qres, hq);  // (long evicted: requested before the out_fc product)
       float xa[16], b[16];
       load_row16(sP2b, b, hq);
 #pragma unroll
       for (int t = 0; t < 16; ++t) xa[t] = acc[t] / l[t] + (b[t] - c1[t]);
-      const float *wo = W + VW_WO + (4 * hq) * 64 + i;
       floatx4 o[4];
-      load_row16(W + VW_WOB, b, hq);
+      load_row16(s_par + 128, b, hq);
 #pragma unroll
       for (int t = 0; t < 16; ++t) o[t >> 2][t & 3] = b[t];
-      ldq8<64>(w, wo, 0);
-      chain64q<64>(o, wo, xa, w, [&](float (&d)[8]) {});
-      float qres[16];
-      load_row16(q_in + g * 64, qres, hq);
+      ldq8<kWStride>(w, wo, 0);
+      chain64q<kWStride>(o, wo, xa, w, [&](float (&d)[8]) {});
 #pragma unroll
       for (int t = 0; t < 16; ++t) x1[t] = o[t >> 2][t & 3] + qres[t];
     }
@@ -917,14 +924,26 @@ PGDVS_API int pgdvs_gnt_view_layer(const float *weights, const float *q_in, cons
   PGDVS_REQUIRE(N >= 0 && V >= 1, "pgdvs_gnt_view_layer: bad shape");
   if (N == 0) return PGDVS_OK;
   const int64_t vtiles = cdiv(N, 16);
-  const unsigned grid = (unsigned)(cdiv(vtiles, 4) < 512 ? cdiv(vtiles, 4) : 512);
+  const unsigned grid = (unsigned)(cdiv(vtiles, 8) < 256 ? cdiv(vtiles, 8) : 256);
   const size_t lds = (size_t)kViewLdsFloats * sizeof(float);
   hipStream_t st = as_stream(stream);
+  static bool configured = false;
+  if (!configured) {
+    for (const void *fn : {reinterpret_cast<const void *>(gnt_view_layer_kernel<true>),
+                           reinterpret_cast<const void *>(gnt_view_layer_kernel<false>)}) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        set_error("gnt_view_layer: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+        return PGDVS_ERR_LAUNCH;
+      }
+    }
+    configured = true;
+  }
   if (stats) {
-    PGDVS_LAUNCH("gnt_view_layer", gnt_view_layer_kernel<true>, dim3(grid), dim3(256), lds, st, weights, q_in,
+    PGDVS_LAUNCH("gnt_view_layer", gnt_view_layer_kernel<true>, dim3(grid), dim3(512), lds, st, weights, q_in,
                  feat, ray_diff, valid, N, V, q_out, stats);
   } else {
-    PGDVS_LAUNCH("gnt_view_layer", gnt_view_layer_kernel<false>, dim3(grid), dim3(256), lds, st, weights, q_in,
+    PGDVS_LAUNCH("gnt_view_layer", gnt_view_layer_kernel<false>, dim3(grid), dim3(512), lds, st, weights, q_in,
                  feat, ray_diff, valid, N, V, q_out, stats);
   }
   if (launch_ff(weights, q_out, N, st) != PGDVS_OK) return PGDVS_ERR_LAUNCH;

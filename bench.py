@@ -379,7 +379,7 @@ def main():
         gflop = 2.0 * Rg * Sg * (1048064 + 84416 * Vg)
         gnt = {"rays": Rg, "samples_per_ray": Sg, "views": Vg, "layers": 8, "ms_per_chunk": round(gdt * 1e3, 2),
                "tflops": round(gflop / gdt / 1e12, 2), "peak_tflops_fp32_mfma": 157.3,
-               "frac_of_peak": round(gflop / gdt / 157.3e12, 4), "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
+               "frac_of_peak": round(gflop / gdt / 157.3e12, 4), "dtype": "f32 (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)",
                "est_seconds_per_1080p_frame": round(gdt * (H * W / Rg), 1),
                "note": "GNT.forward incl. view entropy/std side outputs; synthetic gathered features"}
 

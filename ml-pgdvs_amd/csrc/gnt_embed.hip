@@ -12,6 +12,9 @@
 namespace pgdvs {
 
 constexpr int kEmbStride = 68;  // padded LDS rows (see gnt_view.hip: 4 * 68 = 16 mod 32 banks)
+// the first layer's K-steps take input rows 4*s + hq: the two quarters of a ds_read_b32 lane group
+// are ONE row apart, so its rows are padded to 80 floats (80 = 16 mod 32)
+constexpr int kEmb1Stride = 80;
 
 // packed weights (floats): W1t [4*KS in (zero padded)][64 out], b1 [64], W2t [64 in][64 out], b2 [64]
 template <int KS>
@@ -19,15 +22,15 @@ __global__ void __launch_bounds__(256, 2)
 gnt_embed_kernel(const float *__restrict__ W_arg, const float *__restrict__ rgb_feat, int64_t N, int V, int Cin,
                  float *__restrict__ feat, float *__restrict__ q0, float *__restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];
-  float *s_w1 = s_w, *s_w2 = s_w + 4 * KS * kEmbStride;
+  float *s_w1 = s_w, *s_w2 = s_w + 4 * KS * kEmb1Stride;
   const float *b1g = W_arg + 4 * KS * 64, *w2g = b1g + 64, *b2g = w2g + 4096;
-  stage_f4<4 * KS * 16, 256>(W_arg, s_w1, [](int q) { return (q >> 4) * kEmbStride + 4 * (q & 15); });
+  stage_f4<4 * KS * 16, 256>(W_arg, s_w1, [](int q) { return (q >> 4) * kEmb1Stride + 4 * (q & 15); });
   stage_f4<1024, 256>(w2g, s_w2, [](int q) { return (q >> 4) * kEmbStride + 4 * (q & 15); });
   __syncthreads();
   const int lane = threadIdx.x & 63, i = lane & 15, hq = lane >> 4;
   const int wave = threadIdx.x >> 6;
   // layer 1 takes the raw row as B operand: K-step s <-> input channel 4*s + hq
-  const float *w1 = s_w1 + hq * kEmbStride + i;
+  const float *w1 = s_w1 + hq * kEmb1Stride + i;
   // layer 2 takes layer 1's accumulators: K-step (c,r) <-> hidden unit 16*c + 4*hq + r
   const float *w2 = s_w2 + (4 * hq) * kEmbStride + i;
   float b1[16], b2[16];
@@ -78,7 +81,7 @@ gnt_embed_kernel(const float *__restrict__ W_arg, const float *__restrict__ rgb_
         for (int s = 0; s < KS; s += 2) {
           if (s + 1 < KS) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) wb[mt] = w1[(4 * (s + 1)) * kEmbStride + 16 * mt];
+            for (int mt = 0; mt < 4; ++mt) wb[mt] = w1[(4 * (s + 1)) * kEmb1Stride + 16 * mt];
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -86,7 +89,7 @@ gnt_embed_kernel(const float *__restrict__ W_arg, const float *__restrict__ rgb_
           __builtin_amdgcn_sched_barrier(0);
           if (s + 2 < KS) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) wa[mt] = w1[(4 * (s + 2)) * kEmbStride + 16 * mt];
+            for (int mt = 0; mt < 4; ++mt) wa[mt] = w1[(4 * (s + 2)) * kEmb1Stride + 16 * mt];
           }
           __builtin_amdgcn_sched_barrier(0);
           if (s + 1 < KS) {
@@ -163,7 +166,7 @@ PGDVS_API int pgdvs_gnt_embed(const float *weights, const float *rgb_feat, int64
   constexpr int KS = 9;
   const int64_t tiles = cdiv(N, 16);
   const unsigned grid = (unsigned)(cdiv(tiles, 4) < 512 ? cdiv(tiles, 4) : 512);
-  const size_t lds = (size_t)(4 * KS + 64) * kEmbStride * sizeof(float);
+  const size_t lds = (size_t)(4 * KS * kEmb1Stride + 64 * kEmbStride) * sizeof(float);
   PGDVS_LAUNCH("gnt_embed", gnt_embed_kernel<KS>, dim3(grid), dim3(256), lds, as_stream(stream), weights, rgb_feat, N,
                V, Cin, feat, q0, stats);
   return check_launch("gnt_embed");

@@ -249,6 +249,12 @@ int pgdvs_gnt_posfc(const float *weights, const float *q_in, const float *T, int
                     const float *tv, int64_t tv_stride, int64_t N, int S, float *q_out,
                     pgdvs_stream_t stream);
 
+/* A14, exit of GNT.forward (transformer_network.py:533-535):
+ * rgb_out[R,3] = rgb_fc(mean over the S samples of LayerNorm(q[R,S,64])), eps 1e-5.
+ *   weights: gamma[64], beta[64], rgb_fc weight [3][64], rgb_fc bias[3]. */
+int pgdvs_gnt_head(const float *weights, const float *q, int R, int S, float *rgb_out,
+                   pgdvs_stream_t stream);
+
 /* A14 (view transformer): one fused fp32-MFMA kernel per GNT layer = Transformer2D +
  * Attention2D of pgdvs/models/gnt/models/transformer_network.py:59-169,197-223 (width 64).
  *   weights: pgdvs_gnt_view_weight_floats() floats, packed input-major as laid out in

@@ -242,3 +242,74 @@ PGDVS_API int pgdvs_gnt_posfc(const float *weights, const float *q_in, const flo
                tv, tv_stride, N, S, q_out);
   return check_launch("gnt_posfc");
 }
+
+// ---------------------------------------------------------------------------------------
+// Exit of GNT.forward (transformer_network.py:533-535): rgb = rgb_fc(mean_samples(LayerNorm(q))),
+// LayerNorm eps 1e-5 (nn.LayerNorm default).  One workgroup per ray, one thread per sample (a
+// thread owns whole rows, so the normalisation needs no cross-lane traffic); the per-thread sums
+// are combined in a fixed order through LDS.
+//   weights (floats): gamma[64], beta[64], rgb_fc weight [3][64], rgb_fc bias[3]
+// ---------------------------------------------------------------------------------------
+namespace pgdvs {
+
+__global__ void __launch_bounds__(256)
+gnt_head_kernel(const float *__restrict__ W, const float *__restrict__ q, int R, int S, float *__restrict__ out) {
+  __shared__ float s_part[4][64];
+  __shared__ float s_h[64];
+  const int ray = blockIdx.x;
+  float acc[64];
+#pragma unroll
+  for (int f = 0; f < 64; ++f) acc[f] = 0.0f;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    const float4 *row = reinterpret_cast<const float4 *>(q + ((int64_t)ray * S + s) * 64);
+    float x[64];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float4 v = row[c];
+      x[4 * c] = v.x;
+      x[4 * c + 1] = v.y;
+      x[4 * c + 2] = v.z;
+      x[4 * c + 3] = v.w;
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int f = 0; f < 64; ++f) sum += x[f];
+    const float mean = sum * (1.0f / 64.0f);
+    float var = 0.0f;
+#pragma unroll
+    for (int f = 0; f < 64; ++f) var += (x[f] - mean) * (x[f] - mean);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+    for (int f = 0; f < 64; ++f) acc[f] += (x[f] - mean) * rstd;
+  }
+  // wavefront sums (xor butterfly: every lane ends with the same value, fixed order), then the four wavefronts
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int f = 0; f < 64; ++f) {
+    float v = acc[f];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == f) s_part[wave][f] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int f = threadIdx.x;
+    const float m = (s_part[0][f] + s_part[1][f] + s_part[2][f] + s_part[3][f]) / (float)S;
+    s_h[f] = m * W[f] + W[64 + f];  // gamma * mean(normalised) + beta = mean(LayerNorm(q))
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float o = W[128 + 192 + threadIdx.x];
+    for (int f = 0; f < 64; ++f) o += W[128 + threadIdx.x * 64 + f] * s_h[f];
+    out[(int64_t)ray * 3 + threadIdx.x] = o;
+  }
+}
+
+}  // namespace pgdvs
+
+PGDVS_API int pgdvs_gnt_head(const float *weights, const float *q, int R, int S, float *rgb_out, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(weights && q && rgb_out && R >= 0 && S >= 1, "pgdvs_gnt_head: bad arguments");
+  if (R == 0) return PGDVS_OK;
+  PGDVS_LAUNCH("gnt_head", gnt_head_kernel, dim3((unsigned)R), dim3(256), 0, as_stream(stream), weights, q, R, S, rgb_out);
+  return check_launch("gnt_head");
+}

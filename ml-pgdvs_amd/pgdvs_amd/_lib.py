@@ -51,6 +51,7 @@ SIGNATURES = {
     "pgdvs_gnt_embed_weight_floats": (_i64, [_i]),
     "pgdvs_gnt_embed": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "pgdvs_gnt_posfc": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i, _vp, _vp]),
+    "pgdvs_gnt_head": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pgdvs_gnt_view_weight_floats": (_i64, []),
     "pgdvs_gnt_view_layer": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "pgdvs_gnt_ray_layer": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),

@@ -75,11 +75,10 @@ class Transformer(nn.Module):
 
 
 def _posenc(x, n_freqs, max_log2):
+    """[x, sin(x f0), cos(x f0), sin(x f1), ...] (gnt/common.py Embedder order), all frequencies in one pass"""
     freqs = 2.0 ** torch.linspace(0.0, max_log2, steps=n_freqs, device=x.device)
-    parts = [x]
-    for f in freqs:
-        parts += [torch.sin(x * f), torch.cos(x * f)]
-    return torch.cat(parts, -1)
+    xf = x[..., None, :] * freqs[:, None]  # [..., F, 3]
+    return torch.cat((x, torch.cat((torch.sin(xf), torch.cos(xf)), -1).flatten(-2)), -1)
 
 
 class GNT(nn.Module):
@@ -198,7 +197,10 @@ class GNT(nn.Module):
         if ret_view_std:
             extras["view_std"] = torch.stack(stds, dim=2)
             extras["view_std_normalized"] = torch.stack(stdns, dim=2)
-        outputs = self.rgb_fc(self.norm(q).mean(dim=1))
+        if q.is_cuda and ops.gnt_head_available(self.norm, self.rgb_fc):
+            outputs = ops.gnt_head(self.norm, self.rgb_fc, q)
+        else:
+            outputs = self.rgb_fc(self.norm(q).mean(dim=1))
         if self.ret_alpha:
             return torch.cat([outputs, attn], dim=1), extras
         return outputs, extras

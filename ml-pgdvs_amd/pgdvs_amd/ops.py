@@ -537,6 +537,24 @@ class GntPosFc:
         return out
 
 
+def gnt_head_available(norm, rgb_fc) -> bool:
+    return (_GNT_VIEW_ENABLED and tuple(norm.normalized_shape) == (64,) and abs(norm.eps - 1e-5) < 1e-12
+            and rgb_fc.in_features == 64 and rgb_fc.out_features == 3)
+
+
+def gnt_head(norm, rgb_fc, q):
+    """rgb_fc(norm(q).mean(dim=1)): q[R,S,64] -> [R,3]"""
+    packed = getattr(rgb_fc, "_pgdvs_packed", None)
+    if packed is None or packed.device != q.device:
+        packed = torch.cat([p.detach().float().contiguous().reshape(-1) for p in (norm.weight, norm.bias, rgb_fc.weight, rgb_fc.bias)])
+        rgb_fc._pgdvs_packed = packed
+    qi = _req(q, torch.float32, "q")
+    R, S, _ = qi.shape
+    out = torch.empty((R, 3), dtype=torch.float32, device=q.device)
+    check(_lib.load().pgdvs_gnt_head(_ptr(packed), _ptr(qi), R, S, _ptr(out), _stream()), "pgdvs_gnt_head")
+    return out
+
+
 def pack_ray_layer(layer) -> torch.Tensor:
     """Ray-transformer layer (Transformer) in the same packed layout; view-only regions stay 0."""
     a = layer.attn

@@ -974,6 +974,21 @@ def test_gnt_posfc_mfma_vs_torch():
             np.testing.assert_allclose(N(out), N(ref), rtol=1e-4, atol=3e-5)
 
 
+@pytest.mark.parametrize("S", [1, 37, 256, 300])
+def test_gnt_head_vs_torch(S):
+    from pgdvs_amd.models.gnt.models.transformer_network import GNT
+
+    torch.manual_seed(3 + S)
+    net = GNT(netwidth=64, transformer_depth=1).to(DEV).eval()
+    with torch.no_grad():
+        net.norm.weight.add_(torch.randn_like(net.norm.weight) * 0.3)
+        net.norm.bias.add_(torch.randn_like(net.norm.bias) * 0.3)
+        q = torch.randn(19, S, 64, device=DEV) * 2 + 0.5
+        out = ops.gnt_head(net.norm, net.rgb_fc, q)
+        ref = net.rgb_fc(net.norm(q).mean(dim=1))
+    np.testing.assert_allclose(N(out), N(ref), rtol=1e-5, atol=2e-6)
+
+
 @pytest.mark.parametrize("S", [1, 12, 33, 64, 256])
 def test_gnt_ray_layer_mfma_vs_torch(S):
     """Fused ray-transformer kernel (LN, QKV, 4-head attention over the samples of a ray, out_fc,

@@ -99,6 +99,40 @@ def algorithmic_bytes(name, H, W, S, n_static, n_dyn, K):
     return float(table.get(name, 0.0))
 
 
+def gnt_full_frame(dev, H=288, W=550, V=10, chunk=1024):
+    """seconds per target view of PGDVSRenderer.forward with static_renderer=gnt (random-init
+    8-layer GNT + ResUNet features + dynamic splat + composite) on synthetic inputs"""
+    from pgdvs_amd import synth
+    from pgdvs_amd.instantiate import load_config
+    from pgdvs_amd.renderers.pgdvs_renderer import PGDVSRenderer
+
+    cfg = load_config(static_renderer="gnt")
+    rc = cfg.engine.engine_cfg.render_cfg
+    rc.chunk_size, rc.n_coarse_samples_per_ray = chunk, 256
+    rc.gnt_use_masked_spatial_src, rc.gnt_use_dyn_mask = False, True
+    torch.manual_seed(0)
+    model = PGDVSRenderer(cfg, render_cfg=rc).to(dev).eval()
+    video = synth.make_video(V, H, W, seed=3)
+    d = synth.to_torch(synth.make_view(video, V // 2, seed=1), dev)
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)  # noqa: E731
+    d["rgb_src_spatial"] = T(video["rgbs"])[None]
+    d["dyn_mask_src_spatial"] = T(video["dyn_masks"].astype(np.float32))[None, ..., None]
+    d["flat_cam_src_spatial"] = T(np.stack([synth.flat_cam(H, W, video["K3s"][i], video["c2ws"][i]) for i in range(V)]))[None]
+    d["depth_range"] = T(np.array([[0.8, 5.0]]))
+    with torch.no_grad():
+        ret = model.forward(d, render_cfg=rc, disable_tqdm=True)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(ret["combined_rgb"]).all())
+        t0 = time.perf_counter()
+        model.forward(d, render_cfg=rc, disable_tqdm=True)
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"seconds_per_view": round(dt, 3), "frames_per_s": round(1.0 / dt, 3), "height": H, "width": W, "spatial_views": V,
+            "temporal_views": 2, "samples_per_ray": 256, "chunk_rays": chunk, "weights": "random init",
+            "reference_context": "the reference states ~2 days on 8 A100 for 15 840 such views incl. data loading and metrics "
+                                 "(docs/BENCHMARK_NVIDIA.md:148-149): ~87 s per view per GPU; not the same hardware or scope"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -382,6 +416,13 @@ def main():
                "frac_of_peak": round(gflop / gdt / 157.3e12, 4), "dtype": "f32 (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)",
                "est_seconds_per_1080p_frame": round(gdt * (H * W / Rg), 1),
                "note": "GNT.forward incl. view entropy/std side outputs; synthetic gathered features"}
+        # The whole renderer with the GNT static renderer at the reference's own benchmark setting
+        # (NVIDIA Dynamic Scenes: 288 x 550 targets, 10 spatial + 2 temporal source views, 256 samples
+        # per ray, chunks of 1024 rays).  Informational, never `value`.
+        try:
+            gnt["pgdvs_forward_288x550_10views"] = gnt_full_frame(dev)
+        except Exception as e:  # noqa: BLE001 -- the headline number does not depend on it
+            gnt["pgdvs_forward_288x550_10views"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         frames = args.steps * world

@@ -261,6 +261,17 @@ def main():
         lib.pgdvs_prof_enable(0)
         return t1 - t0, gathered, cnt
 
+    if os.environ.get("PGDVS_BENCH_OP_TABLE"):  # diagnostic: which torch ops / copies one eager view issues
+        from torch.profiler import ProfilerActivity, profile
+
+        step_eager(0, 0)
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            step_eager(1, 0)
+            torch.cuda.synchronize()
+        print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=50),
+              file=sys.stderr)
+
     ref_img = None
     for j in range(max(args.warmup, n_lanes)):
         img = step(j)[0]

@@ -420,6 +420,33 @@ def test_render_view_geo_vs_oracle(H, W, S, rm, K):
     assert mse < 1e-8  # PSNR-equivalent bound (>= 80 dB)
 
 
+def test_config_c2_540p_12_frames_vs_oracle():
+    """BASELINE.json configs[1]: 540p target, 12 source frames -- the whole per-view path (static
+    aggregation, z-buffer raster K=3, flow-warped splat with the outlier filter, composite) against
+    the CPU oracle at the benchmark's own settings (tens of seconds of oracle time)."""
+    H, W, S = 540, 960, 12
+    v = synth.make_video(S, H, W, seed=1234)
+    d = synth.make_view(v, S // 2 - 1, seed=0)
+    cloud, cnt = ops.static_aggregate(T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]), v["K3s"], v["c2ws"], capacity=S * H * W)
+    o_cloud = orc.aggregate_static_pcl(v["rgbs"], v["depths"], v["dyn_masks"], v["K3s"], v["c2ws"])
+    n = int(cnt.item())
+    assert n == o_cloud.shape[0]
+    assert np.array_equal(N(cloud[:n]).view(np.uint32), o_cloud.view(np.uint32))  # ordered, bit-exact
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=True, st_render_pcl_pts_per_pixel=3)
+    data = synth.to_torch(d, DEV)
+    data["st_pcl_rgb"], data["st_pcl_rgb_count"] = cloud[None], cnt
+    with torch.no_grad():
+        ret = model.forward(data, render_cfg=rc)
+    od = dict(d)
+    od["st_pcl_rgb"] = o_cloud[None]
+    o = orc.render_view(od, dict(rc), static_noise=d["static_noise"], alpha=100.0)
+    assert np.array_equal(N(ret["geo_static_mask"]), o["geo_static_mask"])
+    assert np.array_equal(N(ret["render_dyn_mask"]), o["render_dyn_mask"])
+    for k in ["geo_static_rgb", "render_dyn_rgb", "combined_rgb"]:
+        np.testing.assert_allclose(N(ret[k]), o[k], rtol=0, atol=1e-4, err_msg=k)
+    assert float(np.mean((N(ret["combined_rgb"]) - o["combined_rgb"]) ** 2)) < 1e-8
+
+
 def test_dyn_pcl_render_type_vs_oracle():
     v = synth.make_video(3, 54, 96, seed=5)
     d = synth.make_view(v, 0, seed=1)

@@ -1,26 +1,24 @@
-// A14 (view transformer): one fused kernel per GNT layer for Transformer2D + Attention2D
-// (pgdvs/models/gnt/models/transformer_network.py:59-169,197-223) on the fp32 matrix cores.
+// A14: the per-layer kernels of GNT.forward (pgdvs/models/gnt/models/transformer_network.py):
+//   gnt_view_layer   Transformer2D + Attention2D (:59-169,197-223), attention part
+//   gnt_ray_attn     Transformer + Attention, attn_mode="qk" (:231-338), attention part
+//   gnt_ff           the feed-forward block that follows both (:44-55,:218-221)
+// all on the fp32 matrix cores (exact fp32 products, fp32 accumulate: TF32 is off in the
+// reference, pgdvs/run.py:21-24, and outputs must agree to 1e-4).
 //
+// View layer, per (ray,sample) group:
 //   x = LN(q); q' = Wq x
 //   for every source view v:  k = Wk f_v ; vv = Wv k ; pos = P2 relu(P1 d_v + b) + b ;
 //                             a = A2 relu(A1 (k - q' + pos) + b) + b          (64 -> 8 -> 64)
 //   attn = softmax_v(a) (masked);  x = Wo sum_v (vv + pos) * attn + bo + q
-//   q_out = F2 relu(F1 LN(x) + b) + b + x
 //
-// MI355X mapping.  Everything is computed TRANSPOSED: the 64 features run along the MFMA M
-// dimension, 32 (ray,sample) groups along N, so that
-//   * weights are the A operand: lane (i, h) reads Wt[in = feature(t,h)][out = 32*mt + i],
-//     a contiguous 128-byte row segment per half-wave (weights are stored input-major);
-//   * activations are the B operand: lane (j, h) keeps, for ITS group j, the 32 features
-//     feature(t,h) = (t&3) + 8*((t&15)>>2) + 4*h + 32*(t>>4), t = 0..31, in registers;
-//   * the accumulator layout of v_mfma_f32_32x32x2_f32 (row = (r&3) + 8*(r>>2) + 4*h) is the
-//     same feature(t,h) map, so a layer's output registers ARE the next layer's B operand --
-//     the whole chain (k -> vv, k -> attention MLP, FF) never leaves registers, no LDS
-//     transposes;
-//   * the softmax over views is a per-lane online softmax (running max / sum / weighted sum
-//     per feature), no cross-lane traffic; the view loop streams each f_v row once.
-// f32-input MFMA (exact fp32 products, fp32 accumulate): TF32 is off in the reference
-// (pgdvs/run.py:21-24) and outputs must agree to 1e-4.
+// Everything is computed TRANSPOSED: features run along the MFMA M dimension, groups along N;
+// weights are the A operand (input-major rows), activations the B operand, one group per lane
+// column; an accumulator's register layout is the next product's B-operand layout, so chained
+// layers never leave registers.  Tile shapes and helpers: gnt_mfma.h (16-row tiles) for the two
+// attention kernels; the feed-forward block keeps 32-row tiles on v_mfma_f32_32x32x2_f32 (it
+// carries little per-lane state, and a 32-row tile reads each LDS weight half as often).
+// What bounds these kernels (vector-ALU work never overlaps the fp32 MFMA, global loads must
+// not sit in front of accumulator chains): DESIGN.md section 4.
 #include "common.h"
 #include "gnt_mfma.h"
 
@@ -52,94 +50,15 @@ constexpr int VW_F2 = VW_F1B + 256;               // [256 in][64 out]
 constexpr int VW_F2B = VW_F2 + 16384;             // [64]
 constexpr int VW_TOTAL = VW_F2B + 64;
 
+// 32-row tiles (feed-forward block): lane (i, h) keeps, for its row i, the 32 features
 // feature(t,h) = featc(t) + 4*h.  The lane-dependent 4*h always goes into a per-lane BASE
 // pointer and featc(t) stays a compile-time constant, so every access is base + immediate
 // (written as one sum, the compiler merges 4*h with OR and materialises one address register
 // per element).
 __host__ __device__ constexpr int featc(int t) { return (t & 3) + 8 * ((t & 15) >> 2) + 32 * (t >> 4); }
-__device__ __forceinline__ int feat_of(int t, int h) { return featc(t) + 4 * h; }
 
 __device__ __forceinline__ floatx16 mfma(float a, float b, floatx16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// y[32] = W x (+ bias): 64 -> 64.  Wt input-major [64][64]; x, y in feature(t,h) layout.
-__device__ __forceinline__ void lin64x64(const float *__restrict__ Wt, const float *__restrict__ bias,
-                                         const float (&x)[32], float (&y)[32], int i, int h) {
-  const float *wb = Wt + (4 * h) * 64 + i;
-  const float *bb = bias ? bias + 4 * h : nullptr;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    floatx16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = bb ? bb[featc(r + 16 * mt)] : 0.0f;
-#pragma unroll
-    for (int t0 = 0; t0 < 32; t0 += 8) {
-      // keep at most 8 weight registers live: the scheduler must not hoist all 64 loads
-      float w[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) w[u] = wb[featc(t0 + u) * 64 + mt * 32];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc = mfma(w[u], x[t0 + u], acc);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) y[r + 16 * mt] = acc[r];
-  }
-}
-
-// hid[4] = relu(W x + b): 64 -> 8 (M padded to 32).  Wt [64][32]; lane-half h gets hidden 4h..4h+3
-__device__ __forceinline__ void lin64x8_relu(const float *__restrict__ Wt, const float *__restrict__ bias,
-                                             const float (&x)[32], float (&hid)[4], int i, int h) {
-  floatx16 acc;
-  const float *wb = Wt + (4 * h) * 32 + i;
-  const float *bb = bias + 4 * h;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = r < 4 ? bb[r] : 0.0f;
-#pragma unroll
-  for (int t0 = 0; t0 < 32; t0 += 8) {
-    float w[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) w[u] = wb[featc(t0 + u) * 32];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc = mfma(w[u], x[t0 + u], acc);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) hid[r] = fmaxf(acc[r], 0.0f);
-}
-
-// y[32] = W hid + b: 8 -> 64.  Wt [8][64]
-__device__ __forceinline__ void lin8x64(const float *__restrict__ Wt, const float *__restrict__ bias,
-                                        const float (&hid)[4], float (&y)[32], int i, int h) {
-  const float *wb = Wt + (4 * h) * 64 + i;
-  const float *bb = bias + 4 * h;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    floatx16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = bb[featc(r + 16 * mt)];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc = mfma(wb[t * 64 + mt * 32], hid[t], acc);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) y[r + 16 * mt] = acc[r];
-  }
-}
-
-// hid[4] = relu(W d + b): 4 -> 8.  Wt [4][32]; lane-half h supplies d[2t+h]
-__device__ __forceinline__ void lin4x8_relu(const float *__restrict__ Wt, const float *__restrict__ bias,
-                                            const float (&d2)[2], float (&hid)[4], int i, int h) {
-  floatx16 acc;
-  const float *wb = Wt + h * 32 + i;
-  const float *bb = bias + 4 * h;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = r < 4 ? bb[r] : 0.0f;
-#pragma unroll
-  for (int t = 0; t < 2; ++t) acc = mfma(wb[2 * t * 32], d2[t], acc);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) hid[r] = fmaxf(acc[r], 0.0f);
 }
 
 // LayerNorm over the 64 features of a group (32 here, 32 in the partner lane l^32)

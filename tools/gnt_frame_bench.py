@@ -50,4 +50,4 @@ print(f"PGDVSRenderer.forward, GNT static renderer, {H}x{W}, {V} spatial + 2 tem
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     run(); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=16, max_name_column_width=70))
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=30, max_name_column_width=70))

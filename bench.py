@@ -453,7 +453,15 @@ def main():
                 "whole_view_alg_bytes": alg_total,
                 "whole_view_alg_GBps": round(alg_total * fps / 1e9 / max(world, 1), 2),
             },
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "gnt": gnt, "variants": variants, "kernels": kernels,
+            "roofline": roofline,
+            # BASELINE.md section 3 defines the path's roofline figure over the whole view:
+            # bytes(S,P) = (20 S + 120) H W algorithmic bytes per novel view x views per second per GPU
+            "roofline_path": {"bound": "hbm", "achieved": round(alg_total * fps / 1e9 / max(world, 1), 2), "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": round(alg_total * fps / 1e9 / max(world, 1) / HBM_PEAK_GBS, 5),
+                              "alg_bytes_per_view": alg_total,
+                              "note": "all kernels of a view; the path is bound by search / z-buffer / fp64 re-projection work, "
+                                      "not by streaming its inputs (DESIGN.md section 4)"},
+            "cpu_baseline": cpu_baseline, "gnt": gnt, "variants": variants, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

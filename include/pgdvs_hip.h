@@ -15,7 +15,8 @@
  *   - `stream` is a hipStream_t (NULL = default stream); every call only enqueues
  *     work on it and never synchronises or allocates (one diagnostics switch does
  *     synchronise: PGDVS_KNN_STATS=1 in the environment makes the kNN print its ring
- *     histogram to stderr);
+ *     histogram to stderr; PGDVS_KNN_NO_TPQ=1 and PGDVS_KNN_PER_CELL=<n> select kNN search
+ *     variants / the grid density for tuning -- results are identical for any setting);
  *   - return value: 0 on success, negative pgdvs_status on error, message via
  *     pgdvs_last_error() (thread-local);
  *   - no global mutable state; re-entrant per stream.

@@ -10,6 +10,8 @@
 // kRingCap rings (isolated outliers) repeat the search on a second-level grid with
 // kCoarseScale-times larger cells; the few still open after that are scanned exhaustively.
 //
+// Self-queries first go through a THREAD-per-query pass over the 3x3x3 block of their cell
+// (grid_query_tpq_kernel, below); what that leaves open, and cross-set queries, use:
 // One WAVEFRONT per query: the 64 lanes evaluate 64 candidates per step with coalesced
 // 16-byte loads of the cell-sorted point array; the sorted best-list lives one value per
 // lane in a register (lane k holds the k-th smallest), so an insertion is a ballot, one DPP
@@ -23,6 +25,9 @@ namespace pgdvs {
 
 constexpr int kGridMaxCells = 1 << 24;
 constexpr int kRingCap = 24;
+// After the thread-per-query pass the ring search only sees the sparse remainder, whose long
+// searches are no longer hidden behind the bulk: hand them to the coarse grid after a few rings.
+constexpr int kRingCapAfterTpq = 3;
 constexpr float kTargetPerCellDefault = 24.0f;
 
 struct GridParams {
@@ -671,6 +676,164 @@ grid_query_body(const GridParams *__restrict__ gp, const float4 *__restrict__ so
   }
 }
 
+// ---- first pass of self-queries: one THREAD per query, ring 1 only ----------------------
+// With ~24 points per occupied cell, 99.6 % of the queries of a depth-map cloud are settled by
+// the 3x3x3 block around their own cell (ring histogram, PGDVS_KNN_STATS=1).  For those the
+// wavefront-per-query search above spends most of its ~1050 vector instructions per query on
+// serial insertions and on a 64-wide sort; here a lane owns a query and keeps its K+1 best in
+// registers as a sorted list, inserting with a chain of (min, max) pairs.  Lanes are
+// consecutive in cell-sorted order, so a wavefront's lanes walk (nearly) the same nine x-runs
+// of the sorted point array: the per-lane candidate loads coalesce into broadcasts.  A
+// candidate that beats the lane's (K+1)-th best is parked in a 4-deep per-lane queue; the
+// 2*(K+1)-instruction insertion chain runs only when some lane's queue is full, i.e. about
+// once per four *accepted* candidates of the busiest lane instead of once per candidate.
+// About 350 vector instructions per query.  Queries whose list is not provably complete after
+// ring 1 (the same criterion as above) are handed to the wavefront-per-query search.
+// The average is summed in the same 64-slot butterfly order as knn_finish.
+constexpr int kTpqQueue = 4;
+
+template <int KK>
+__device__ __forceinline__ void tpq_insert(float (&a)[KK], float c) {
+#pragma unroll
+  for (int i = 0; i < KK; ++i) {
+    const float lo = __builtin_fminf(a[i], c);
+    c = __builtin_fmaxf(a[i], c);
+    a[i] = lo;
+  }
+}
+
+template <int KK>
+__global__ void __launch_bounds__(256)
+grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted,
+                      const int32_t *__restrict__ cell_start, int first_col, float *__restrict__ avg_out,
+                      int32_t *__restrict__ open_count, int32_t *__restrict__ open_list) {
+  __shared__ int2 s_run[9][256];
+  __shared__ float s_bd[9][256];
+  const GridParams g = *gp;
+  const int n = g.n;
+  const int tid = threadIdx.x;
+  // persistent workgroups (no barrier is used: every wavefront only touches its own LDS columns)
+  for (int q0 = blockIdx.x * 256; q0 < n; q0 += gridDim.x * 256) {
+  const int q = q0 + tid;
+  const bool live = q < n;
+  const float4 qp = sorted[live ? q : n - 1];
+  const float qx = qp.x, qy = qp.y, qz = qp.z;
+  const int cx = cell_coord(qx, g.mn[0], g.inv_h, g.G[0]);
+  const int cy = cell_coord(qy, g.mn[1], g.inv_h, g.G[1]);
+  const int cz = cell_coord(qz, g.mn[2], g.inv_h, g.G[2]);
+  // the nine (dy,dz) rows of the block as x-runs, nearest first (same order as the ring-1 pass above)
+  {
+    const int x0 = cx - 1 < 0 ? 0 : cx - 1;
+    const int x1 = cx + 1 >= g.G[0] ? g.G[0] - 1 : cx + 1;
+    const float bx = box_axis_dist2(qx, g.mn[0], g.h, x0, x1, g.G[0]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int row_id = (int)((0x862071534ull >> (k * 4)) & 15);
+      const int dz = row_id / 3 - 1, dy = row_id % 3 - 1;
+      const int z = cz + dz, y = cy + dy;
+      int2 se = make_int2(0, 0);
+      float bd = 0.0f;
+      if (live && z >= 0 && z < g.G[2] && y >= 0 && y < g.G[1]) {
+        const int row = (z * g.G[1] + y) * g.G[0];
+        se.x = cell_start[row + x0];
+        se.y = cell_start[row + x1 + 1];
+        bd = bx + box_axis_dist2(qy, g.mn[1], g.h, y, y, g.G[1]) + box_axis_dist2(qz, g.mn[2], g.h, z, z, g.G[2]);
+      }
+      s_run[k][tid] = se;
+      s_bd[k][tid] = bd;
+    }
+  }
+  float a[KK];
+#pragma unroll
+  for (int i = 0; i < KK; ++i) a[i] = __builtin_inff();
+  float mx = __builtin_inff();
+  float qd[kTpqQueue];
+#pragma unroll
+  for (int u = 0; u < kTpqQueue; ++u) qd[u] = __builtin_inff();
+  int qc = 0;
+  int k = -1, j = 0, e = 0;
+  float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);  // candidate j, requested one step ahead
+  for (;;) {
+    if (j >= e && k < 9) {  // this lane's run is exhausted: next row (one per step)
+      ++k;
+      if (k < 9) {
+        const int2 se = s_run[k][tid];
+        j = se.x;
+        e = s_bd[k][tid] < mx ? se.y : se.x;  // no point of the run can enter the list: skip it
+        if (j < e) pn = sorted[j];
+      }
+    }
+    const bool act = j < e;
+    if (__builtin_amdgcn_ballot_w64(act || k < 9) == 0) break;
+    if (act) {
+      const float d = dist2(qx, qy, qz, pn);
+      ++j;
+      if (j < e) pn = sorted[j];
+      if (d < mx) {  // (stale threshold: a candidate that no longer qualifies lands beyond column K)
+#pragma unroll
+        for (int u = kTpqQueue - 1; u > 0; --u) qd[u] = qd[u - 1];
+        qd[0] = d;
+        ++qc;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(qc == kTpqQueue) != 0) {
+#pragma unroll
+      for (int u = 0; u < kTpqQueue; ++u) {
+        tpq_insert<KK>(a, qd[u]);
+        qd[u] = __builtin_inff();
+        __builtin_amdgcn_sched_barrier(0);  // one chain at a time: interleaved chains double the live registers
+      }
+      qc = 0;
+      mx = a[KK - 1];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kTpqQueue; ++u) {
+    tpq_insert<KK>(a, qd[u]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  mx = a[KK - 1];
+  if (!live) continue;
+  // complete?  distance to the nearest face of the 3x3x3 block that still has cells behind it
+  float db = __builtin_inff();
+  bool open = false;
+  const int c[3] = {cx, cy, cz};
+  const float qv[3] = {qx, qy, qz};
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    if (c[ax] - 1 > 0) {
+      open = true;
+      db = fminf(db, qv[ax] - (g.mn[ax] + (float)(c[ax] - 1) * g.h));
+    }
+    if (c[ax] + 1 < g.G[ax] - 1) {
+      open = true;
+      db = fminf(db, (g.mn[ax] + (float)(c[ax] + 2) * g.h) - qv[ax]);
+    }
+  }
+  bool done = !open;
+  if (open) {
+    const float safe = db - 0.02f * g.h;
+    done = safe > 0.0f && mx <= safe * safe;
+  }
+  if (!done) {
+    open_list[atomicAdd(open_count, 1)] = q;
+    continue;
+  }
+  // mean over columns first_col..K in the 64-slot butterfly order of knn_finish (zeros skipped: x + 0 = x)
+#pragma unroll
+  for (int i = 0; i < KK; ++i) a[i] = (i >= first_col && i < n) ? a[i] : 0.0f;
+  int len = KK;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int i = 0; i < off; ++i)
+      if (i + off < len) a[i] = a[i] + a[i + off];
+    len = len < off ? len : off;
+  }
+  avg_out[__float_as_int(qp.w)] = a[0] / (float)(KK - first_col);
+  }
+}
+
 // first level (all queries) and second level (the listed open queries on the coarse grid): the
 // same search, two kernel symbols so that profiles keep them apart
 __global__ void __launch_bounds__(256)
@@ -789,6 +952,7 @@ struct GridWs {
   int32_t *cell_count, *cursor, *cell_start, *block_sums, *cell_of;
   float4 *sorted;
   int32_t *fb_count, *fb_list;
+  int32_t *open_count, *open_list;  // queries the thread-per-query pass left to the ring search
   float *fb_bound;
   float *fb_partial;  // [kFbMaxSliced][kFbSlices][64]
   int32_t *stats;  // [16] ring histogram, filled only when PGDVS_KNN_STATS=1 (diagnostics)
@@ -815,6 +979,7 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   w.stats = reinterpret_cast<int32_t *>(p + off + 128);
   w.fb_count = reinterpret_cast<int32_t *>(p + off + 192);
   w.fb2_count = reinterpret_cast<int32_t *>(p + off + 196);
+  w.open_count = reinterpret_cast<int32_t *>(p + off + 200);
   off += 256;
   w.gp = reinterpret_cast<GridParams *>(p + off);
   off += 256;
@@ -835,6 +1000,8 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   off += align_up((qcap > 0 ? qcap : 1) * 4, 256);
   w.fb_bound = reinterpret_cast<float *>(p + off);
   off += align_up((qcap > 0 ? qcap : 1) * 4, 256);
+  w.open_list = reinterpret_cast<int32_t *>(p + off);
+  off += align_up((capacity > 0 ? capacity : 1) * 4, 256);
   w.fb_partial = reinterpret_cast<float *>(p + off);
   off += align_up((int64_t)kFbMaxSliced * kFbSlices * 64 * 4, 256);
   w.gp2 = reinterpret_cast<GridParams *>(p + off);
@@ -918,9 +1085,34 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   const char *env = getenv("PGDVS_KNN_STATS");
   int32_t *stats = (env && env[0] == '1') ? ws.stats : nullptr;
   const unsigned gq = (unsigned)(cdiv(nq_cap, 4) < 256 * 8 ? (cdiv(nq_cap, 4) > 0 ? cdiv(nq_cap, 4) : 1) : 256 * 8);
-  PGDVS_LAUNCH("grid_query", grid_query_kernel, dim3(gq), dim3(256), 0, st, ws.gp, ws.sorted,
-               ws.cell_start, KK, qs, avg_out, stats, kRingCap,
-               ws.fb_count, ws.fb_list, ws.fb_bound);
+  const char *no_tpq = getenv("PGDVS_KNN_NO_TPQ");  // diagnostics: force the wavefront-per-query search
+  bool tpq = qpts == nullptr && !(no_tpq && no_tpq[0] == '1');
+  if (tpq) {
+    const unsigned gt = (unsigned)(cdiv(capacity, 256) < 2560 ? (cdiv(capacity, 256) > 0 ? cdiv(capacity, 256) : 1) : 2560);
+    switch (KK) {
+#define PGDVS_TPQ_CASE(N)                                                                                        \
+  case N:                                                                                                        \
+    PGDVS_LAUNCH("grid_query_tpq", grid_query_tpq_kernel<N>, dim3(gt), dim3(256), 0, st, ws.gp, ws.sorted,      \
+                 ws.cell_start, qs.first_col, avg_out, ws.open_count, ws.open_list);                             \
+    break;
+      PGDVS_TPQ_CASE(5)
+      PGDVS_TPQ_CASE(9)
+      PGDVS_TPQ_CASE(17)
+      PGDVS_TPQ_CASE(21)
+      PGDVS_TPQ_CASE(51)
+#undef PGDVS_TPQ_CASE
+      default:
+        tpq = false;
+    }
+  }
+  QuerySrc qs1 = qs;
+  if (tpq) {  // the ring search only sees what the first pass left open
+    qs1.list = ws.open_list;
+    qs1.list_count = ws.open_count;
+  }
+  PGDVS_LAUNCH("grid_query", grid_query_kernel, dim3(tpq ? (gq < 256 ? gq : 256) : gq), dim3(256), 0, st, ws.gp,
+               ws.sorted, ws.cell_start, KK, qs1, avg_out, stats, tpq ? kRingCapAfterTpq : kRingCap, ws.fb_count, ws.fb_list,
+               ws.fb_bound);
   // Second level: the queries still open after kRingCap rings (isolated points, far from
   // everything in units of the cell size) repeat the ring search on a grid with
   // kCoarseScale-times larger cells before anything is scanned exhaustively.  All of it is

@@ -173,6 +173,27 @@ def test_knn_grid_exact_on_hard_distributions(kind):
     assert np.array_equal(a_pad.view(np.uint32), ref.view(np.uint32))
 
 
+@pytest.mark.parametrize("K", [8, 20, 50])
+def test_knn_search_variants_agree_at_benchmark_size(K, monkeypatch):
+    """two depth-map-like sheets of 150k points each (the 1080p filter input is 311k): the
+    thread-per-query first pass + ring search must give bit-identical means to the pure
+    wavefront-per-query ring search (itself pinned against the oracle above)"""
+    rng = np.random.default_rng(K)
+    n = 300_000
+    u = rng.uniform(-1, 1, (n, 2))
+    z = 2 + 0.3 * np.sin(3 * u[:, 0]) + np.where(np.arange(n) % 2 == 0, 0.0, 0.004)
+    pts = np.stack([u[:, 0] * z, u[:, 1] * z * 0.6, z], 1)
+    pts[:400] += rng.normal(0, 0.5, (400, 3))  # flying pixels
+    pts = pts.astype(np.float32)
+    cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
+    monkeypatch.setenv("PGDVS_KNN_NO_TPQ", "1")
+    a0 = N(ops.knn_mean_dist(T(pts), cnt, K, algo=2))
+    monkeypatch.delenv("PGDVS_KNN_NO_TPQ")
+    a1 = N(ops.knn_mean_dist(T(pts), cnt, K, algo=2))
+    assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
+    assert np.isfinite(a1).all() and float(a1.max()) > 10 * float(np.median(a1))
+
+
 def test_backwarp_l1(golden_dir):
     g = _load(golden_dir, "backwarp_l1.npz")
     l1 = N(ops.backwarp_l1(T(g["rgb1"]), T(g["rgb2"]), T(g["flow"])))

@@ -90,6 +90,7 @@ def algorithmic_bytes(name, H, W, S, n_static, n_dyn, K):
         "dyn_splat_finish": P * (20 + 12 + 16 + 36),
         "knn_mean_dist": n_dyn * 12 + n_dyn * 4,
         "grid_query": n_dyn * 16 + n_dyn * 4,
+        "grid_query_tpq": n_dyn * 16 + n_dyn * 4,  # cell-sorted points in, one mean per point out
         "grid_fallback": n_dyn * 16,
         "grid_count": n_dyn * 16, "grid_fill": n_dyn * 32, "stat_pass": n_dyn * 4,
         "gather_rows": n_dyn * (4 + 12 + 12),

@@ -703,7 +703,7 @@ __device__ __forceinline__ void tpq_insert(float (&a)[KK], float c) {
 }
 
 template <int KK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted,
                       const int32_t *__restrict__ cell_start, int first_col, float *__restrict__ avg_out,
                       int32_t *__restrict__ open_count, int32_t *__restrict__ open_list) {
@@ -752,23 +752,27 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
   for (int u = 0; u < kTpqQueue; ++u) qd[u] = __builtin_inff();
   int qc = 0;
   int k = -1, j = 0, e = 0;
-  float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);  // candidate j, requested one step ahead
-  for (;;) {
-    if (j >= e && k < 9) {  // this lane's run is exhausted: next row (one per step)
+  // Two candidate buffers: each half-step requests a candidate into one buffer -- for every lane,
+  // unconditionally, from a clamped index, so that no exec-masked move forces a wait right
+  // behind the load -- and evaluates the candidate the previous half-step requested into the
+  // other.  The load of a candidate is thus always a full half-step (and the other wavefronts'
+  // turns) ahead of its use.
+  float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), cb = ca;
+  bool va = false, vb = false;
+  auto half_step = [&](float4 &c_issue, bool &v_issue, const float4 &c_use, const bool v_use) -> bool {
+    if (j >= e && k < 9) {  // this lane's run is exhausted: next row (one per half-step)
       ++k;
       if (k < 9) {
         const int2 se = s_run[k][tid];
         j = se.x;
         e = s_bd[k][tid] < mx ? se.y : se.x;  // no point of the run can enter the list: skip it
-        if (j < e) pn = sorted[j];
       }
     }
-    const bool act = j < e;
-    if (__builtin_amdgcn_ballot_w64(act || k < 9) == 0) break;
-    if (act) {
-      const float d = dist2(qx, qy, qz, pn);
-      ++j;
-      if (j < e) pn = sorted[j];
+    v_issue = j < e;
+    c_issue = sorted[v_issue ? j : 0];
+    j += v_issue ? 1 : 0;
+    if (v_use) {
+      const float d = dist2(qx, qy, qz, c_use);
       if (d < mx) {  // (stale threshold: a candidate that no longer qualifies lands beyond column K)
 #pragma unroll
         for (int u = kTpqQueue - 1; u > 0; --u) qd[u] = qd[u - 1];
@@ -786,6 +790,11 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
       qc = 0;
       mx = a[KK - 1];
     }
+    return __builtin_amdgcn_ballot_w64(v_issue || k < 9) != 0;  // anything requested or left to visit?
+  };
+  for (;;) {
+    if (!half_step(cb, vb, ca, va)) break;
+    if (!half_step(ca, va, cb, vb)) break;
   }
 #pragma unroll
   for (int u = 0; u < kTpqQueue; ++u) {

@@ -681,25 +681,26 @@ grid_query_body(const GridParams *__restrict__ gp, const float4 *__restrict__ so
 // the 3x3x3 block around their own cell (ring histogram, PGDVS_KNN_STATS=1).  For those the
 // wavefront-per-query search above spends most of its ~1050 vector instructions per query on
 // serial insertions and on a 64-wide sort; here a lane owns a query and keeps its K+1 best in
-// registers as a sorted list, inserting with a chain of (min, max) pairs.  Lanes are
+// registers as a sorted list, inserting with one median-of-three per slot.  Lanes are
 // consecutive in cell-sorted order, so a wavefront's lanes walk (nearly) the same nine x-runs
 // of the sorted point array: the per-lane candidate loads coalesce into broadcasts.  A
 // candidate that beats the lane's (K+1)-th best is parked in a 4-deep per-lane queue; the
-// 2*(K+1)-instruction insertion chain runs only when some lane's queue is full, i.e. about
+// (K+1)-instruction insertion chain runs only when some lane's queue is full, i.e. about
 // once per four *accepted* candidates of the busiest lane instead of once per candidate.
 // About 350 vector instructions per query.  Queries whose list is not provably complete after
 // ring 1 (the same criterion as above) are handed to the wavefront-per-query search.
 // The average is summed in the same 64-slot butterfly order as knn_finish.
 constexpr int kTpqQueue = 4;
 
+// insert c into the ascending list a (the largest element drops out): slot i keeps its value
+// if that is <= c, takes c if its left neighbour is <= c < a[i], and takes the left neighbour
+// otherwise -- the median of (a[i-1], a[i], c), one instruction per slot, evaluated from the top
+// down so that every slot still sees its neighbour's old value
 template <int KK>
 __device__ __forceinline__ void tpq_insert(float (&a)[KK], float c) {
 #pragma unroll
-  for (int i = 0; i < KK; ++i) {
-    const float lo = __builtin_fminf(a[i], c);
-    c = __builtin_fmaxf(a[i], c);
-    a[i] = lo;
-  }
+  for (int i = KK - 1; i > 0; --i) a[i] = __builtin_amdgcn_fmed3f(a[i - 1], a[i], c);
+  a[0] = __builtin_fminf(a[0], c);
 }
 
 template <int KK>

@@ -54,6 +54,25 @@ __device__ __forceinline__ TileBox tile_box(const RasterCam &rc, float3 p, float
   return b;
 }
 
+// maximum over the wavefront as a scalar: DPP butterflies inside each row of 16 lanes, row
+// broadcasts across rows (the total lands in lane 63), no LDS round trips
+__device__ __forceinline__ int wave_max_i32_scalar(int v) {
+  int t;
+  t = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+  v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);  // row_mirror
+  v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  v = t > v ? t : v;
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ int wave_max_i32(int v) {
   for (int off = 32; off > 0; off >>= 1) {
     int o = __shfl_xor(v, off, 64);
@@ -240,8 +259,14 @@ raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ 
     __syncthreads();
     int m = (int)((end - base) < 256 ? (end - base) : 256);
     for (int sub = 0; sub < m; sub += 64) {
+      // hierarchical z: once every pixel of the quadrant holds K entries, a point strictly behind the
+      // farthest of their K-th depths cannot enter any list (keys order by (z, id); z >= 0, so
+      // the bit patterns order like the values; an empty slot counts as +inf, pixels outside the
+      // image as 0)
+      const int zcull = wave_max_i32_scalar(inside ? (q.has(K - 1) ? (int)(q.key[K - 1] >> 32) : 0x7fffffff) : 0);
       float4 c = s_pt[(sub + lane) & 255];
-      bool hit = (sub + lane) < m && c.x >= bx_lo && c.x <= bx_hi && c.y >= by_lo && c.y <= by_hi;
+      bool hit = (sub + lane) < m && c.x >= bx_lo && c.x <= bx_hi && c.y >= by_lo && c.y <= by_hi &&
+                 __float_as_int(c.z) <= zcull;
       unsigned long long mask = __ballot(hit);
       if (!mask) continue;
       // compact the survivors of this wave into its own LDS strip, pad to a multiple of 4

@@ -27,6 +27,9 @@ struct ProjF64 {
   double K3[9];
   double w2c[16];
   int affine;  // w2c's last row is exactly (0,0,0,1): vc[3] == 1 and x/vc[3] == x bit for bit
+  // K3 = [[fx,0,cx],[0,fy,cy],[0,0,1]] exactly: the skipped terms are +-0 (finite points) and
+  // 1*z, so only the sign of an exact zero can differ -- which no decision below depends on
+  int ksparse;
 };
 
 // Decides `q >= 0 && q <= hi` and trunc(q) for q = a / b (correctly rounded fp64 division,
@@ -92,12 +95,18 @@ agg_mark_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ count
       cz = vc[2] / s;
     }
     double pp[3];
+    if (pj.ksparse) {
+      pp[0] = pj.K3[0] * cx + pj.K3[2] * cz;
+      pp[1] = pj.K3[4] * cy + pj.K3[5] * cz;
+      pp[2] = cz;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      double s = pj.K3[k * 3 + 0] * cx;
-      s = s + pj.K3[k * 3 + 1] * cy;
-      s = s + pj.K3[k * 3 + 2] * cz;
-      pp[k] = s;
+      for (int k = 0; k < 3; ++k) {
+        double s = pj.K3[k * 3 + 0] * cx;
+        s = s + pj.K3[k * 3 + 1] * cy;
+        s = s + pj.K3[k * 3 + 2] * cz;
+        pp[k] = s;
+      }
     }
     int row, col;
     if (!trunc_div_in_range(pp[1], pp[2], H - 1, row)) continue;
@@ -379,6 +388,7 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
       return PGDVS_ERR_INVALID;
     }
     pj.affine = pj.w2c[12] == 0.0 && pj.w2c[13] == 0.0 && pj.w2c[14] == 0.0 && pj.w2c[15] == 1.0;
+    pj.ksparse = K3[1] == 0.0 && K3[3] == 0.0 && K3[6] == 0.0 && K3[7] == 0.0 && K3[8] == 1.0;
     // rays use K and c2w cast to fp32 (torch.FloatTensor, nvidia_eval.py:841-842)
     float flat[34];
     flat[0] = (float)H;

@@ -345,8 +345,14 @@ def main():
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dom, H, W, S),
                         "alg_bytes_per_launch": ab, "avg_launch_ms": kernels[dom]["avg_ms"],
-                        "note": "dominant kernel by time; it is a VALU/latency-bound search kernel, not an HBM stream "
-                                "(DESIGN.md section 4) -- per-kernel alg_GBps of the streaming kernels are in 'kernels'"}
+                        "launches_per_view": kernels[dom]["launches_per_step"],
+                        "event_bracket_overhead_ms": round(float(lib.pgdvs_prof_overhead_ms()), 5),
+                        "note": ("dominant kernel by time per view (HIP events on the launch stream, one view at a time, the "
+                                 "empty-launch bracket cost subtracted); "
+                                 + ("a VALU-bound search kernel, not an HBM stream" if dom in ("raster_tile", "grid_query", "grid_query_tpq")
+                                    else "a short kernel launched once per source frame, bound by its dependent global round trips "
+                                         "(tile counts -> ordered offsets -> append), not by bandwidth")
+                                 + " (DESIGN.md section 4); the whole path's figure is roofline_path")}
 
     # ---------------- informational variants (never `value`): what the reference's own flow would
     # time per view -- it aggregates the static cloud ONCE per scene at dataset construction

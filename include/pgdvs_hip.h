@@ -65,6 +65,9 @@ const char *pgdvs_build_arch(void);
  * wide switch meant for bench.py; leave it off in production. */
 void pgdvs_prof_enable(int on);
 int pgdvs_prof_report(char *buf, int buf_len);
+/* the fixed cost of one (event, launch, event) bracket that pgdvs_prof_report subtracts from
+ * every record (measured once with an empty kernel) */
+double pgdvs_prof_overhead_ms(void);
 
 /* ---- cameras ------------------------------------------------------------- */
 /* flat_cams[n,34] -> cam_blocks[n,80].  Replaces the torch.inverse / bmm chains of

@@ -60,6 +60,38 @@ void prof_end(hipStream_t s) {
 }
 }  // namespace pgdvs
 
+namespace pgdvs {
+__global__ void prof_null_kernel() {}
+
+// What an (event, launch, event) bracket measures beyond the kernel itself: the dispatch of an
+// empty kernel between two event markers on an idle stream (minimum of 32 tries).  Subtracted
+// from every record so that the durations of short kernels agree with a kernel trace.
+static double prof_bracket_overhead_ms() {
+  static double cached = -1.0;
+  if (cached >= 0.0) return cached;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0.0;
+  double best = 1e30;
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < 32; ++i) {
+    (void)hipEventRecord(a, nullptr);
+    prof_null_kernel<<<1, 64, 0, nullptr>>>();
+    (void)hipEventRecord(b, nullptr);
+    (void)hipEventSynchronize(b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) == hipSuccess && ms > 0.f && ms < best) best = ms;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  cached = best < 1e29 ? best : 0.0;
+  return cached;
+}
+}  // namespace pgdvs
+
+extern "C" __attribute__((visibility("default"))) double pgdvs_prof_overhead_ms(void) {
+  return pgdvs::prof_bracket_overhead_ms();
+}
+
 extern "C" __attribute__((visibility("default"))) void pgdvs_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(pgdvs::g_prof_mu);
   pgdvs::g_prof_on = on != 0;
@@ -75,13 +107,14 @@ extern "C" __attribute__((visibility("default"))) int pgdvs_prof_report(char *bu
     recs.swap(g_prof_recs);
   }
   std::map<std::string, std::pair<int, double>> agg;
+  const double overhead = recs.empty() ? 0.0 : prof_bracket_overhead_ms();
   for (auto &r : recs) {
     (void)hipEventSynchronize(r.b);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, r.a, r.b);
     auto &e = agg[r.name];
     e.first += 1;
-    e.second += ms;
+    e.second += ms > overhead ? ms - overhead : 0.0;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_pool.push_back(r.a);
     g_prof_pool.push_back(r.b);

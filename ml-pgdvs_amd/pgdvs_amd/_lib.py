@@ -23,6 +23,7 @@ SIGNATURES = {
     "pgdvs_build_arch": (C.c_char_p, []),
     "pgdvs_prof_enable": (None, [_i]),
     "pgdvs_prof_report": (_i, [C.c_char_p, _i]),
+    "pgdvs_prof_overhead_ms": (C.c_double, []),
     "pgdvs_cam_prep": (_i, [_vp, _i, _vp, _vp]),
     "pgdvs_get_rays": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pgdvs_dyn_warp": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

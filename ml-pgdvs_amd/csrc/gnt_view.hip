@@ -299,7 +299,10 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       float k[16];
       const bool ok = ok_nx != 0;
       const float dv = d_nx;
-      {  // k = Wk f
+      // When no group of the tile sees this source view (samples of a ray leave a view's frustum
+      // together) its 161 MFMAs would only be multiplied by zero attention and skipped statistics.
+      const bool seen = __builtin_amdgcn_ballot_w64(ok) != 0;
+      if (seen) {  // k = Wk f
         floatx4 c[4] = {};
         chain64q<kWStride>(c, wk, f_nx, w, [&](float (&d)[8]) { ldn8<kA1Stride>(d, wa1, 0); });
 #pragma unroll
@@ -312,6 +315,7 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
         ok_nx = valid[row + 1];
         d_nx = ray_diff[(row + 1) * 4 + hq];
       }
+      if (seen) {
       float a[16], hid[4], hk[2];
       floatx4 pq[4];
       {  // pq = P2 relu(P1 d + b) + b - q'   (4 -> 8 -> 64)
@@ -400,6 +404,7 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
           acc[t] = __builtin_fmaf(e, lv[t >> 2][t & 3], acc[t]);
         }
       }
+          }
     }
     // x = Wo (acc / l + q') + bo + q ;  q_out = FF(LN(x)) + x
     float x1[16];

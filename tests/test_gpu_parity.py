@@ -802,6 +802,22 @@ def test_gnt_gather_vs_reference_and_oracle(golden_dir, tag):
     assert V == out["mask"].shape[2]
 
 
+@pytest.mark.parametrize("n_rays", [1, 5, 13])
+def test_gnt_gather_ragged_sizes(golden_dir, n_rays):
+    """item counts that are not multiples of the 8 items a wavefront of the gather kernel owns:
+    a prefix of the rays must give exactly the prefix of the full result"""
+    g = _load(golden_dir, "gnt_small.npz")
+    cams = ops.cam_prep(T(g["cams_src"]))
+    camt = ops.cam_prep(T(g["cam_tgt"]))
+    feat_cl = T(g["featmaps"]).permute(0, 2, 3, 1).contiguous()
+    args = (T(g["depth_range"]), int(g["Ss"]), True, camt, cams, T(g["src_rgbs"][0]), feat_cl, T(g["inv_masks"][0, ..., 0]))
+    full = ops.gnt_gather(T(g["ray_o"]), T(g["ray_d"]), *args)
+    part = ops.gnt_gather(T(g["ray_o"][:n_rays]), T(g["ray_d"][:n_rays]), *args)
+    assert (n_rays * int(g["Ss"]) * int(g["V"])) % 8 != 0 or n_rays == 1
+    for k in ("rgb_feat", "ray_diff", "mask", "mask_inbound", "pts", "z_vals"):
+        assert torch.equal(part[k], full[k][:n_rays]), k
+
+
 @pytest.mark.parametrize("tag", ["nomask", "dynmask"])
 def test_gnt_forward_vs_reference(golden_dir, tag):
     m, g = _gnt_model(golden_dir)

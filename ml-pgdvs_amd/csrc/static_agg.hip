@@ -37,12 +37,16 @@ struct ProjF64 {
 // Newton-refined reciprocal is within ~1e-15 relative of q; unless q' lies within 1e-13
 // relative of an integer (all decision boundaries are integers) the decisions on q' and q
 // coincide.  Otherwise fall back to the exact division.
-__device__ __forceinline__ bool trunc_div_in_range(double a, double b, int hi, int &out) {
+__device__ __forceinline__ double refined_rcp(double b) {
   double r = __builtin_amdgcn_rcp(b);
   double e = __builtin_fma(-b, r, 1.0);
   r = __builtin_fma(r, e, r);
   e = __builtin_fma(-b, r, 1.0);
-  r = __builtin_fma(r, e, r);
+  return __builtin_fma(r, e, r);
+}
+
+// r = refined_rcp(b): both image coordinates divide by the same depth
+__device__ __forceinline__ bool trunc_div_in_range(double a, double b, double r, int hi, int &out) {
   double q = a * r;
   double f = floor(q);
   double dist = fmin(q - f, (f + 1.0) - q);
@@ -109,8 +113,9 @@ agg_mark_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ count
       }
     }
     int row, col;
-    if (!trunc_div_in_range(pp[1], pp[2], H - 1, row)) continue;
-    if (!trunc_div_in_range(pp[0], pp[2], W - 1, col)) continue;
+    const double rz = refined_rcp(pp[2]);
+    if (!trunc_div_in_range(pp[1], pp[2], rz, H - 1, row)) continue;
+    if (!trunc_div_in_range(pp[0], pp[2], rz, W - 1, col)) continue;
     occ[(int64_t)row * W + col] = (uint16_t)frame;
   }
 }

@@ -117,13 +117,34 @@ __device__ __forceinline__ float linspace_pm1(int i, int steps) {
   return 1.0f - step * (float)(steps - 1 - i);
 }
 
+// Which target pixels can receive dynamic content at all: the corners of every source pixel with
+// a non-zero mask.  The rendered colour and mask are multiplied by (splatted mask / norm > 1e-3)
+// afterwards (pgdvs_renderer_dyn.py:200-202), so whatever the ~85 % static source pixels add to
+// a target pixel outside this set is multiplied by zero: the scatter below skips a static source
+// pixel none of whose corners is flagged, before its backwarp, exponential and 16 atomics (the
+// L2 atomic rate, ~270 G/s, is what bounds the scatter).  Identical results for finite inputs (a
+// non-finite static colour no longer turns an untouched target pixel into NaN).
+__global__ void __launch_bounds__(256)
+dyn_splat_flag_kernel(int H, int W, const float *__restrict__ flow_1_to_tgt,
+                      const float *__restrict__ valid_mask, uint8_t *__restrict__ flags) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int P = H * W;
+  if (p >= P) return;
+  if (valid_mask[p] == 0.0f) return;
+  int y = p / W, x = p - y * W;
+  SplatCorners c = splat_corners(x, y, flow_1_to_tgt[p], flow_1_to_tgt[(size_t)P + p], H, W);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (c.idx[k] >= 0) flags[c.idx[k]] = 1;
+}
+
 // acc planes: 0..2 rgb*e, 3 e, 4 mask*e
 __global__ void __launch_bounds__(256)
 dyn_splat_scatter_kernel(int H, int W, const float *__restrict__ rgb1,
                          const float *__restrict__ rgb2, const float *__restrict__ flow12,
                          const float *__restrict__ flow_1_to_tgt,
                          const float *__restrict__ valid_mask, const float *__restrict__ noise,
-                         float alpha, float *__restrict__ acc) {
+                         float alpha, float *__restrict__ acc, const uint8_t *__restrict__ flags) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int P = H * W;
   if (p >= P) return;
@@ -131,6 +152,12 @@ dyn_splat_scatter_kernel(int H, int W, const float *__restrict__ rgb1,
   SplatCorners c = splat_corners(x, y, flow_1_to_tgt[p], flow_1_to_tgt[(size_t)P + p], H, W);
   if (!c.any) return;
   const float m = valid_mask[p];
+  if (m == 0.0f) {
+    bool wanted = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wanted = wanted || (c.idx[k] >= 0 && flags[c.idx[k]] != 0);
+    if (!wanted) return;
+  }
   // rgb_src_1 = rgb*mask + clamp(randn,0,1)*(1-mask)   (pgdvs_renderer_dyn.py:177-182)
   float c1[3];
 #pragma unroll
@@ -308,7 +335,8 @@ PGDVS_API int pgdvs_softsplat_fwd(const float *in, const float *flow, const floa
 }
 
 PGDVS_API int64_t pgdvs_dyn_splat_workspace_bytes(int H, int W) {
-  return align_up((int64_t)5 * H * W * (int64_t)sizeof(float), 256);
+  // five accumulator planes + one flag byte per target pixel
+  return align_up((int64_t)5 * H * W * (int64_t)sizeof(float) + (int64_t)H * W, 256);
 }
 
 PGDVS_API int pgdvs_dyn_splat_composite(int H, int W, const float *rgb1, const float *rgb2,
@@ -331,14 +359,17 @@ PGDVS_API int pgdvs_dyn_splat_composite(int H, int W, const float *rgb1, const f
   hipStream_t st = as_stream(stream);
   const int P = H * W;
   float *acc = reinterpret_cast<float *>(workspace);
-  hipError_t e = hipMemsetAsync(acc, 0, (size_t)5 * P * sizeof(float), st);
+  uint8_t *flags = reinterpret_cast<uint8_t *>(acc + (size_t)5 * P);
+  hipError_t e = hipMemsetAsync(acc, 0, (size_t)5 * P * sizeof(float) + (size_t)P, st);
   if (e != hipSuccess) {
     set_error("dyn_splat memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
   }
   dim3 grid((unsigned)cdiv(P, 256)), block(256);
+  PGDVS_LAUNCH("dyn_splat_flag", dyn_splat_flag_kernel, grid, block, 0, st, H, W, flow_1_to_tgt, valid_dyn_mask_1,
+               flags);
   PGDVS_LAUNCH("dyn_splat_scatter", dyn_splat_scatter_kernel, grid, block, 0, st, H, W, rgb1, rgb2, flow12,
-                     flow_1_to_tgt, valid_dyn_mask_1, noise, alpha, acc);
+                     flow_1_to_tgt, valid_dyn_mask_1, noise, alpha, acc, (const uint8_t *)flags);
   PGDVS_LAUNCH("dyn_splat_finish", dyn_splat_finish_kernel, grid, block, 0, st, P, acc, static_rgb,
                      render_dyn_rgb, render_dyn_mask, combined, combined_static, combined_dyn);
   return check_launch("dyn_splat_composite");

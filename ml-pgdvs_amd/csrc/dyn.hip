@@ -349,7 +349,7 @@ PGDVS_API int pgdvs_scatter_keep(const int32_t *idx, const uint8_t *flag, const 
                                  pgdvs_stream_t stream) {
   PGDVS_REQUIRE(idx && flag && count && keep && P >= 0, "pgdvs_scatter_keep: bad arguments");
   if (P == 0) return PGDVS_OK;
-  hipError_t e = hipMemsetAsync(keep, 0, (size_t)P, as_stream(stream));
+  hipError_t e = fill_async(keep, 0, (size_t)P, as_stream(stream));
   if (e != hipSuccess) {
     set_error("scatter_keep memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;

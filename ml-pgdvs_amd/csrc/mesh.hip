@@ -197,7 +197,7 @@ PGDVS_API int pgdvs_mesh_render(const float *cam_tgt, int H, int W, const uint8_
   float4 *ndc = reinterpret_cast<float4 *>(p + 256);
   unsigned long long *zkey = reinterpret_cast<unsigned long long *>(p + 256 + align_up(P * 16, 256));
   hipError_t e = hipMemsetAsync(first, 0x7f, 4, st);
-  if (e == hipSuccess) e = hipMemsetAsync(zkey, 0xff, P * 8, st);
+  if (e == hipSuccess) e = fill_async(zkey, 0xff, (size_t)P * 8, st);
   if (e != hipSuccess) {
     set_error("mesh_render memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;

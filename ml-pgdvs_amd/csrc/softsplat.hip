@@ -306,7 +306,7 @@ PGDVS_API int pgdvs_softsplat_fwd(const float *in, const float *flow, const floa
   dim3 grid((unsigned)cdiv(P, 256), B), block(256);
   hipError_t e;
   if (mode == 0) {
-    e = hipMemsetAsync(out, 0, (size_t)B * C * P * sizeof(float), st);
+    e = fill_async(out, 0, (size_t)B * C * P * sizeof(float), st);
     if (e != hipSuccess) {
       set_error("softsplat memset: %s", hipGetErrorString(e));
       return PGDVS_ERR_LAUNCH;
@@ -319,7 +319,7 @@ PGDVS_API int pgdvs_softsplat_fwd(const float *in, const float *flow, const floa
     return PGDVS_ERR_WORKSPACE;
   }
   float *acc = reinterpret_cast<float *>(workspace);
-  e = hipMemsetAsync(acc, 0, (size_t)B * (C + 1) * P * sizeof(float), st);
+  e = fill_async(acc, 0, (size_t)B * (C + 1) * P * sizeof(float), st);
   if (e != hipSuccess) {
     set_error("softsplat memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
@@ -360,7 +360,7 @@ PGDVS_API int pgdvs_dyn_splat_composite(int H, int W, const float *rgb1, const f
   const int P = H * W;
   float *acc = reinterpret_cast<float *>(workspace);
   uint8_t *flags = reinterpret_cast<uint8_t *>(acc + (size_t)5 * P);
-  hipError_t e = hipMemsetAsync(acc, 0, (size_t)5 * P * sizeof(float) + (size_t)P, st);
+  hipError_t e = fill_async(acc, 0, (size_t)5 * P * sizeof(float) + (size_t)P, st);
   if (e != hipSuccess) {
     set_error("dyn_splat memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;

@@ -377,7 +377,7 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
   hipStream_t st = as_stream(stream);
   const int64_t P = (int64_t)H * W;
   hipError_t e = hipMemsetAsync(ws.state, 0, (size_t)ws.state_bytes, st);
-  if (e == hipSuccess) e = hipMemsetAsync(ws.occ, 0, (size_t)P * 2, st);
+  if (e == hipSuccess) e = fill_async(ws.occ, 0, (size_t)P * 2, st);
   if (e != hipSuccess) {
     set_error("static_aggregate memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;

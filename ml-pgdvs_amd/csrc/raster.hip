@@ -278,12 +278,15 @@ raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ 
       // from moving the reads above the writes
       __builtin_amdgcn_wave_barrier();
       for (int j = 0; j < cnt; j += 4) {
+        // the four (broadcast) LDS reads go out together: one wait per group instead of one per point
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = strip[j + u];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          float4 p = strip[j + u];
-          float dx = p.x - xf, dy = p.y - yf;
+          float dx = p[u].x - xf, dy = p[u].y - yf;
           float d2 = dx * dx + dy * dy;
-          if (d2 < r2) q.insert(p.z, __float_as_int(p.w), d2);
+          if (d2 < r2) q.insert(p[u].z, __float_as_int(p[u].w), d2);
         }
       }
       __builtin_amdgcn_wave_barrier();

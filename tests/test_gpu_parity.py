@@ -324,6 +324,30 @@ def test_points_raster_vs_oracle(H, W, n, K, radius):
     assert np.array_equal(N(r["mask"]), (ones[..., 0] > 0).astype(np.float32))
 
 
+@pytest.mark.parametrize("K", [1, 3])
+def test_points_raster_dense_layers_vs_oracle(K):
+    """tens of disc hits per pixel from stacked depth layers (with exact depth ties): every pixel's
+    list fills early, so the wave-level depth cull of the tile kernel is active for most of
+    each tile's list -- results must still be the oracle's bit for bit"""
+    rng = np.random.default_rng(17 + K)
+    H, W, n, radius = 48, 56, 30000, 0.07
+    fc = synth.flat_cam(H, W, *synth.frame_camera(1, 4, H, W))
+    layer = rng.integers(0, 6, n)
+    z = 1.0 + 0.15 * layer + np.where(rng.random(n) < 0.5, 0.0, rng.uniform(0, 0.02, n))  # half of them tie exactly
+    xy = rng.uniform(-1.3, 1.3, (n, 2)) * z[:, None] * 0.6
+    pts = np.concatenate([xy, z[:, None]], 1).astype(np.float32)
+    order = rng.permutation(n)  # far layers arrive before near ones as often as not
+    pts = pts[order]
+    rgb = rng.random((n, 3), dtype=np.float32)
+    cloud = T(np.concatenate([pts, rgb], 1))
+    r = ops.points_raster(cloud, cloud[:, 3:], ops.cam_prep(T(fc)), radius, K, H, W, want_fragments=True)
+    idx, zbuf, d2 = orc.rasterize_points(pts, fc, H, W, radius, K)
+    assert float((idx[..., K - 1] >= 0).mean()) > 0.95  # lists are full almost everywhere
+    assert np.array_equal(N(r["idx"]), idx)
+    assert np.array_equal(N(r["zbuf"]).view(np.uint32), zbuf.view(np.uint32))
+    assert np.array_equal(N(r["dist2"]).view(np.uint32), d2.view(np.uint32))
+
+
 def test_points_raster_device_count_and_planar():
     rng = np.random.default_rng(3)
     H, W, n = 30, 44, 600

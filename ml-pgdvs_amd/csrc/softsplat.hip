@@ -20,8 +20,9 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float v) {
 }
 
 struct SplatCorners {
-  int idx[4];   // flat destination index (y*W+x) or -1
+  int idx[4];   // flat destination index (y*W+x) or -1; order nw, ne, sw, se
   float w[4];
+  int x0, y0;   // target pixel of the nw corner (may lie outside the image)
   bool any;
 };
 
@@ -30,6 +31,8 @@ __device__ __forceinline__ SplatCorners splat_corners(int x, int y, float fx, fl
                                                       int W) {
   SplatCorners c;
   c.any = false;
+  c.x0 = 0;
+  c.y0 = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) c.idx[k] = -1;
   float X = (float)x + fx;
@@ -39,6 +42,8 @@ __device__ __forceinline__ SplatCorners splat_corners(int x, int y, float fx, fl
   // (int) floor() of a value outside [-2, size] can only fail the bounds tests
   if (flx < -2.0f || flx > (float)W || fly < -2.0f || fly > (float)H) return c;
   int nwx = (int)flx, nwy = (int)fly;
+  c.x0 = nwx;
+  c.y0 = nwy;
   int nex = nwx + 1, ney = nwy;
   int swx = nwx, swy = nwy + 1;
   int sex = nwx + 1, sey = nwy + 1;
@@ -139,66 +144,123 @@ dyn_splat_flag_kernel(int H, int W, const float *__restrict__ flow_1_to_tgt,
 }
 
 // acc planes: 0..2 rgb*e, 3 e, 4 mask*e
+// One workgroup per 16x16 tile of source pixels.  The scatter is bound by the L2 atomic rate,
+// and neighbouring source pixels land on the same target pixels (every target pixel of a smooth
+// flow field collects ~4 bilinear contributions per plane): the tile's contributions are first
+// summed in an LDS window anchored at the tile's smallest target coordinates (LDS float atomics),
+// then each touched target pixel receives ONE global atomic per plane.  Corners that fall outside
+// the window (flows that diverge by more than kSplatWin - 17 pixels inside a tile) go to global
+// memory directly.
+constexpr int kSplatTile = 16, kSplatWin = 40;
+
 __global__ void __launch_bounds__(256)
 dyn_splat_scatter_kernel(int H, int W, const float *__restrict__ rgb1,
                          const float *__restrict__ rgb2, const float *__restrict__ flow12,
                          const float *__restrict__ flow_1_to_tgt,
                          const float *__restrict__ valid_mask, const float *__restrict__ noise,
                          float alpha, float *__restrict__ acc, const uint8_t *__restrict__ flags) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float s_acc[5][kSplatWin * kSplatWin];
+  __shared__ int s_org[2];
   const int P = H * W;
-  if (p >= P) return;
-  int y = p / W, x = p - y * W;
-  SplatCorners c = splat_corners(x, y, flow_1_to_tgt[p], flow_1_to_tgt[(size_t)P + p], H, W);
-  if (!c.any) return;
-  const float m = valid_mask[p];
-  if (m == 0.0f) {
-    bool wanted = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) wanted = wanted || (c.idx[k] >= 0 && flags[c.idx[k]] != 0);
-    if (!wanted) return;
+  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  const int x = blockIdx.x * kSplatTile + lx, y = blockIdx.y * kSplatTile + ly;
+  const int p = y * W + x;
+  if (threadIdx.x == 0) {
+    s_org[0] = 0x7fffffff;
+    s_org[1] = 0x7fffffff;
   }
-  // rgb_src_1 = rgb*mask + clamp(randn,0,1)*(1-mask)   (pgdvs_renderer_dyn.py:177-182)
-  float c1[3];
+  SplatCorners c;
+  c.any = false;
+  float m = 0.0f;
+  bool part = false;
+  if (x < W && y < H) {
+    c = splat_corners(x, y, flow_1_to_tgt[p], flow_1_to_tgt[(size_t)P + p], H, W);
+    if (c.any) {
+      m = valid_mask[p];
+      part = true;
+      if (m == 0.0f) {
+        bool wanted = false;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float nz = noise ? clampf(noise[(size_t)k * P + p], 0.0f, 1.0f) : 0.0f;
-    c1[k] = rgb1[(size_t)p * 3 + k] * m + nz * (1.0f - m);
+        for (int k = 0; k < 4; ++k) wanted = wanted || (c.idx[k] >= 0 && flags[c.idx[k]] != 0);
+        part = wanted;
+      }
+    }
   }
-  // backwarp rgb2 by flow12, align_corners=True (pgdvs_renderer_base.py:91-138)
-  float2 f12 = reinterpret_cast<const float2 *>(flow12)[p];
-  const float hw_x = ((float)W - 1.0f) / 2.0f, hw_y = ((float)H - 1.0f) / 2.0f;
-  float gx = linspace_pm1(x, W) + f12.x / hw_x;
-  float gy = linspace_pm1(y, H) + f12.y / hw_y;
-  float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
-  float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
-  bool fin = isfinite(ix) && isfinite(iy) && fabsf(ix) < 1e9f && fabsf(iy) < 1e9f;
-  float x0f = floorf(ix), y0f = floorf(iy);
-  int x0 = fin ? (int)x0f : -10, y0 = fin ? (int)y0f : -10, x1 = x0 + 1, y1 = y0 + 1;
-  float wnw = ((float)x1 - ix) * ((float)y1 - iy);
-  float wne = (ix - (float)x0) * ((float)y1 - iy);
-  float wsw = ((float)x1 - ix) * (iy - (float)y0);
-  float wse = (ix - (float)x0) * (iy - (float)y0);
-  bool inx0 = x0 >= 0 && x0 < W, inx1 = x1 >= 0 && x1 < W;
-  bool iny0 = y0 >= 0 && y0 < H, iny1 = y1 >= 0 && y1 < H;
-  float s = 0.0f;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float a = 0.0f;
-    if (inx0 && iny0) a = a + rgb2[((size_t)y0 * W + x0) * 3 + k] * wnw;
-    if (inx1 && iny0) a = a + rgb2[((size_t)y0 * W + x1) * 3 + k] * wne;
-    if (inx0 && iny1) a = a + rgb2[((size_t)y1 * W + x0) * 3 + k] * wsw;
-    if (inx1 && iny1) a = a + rgb2[((size_t)y1 * W + x1) * 3 + k] * wse;
-    s = s + fabsf(c1[k] - a);
+  if (!__syncthreads_or(part ? 1 : 0)) return;  // nothing of this tile can matter
+  if (part) {  // window origin: the smallest in-image target coordinates of the tile
+    atomicMin(&s_org[0], c.x0 < 0 ? 0 : c.x0);
+    atomicMin(&s_org[1], c.y0 < 0 ? 0 : c.y0);
   }
-  float l1 = s / 3.0f;
-  // metric = clip(-alpha*L1, -alpha, alpha); soft mode weight exp(metric)
-  float e = expf(clampf(-alpha * l1, -alpha, alpha));
+  for (int i = threadIdx.x; i < 5 * kSplatWin * kSplatWin / 4; i += 256)
+    reinterpret_cast<float4 *>(&s_acc[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const int ox = s_org[0], oy = s_org[1];
+  if (part) {
+    // rgb_src_1 = rgb*mask + clamp(randn,0,1)*(1-mask)   (pgdvs_renderer_dyn.py:177-182)
+    float c1[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) splat_value(acc + (size_t)k * P, c, c1[k] * e);
-  splat_value(acc + (size_t)3 * P, c, e);
-  float me = m * e;
-  if (me != 0.0f) splat_value(acc + (size_t)4 * P, c, me);
+    for (int k = 0; k < 3; ++k) {
+      float nz = noise ? clampf(noise[(size_t)k * P + p], 0.0f, 1.0f) : 0.0f;
+      c1[k] = rgb1[(size_t)p * 3 + k] * m + nz * (1.0f - m);
+    }
+    // backwarp rgb2 by flow12, align_corners=True (pgdvs_renderer_base.py:91-138)
+    float2 f12 = reinterpret_cast<const float2 *>(flow12)[p];
+    const float hw_x = ((float)W - 1.0f) / 2.0f, hw_y = ((float)H - 1.0f) / 2.0f;
+    float gx = linspace_pm1(x, W) + f12.x / hw_x;
+    float gy = linspace_pm1(y, H) + f12.y / hw_y;
+    float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    bool fin = isfinite(ix) && isfinite(iy) && fabsf(ix) < 1e9f && fabsf(iy) < 1e9f;
+    float x0f = floorf(ix), y0f = floorf(iy);
+    int x0 = fin ? (int)x0f : -10, y0 = fin ? (int)y0f : -10, x1 = x0 + 1, y1 = y0 + 1;
+    float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+    float wne = (ix - (float)x0) * ((float)y1 - iy);
+    float wsw = ((float)x1 - ix) * (iy - (float)y0);
+    float wse = (ix - (float)x0) * (iy - (float)y0);
+    bool inx0 = x0 >= 0 && x0 < W, inx1 = x1 >= 0 && x1 < W;
+    bool iny0 = y0 >= 0 && y0 < H, iny1 = y1 >= 0 && y1 < H;
+    float sabs = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float a = 0.0f;
+      if (inx0 && iny0) a = a + rgb2[((size_t)y0 * W + x0) * 3 + k] * wnw;
+      if (inx1 && iny0) a = a + rgb2[((size_t)y0 * W + x1) * 3 + k] * wne;
+      if (inx0 && iny1) a = a + rgb2[((size_t)y1 * W + x0) * 3 + k] * wsw;
+      if (inx1 && iny1) a = a + rgb2[((size_t)y1 * W + x1) * 3 + k] * wse;
+      sabs = sabs + fabsf(c1[k] - a);
+    }
+    float l1 = sabs / 3.0f;
+    // metric = clip(-alpha*L1, -alpha, alpha); soft mode weight exp(metric)
+    float e = expf(clampf(-alpha * l1, -alpha, alpha));
+    const float me = m * e;
+    const float val[5] = {c1[0] * e, c1[1] * e, c1[2] * e, e, me};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (c.idx[k] < 0) continue;
+      const int wx = c.x0 + (k & 1) - ox, wy = c.y0 + (k >> 1) - oy;
+      const bool in_win = wx >= 0 && wx < kSplatWin && wy >= 0 && wy < kSplatWin;
+#pragma unroll
+      for (int pl = 0; pl < 5; ++pl) {
+        const float v = val[pl];
+        if (pl == 4 && me == 0.0f) continue;
+        if (c.w[k] == 0.0f && isfinite(v)) continue;  // adding +-0 changes nothing (splat_value's rule)
+        if (in_win)
+          __hip_atomic_fetch_add(&s_acc[pl][wy * kSplatWin + wx], v * c.w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else
+          atomic_add_f32(acc + (size_t)pl * P + c.idx[k], v * c.w[k]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kSplatWin * kSplatWin; i += 256) {
+    const int ty = oy + i / kSplatWin, tx = ox + i % kSplatWin;
+    if (tx >= W || ty >= H) continue;
+#pragma unroll
+    for (int pl = 0; pl < 5; ++pl) {
+      const float v = s_acc[pl][i];
+      if (v != 0.0f) atomic_add_f32(acc + (size_t)pl * P + (size_t)ty * W + tx, v);
+    }
+  }
 }
 
 // normalise, threshold, mask and composite (pgdvs_renderer_dyn.py:200-202,
@@ -368,7 +430,8 @@ PGDVS_API int pgdvs_dyn_splat_composite(int H, int W, const float *rgb1, const f
   dim3 grid((unsigned)cdiv(P, 256)), block(256);
   PGDVS_LAUNCH("dyn_splat_flag", dyn_splat_flag_kernel, grid, block, 0, st, H, W, flow_1_to_tgt, valid_dyn_mask_1,
                flags);
-  PGDVS_LAUNCH("dyn_splat_scatter", dyn_splat_scatter_kernel, grid, block, 0, st, H, W, rgb1, rgb2, flow12,
+  const dim3 tgrid((unsigned)cdiv(W, kSplatTile), (unsigned)cdiv(H, kSplatTile));
+  PGDVS_LAUNCH("dyn_splat_scatter", dyn_splat_scatter_kernel, tgrid, block, 0, st, H, W, rgb1, rgb2, flow12,
                      flow_1_to_tgt, valid_dyn_mask_1, noise, alpha, acc, (const uint8_t *)flags);
   PGDVS_LAUNCH("dyn_splat_finish", dyn_splat_finish_kernel, grid, block, 0, st, P, acc, static_rgb,
                      render_dyn_rgb, render_dyn_mask, combined, combined_static, combined_dyn);

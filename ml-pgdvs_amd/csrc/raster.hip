@@ -38,8 +38,12 @@ __device__ __forceinline__ TileBox tile_box(const RasterCam &rc, float3 p, float
   float offx = rc.range_x / 2.0f, offy = rc.range_y / 2.0f;
   float xc = (float)(W - 1) - ((p.x + offx) * (float)W - offx) / rc.range_x;
   float yc = (float)(H - 1) - ((p.y + offy) * (float)H - offy) / rc.range_y;
-  float rpx = radius * (float)W / rc.range_x + 1.5f;
-  float rpy = radius * (float)H / rc.range_y + 1.5f;
+  // xc, yc are in pixel-index units (pixel i is centred at i): the disc touches the pixels with
+  // |i - xc| < radius in pixels.  The margin only has to cover the rounding of this inversion
+  // against the forward pix_to_ndc used by the tile kernel (~1e-3 px at 4k); floor/ceil add up to
+  // one more pixel.  (A margin of 1.5 px put 24 % more entries into the tile lists.)
+  float rpx = radius * (float)W / rc.range_x + 0.0625f;
+  float rpy = radius * (float)H / rc.range_y + 0.0625f;
   float x0 = floorf(xc - rpx), x1 = ceilf(xc + rpx);
   float y0 = floorf(yc - rpy), y1 = ceilf(yc + rpy);
   if (x1 < 0.0f || y1 < 0.0f || x0 > (float)(W - 1) || y0 > (float)(H - 1)) return b;
@@ -53,6 +57,7 @@ __device__ __forceinline__ TileBox tile_box(const RasterCam &rc, float3 p, float
   (void)nty;
   return b;
 }
+
 
 // maximum over the wavefront as a scalar: DPP butterflies inside each row of 16 lanes, row
 // broadcasts across rows (the total lands in lane 63), no LDS round trips
@@ -73,14 +78,6 @@ __device__ __forceinline__ int wave_max_i32_scalar(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-__device__ __forceinline__ int wave_max_i32(int v) {
-  for (int off = 32; off > 0; off >>= 1) {
-    int o = __shfl_xor(v, off, 64);
-    v = o > v ? o : v;
-  }
-  return v;
-}
-
 __global__ void __launch_bounds__(256)
 raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_host,
                             const int64_t *__restrict__ n_dev, const float *__restrict__ cam,
@@ -99,7 +96,7 @@ raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, i
       ndc4[i] = make_float4(p.x, p.y, p.z, 0.0f);
       b = tile_box(rc, p, radius, H, W, ntx, nty);
     }
-    int nx = wave_max_i32(b.tx1 - b.tx0 + 1), ny = wave_max_i32(b.ty1 - b.ty0 + 1);
+    int nx = wave_max_i32_scalar(b.tx1 - b.tx0 + 1), ny = wave_max_i32_scalar(b.ty1 - b.ty0 + 1);
     for (int jy = 0; jy < ny; ++jy)
       for (int jx = 0; jx < nx; ++jx) {
         int tx = b.tx0 + jx, ty = b.ty0 + jy;
@@ -155,7 +152,7 @@ raster_fill_kernel(int64_t n_host, const int64_t *__restrict__ n_dev,
       float4 q = ndc4[i];
       b = tile_box(rc, make_float3(q.x, q.y, q.z), radius, H, W, ntx, nty);
     }
-    int nx = wave_max_i32(b.tx1 - b.tx0 + 1), ny = wave_max_i32(b.ty1 - b.ty0 + 1);
+    int nx = wave_max_i32_scalar(b.tx1 - b.tx0 + 1), ny = wave_max_i32_scalar(b.ty1 - b.ty0 + 1);
     for (int jy = 0; jy < ny; ++jy)
       for (int jx = 0; jx < nx; ++jx) {
         int tx = b.tx0 + jx, ty = b.ty0 + jy;

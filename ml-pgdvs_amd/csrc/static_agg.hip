@@ -19,6 +19,8 @@
 //            row-major pixel order -- the order numpy's boolean indexing produces (point ids
 //            matter: the rasteriser breaks z ties by id).
 // No host synchronisation: the running point counts live on the device.
+#include <cmath>
+
 #include "common.h"
 
 namespace pgdvs {
@@ -30,6 +32,15 @@ struct ProjF64 {
   // K3 = [[fx,0,cx],[0,fy,cy],[0,0,1]] exactly: the skipped terms are +-0 (finite points) and
   // 1*z, so only the sign of an exact zero can differ -- which no decision below depends on
   int ksparse;
+  // Screening form: M = K3 . w2c[0:3] composed on the host.  q~ = (M X)_k / (M X)_2 evaluated
+  // with 9 FMAs differs from the value of the reference operation order by at most
+  // tol_scale * max(|x|,|y|,|z|,1) * (1 + |q|) / |(M X)_2| (both are fp64 evaluations of the same
+  // real number; tol_scale = 64 ulp x the largest row sum of |K3| |w2c|).  Decisions only change
+  // at integers, so a q~ farther than that from every integer decides like the reference; the
+  // others (one in ~1e9) take the reference operation order below.
+  double M[12];
+  double tol_scale;
+  int screen;  // affine w2c and finite matrices
 };
 
 // Decides `q >= 0 && q <= hi` and trunc(q) for q = a / b (correctly rounded fp64 division,
@@ -78,6 +89,22 @@ agg_mark_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ count
       nx = xyz[(i + stride) * 3 + 0];
       ny = xyz[(i + stride) * 3 + 1];
       nz = xyz[(i + stride) * 3 + 2];
+    }
+    if (pj.screen) {
+      const double s0 = __builtin_fma(pj.M[0], x, __builtin_fma(pj.M[1], y, __builtin_fma(pj.M[2], z, pj.M[3])));
+      const double s1 = __builtin_fma(pj.M[4], x, __builtin_fma(pj.M[5], y, __builtin_fma(pj.M[6], z, pj.M[7])));
+      const double s2 = __builtin_fma(pj.M[8], x, __builtin_fma(pj.M[9], y, __builtin_fma(pj.M[10], z, pj.M[11])));
+      const double r = refined_rcp(s2);
+      const double qx = s0 * r, qy = s1 * r;
+      const double tol = pj.tol_scale * fmax(fmax(fabs(x), fabs(y)), fmax(fabs(z), 1.0)) * fabs(r);
+      const double fx = floor(qx), fy = floor(qy);
+      const double dx = fmin(qx - fx, (fx + 1.0) - qx), dy = fmin(qy - fy, (fy + 1.0) - qy);
+      // (false for NaN / inf as well: those take the reference path)
+      if (dx > tol * (1.0 + fabs(qx)) && dy > tol * (1.0 + fabs(qy))) {
+        if (qy >= 0.0 && qy <= (double)(H - 1) && qx >= 0.0 && qx <= (double)(W - 1))
+          occ[(int64_t)(int)qy * W + (int)qx] = (uint16_t)frame;
+        continue;
+      }
     }
     double vc[4];
 #pragma unroll
@@ -394,6 +421,26 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
     }
     pj.affine = pj.w2c[12] == 0.0 && pj.w2c[13] == 0.0 && pj.w2c[14] == 0.0 && pj.w2c[15] == 1.0;
     pj.ksparse = K3[1] == 0.0 && K3[3] == 0.0 && K3[6] == 0.0 && K3[7] == 0.0 && K3[8] == 1.0;
+    {
+      double rmax = 0.0;
+      bool finite = true;
+      for (int r = 0; r < 3; ++r) {
+        double rowsum = 0.0;
+        for (int c = 0; c < 4; ++c) {
+          double m = 0.0, a = 0.0;
+          for (int k = 0; k < 3; ++k) {
+            m += K3[r * 3 + k] * pj.w2c[k * 4 + c];
+            a += fabs(K3[r * 3 + k]) * fabs(pj.w2c[k * 4 + c]);
+          }
+          pj.M[r * 4 + c] = m;
+          rowsum += a;
+          finite = finite && std::isfinite(m) && std::isfinite(a);
+        }
+        rmax = rowsum > rmax ? rowsum : rmax;
+      }
+      pj.tol_scale = 64.0 * 1.1102230246251565e-16 * rmax;
+      pj.screen = pj.affine && finite && rmax > 0.0;
+    }
     // rays use K and c2w cast to fp32 (torch.FloatTensor, nvidia_eval.py:841-842)
     float flat[34];
     flat[0] = (float)H;

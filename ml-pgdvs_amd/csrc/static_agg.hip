@@ -20,6 +20,7 @@
 //            matter: the rasteriser breaks z ties by id).
 // No host synchronisation: the running point counts live on the device.
 #include <cmath>
+#include <vector>
 
 #include "common.h"
 
@@ -67,16 +68,87 @@ __device__ __forceinline__ bool trunc_div_in_range(double a, double b, double r,
   return true;
 }
 
-// _compute_pcl_proj_mask, nvidia_eval_pure_geo.py:257-277 (no z>0 test, no epsilon,
-// closed bounds, astype(int) truncation)
+// per-frame projection constants live in the workspace (written by agg_params_kernel): the
+// marking kernel keeps only the screening form of its frames in registers and reads the
+// reference form through this pointer in the rare doubtful case
+struct ProjChunk {
+  ProjF64 p[8];
+};
+
+__global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, int first, int n) {
+  const int words = (int)(sizeof(ProjF64) / 4);
+  for (int k = threadIdx.x; k < n * words; k += blockDim.x)
+    reinterpret_cast<uint32_t *>(dst + first)[k] = reinterpret_cast<const uint32_t *>(&c.p[0])[k];
+}
+
+// _compute_pcl_proj_mask, nvidia_eval_pure_geo.py:257-277 in the reference operation order (no
+// z>0 test, no epsilon, closed bounds, astype(int) truncation)
+__device__ __attribute__((noinline)) void mark_reference_order(const ProjF64 *__restrict__ pj, double x, double y,
+                                                               double z, int H, int W, int frame,
+                                                               uint16_t *__restrict__ occ) {
+  double vc[4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double s = pj->w2c[k * 4 + 0] * x;
+    s = s + pj->w2c[k * 4 + 1] * y;
+    s = s + pj->w2c[k * 4 + 2] * z;
+    s = s + pj->w2c[k * 4 + 3];
+    vc[k] = s;
+  }
+  double cx = vc[0], cy = vc[1], cz = vc[2];
+  if (!pj->affine) {
+    double s = pj->w2c[12] * x;
+    s = s + pj->w2c[13] * y;
+    s = s + pj->w2c[14] * z;
+    s = s + pj->w2c[15];
+    cx = vc[0] / s;
+    cy = vc[1] / s;
+    cz = vc[2] / s;
+  }
+  double pp[3];
+  if (pj->ksparse) {
+    pp[0] = pj->K3[0] * cx + pj->K3[2] * cz;
+    pp[1] = pj->K3[4] * cy + pj->K3[5] * cz;
+    pp[2] = cz;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double s = pj->K3[k * 3 + 0] * cx;
+      s = s + pj->K3[k * 3 + 1] * cy;
+      s = s + pj->K3[k * 3 + 2] * cz;
+      pp[k] = s;
+    }
+  }
+  int row, col;
+  const double rz = refined_rcp(pp[2]);
+  if (!trunc_div_in_range(pp[1], pp[2], rz, H - 1, row)) return;
+  if (!trunc_div_in_range(pp[0], pp[2], rz, W - 1, col)) return;
+  occ[(int64_t)row * W + col] = (uint16_t)frame;
+}
+
+// Stamps, for NF consecutive frames f0 .. f0+NF-1, the pixels hit by the points [*begin, *end)
+// of the accumulated cloud.  The kernel is bound by reading the cloud (each pass re-reads up to
+// 42 MB out of the Infinity Cache), so two frames share one pass over the bulk of the points.
+template <int NF>
 __global__ void __launch_bounds__(256)
-agg_mark_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ count, ProjF64 pj,
-                int H, int W, int frame, uint16_t *__restrict__ occ) {
-  const int64_t n = *count;
+agg_mark_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ begin_p,
+                const int64_t *__restrict__ end_p, const ProjF64 *__restrict__ proj, int f0, int H, int W,
+                uint16_t *__restrict__ occ0, uint16_t *__restrict__ occ1) {
+  const int64_t begin = begin_p ? *begin_p : 0;
+  const int64_t n = *end_p;
+  double M[NF][12], tscale[NF];
+  bool screen[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) M[f][k] = proj[f0 + f].M[k];
+    tscale[f] = proj[f0 + f].tol_scale;
+    screen[f] = proj[f0 + f].screen != 0;
+  }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // the whole grid is resident, so a thread walks several points: the next point's load is
-  // issued before the current point's ~80 fp64 operations
+  // issued before the current point's fp64 operations
   float nx = 0.0f, ny = 0.0f, nz = 0.0f;
   if (i < n) {
     nx = xyz[i * 3 + 0];
@@ -90,60 +162,30 @@ agg_mark_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ count
       ny = xyz[(i + stride) * 3 + 1];
       nz = xyz[(i + stride) * 3 + 2];
     }
-    if (pj.screen) {
-      const double s0 = __builtin_fma(pj.M[0], x, __builtin_fma(pj.M[1], y, __builtin_fma(pj.M[2], z, pj.M[3])));
-      const double s1 = __builtin_fma(pj.M[4], x, __builtin_fma(pj.M[5], y, __builtin_fma(pj.M[6], z, pj.M[7])));
-      const double s2 = __builtin_fma(pj.M[8], x, __builtin_fma(pj.M[9], y, __builtin_fma(pj.M[10], z, pj.M[11])));
-      const double r = refined_rcp(s2);
-      const double qx = s0 * r, qy = s1 * r;
-      const double tol = pj.tol_scale * fmax(fmax(fabs(x), fabs(y)), fmax(fabs(z), 1.0)) * fabs(r);
-      const double fx = floor(qx), fy = floor(qy);
-      const double dx = fmin(qx - fx, (fx + 1.0) - qx), dy = fmin(qy - fy, (fy + 1.0) - qy);
-      // (false for NaN / inf as well: those take the reference path)
-      if (dx > tol * (1.0 + fabs(qx)) && dy > tol * (1.0 + fabs(qy))) {
-        if (qy >= 0.0 && qy <= (double)(H - 1) && qx >= 0.0 && qx <= (double)(W - 1))
-          occ[(int64_t)(int)qy * W + (int)qx] = (uint16_t)frame;
-        continue;
-      }
-    }
-    double vc[4];
+    const double amax = fmax(fmax(fabs(x), fabs(y)), fmax(fabs(z), 1.0));
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      double s = pj.w2c[k * 4 + 0] * x;
-      s = s + pj.w2c[k * 4 + 1] * y;
-      s = s + pj.w2c[k * 4 + 2] * z;
-      s = s + pj.w2c[k * 4 + 3];
-      vc[k] = s;
-    }
-    double cx = vc[0], cy = vc[1], cz = vc[2];
-    if (!pj.affine) {
-      double s = pj.w2c[12] * x;
-      s = s + pj.w2c[13] * y;
-      s = s + pj.w2c[14] * z;
-      s = s + pj.w2c[15];
-      cx = vc[0] / s;
-      cy = vc[1] / s;
-      cz = vc[2] / s;
-    }
-    double pp[3];
-    if (pj.ksparse) {
-      pp[0] = pj.K3[0] * cx + pj.K3[2] * cz;
-      pp[1] = pj.K3[4] * cy + pj.K3[5] * cz;
-      pp[2] = cz;
-    } else {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        double s = pj.K3[k * 3 + 0] * cx;
-        s = s + pj.K3[k * 3 + 1] * cy;
-        s = s + pj.K3[k * 3 + 2] * cz;
-        pp[k] = s;
+    for (int f = 0; f < NF; ++f) {
+      uint16_t *occ = f == 0 ? occ0 : occ1;
+      const int frame = f0 + f;
+      bool decided = false;
+      if (screen[f]) {
+        const double s0 = __builtin_fma(M[f][0], x, __builtin_fma(M[f][1], y, __builtin_fma(M[f][2], z, M[f][3])));
+        const double s1 = __builtin_fma(M[f][4], x, __builtin_fma(M[f][5], y, __builtin_fma(M[f][6], z, M[f][7])));
+        const double s2 = __builtin_fma(M[f][8], x, __builtin_fma(M[f][9], y, __builtin_fma(M[f][10], z, M[f][11])));
+        const double r = refined_rcp(s2);
+        const double qx = s0 * r, qy = s1 * r;
+        const double tol = tscale[f] * amax * fabs(r);
+        const double fx = floor(qx), fy = floor(qy);
+        const double dx = fmin(qx - fx, (fx + 1.0) - qx), dy = fmin(qy - fy, (fy + 1.0) - qy);
+        // (false for NaN / inf as well: those take the reference path)
+        if (dx > tol * (1.0 + fabs(qx)) && dy > tol * (1.0 + fabs(qy))) {
+          if (qy >= 0.0 && qy <= (double)(H - 1) && qx >= 0.0 && qx <= (double)(W - 1))
+            occ[(int64_t)(int)qy * W + (int)qx] = (uint16_t)frame;
+          decided = true;
+        }
       }
+      if (!decided) mark_reference_order(proj + frame, x, y, z, H, W, frame, occ);
     }
-    int row, col;
-    const double rz = refined_rcp(pp[2]);
-    if (!trunc_div_in_range(pp[1], pp[2], rz, H - 1, row)) continue;
-    if (!trunc_div_in_range(pp[0], pp[2], rz, W - 1, col)) continue;
-    occ[(int64_t)row * W + col] = (uint16_t)frame;
   }
 }
 
@@ -349,6 +391,8 @@ struct AggWs {
   unsigned long long *desc;
   uint16_t *occ;
   float *xyz;
+  uint16_t *occ2;
+  ProjF64 *proj;
   int64_t total_bytes;
 };
 
@@ -373,6 +417,10 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   off += align_up(P * 2 + 32, 256);
   w.xyz = reinterpret_cast<float *>(p + off);
   off += align_up((capacity > 0 ? capacity : 1) * 12, 256);
+  w.occ2 = reinterpret_cast<uint16_t *>(p + off);  // directly behind... (own region: odd frames)
+  off += align_up(P * 2 + 32, 256);
+  w.proj = reinterpret_cast<ProjF64 *>(p + off);
+  off += align_up((int64_t)S * (int64_t)sizeof(ProjF64), 256);
   w.total_bytes = off;
   return w;
 }
@@ -405,61 +453,69 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
   const int64_t P = (int64_t)H * W;
   hipError_t e = hipMemsetAsync(ws.state, 0, (size_t)ws.state_bytes, st);
   if (e == hipSuccess) e = fill_async(ws.occ, 0, (size_t)P * 2, st);
+  if (e == hipSuccess) e = fill_async(ws.occ2, 0, (size_t)P * 2, st);
   if (e != hipSuccess) {
     set_error("static_aggregate memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
   }
-  const int tiles = (int)cdiv(P, kSelTile);
-  for (int i = 0; i < S; ++i) {
-    const double *K3 = K3s_host + (size_t)i * 9;
-    const double *c2w = c2ws_host + (size_t)i * 16;
-    ProjF64 pj;
-    for (int k = 0; k < 9; ++k) pj.K3[k] = K3[k];
-    if (inv_f64(c2w, pj.w2c, 4) != 0) {
-      set_error("pgdvs_static_aggregate: singular c2w for frame %d", i);
-      return PGDVS_ERR_INVALID;
-    }
-    pj.affine = pj.w2c[12] == 0.0 && pj.w2c[13] == 0.0 && pj.w2c[14] == 0.0 && pj.w2c[15] == 1.0;
-    pj.ksparse = K3[1] == 0.0 && K3[3] == 0.0 && K3[6] == 0.0 && K3[7] == 0.0 && K3[8] == 1.0;
-    {
-      double rmax = 0.0;
-      bool finite = true;
-      for (int r = 0; r < 3; ++r) {
-        double rowsum = 0.0;
-        for (int c = 0; c < 4; ++c) {
-          double m = 0.0, a = 0.0;
-          for (int k = 0; k < 3; ++k) {
-            m += K3[r * 3 + k] * pj.w2c[k * 4 + c];
-            a += fabs(K3[r * 3 + k]) * fabs(pj.w2c[k * 4 + c]);
-          }
-          pj.M[r * 4 + c] = m;
-          rowsum += a;
-          finite = finite && std::isfinite(m) && std::isfinite(a);
-        }
-        rmax = rowsum > rmax ? rowsum : rmax;
+  // ---- per-frame constants: projection (fp64, device-resident) and ray setup (fp32, by value)
+  std::vector<CamBlock> cams((size_t)S);
+  {
+    ProjChunk chunk;
+    for (int i = 0; i < S; ++i) {
+      const double *K3 = K3s_host + (size_t)i * 9;
+      const double *c2w = c2ws_host + (size_t)i * 16;
+      ProjF64 &pj = chunk.p[i % 8];
+      for (int k = 0; k < 9; ++k) pj.K3[k] = K3[k];
+      if (inv_f64(c2w, pj.w2c, 4) != 0) {
+        set_error("pgdvs_static_aggregate: singular c2w for frame %d", i);
+        return PGDVS_ERR_INVALID;
       }
-      pj.tol_scale = 64.0 * 1.1102230246251565e-16 * rmax;
-      pj.screen = pj.affine && finite && rmax > 0.0;
+      pj.affine = pj.w2c[12] == 0.0 && pj.w2c[13] == 0.0 && pj.w2c[14] == 0.0 && pj.w2c[15] == 1.0;
+      pj.ksparse = K3[1] == 0.0 && K3[3] == 0.0 && K3[6] == 0.0 && K3[7] == 0.0 && K3[8] == 1.0;
+      {
+        double rmax = 0.0;
+        bool finite = true;
+        for (int r = 0; r < 3; ++r) {
+          double rowsum = 0.0;
+          for (int c = 0; c < 4; ++c) {
+            double m = 0.0, a = 0.0;
+            for (int k = 0; k < 3; ++k) {
+              m += K3[r * 3 + k] * pj.w2c[k * 4 + c];
+              a += fabs(K3[r * 3 + k]) * fabs(pj.w2c[k * 4 + c]);
+            }
+            pj.M[r * 4 + c] = m;
+            rowsum += a;
+            finite = finite && std::isfinite(m) && std::isfinite(a);
+          }
+          rmax = rowsum > rmax ? rowsum : rmax;
+        }
+        pj.tol_scale = 64.0 * 1.1102230246251565e-16 * rmax;
+        pj.screen = pj.affine && finite && rmax > 0.0;
+      }
+      // rays use K and c2w cast to fp32 (torch.FloatTensor, nvidia_eval.py:841-842)
+      float flat[34];
+      flat[0] = (float)H;
+      flat[1] = (float)W;
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c)
+          flat[2 + r * 4 + c] = (r < 3 && c < 3) ? (float)K3[r * 3 + c] : (r == c ? 1.0f : 0.0f);
+      for (int k = 0; k < 16; ++k) flat[18 + k] = (float)c2w[k];
+      if (cam_block_from_flat(flat, cams[(size_t)i].v) != 0) {
+        set_error("pgdvs_static_aggregate: singular intrinsics for frame %d", i);
+        return PGDVS_ERR_INVALID;
+      }
+      if (i % 8 == 7 || i == S - 1) {
+        const int first = i - i % 8, cnt = i % 8 + 1;
+        PGDVS_LAUNCH("agg_params", agg_params_kernel, dim3(1), dim3(256), 0, st, chunk, ws.proj, first, cnt);
+      }
     }
-    // rays use K and c2w cast to fp32 (torch.FloatTensor, nvidia_eval.py:841-842)
-    float flat[34];
-    flat[0] = (float)H;
-    flat[1] = (float)W;
-    for (int r = 0; r < 4; ++r)
-      for (int c = 0; c < 4; ++c)
-        flat[2 + r * 4 + c] = (r < 3 && c < 3) ? (float)K3[r * 3 + c] : (r == c ? 1.0f : 0.0f);
-    for (int k = 0; k < 16; ++k) flat[18 + k] = (float)c2w[k];
-    CamBlock cam;
-    if (cam_block_from_flat(flat, cam.v) != 0) {
-      set_error("pgdvs_static_aggregate: singular intrinsics for frame %d", i);
-      return PGDVS_ERR_INVALID;
-    }
-    if (i > 0)
-      PGDVS_LAUNCH("agg_mark", agg_mark_kernel, dim3(2048), dim3(256), 0, st, (const float *)ws.xyz,
-                   (const int64_t *)(ws.cnts + i), pj, H, W, i, ws.occ);
+  }
+  const int tiles = (int)cdiv(P, kSelTile);
+  auto select = [&](int i) {
     SelArgs a;
     a.dyn_mask = dyn_masks + (size_t)i * P;
-    a.occ = ws.occ;
+    a.occ = (i & 1) ? ws.occ2 : ws.occ;
     a.depth = depths + (size_t)i * P;
     a.rgb = rgbs + (size_t)i * P * 3;
     a.cloud = out;
@@ -475,7 +531,28 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
     a.P = (int)P;
     a.W = W;
     a.tiles = tiles;
-    PGDVS_LAUNCH("agg_select", agg_select_kernel, dim3(tiles), dim3(kSelThreads), 0, st, a, cam);
+    PGDVS_LAUNCH("agg_select", agg_select_kernel, dim3(tiles), dim3(kSelThreads), 0, st, a, cams[(size_t)i]);
+  };
+  // cnts[i] = points in the cloud before frame i.  Frames are handled in pairs: one pass over the
+  // points known before frame i stamps the occupancy of frames i AND i+1 (even frames use occ, odd
+  // ones occ2), frame i is selected, then only ITS new points are stamped into frame i+1.
+  select(0);
+  for (int i = 1; i < S; i += 2) {
+    uint16_t *occ_i = (i & 1) ? ws.occ2 : ws.occ, *occ_n = (i & 1) ? ws.occ : ws.occ2;
+    if (i + 1 < S) {
+      PGDVS_LAUNCH("agg_mark", agg_mark_kernel<2>, dim3(2048), dim3(256), 0, st, (const float *)ws.xyz,
+                   (const int64_t *)nullptr, (const int64_t *)(ws.cnts + i), (const ProjF64 *)ws.proj, i, H, W, occ_i, occ_n);
+    } else {
+      PGDVS_LAUNCH("agg_mark", agg_mark_kernel<1>, dim3(2048), dim3(256), 0, st, (const float *)ws.xyz,
+                   (const int64_t *)nullptr, (const int64_t *)(ws.cnts + i), (const ProjF64 *)ws.proj, i, H, W, occ_i, occ_i);
+    }
+    select(i);
+    if (i + 1 < S) {
+      PGDVS_LAUNCH("agg_mark_new", agg_mark_kernel<1>, dim3(256), dim3(256), 0, st, (const float *)ws.xyz,
+                   (const int64_t *)(ws.cnts + i), (const int64_t *)(ws.cnts + i + 1), (const ProjF64 *)ws.proj, i + 1, H,
+                   W, occ_n, occ_n);
+      select(i + 1);
+    }
   }
   return check_launch("static_aggregate");
 }

@@ -413,10 +413,11 @@ def test_pure_geo_dataset_static_cloud_vs_reference(golden_dir, tmp_path):
     np.testing.assert_allclose(item["flat_cam_tgt"].numpy(), g["pg_flat_cam_tgt"], rtol=1e-6)
 
 
-@pytest.mark.parametrize("S,H,W", [(4, 53, 37), (3, 100, 123), (2, 2200, 2000)])
+@pytest.mark.parametrize("S,H,W", [(4, 53, 37), (3, 100, 123), (2, 2200, 2000), (1, 60, 84), (5, 60, 84), (6, 47, 61), (9, 60, 84)])
 def test_static_aggregation_shapes_vs_oracle(S, H, W):
     """frame sizes that are not multiples of the 16-pixel vector width (unaligned mask rows of
-    later frames), a partial last tile, and > 1024 tiles (ticketed tile ids)"""
+    later frames), a partial last tile, > 1024 tiles (ticketed tile ids), and odd / even frame
+    counts (frames are marked in pairs; a single frame has no marking pass at all)"""
     from pgdvs_amd.datasets.static_aggregation import aggregate_static_pcl
 
     v = synth.make_video(S, H, W, seed=S * 7 + W)

@@ -280,32 +280,41 @@ def main():
     join_lanes()
     torch.cuda.synchronize()
     if args.launch == "auto":
-        # is the host keeping up?  enqueue a few views eagerly and compare the time the host needs
-        # to issue them with the time the GPU needs to run them; a busy host (shared box) can
-        # take several times its usual 0.7 ms per view, and then graph replay is the faster path
-        n_try = 2 * n_lanes
-        t0 = time.perf_counter()
-        for j in range(n_try):
-            step_eager(j)
-        t_host = time.perf_counter() - t0
-        join_lanes()
-        torch.cuda.synchronize()
-        t_all = time.perf_counter() - t0
-        host_bound = t_host > 0.8 * t_all
+        # Eager launches or graph replay?  Measured, not guessed: a few views each way during warm-up.
+        # Eager costs the host ~0.7 ms per view when it is idle -- below the ~1.3 ms the GPU needs -- but
+        # several times that on a busy shared box; replay costs the host ~0.4 ms and the GPU the copies
+        # of a view's inputs into the graph's static buffers.
+        n_try = 3 * n_lanes
+
+        def probe(fn):
+            t0 = time.perf_counter()
+            for j in range(n_try):
+                fn(j)
+            t_host = time.perf_counter() - t0
+            join_lanes()
+            torch.cuda.synchronize()
+            return t_host, time.perf_counter() - t0
+
+        th_e, t_eager = probe(step_eager)
+        build_graphs()
+        t_graph = float("inf")
+        if graphs is not None:
+            for j in range(n_lanes):
+                step_graph(j)
+            join_lanes()
+            torch.cuda.synchronize()
+            _, t_graph = probe(step_graph)
         if world > 1:  # every rank must take the same path (collectives inside the timed loop)
-            flag = torch.tensor([1.0 if host_bound else 0.0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            host_bound = bool(flag.item() > 0)
-        if host_bound:
-            build_graphs()
-            if graphs is not None:
-                graph_note += f" (auto: host enqueue {t_host / n_try * 1e3:.2f} ms/view of {t_all / n_try * 1e3:.2f} ms)"
-                for j in range(n_lanes):
-                    step(j)
-                join_lanes()
-                torch.cuda.synchronize()
+            tt = torch.tensor([t_eager, min(t_graph, 1e9)], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            t_eager, t_graph = float(tt[0].item()) / world, float(tt[1].item()) / world
+        probe_note = (f"auto: eager {t_eager / n_try * 1e3:.2f} ms/view with {th_e / n_try * 1e3:.2f} ms of host enqueue, "
+                      f"graph replay {t_graph / n_try * 1e3:.2f} ms/view")
+        if graphs is not None and t_graph < 0.97 * t_eager:
+            graph_note += f" ({probe_note})"
         else:
-            graph_note = f"eager launches (auto: host enqueue {t_host / n_try * 1e3:.2f} ms/view of {t_all / n_try * 1e3:.2f} ms)"
+            graphs = None
+            graph_note = f"eager launches ({probe_note})"
 
     elapsed, gathered, cnt = timed(args.steps, profile=False)
     host_ms = host_enqueue[0] / args.steps * 1e3

@@ -262,6 +262,22 @@ def main():
         lib.pgdvs_prof_enable(0)
         return t1 - t0, gathered, cnt
 
+    if os.environ.get("PGDVS_BENCH_HOST_PROFILE"):  # diagnostic: where the host time of an eager view goes
+        import cProfile
+        import pstats
+
+        for j in range(6):
+            step_eager(j, 0)
+        torch.cuda.synchronize()
+        pr = cProfile.Profile()
+        pr.enable()
+        for j in range(60):
+            step_eager(j, 0)
+            if j % 6 == 5:
+                torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
+
     if os.environ.get("PGDVS_BENCH_OP_TABLE"):  # diagnostic: which torch ops / copies one eager view issues
         from torch.profiler import ProfilerActivity, profile
 

@@ -25,28 +25,37 @@ def _map_tensors(obj, fn):
     return obj
 
 
-def _copy_into(dst, src):
+def _copy_into(dst, src, seen, path=()):
+    """copy the leaves of ``src`` into the static buffers ``dst``; a leaf that is the very tensor
+    object copied last time, unmodified since (same ``_version``), is already in place"""
     if isinstance(dst, torch.Tensor):
-        dst.copy_(src, non_blocking=True)
+        if dst.is_cuda:
+            last = seen.get(path)
+            if last is not None and last[0] is src and last[1] == src._version:
+                return
+            dst.copy_(src, non_blocking=True)
+            seen[path] = (src, src._version)
     elif isinstance(dst, dict):
         for k in dst:
-            _copy_into(dst[k], src[k])
+            _copy_into(dst[k], src[k], seen, path + (k,))
     elif isinstance(dst, (list, tuple)):
-        for d, s in zip(dst, src):
-            _copy_into(d, s)
+        for i, (d, s_) in enumerate(zip(dst, src)):
+            _copy_into(d, s_, seen, path + (i,))
 
 
 class GraphedRender:
     """``out = GraphedRender(fn, example_inputs)(inputs)``: ``fn(inputs) -> tensor or tuple of
     tensors`` is captured once on ``stream`` (default: a new stream) with static copies of
     ``example_inputs`` (a possibly nested dict / list of GPU tensors; other leaves are passed
-    through unchanged).  Each call copies ``inputs`` into the static buffers and replays; the
+    through unchanged).  Each call copies ``inputs`` into the static buffers (leaves that are the
+    same unmodified tensor objects as in the previous call are skipped) and replays; the
     returned tensors are the graph's output buffers and are overwritten by the next call."""
 
     def __init__(self, fn, example_inputs, stream=None, warmup=2):
         self.stream = stream if stream is not None else torch.cuda.Stream()
         self.static_in = _map_tensors(example_inputs, lambda t: t.clone() if t.is_cuda else t)
         self.graph = torch.cuda.CUDAGraph()
+        self._seen = {}  # input leaf -> (tensor copied last, its version): unchanged inputs are not copied again
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):  # allocator / lazy-init effects happen outside the capture
@@ -58,6 +67,6 @@ class GraphedRender:
     def __call__(self, inputs):
         """enqueue on ``self.stream``: input copies + one graph launch"""
         with torch.cuda.stream(self.stream):
-            _copy_into(self.static_in, inputs)
+            _copy_into(self.static_in, inputs, self._seen)
             self.graph.replay()
         return self.static_out

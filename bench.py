@@ -329,10 +329,21 @@ def main():
         if graphs is not None and t_graph < 0.97 * t_eager:
             graph_note += f" ({probe_note})"
         else:
-            graphs = None
+            # (the graphs stay alive until the process ends: releasing their memory pools here would
+            # put allocator traffic -- frees, re-allocations, implicit synchronisations -- into the timed loop)
+            unused_graphs, graphs = graphs, None  # noqa: F841
             graph_note = f"eager launches ({probe_note})"
 
+    import gc
+
+    # the K output images are retained until the end of the timed region: have their blocks in the
+    # caching allocator already, so that no hipMalloc (and its implicit synchronisation) falls into it
+    spare = [torch.empty_like(ref_img) for _ in range(args.steps + 2 * n_lanes)]
+    del spare
+    gc.collect()
+    gc.disable()  # no collector pauses inside the timed loop
     elapsed, gathered, cnt = timed(args.steps, profile=False)
+    gc.enable()
     host_ms = host_enqueue[0] / args.steps * 1e3
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:

@@ -172,35 +172,27 @@ raster_fill_kernel(int64_t n_host, const int64_t *__restrict__ n_dev,
 template <int K>
 struct TopK {
   unsigned long long key[K];
-  float d[K];
   static constexpr unsigned long long kEmpty = ~0ull;
   __device__ __forceinline__ void init() {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      key[k] = kEmpty;
-      d[k] = -1.0f;
-    }
+    for (int k = 0; k < K; ++k) key[k] = kEmpty;
   }
   __device__ __forceinline__ bool has(int k) const { return key[k] != kEmpty; }
   __device__ __forceinline__ int id(int k) const { return (int)(unsigned)(key[k] & 0xffffffffull); }
   __device__ __forceinline__ float z(int k) const { return __uint_as_float((unsigned)(key[k] >> 32)); }
-  // keep the K smallest by (z, id)
-  // pz_canon: z with -0.0 already folded to +0.0 (pytorch3d keeps z == 0 points; order by id)
-  __device__ __forceinline__ void insert(float pz_canon, int pid, float pd) {
-    const unsigned long long kk = ((unsigned long long)__float_as_uint(pz_canon) << 32) | (unsigned)pid;
-    if (!(kk < key[K - 1])) return;
-    key[K - 1] = kk;
-    d[K - 1] = pd;
+  // keep the K smallest keys, sorted; the caller has checked kk < key[K-1].  The list is
+  // sorted, so "kk < key[k]" is monotone in k and every slot is a two-level select: take the
+  // left neighbour if kk goes in front of it, else kk if it goes in front of this one.
+  // (The squared distance is not carried along: the epilogue recomputes it from the id with the
+  // same two subtractions, two products and one sum.)
+  __device__ __forceinline__ void insert_below_last(unsigned long long kk) {
+    bool c[K];
 #pragma unroll
-    for (int k = K - 1; k > 0; --k) {
-      const bool sw = key[k] < key[k - 1];
-      const unsigned long long ka = key[k], kb = key[k - 1];
-      const float da = d[k], db = d[k - 1];
-      key[k] = sw ? kb : ka;
-      key[k - 1] = sw ? ka : kb;
-      d[k] = sw ? db : da;
-      d[k - 1] = sw ? da : db;
-    }
+    for (int k = 0; k < K - 1; ++k) c[k] = kk < key[k];
+    c[K - 1] = true;
+#pragma unroll
+    for (int k = K - 1; k > 0; --k) key[k] = c[k - 1] ? key[k - 1] : (c[k] ? kk : key[k]);
+    key[0] = c[0] ? kk : key[0];
   }
 };
 
@@ -249,9 +241,9 @@ raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ 
     if (e < end) {
       int id = lists[e];
       float4 p = ndc4[id];
-      p.z = p.z + 0.0f;  // -0.0 -> +0.0 once, so that the z bits order like the values
-      p.w = __int_as_float(id);
-      s_pt[threadIdx.x] = p;
+      // -0.0 -> +0.0 once, so that the z bits order like the values; (id, z) in this order is the
+      // key's (low, high) register pair
+      s_pt[threadIdx.x] = make_float4(p.x, p.y, __int_as_float(id), p.z + 0.0f);
     }
     __syncthreads();
     int m = (int)((end - base) < 256 ? (end - base) : 256);
@@ -263,7 +255,7 @@ raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ 
       const int zcull = wave_max_i32_scalar(inside ? (q.has(K - 1) ? (int)(q.key[K - 1] >> 32) : 0x7fffffff) : 0);
       float4 c = s_pt[(sub + lane) & 255];
       bool hit = (sub + lane) < m && c.x >= bx_lo && c.x <= bx_hi && c.y >= by_lo && c.y <= by_hi &&
-                 __float_as_int(c.z) <= zcull;
+                 __float_as_int(c.w) <= zcull;
       unsigned long long mask = __ballot(hit);
       if (!mask) continue;
       // compact the survivors of this wave into its own LDS strip, pad to a multiple of 4
@@ -283,7 +275,10 @@ raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ 
         for (int u = 0; u < 4; ++u) {
           float dx = p[u].x - xf, dy = p[u].y - yf;
           float d2 = dx * dx + dy * dy;
-          if (d2 < r2) q.insert(p[u].z, __float_as_int(p[u].w), d2);
+          const unsigned long long kk =
+              ((unsigned long long)__float_as_uint(p[u].w) << 32) | __float_as_uint(p[u].z);
+          // one branch for both tests (bitwise &: no short-circuit)
+          if ((d2 < r2) & (kk < q.key[K - 1])) q.insert_below_last(kk);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -291,11 +286,22 @@ raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ 
   }
   if (!inside) return;
   const size_t pix = (size_t)yi * W + xi;
+  // squared distances of the kept points: the loop's own arithmetic on the same operands
+  float qd[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    qd[k] = -1.0f;
+    if (q.has(k)) {
+      const float4 p = ndc4[q.id(k)];
+      float dx = p.x - xf, dy = p.y - yf;
+      qd[k] = dx * dx + dy * dy;
+    }
+  }
   // NormWeightedCompositor: w = 1 - d2/r2, t = max(sum w, 1e-4), out = sum w*f/t
   float t = 0.0f;
 #pragma unroll
   for (int k = 0; k < K; ++k)
-    if (q.has(k)) t = t + (1.0f - q.d[k] / r2);
+    if (q.has(k)) t = t + (1.0f - qd[k] / r2);
   t = t > 1e-4f ? t : 1e-4f;
   float acc[3] = {0.f, 0.f, 0.f}, ones = 0.0f;
 #pragma unroll
@@ -303,9 +309,9 @@ raster_tile_kernel(const float4 *__restrict__ ndc4, const int32_t *__restrict__ 
     bool has = q.has(k);
     if (idx_out) idx_out[pix * K + k] = has ? (int64_t)q.id(k) : (int64_t)-1;
     if (zbuf_out) zbuf_out[pix * K + k] = has ? q.z(k) : -1.0f;
-    if (dist_out) dist_out[pix * K + k] = has ? q.d[k] : -1.0f;
+    if (dist_out) dist_out[pix * K + k] = qd[k];
     if (has) {
-      float w = 1.0f - q.d[k] / r2;
+      float w = 1.0f - qd[k] / r2;
       ones = ones + w * 1.0f / t;
       if (rgb_out) {
         const float *f = feat + (int64_t)q.id(k) * feat_stride;

@@ -246,7 +246,8 @@ def main():
 
     def timed(n_steps, profile):
         lib.pgdvs_prof_enable(1 if profile else 0)
-        gather = pdist.AsyncImageGather(dst=0)  # step j's image travels while step j+1 renders
+        # step j's image travels while step j+1 renders; rank 0 receives into one stack allocated here
+        gather = pdist.AsyncImageGather(dst=0, n_steps=n_steps, like=ref_img)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -54,19 +54,32 @@ class AsyncImageGather:
     """Per-step asynchronous gather of the rendered images to ``dst``: step j's transfer (RCCL
     over xGMI, its own stream) overlaps with the rendering of step j+1, so only the last image
     is exposed.  ``finish()`` waits for all transfers and returns, on ``dst``, the stack
-    [n_steps * world, ...] in view order (view = step * world + rank), else None."""
+    [n_steps * world, ...] in view order (view = step * world + rank), else None.
 
-    def __init__(self, dst: int = 0):
+    With ``n_steps`` and ``like`` (one image) the receive stack is allocated once, up front, and
+    every step's gather lands directly in its slices: no allocation and no final concatenation
+    on ``dst`` while steps are in flight (at 1080p and 8 ranks a step brings 200 MB to ``dst``)."""
+
+    def __init__(self, dst: int = 0, n_steps: int | None = None, like: torch.Tensor | None = None):
         self.dst = dst
         self.works, self.bufs, self.keep = [], [], []
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.stack = None
+        if self.on and n_steps and like is not None and dist.get_rank() == dst:
+            self.stack = torch.empty((n_steps, dist.get_world_size()) + tuple(like.shape), dtype=like.dtype, device=like.device)
 
     def submit(self, img: torch.Tensor) -> None:
         img = img.contiguous()
         self.keep.append(img)
         if not self.on:
             return
-        bufs = [torch.empty_like(img) for _ in range(dist.get_world_size())] if dist.get_rank() == self.dst else None
+        bufs = None
+        if dist.get_rank() == self.dst:
+            j = len(self.works)
+            if self.stack is not None and j < self.stack.shape[0] and tuple(img.shape) == tuple(self.stack.shape[2:]):
+                bufs = list(self.stack[j].unbind(0))
+            else:
+                bufs = [torch.empty_like(img) for _ in range(dist.get_world_size())]
         self.bufs.append(bufs)
         self.works.append(dist.gather(img, bufs, dst=self.dst, async_op=True))
 
@@ -77,4 +90,8 @@ class AsyncImageGather:
             w.wait()
         if dist.get_rank() != self.dst:
             return None
+        n = len(self.works)
+        if self.stack is not None and n <= self.stack.shape[0] and all(
+                b[0].data_ptr() == self.stack[j, 0].data_ptr() for j, b in enumerate(self.bufs)):
+            return self.stack[:n].flatten(0, 2)  # [step, rank, 1-or-more images, ...] -> view order
         return torch.cat([torch.cat(b, 0) for b in self.bufs], 0)

@@ -99,14 +99,17 @@ mine = shard_indices(n_views, rank, world)
 local = torch.stack([torch.full((3, 4, 6), float(v)) for v in mine])
 out = gather_image_stack(local, n_views)
 m = reduce_metrics(torch.tensor([1.0, float(rank)]))
-ag = AsyncImageGather()
-for step in range(3):
-    ag.submit(torch.full((1, 3, 2, 2), float(step * world + rank)))
-stack = ag.finish()
-if rank == 0:
-    assert [int(stack[i, 0, 0, 0]) for i in range(3 * world)] == list(range(3 * world)), stack[:, 0, 0, 0]
-else:
-    assert stack is None
+for kw in ({}, dict(n_steps=3, like=torch.empty(1, 3, 2, 2)), dict(n_steps=2, like=torch.empty(1, 3, 2, 2))):
+    ag = AsyncImageGather(**kw)  # per-step buffers / preallocated stack / stack too short for the third step
+    for step in range(3):
+        ag.submit(torch.full((1, 3, 2, 2), float(step * world + rank)))
+    stack = ag.finish()
+    if rank == 0:
+        assert stack.shape == (3 * world, 3, 2, 2), stack.shape
+        assert [int(stack[i, 0, 0, 0]) for i in range(3 * world)] == list(range(3 * world)), stack[:, 0, 0, 0]
+        assert (ag.stack is not None) == bool(kw)
+    else:
+        assert stack is None
 if rank == 0:
     assert out.shape == (n_views, 3, 4, 6), out.shape
     assert [int(out[i, 0, 0, 0]) for i in range(n_views)] == list(range(n_views))

@@ -299,6 +299,16 @@ def main():
         ref_img = img if j == 0 else ref_img
     join_lanes()
     torch.cuda.synchronize()
+    if world > 1:
+        # RCCL sets its point-to-point connections up at the first send / receive between two ranks:
+        # have that (and the receive path on rank 0) behind us before the timed region
+        g = pdist.AsyncImageGather(dst=0, n_steps=2, like=ref_img)
+        g.submit(ref_img)
+        g.submit(ref_img)
+        g.finish()
+        del g
+        torch.cuda.synchronize()
+        barrier()
     if args.launch == "auto":
         # Eager launches or graph replay?  Measured, not guessed: a few views each way during warm-up.
         # Eager costs the host ~0.7 ms per view when it is idle -- below the ~1.3 ms the GPU needs -- but

@@ -52,9 +52,9 @@ def measured_traffic(kernel, H, W, S):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--graph-lanes", type=int, default=2, help="views in flight when replaying HIP graphs")
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--frames", type=int, default=24)

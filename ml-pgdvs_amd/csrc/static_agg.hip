@@ -189,7 +189,7 @@ agg_mark_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ begin
   }
 }
 
-constexpr int kSelThreads = 256;
+constexpr int kSelThreads = 512;
 constexpr int kSelItems = 16;
 constexpr int kSelTile = kSelThreads * kSelItems;
 constexpr unsigned kSelSpinLimit = 1u << 22;

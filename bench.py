@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--no-outlier", action="store_true", help="dyn_pcl_remove_outlier=false (YAML default)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent target views rendered concurrently, each on its own pair of HIP streams")
+    ap.add_argument("--stream-pool", type=int, default=0, help="experiment: lanes draw their (main, side) streams from a pool of this many")
+    ap.add_argument("--lane-priorities", default="", help="experiment: stream priorities, main/side per lane, e.g. -1,-1,0,0,0,0")
     ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
                     help="eager: enqueue every kernel of every view from Python; graph: replay one captured HIP graph "
                          "per lane; auto: eager unless the host turns out to be the bottleneck during warm-up")
@@ -175,7 +177,15 @@ def main():
     # in flight per GPU, each on its own (main, side) stream pair, so one view's launch-bound
     # chains fill the gaps of another's.  Every view still runs the complete path.
     n_lanes = max(1, args.inflight)
-    lanes = [(torch.cuda.Stream(device=dev) if n_lanes > 1 else None, torch.cuda.Stream(device=dev)) for _ in range(n_lanes)]
+    if args.stream_pool > 0 and n_lanes > 1:
+        pool = [torch.cuda.Stream(device=dev) for _ in range(args.stream_pool)]
+        lanes = [(pool[(2 * i) % len(pool)], pool[(2 * i + 1) % len(pool)]) for i in range(n_lanes)]
+    elif args.lane_priorities and n_lanes > 1:
+        pr = [int(x) for x in args.lane_priorities.split(",")]
+        lanes = [(torch.cuda.Stream(device=dev, priority=pr[(2 * i) % len(pr)]), torch.cuda.Stream(device=dev, priority=pr[(2 * i + 1) % len(pr)]))
+                 for i in range(n_lanes)]
+    else:
+        lanes = [(torch.cuda.Stream(device=dev) if n_lanes > 1 else None, torch.cuda.Stream(device=dev)) for _ in range(n_lanes)]
 
     def render_view(data, side):
         """the whole per-view path: A12 + A9 on the current stream, A1-A5 on `side`, A6-A8 + A11"""

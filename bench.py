@@ -336,7 +336,16 @@ def main():
             return t_host, time.perf_counter() - t0
 
         th_e, t_eager = probe(step_eager)
-        build_graphs()
+        # replay can only win when the host is the limit: its enqueue time then fills (nearly) the whole
+        # wall time of the probe.  Otherwise no graph is built at all -- building them leaves the process
+        # in a state in which eager launches measure ~2 % slower (825-831 against 840-849 frames/s).
+        host_bound = th_e > float(os.environ.get("PGDVS_BENCH_HOST_BOUND_RATIO", "0.85")) * t_eager  # (0 forces the replay probe)
+        if world > 1:
+            hb = torch.tensor([1.0 if host_bound else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(hb, op=dist.ReduceOp.MAX)
+            host_bound = bool(hb.item() > 0)
+        if host_bound:
+            build_graphs()
         t_graph = float("inf")
         if graphs is not None:
             for j in range(n_lanes):
@@ -349,7 +358,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
             t_eager, t_graph = float(tt[0].item()) / world, float(tt[1].item()) / world
         probe_note = (f"auto: eager {t_eager / n_try * 1e3:.2f} ms/view with {th_e / n_try * 1e3:.2f} ms of host enqueue, "
-                      f"graph replay {t_graph / n_try * 1e3:.2f} ms/view")
+                      + (f"graph replay {t_graph / n_try * 1e3:.2f} ms/view" if host_bound else "host not the limit: no graphs built"))
         if graphs is not None and t_graph < 0.97 * t_eager:
             graph_note += f" ({probe_note})"
         else:

@@ -1,6 +1,8 @@
 #!/bin/bash
-# how busy the GPU is with three views in flight: union of kernel intervals, idle gaps, mean
-# number of kernels running (kernel trace of a default-style run; the tracer slows the host a bit)
+# kernel trace of a default-style run with three views in flight: union of kernel intervals, idle
+# gaps, mean number of kernels running, kernel time per view.  Under the tracer the run is ~1.5x
+# slower and at most two kernels overlap (mean 1.1): read the per-kernel times per view from it,
+# not the overlap an untraced run reaches.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/q_ov

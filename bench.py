@@ -67,6 +67,7 @@ def parse():
                     help="independent target views rendered concurrently, each on its own pair of HIP streams")
     ap.add_argument("--stream-pool", type=int, default=0, help="experiment: lanes draw their (main, side) streams from a pool of this many")
     ap.add_argument("--lane-priorities", default="", help="experiment: stream priorities, main/side per lane, e.g. -1,-1,0,0,0,0")
+    ap.add_argument("--run-ahead", type=int, default=6, help="views the host may have enqueued beyond the last finished one")
     ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
                     help="eager: enqueue every kernel of every view from Python; graph: replay one captured HIP graph "
                          "per lane; auto: eager unless the host turns out to be the bottleneck during warm-up")
@@ -253,6 +254,7 @@ def main():
             dist.barrier(device_ids=[local_rank])
 
     host_enqueue = [0.0]
+    mem_probe = {}
 
     def timed(n_steps, profile):
         lib.pgdvs_prof_enable(1 if profile else 0)
@@ -260,19 +262,34 @@ def main():
         gather = pdist.AsyncImageGather(dst=0, n_steps=n_steps, like=ref_img)
         barrier()
         torch.cuda.synchronize()
+        mem_probe["before"] = torch.cuda.memory_stats(dev)
+        mem_probe["segments"] = ({(x["address"], x["total_size"]) for x in torch.cuda.memory_snapshot()}
+                                 if os.environ.get("PGDVS_BENCH_MEM") else None)
         t0 = time.perf_counter()
+        done = []
         for j in range(n_steps):
+            # bounded run-ahead: the host enqueues a view in ~0.7 ms and the GPU renders one in ~1.2, so an
+            # unbounded loop gets tens of views ahead, and every view enqueued but not yet executed pins the
+            # workspace blocks its two streams share (the caching allocator cannot hand a block that
+            # another stream used back before that stream's work has run): the pool then grows by
+            # hipMalloc calls in the middle of the timed region, each of which drains the pipeline
+            if len(done) >= args.run_ahead:
+                done[j - args.run_ahead].synchronize()
             # per-kernel HIP events need real launches; one view at a time, so that a kernel's
             # duration is its own and not the queueing behind the other lanes' kernels
             img, cnt, main = step(j, eager=profile, lane=0 if profile else None)
             with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
                 gather.submit(img)
-        host_enqueue[0] = time.perf_counter() - t0  # host time to enqueue everything (no sync yet)
+                ev = torch.cuda.Event()
+                ev.record()
+            done.append(ev)
+        host_enqueue[0] = time.perf_counter() - t0  # host time to enqueue everything (incl. the waits of the run-ahead bound)
         join_lanes()
         gathered = gather.finish()
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
+        mem_probe["after"] = torch.cuda.memory_stats(dev)
         lib.pgdvs_prof_enable(0)
         return t1 - t0, gathered, cnt
 
@@ -369,14 +386,29 @@ def main():
 
     import gc
 
-    # the K output images are retained until the end of the timed region: have their blocks in the
-    # caching allocator already, so that no hipMalloc (and its implicit synchronisation) falls into it
-    spare = [torch.empty_like(ref_img) for _ in range(args.steps + 2 * n_lanes)]
-    del spare
+    # untimed rehearsal through the same loop: the allocator's pools reach the state the bounded
+    # run-ahead needs, so that the timed region allocates from them only (`device_mallocs_in_timed_region`)
+    timed(2 * args.run_ahead + n_lanes, profile=False)
     gc.collect()
     gc.disable()  # no collector pauses inside the timed loop
     elapsed, gathered, cnt = timed(args.steps, profile=False)
     gc.enable()
+    ms0, ms1, seg0 = mem_probe["before"], mem_probe["after"], mem_probe["segments"]
+    mem_note = {"device_mallocs_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+                "reserved_GB_peak": round(ms1.get("reserved_bytes.all.peak", 0) / 1e9, 2),
+                "allocated_GB_peak": round(ms1.get("allocated_bytes.all.peak", 0) / 1e9, 2)}
+    if os.environ.get("PGDVS_BENCH_MEM"):  # diagnostic: which segments the timed region had to get from the device
+        print("mem:", mem_note, file=sys.stderr)
+        known = {id(m): f"lane{i}.main" for i, (m, _) in enumerate(lanes) if m is not None}
+        names = {}
+        for i, (m, sd) in enumerate(lanes):
+            if m is not None:
+                names[m.cuda_stream] = f"lane{i}.main"
+            names[sd.cuda_stream] = f"lane{i}.side"
+        for x in torch.cuda.memory_snapshot():
+            if (x["address"], x["total_size"]) not in seg0:
+                print(f"  new segment {x['total_size'] / 1e6:9.1f} MB on {names.get(x['stream'], x['stream'])}: blocks "
+                      + ", ".join(f"{b['size'] / 1e6:.1f}{'*' if b['state'] == 'active_allocated' else ''}" for b in x["blocks"][:8]), file=sys.stderr)
     host_ms = host_enqueue[0] / args.steps * 1e3
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -524,7 +556,7 @@ def main():
                 "workload": f"{W}x{H} target view, {S} source frames resident in HBM: static aggregation (A12) + "
                             f"point z-buffer raster K={K} (A9) + flow-warped dynamic splat (A1-A8, outlier filter "
                             f"{'on' if not args.no_outlier else 'off'}) + composite (A11)",
-                "views_in_flight": (len(graphs) if graphs else n_lanes), "launch": graph_note, "height": H, "width": W, "src_frames": S, "static_points": n_static, "dyn_pixels": n_dyn,
+                "views_in_flight": (len(graphs) if graphs else n_lanes), "host_run_ahead_views": args.run_ahead, "memory": mem_note, "launch": graph_note, "height": H, "width": W, "src_frames": S, "static_points": n_static, "dyn_pixels": n_dyn,
                 "parallelism": f"frames sharded over {world} GPU(s), RCCL gather of the image stack" if world > 1 else "1 GPU",
                 "whole_view_alg_bytes": alg_total,
                 "whole_view_alg_GBps": round(alg_total * fps / 1e9 / max(world, 1), 2),

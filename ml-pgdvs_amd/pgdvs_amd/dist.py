@@ -56,26 +56,35 @@ class AsyncImageGather:
     is exposed.  ``finish()`` waits for all transfers and returns, on ``dst``, the stack
     [n_steps * world, ...] in view order (view = step * world + rank), else None.
 
-    With ``n_steps`` and ``like`` (one image) the receive stack is allocated once, up front, and
-    every step's gather lands directly in its slices: no allocation and no final concatenation
-    on ``dst`` while steps are in flight (at 1080p and 8 ranks a step brings 200 MB to ``dst``)."""
+    With ``n_steps`` and ``like`` (one image) every buffer is allocated once, up front: each rank
+    copies its image into a slice of a local stack (the renderer's own output block -- which the
+    image shares with the renderer's other outputs -- is free again right after the step), and
+    ``dst`` receives every step directly into the slices of one receive stack.  Nothing is
+    allocated or concatenated while steps are in flight (at 1080p and 8 ranks a step brings
+    200 MB to ``dst``; a caching-allocator miss there is a hipMalloc in the middle of the pipeline)."""
 
     def __init__(self, dst: int = 0, n_steps: int | None = None, like: torch.Tensor | None = None):
         self.dst = dst
         self.works, self.bufs, self.keep = [], [], []
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        self.stack = None
-        if self.on and n_steps and like is not None and dist.get_rank() == dst:
-            self.stack = torch.empty((n_steps, dist.get_world_size()) + tuple(like.shape), dtype=like.dtype, device=like.device)
+        self.local = self.stack = None
+        if n_steps and like is not None:
+            self.local = torch.empty((n_steps,) + tuple(like.shape), dtype=like.dtype, device=like.device)
+            if self.on and dist.get_rank() == dst:
+                self.stack = torch.empty((n_steps, dist.get_world_size()) + tuple(like.shape), dtype=like.dtype, device=like.device)
 
     def submit(self, img: torch.Tensor) -> None:
-        img = img.contiguous()
+        j = len(self.keep)
+        if self.local is not None and j < self.local.shape[0] and tuple(img.shape) == tuple(self.local.shape[1:]):
+            self.local[j].copy_(img)  # on the caller's current stream, like the gather below
+            img = self.local[j]
+        else:
+            img = img.contiguous()
         self.keep.append(img)
         if not self.on:
             return
         bufs = None
         if dist.get_rank() == self.dst:
-            j = len(self.works)
             if self.stack is not None and j < self.stack.shape[0] and tuple(img.shape) == tuple(self.stack.shape[2:]):
                 bufs = list(self.stack[j].unbind(0))
             else:
@@ -84,13 +93,18 @@ class AsyncImageGather:
         self.works.append(dist.gather(img, bufs, dst=self.dst, async_op=True))
 
     def finish(self):
+        n = len(self.keep)
         if not self.on:
-            return torch.cat(self.keep, 0) if self.keep else None
+            if not self.keep:
+                return None
+            if self.local is not None and n <= self.local.shape[0] and all(
+                    k.data_ptr() == self.local[j].data_ptr() for j, k in enumerate(self.keep)):
+                return self.local[:n].flatten(0, 1)
+            return torch.cat(self.keep, 0)
         for w in self.works:
             w.wait()
         if dist.get_rank() != self.dst:
             return None
-        n = len(self.works)
         if self.stack is not None and n <= self.stack.shape[0] and all(
                 b[0].data_ptr() == self.stack[j, 0].data_ptr() for j, b in enumerate(self.bufs)):
             return self.stack[:n].flatten(0, 2)  # [step, rank, 1-or-more images, ...] -> view order

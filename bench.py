@@ -178,6 +178,7 @@ def main():
     # in flight per GPU, each on its own (main, side) stream pair, so one view's launch-bound
     # chains fill the gaps of another's.  Every view still runs the complete path.
     n_lanes = max(1, args.inflight)
+    args.run_ahead = max(args.run_ahead, n_lanes + 1)  # the bound must leave every lane a view to work on
     if args.stream_pool > 0 and n_lanes > 1:
         pool = [torch.cuda.Stream(device=dev) for _ in range(args.stream_pool)]
         lanes = [(pool[(2 * i) % len(pool)], pool[(2 * i + 1) % len(pool)]) for i in range(n_lanes)]

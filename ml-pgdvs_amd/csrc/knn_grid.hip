@@ -704,7 +704,7 @@ __device__ __forceinline__ void tpq_insert(float (&a)[KK], float c) {
 }
 
 template <int KK>
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(256, 5)
 grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted,
                       const int32_t *__restrict__ cell_start, int first_col, float *__restrict__ avg_out,
                       int32_t *__restrict__ open_count, int32_t *__restrict__ open_list) {

@@ -540,7 +540,7 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
   for (int i = 1; i < S; i += 2) {
     uint16_t *occ_i = (i & 1) ? ws.occ2 : ws.occ, *occ_n = (i & 1) ? ws.occ : ws.occ2;
     if (i + 1 < S) {
-      PGDVS_LAUNCH("agg_mark", agg_mark_kernel<2>, dim3(2048), dim3(256), 0, st, (const float *)ws.xyz,
+      PGDVS_LAUNCH("agg_mark", agg_mark_kernel<2>, dim3(4096), dim3(256), 0, st, (const float *)ws.xyz,
                    (const int64_t *)nullptr, (const int64_t *)(ws.cnts + i), (const ProjF64 *)ws.proj, i, H, W, occ_i, occ_n);
     } else {
       PGDVS_LAUNCH("agg_mark", agg_mark_kernel<1>, dim3(2048), dim3(256), 0, st, (const float *)ws.xyz,

@@ -147,8 +147,8 @@ agg_mark_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ begin
   }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // the whole grid is resident, so a thread walks several points: the next point's load is
-  // issued before the current point's fp64 operations
+  // a thread walks several points (grid-stride): the next point's load is issued before the
+  // current point's fp64 operations
   float nx = 0.0f, ny = 0.0f, nz = 0.0f;
   if (i < n) {
     nx = xyz[i * 3 + 0];

@@ -72,7 +72,80 @@ def parse():
                     help="eager: enqueue every kernel of every view from Python; graph: replay one captured HIP graph "
                          "per lane; auto: eager unless the host turns out to be the bottleneck during warm-up")
     ap.add_argument("--gnt-rays", type=int, default=1024, help="rays of the GNT sub-benchmark chunk (0 = skip)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: exercise the launcher, the view sharding, the per-step gather and the timing "
+                         "protocol on CPU tensors over gloo (tests); prints a line with dry_run=true and value=null")
+    ap.add_argument("--dry-fail-rank", type=int, default=-1, help="(dry run) this rank exits non-zero: launcher error path")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """``python bench.py --gpus N`` without a launcher around it: start N fresh rank processes (one per
+    GPU) through torch.distributed.run, as the reference's run.py:158-176 spawns its own workers.  This
+    process has made no GPU call (importing torch and parsing flags do not initialise HIP) and makes none:
+    it only waits, relays the children's output (rank 0 prints the JSON line) and returns their exit code,
+    which is non-zero if any rank failed."""
+    import subprocess
+
+    n_dev = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if not args.dry_run and n_dev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL fails on this host driver without it
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(pathlib.Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_main(args, world, rank):
+    """The N-rank protocol of the benchmark without the renderer: same sharding (`(j + rank) % n_views`),
+    same per-step asynchronous gather into a preallocated stack, same barrier / max-over-ranks timing,
+    same JSON keys -- on CPU tensors over gloo.  Test infrastructure for the launcher; measures nothing."""
+    from pgdvs_amd import dist as pdist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == args.gpus, f"world size {dist.get_world_size()} != --gpus {args.gpus}"
+    if rank == args.dry_fail_rank:
+        print(f"rank {rank}: failing on request", file=sys.stderr)
+        sys.exit(3)
+    like = torch.empty(1, 3, 4, 6)
+    gather = pdist.AsyncImageGather(dst=0, n_steps=args.steps, like=like)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for j in range(args.steps):
+        gather.submit(torch.full_like(like, float(j * world + rank)))  # image of view j * world + rank
+    out = gather.finish()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(x.item()) for x in allt]
+    if rank == 0:
+        assert out.shape[0] == args.steps * world and [float(x) for x in out[:, 0, 0, 0]] == [float(v) for v in range(args.steps * world)]
+        print(json.dumps({"metric": "novel-view frames/s at 1080p x 24 src frames; achieved HBM GB/s vs gfx950 peak",
+                          "value": None, "unit": "frames/s", "dry_run": True, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(max(per_rank) / max(args.steps, 1) * 1e3, 3),
+                          "scaling": "weak", "views_gathered": int(out.shape[0]),
+                          "per_rank_seconds": [round(x, 4) for x in per_rank],
+                          "gather_bytes_to_rank0": int(like.numel() * 4 * args.steps * (world - 1))}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def algorithmic_bytes(name, H, W, S, n_static, n_dyn, K):
@@ -140,15 +213,21 @@ def gnt_full_frame(dev, H=288, W=550, V=10, chunk=1024):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))  # before anything touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU"
+    if args.dry_run:
+        return dry_main(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == args.gpus, f"world size {dist.get_world_size()} != --gpus {args.gpus}"
 
     from pgdvs_amd import _lib, dist as pdist, ops, synth
     from pgdvs_amd.instantiate import load_config
@@ -412,7 +491,11 @@ def main():
                       + ", ".join(f"{b['size'] / 1e6:.1f}{'*' if b['state'] == 'active_allocated' else ''}" for b in x["blocks"][:8]), file=sys.stderr)
     host_ms = host_enqueue[0] / args.steps * 1e3
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    per_rank_s = [elapsed]
     if world > 1:
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_s = [float(x.item()) for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     n_static = int(cnt.item())
@@ -559,6 +642,8 @@ def main():
                             f"{'on' if not args.no_outlier else 'off'}) + composite (A11)",
                 "views_in_flight": (len(graphs) if graphs else n_lanes), "host_run_ahead_views": args.run_ahead, "memory": mem_note, "launch": graph_note, "height": H, "width": W, "src_frames": S, "static_points": n_static, "dyn_pixels": n_dyn,
                 "parallelism": f"frames sharded over {world} GPU(s), RCCL gather of the image stack" if world > 1 else "1 GPU",
+                "per_rank_frames_per_s": [round(args.steps / x, 2) for x in per_rank_s],
+                "gather_bytes_to_rank0": int(3 * H * W * 4 * args.steps * (world - 1)),
                 "whole_view_alg_bytes": alg_total,
                 "whole_view_alg_GBps": round(alg_total * fps / 1e9 / max(world, 1), 2),
             },

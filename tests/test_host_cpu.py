@@ -133,6 +133,38 @@ def test_gather_world_size_2_gloo(tmp_path):
     assert "GATHER_OK" in r.stdout
 
 
+def _bench(*flags, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), *flags], capture_output=True, text=True, timeout=300, env=env)
+
+
+def test_bench_gpus_2_starts_two_ranks_dry():
+    """`python bench.py --gpus 2` (the driver's form, no launcher around it) must start two ranks by
+    itself, shard the views, gather them to rank 0 and relay ONE JSON line (reference: run.py:158-176)."""
+    import json
+
+    r = _bench("--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run")
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["value"] is None
+    assert out["views_gathered"] == 8 and len(out["per_rank_seconds"]) == 2
+    assert out["gather_bytes_to_rank0"] == 4 * 3 * 4 * 6 * 4
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    r = _bench("--gpus", "2", "--steps", "2", "--dry-run", "--dry-fail-rank", "1")
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_rejects_world_size_mismatch():
+    r = _bench("--gpus", "2", "--dry-run", env_extra={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in r.stderr
+
+
 def test_gnt_modules_match_reference_golden(golden_dir):
     """Host-side GNT modules (state-dict layout, seeded init order, dense mask-driven
     formulation of the view/ray transformers) against vectors produced by the reference."""

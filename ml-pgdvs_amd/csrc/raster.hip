@@ -83,7 +83,10 @@ raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, i
                             const int64_t *__restrict__ n_dev, const float *__restrict__ cam,
                             float radius, int H, int W, int ntx, int nty,
                             float4 *__restrict__ ndc4, int32_t *__restrict__ tile_count) {
-  const int64_t n = n_dev ? *n_dev : n_host;
+  // a device-side count never exceeds the rows the caller sized the workspace for (and a
+  // negative one -- the aggregation's error status -- renders nothing)
+  int64_t n = n_dev ? *n_dev : n_host;
+  n = n > n_host ? n_host : (n < 0 ? 0 : n);
   RasterCam rc = make_raster_cam(cam, H, W);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t n_round = (n + 63) / 64 * 64;  // keep whole wavefronts in the loop
@@ -141,7 +144,10 @@ raster_fill_kernel(int64_t n_host, const int64_t *__restrict__ n_dev,
                    const float4 *__restrict__ ndc4, const int32_t *__restrict__ offsets,
                    int32_t *__restrict__ cursor, int32_t *__restrict__ lists,
                    int64_t list_capacity) {
-  const int64_t n = n_dev ? *n_dev : n_host;
+  // a device-side count never exceeds the rows the caller sized the workspace for (and a
+  // negative one -- the aggregation's error status -- renders nothing)
+  int64_t n = n_dev ? *n_dev : n_host;
+  n = n > n_host ? n_host : (n < 0 ? 0 : n);
   RasterCam rc = make_raster_cam(cam, H, W);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t n_round = (n + 63) / 64 * 64;
@@ -366,7 +372,6 @@ static RasterWs raster_ws_layout(void *base, int64_t n, int H, int W, float radi
   w.offsets = reinterpret_cast<int32_t *>(p + off);
   off += align_up((ntiles + 1) * 4, 256);
   w.list_capacity = (n > 0 ? n : 1) * max_tiles_per_point(radius, H, W);
-  if (w.list_capacity >= (1ll << 31)) w.list_capacity = (1ll << 31) - 1;
   w.lists = reinterpret_cast<int32_t *>(p + off);
   off += align_up(w.list_capacity * 4, 256);
   w.total_bytes = off;
@@ -379,7 +384,12 @@ using namespace pgdvs;
 
 PGDVS_API int64_t pgdvs_points_raster_workspace_bytes(int64_t n_points, int H, int W, float radius) {
   if (n_points < 0 || H <= 0 || W <= 0) return -1;
-  return raster_ws_layout(nullptr, n_points, H, W, radius).total_bytes;
+  const RasterWs w = raster_ws_layout(nullptr, n_points, H, W, radius);
+  if (w.list_capacity >= (1ll << 31)) {
+    set_error("pgdvs_points_raster: %lld points x this radius exceeds the 2^31 tile-list entries supported", (long long)n_points);
+    return PGDVS_ERR_UNSUPPORTED;
+  }
+  return w.total_bytes;
 }
 
 template <int K>
@@ -408,6 +418,11 @@ PGDVS_API int pgdvs_points_raster(const float *pts, int64_t pts_stride, const fl
     return PGDVS_ERR_UNSUPPORTED;
   }
   RasterWs ws = raster_ws_layout(workspace, n_points, H, W, radius);
+  if (ws.list_capacity >= (1ll << 31)) {  // int32 list offsets
+    set_error("pgdvs_points_raster: %lld points x %lld tiles per point exceeds the 2^31 tile-list entries supported",
+              (long long)n_points, (long long)(ws.list_capacity / (n_points > 0 ? n_points : 1)));
+    return PGDVS_ERR_UNSUPPORTED;
+  }
   if (!workspace || workspace_bytes < ws.total_bytes) {
     set_error("pgdvs_points_raster: workspace too small (%lld < %lld)", (long long)workspace_bytes,
               (long long)ws.total_bytes);

@@ -207,12 +207,11 @@ struct SelArgs {
   float *cloud;              // [capacity,6]
   float *xyz;                // [capacity,3] packed copy for the mark pass
   int64_t *cnts;             // [S+1] cloud size before each frame; cnts[S] = final
-  int64_t *count_out;
   unsigned long long *desc;  // [tiles]
   int32_t *ticket;           // [S]
   int32_t *error;            // set when a look-back spin gives up
   int64_t capacity;
-  int frame, last_frame, P, W, tiles;
+  int frame, P, W, tiles;
 };
 
 // selection flags of 16 consecutive pixels: static and (frame 0 or) not stamped by this
@@ -252,9 +251,10 @@ __global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamB
   __shared__ long long s_excl;
   __shared__ uint16_t s_list[kSelTile];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // dynamic tile id: a tile's predecessors are always owned by blocks that already run
-  // (with <= 1024 tiles the whole grid is resident and blockIdx order is as good)
-  if (tid == 0) s_tile = (a.tiles <= 1024) ? (int)blockIdx.x : atomicAdd(&a.ticket[a.frame], 1);
+  // dynamic tile id (one atomic per block): a tile's predecessors are always owned by blocks that
+  // already run, whatever order the dispatcher starts blocks in (blockIdx order is NOT dispatch
+  // order: workgroups go round-robin over the 8 XCDs, and other views' kernels share the CUs)
+  if (tid == 0) s_tile = atomicAdd(&a.ticket[a.frame], 1);
   __syncthreads();
   const int tile = s_tile;
   const int base = tile * kSelTile + tid * kSelItems;
@@ -311,7 +311,6 @@ __global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamB
     int64_t n = cloud_base + s_excl + total;
     n = n > a.capacity ? a.capacity : n;
     a.cnts[a.frame + 1] = n;
-    if (a.frame == a.last_frame) *a.count_out = n;
   }
   // Ordered append (tmp_pcl[tmp_st_mask], tmp_img[tmp_st_mask] :247-251): the tile's selected
   // pixels are first compacted into an LDS list (row-major rank order), then the whole block
@@ -380,6 +379,13 @@ __global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamB
     xq.z = X[2];
     *reinterpret_cast<f3 *>(xyz + pos * 3) = xq;
   }
+}
+
+// the count the caller sees: the cloud size, or -1 when a look-back spin gave up in any frame
+// (the cloud is then not trustworthy; hosts that read the count raise, see ops.static_aggregate)
+__global__ void agg_finalize_kernel(const int64_t *__restrict__ cnts, const int32_t *__restrict__ error, int S,
+                                    int64_t *__restrict__ count_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *count_out = *error ? -1 : cnts[S];
 }
 
 struct AggWs {
@@ -521,13 +527,11 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
     a.cloud = out;
     a.xyz = ws.xyz;
     a.cnts = ws.cnts;
-    a.count_out = count_out;
     a.desc = ws.desc;
     a.ticket = ws.ticket;
     a.error = ws.error;
     a.capacity = capacity;
     a.frame = i;
-    a.last_frame = S - 1;
     a.P = (int)P;
     a.W = W;
     a.tiles = tiles;
@@ -554,5 +558,7 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
       select(i + 1);
     }
   }
+  PGDVS_LAUNCH("agg_finalize", agg_finalize_kernel, dim3(1), dim3(64), 0, st, (const int64_t *)ws.cnts,
+               (const int32_t *)ws.error, S, count_out);
   return check_launch("static_aggregate");
 }

@@ -30,4 +30,4 @@ def aggregate_static_pcl(rgbs, depths, dyn_masks, K3s, c2ws, *, sync=True, capac
     buf, cnt = ops.static_aggregate(rgbs, depths, dyn_masks, K3s, c2ws, capacity=capacity)
     if not sync:
         return buf, cnt
-    return buf[: int(cnt.item())]
+    return buf[: ops.checked_count(cnt, "pgdvs_static_aggregate")]

@@ -107,8 +107,10 @@ class GNT(nn.Module):
         rows), cnt[R,S] number of valid views."""
         from .... import ops
 
-        if q.is_cuda and ops.gnt_view_available(q.shape[-1], feat.shape[2]):
-            return ops.gnt_view_layer(layer, q, feat, ray_diff, valid, want_stats)
+        if q.is_cuda and not ops.needs_autograd(layer, q, feat):
+            if ops.gnt_view_available(q.shape[-1], feat.shape[2]):
+                return ops.gnt_view_layer(layer, q, feat, ray_diff, valid, want_stats)
+            ops.gnt_fallback("pgdvs_gnt_view_layer", f"width {q.shape[-1]} with {feat.shape[2]} source views (needs 64 and <= 64)")
         a = layer.attn
         x = layer.attn_norm(q)
         qq = a.q_fc(x)
@@ -138,8 +140,11 @@ class GNT(nn.Module):
 
         a = layer.attn
         R, S, D = q.shape
-        if q.is_cuda and ops.gnt_ray_available(D, S, a.n_heads):
-            return ops.gnt_ray_layer(layer, q, want_attn)
+        if q.is_cuda and not ops.needs_autograd(layer, q):
+            if ops.gnt_ray_available(D, S, a.n_heads):
+                return ops.gnt_ray_layer(layer, q, want_attn)
+            ops.gnt_fallback("pgdvs_gnt_ray_layer", f"width {D}, {a.n_heads} heads, {S} samples per ray "
+                                                    f"(needs 64, 4 and <= {ops.GNT_RAY_MAX_SAMPLES})")
         hd = D // a.n_heads
         x = layer.attn_norm(q)
         sp = lambda t: t.view(R, S, a.n_heads, hd).permute(0, 2, 1, 3)
@@ -157,7 +162,10 @@ class GNT(nn.Module):
         input_pts = _posenc(pts.float(), self.pos_freqs, self.max_log2)
         from .... import ops
 
-        fused = rgb_feat.is_cuda and ops.gnt_embed_available(self.rgbfeat_fc, rgb_feat.shape[-1])
+        hip = rgb_feat.is_cuda and not ops.needs_autograd(self, rgb_feat)
+        fused = hip and ops.gnt_embed_available(self.rgbfeat_fc, rgb_feat.shape[-1])
+        if hip and not fused:
+            ops.gnt_fallback("pgdvs_gnt_embed", f"{rgb_feat.shape[-1]} input channels / this rgbfeat_fc (needs 33..36 -> 64 -> 64)")
         if fused:
             feat, q, std0 = ops.gnt_embed(self.rgbfeat_fc, rgb_feat, ret_view_std)
         else:
@@ -180,8 +188,10 @@ class GNT(nn.Module):
             stdns.append((s0 / (feat.abs().mean(2) + TINY_NUMBER)).mean(-1))
         attn = None
         posfc = None
-        if rgb_feat.is_cuda and ops.gnt_posfc_available(self.q_fcs, q.shape[-1]):
+        if hip and ops.gnt_posfc_available(self.q_fcs, q.shape[-1]):
             posfc = ops.GntPosFc(self.q_fcs, input_pts, input_views[:, 0])
+        elif hip:
+            ops.gnt_fallback("pgdvs_gnt_posfc", f"width {q.shape[-1]} (needs 64)")
         for i, (vl, qfc, rl) in enumerate(zip(self.view_crosstrans, self.q_fcs, self.view_selftrans)):
             q, stats = self._view_layer(vl, q, feat, ray_diff, valid, cnt, want_stats)
             if i % 2 == 0:
@@ -197,9 +207,11 @@ class GNT(nn.Module):
         if ret_view_std:
             extras["view_std"] = torch.stack(stds, dim=2)
             extras["view_std_normalized"] = torch.stack(stdns, dim=2)
-        if q.is_cuda and ops.gnt_head_available(self.norm, self.rgb_fc):
+        if hip and ops.gnt_head_available(self.norm, self.rgb_fc):
             outputs = ops.gnt_head(self.norm, self.rgb_fc, q)
         else:
+            if hip:
+                ops.gnt_fallback("pgdvs_gnt_head", f"width {q.shape[-1]} (needs 64, eps 1e-5)")
             outputs = self.rgb_fc(self.norm(q).mean(dim=1))
         if self.ret_alpha:
             return torch.cat([outputs, attn], dim=1), extras

@@ -58,6 +58,9 @@ def _ptr(t):
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
+    if int(nbytes) < 0:  # the *_workspace_bytes entry points return a negative status for shapes they reject
+        msg = _lib.load().pgdvs_last_error().decode("utf-8", "replace")
+        raise PgdvsHipError(f"workspace query rejected the shape (status {int(nbytes)}): {msg}")
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
@@ -357,6 +360,16 @@ def static_aggregate(rgbs, depths, dyn_masks, K3s, c2ws, capacity: int | None = 
     return out, cnt
 
 
+def checked_count(cnt, what: str) -> int:
+    """Host read of a device-side count that doubles as a status word: negative = the kernel chain
+    reported an internal error (e.g. ``agg_select``'s ordered-offset look-back gave up) and its
+    output must not be used."""
+    n = int(cnt.item())
+    if n < 0:
+        raise PgdvsHipError(f"{what}: device-side error flag set (count {n}); the output is not valid")
+    return n
+
+
 def combine(static_rgb, dyn_rgb, dyn_mask):
     """[B,3,H,W], [B,3,H,W], [B,1,H,W] -> combined, combined_static, combined_dyn."""
     st = _req(static_rgb, torch.float32, "static_rgb")
@@ -403,6 +416,55 @@ def gnt_gather(ray_o, ray_d, depth_range, n_samples: int, inv_uniform: bool, cam
     return out
 
 
+# ---- packed-weight caches of the fused GNT kernels ---------------------------------------
+def _param_key(*modules):
+    """(storage address, in-place version) of every parameter: changes on `.to(device)`, on
+    `load_state_dict` (in-place copies bump `_version`) and on optimiser steps."""
+    return tuple((p.data_ptr(), p._version) for m in modules for p in m.parameters())
+
+
+def _packed(owner, build, *modules):
+    """Packed copy of `modules`' parameters cached on `owner`, rebuilt whenever a parameter was moved or
+    written since it was packed (a checkpoint loaded after a warm-up forward must not keep the old weights)."""
+    key = _param_key(*(modules or (owner,)))
+    hit = getattr(owner, "_pgdvs_packed", None)
+    if hit is None or hit[0] != key:
+        hit = (key, build())
+        object.__setattr__(owner, "_pgdvs_packed", hit)  # plain attribute: never a submodule / buffer / state_dict entry
+    return hit[1]
+
+
+def needs_autograd(*modules_and_tensors) -> bool:
+    """The fused kernels return tensors without autograd history: they may run only when nobody can ask
+    for gradients through them (inference under no_grad, or nothing on the path requires grad)."""
+    if not torch.is_grad_enabled():
+        return False
+    for x in modules_and_tensors:
+        if isinstance(x, torch.Tensor):
+            if x.requires_grad:
+                return True
+        elif x is not None and any(p.requires_grad for p in x.parameters()):
+            return True
+    return False
+
+
+_fallback_seen = set()
+
+
+def gnt_fallback(kernel: str, why: str) -> None:
+    """A CUDA tensor is about to take the torch branch of a GNT stage because the fused kernel does not
+    cover its shape: say so once per (kernel, reason); raise instead under PGDVS_GNT_STRICT=1."""
+    import os
+    import warnings
+
+    msg = f"pgdvs_amd: {kernel} does not cover {why}; this stage runs on torch/rocBLAS (results identical, slower)"
+    if os.environ.get("PGDVS_GNT_STRICT", "0") not in ("", "0"):
+        raise PgdvsHipError(msg)
+    if (kernel, why) not in _fallback_seen:
+        _fallback_seen.add((kernel, why))
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 # ---- GNT view-transformer contraction on MFMA (csrc/gnt_view.hip) ------------------------
 def gnt_view_available(dim: int, n_views: int) -> bool:
     """True when the fused MFMA view-layer kernel handles this shape (width 64)."""
@@ -443,10 +505,7 @@ def pack_view_layer(layer) -> torch.Tensor:
 
 def gnt_view_layer(layer, q, feat, ray_diff, valid, want_stats):
     """q[R,S,64], feat[R,S,V,64], ray_diff[R,S,V,4], valid[R,S,V] bool -> (q_out, stats or None)."""
-    packed = getattr(layer, "_pgdvs_packed", None)
-    if packed is None or packed.device != q.device:
-        packed = pack_view_layer(layer)
-        layer._pgdvs_packed = packed  # parameters are frozen at inference (static renderer is .eval())
+    packed = _packed(layer, lambda: pack_view_layer(layer))
     R, S, V = feat.shape[0], feat.shape[1], feat.shape[2]
     N = R * S
     qi = _req(q, torch.float32, "q")
@@ -483,10 +542,7 @@ def pack_embed(mlp) -> torch.Tensor:
 
 def gnt_embed(mlp, rgb_feat, want_std: bool):
     """rgb_feat[R,S,V,Cin] -> feat[R,S,V,64], q0[R,S,64], (std[R,S], std_normalized[R,S]) or None."""
-    packed = getattr(mlp, "_pgdvs_packed", None)
-    if packed is None or packed.device != rgb_feat.device:
-        packed = pack_embed(mlp)
-        mlp._pgdvs_packed = packed
+    packed = _packed(mlp, lambda: pack_embed(mlp))
     x = _req(rgb_feat, torch.float32, "rgb_feat")
     R, S, V, cin = x.shape
     N = R * S
@@ -517,17 +573,16 @@ class GntPosFc:
         self.ids = [i for i, m in enumerate(q_fcs) if not isinstance(m, torch.nn.Identity)]
         mlps = [q_fcs[i] for i in self.ids]
         P, Pv = pe_pts.shape[-1], pe_view.shape[-1]
-        cache = getattr(q_fcs, "_pgdvs_packed", None)
-        if cache is None or cache[0].device != pe_pts.device:
+        def build():
             wp = torch.cat([m[0].weight.detach().float()[:, 64:64 + P] for m in mlps], 0).t().contiguous()  # [P, 64 L]
             wv = torch.cat([m[0].weight.detach().float()[:, 64 + P:64 + P + Pv] for m in mlps], 0).t().contiguous()
             b1 = torch.cat([m[0].bias.detach().float() for m in mlps], 0)
             packed = [torch.cat([m[0].weight.detach().float()[:, :64].t().contiguous().reshape(-1),
                                  m[2].weight.detach().float().t().contiguous().reshape(-1),
                                  m[2].bias.detach().float()]) for m in mlps]
-            cache = (wp, wv, b1, packed)
-            q_fcs._pgdvs_packed = cache  # parameters are frozen at inference
-        wp, wv, b1, self.packed = cache
+            return (wp, wv, b1, packed)
+
+        wp, wv, b1, self.packed = _packed(q_fcs, build)
         R, S = pe_pts.shape[0], pe_pts.shape[1]
         self.R, self.S = R, S
         self.T = pe_pts.reshape(R * S, P).float() @ wp        # [N, 64 L]
@@ -551,10 +606,8 @@ def gnt_head_available(norm, rgb_fc) -> bool:
 
 def gnt_head(norm, rgb_fc, q):
     """rgb_fc(norm(q).mean(dim=1)): q[R,S,64] -> [R,3]"""
-    packed = getattr(rgb_fc, "_pgdvs_packed", None)
-    if packed is None or packed.device != q.device:
-        packed = torch.cat([p.detach().float().contiguous().reshape(-1) for p in (norm.weight, norm.bias, rgb_fc.weight, rgb_fc.bias)])
-        rgb_fc._pgdvs_packed = packed
+    packed = _packed(rgb_fc, lambda: torch.cat([p.detach().float().contiguous().reshape(-1)
+                                                for p in (norm.weight, norm.bias, rgb_fc.weight, rgb_fc.bias)]), norm, rgb_fc)
     qi = _req(q, torch.float32, "q")
     R, S, _ = qi.shape
     out = torch.empty((R, 3), dtype=torch.float32, device=q.device)
@@ -578,16 +631,16 @@ def pack_ray_layer(layer) -> torch.Tensor:
     return packed
 
 
+GNT_RAY_MAX_SAMPLES = 256  # K and V of one ray live in LDS (csrc/gnt_view.hip)
+
+
 def gnt_ray_available(dim: int, n_samples: int, n_heads: int) -> bool:
-    return _GNT_VIEW_ENABLED and dim == 64 and n_heads == 4 and 1 <= n_samples <= 256
+    return _GNT_VIEW_ENABLED and dim == 64 and n_heads == 4 and 1 <= n_samples <= GNT_RAY_MAX_SAMPLES
 
 
 def gnt_ray_layer(layer, q, want_attn: bool):
     """q[R,S,64] -> (q_out[R,S,64], weights[R,S] or None)."""
-    packed = getattr(layer, "_pgdvs_packed", None)
-    if packed is None or packed.device != q.device:
-        packed = pack_ray_layer(layer)
-        layer._pgdvs_packed = packed
+    packed = _packed(layer, lambda: pack_ray_layer(layer))
     qi = _req(q, torch.float32, "q")
     R, S, _ = qi.shape
     out = torch.empty_like(qi)

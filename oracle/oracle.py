@@ -417,6 +417,26 @@ def rasterize_points(pts, flat_cam_tgt, H, W, radius, K):
     return idx, zbuf, d2
 
 
+def points_to_ndc(pts, flat_cam_tgt, H, W):
+    cam = cam_prep(flat_cam_tgt)
+    pts = _f32(pts).reshape(-1, 3)
+    ndc = np.empty((pts.shape[0], 3), np.float32)
+    lib().orc_points_to_ndc(_p(cam, _c_float_p), H, W, _p(pts, _c_float_p), ctypes.c_int64(pts.shape[0]), ctypes.c_int64(3),
+                            _p(ndc, _c_float_p))
+    return ndc
+
+
+def rasterize_points_window(ndc, H, W, radius, K, y0, y1, x0, x1):
+    """The naive rasteriser on the pixel window [y0,y1) x [x0,x1) of the H x W image, all points tested:
+    (idx, zbuf, d2)[y1-y0, x1-x0, K] -- what the full-size call returns on that window."""
+    ndc = _f32(ndc).reshape(-1, 3)
+    sh = (y1 - y0, x1 - x0, K)
+    idx, zbuf, d2 = np.empty(sh, np.int64), np.empty(sh, np.float32), np.empty(sh, np.float32)
+    lib().orc_raster_points_window(_p(ndc, _c_float_p), ctypes.c_int64(ndc.shape[0]), H, W, ctypes.c_float(radius), int(K),
+                                   int(y0), int(y1), int(x0), int(x1), _p(idx, _c_i64_p), _p(zbuf, _c_float_p), _p(d2, _c_float_p))
+    return idx, zbuf, d2
+
+
 def composite(idx, d2, radius, feat):
     H, W, K = idx.shape
     out = np.empty((H, W, 3), np.float32)

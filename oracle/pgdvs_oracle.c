@@ -622,18 +622,38 @@ ORC_API void orc_points_to_ndc(const float *cam, int H, int W, const float *pts,
   }
 }
 
+static void raster_points_window(const float *ndc, int64_t N, int H, int W, float radius, int K,
+                                 int y0, int y1, int x0, int x1, int64_t *idx, float *zbuf,
+                                 float *dist2);
+
 ORC_API void orc_raster_points_naive(const float *ndc, int64_t N, int H, int W, float radius,
                                      int K, int64_t *idx, float *zbuf, float *dist2) {
+  raster_points_window(ndc, N, H, W, radius, K, 0, H, 0, W, idx, zbuf, dist2);
+}
+
+/* The same naive loop restricted to the pixel window [y0,y1) x [x0,x1) of the H x W image:
+ * every point is still tested against every pixel of the window, so a 1080p view with millions
+ * of points can be checked on a few windows in seconds.  Outputs are [y1-y0, x1-x0, K]. */
+ORC_API void orc_raster_points_window(const float *ndc, int64_t N, int H, int W, float radius,
+                                      int K, int y0, int y1, int x0, int x1, int64_t *idx,
+                                      float *zbuf, float *dist2) {
+  raster_points_window(ndc, N, H, W, radius, K, y0, y1, x0, x1, idx, zbuf, dist2);
+}
+
+static void raster_points_window(const float *ndc, int64_t N, int H, int W, float radius, int K,
+                                 int y0, int y1, int x0, int x1, int64_t *idx, float *zbuf,
+                                 float *dist2) {
   const float r2 = radius * radius;
+  const int WW = x1 - x0;
 #pragma omp parallel
   {
     float *qz = (float *)malloc(sizeof(float) * (size_t)K);
     float *qd = (float *)malloc(sizeof(float) * (size_t)K);
     int64_t *qi = (int64_t *)malloc(sizeof(int64_t) * (size_t)K);
-#pragma omp for schedule(dynamic, 4)
-    for (int yi = 0; yi < H; ++yi) {
-      float yf = pix_to_ndc(H - 1 - yi, H, W);
-      for (int xi = 0; xi < W; ++xi) {
+#pragma omp for schedule(dynamic, 1) collapse(2)
+    for (int yi = y0; yi < y1; ++yi) {
+      for (int xi = x0; xi < x1; ++xi) {
+        float yf = pix_to_ndc(H - 1 - yi, H, W);
         float xf = pix_to_ndc(W - 1 - xi, W, H);
         int cnt = 0;
         for (int64_t p = 0; p < N; ++p) {
@@ -668,7 +688,7 @@ ORC_API void orc_raster_points_naive(const float *ndc, int64_t N, int H, int W, 
             qd[k] = d2;
           }
         }
-        size_t o = ((size_t)yi * W + xi) * K;
+        size_t o = ((size_t)(yi - y0) * WW + (xi - x0)) * K;
         for (int k = 0; k < K; ++k) {
           if (k < cnt) {
             idx[o + k] = qi[k];

@@ -1,0 +1,334 @@
+"""GPU tests added in round 2 (MI355X): dispatch hygiene of the fused GNT kernels (weight caches,
+autograd guard, loud fallbacks at the shape boundaries), the aggregation's status word with several
+views in flight, and BASELINE.json's configurations at their stated sizes against the oracle."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402  (checker only)
+from pgdvs_amd import ops, synth  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from pgdvs_amd import _lib
+
+    _lib.load()
+
+
+# ---------------------------------------------------------------- GNT dispatch hygiene
+def _gnt_inputs(R=7, S=16, V=5, seed=0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    r = lambda *sh: torch.randn(*sh, device=DEV, generator=g)  # noqa: E731
+    mask = (torch.rand(R, S, V, 1, device=DEV, generator=g) < 0.8).float()
+    return r(R, S, V, 35), r(R, S, V, 4), mask, r(R, S, 3), r(R, 3)
+
+
+def test_gnt_packed_weights_follow_load_state_dict():
+    """a checkpoint loaded AFTER a warm-up forward must be the one the fused kernels use
+    (round-1 caches were invalidated on device changes only)"""
+    from pgdvs_amd.models.gnt.models.transformer_network import GNT
+
+    torch.manual_seed(0)
+    a = GNT(netwidth=64, transformer_depth=2).to(DEV).eval()
+    torch.manual_seed(1)
+    b = GNT(netwidth=64, transformer_depth=2).to(DEV).eval()
+    x = _gnt_inputs()
+    with torch.no_grad():
+        out_a = a(*x)[0].clone()
+        out_b = b(*x)[0].clone()
+        assert not torch.allclose(out_a, out_b, atol=1e-3)
+        a.load_state_dict(b.state_dict())  # in-place copies: same storage, new contents
+        out_a2 = a(*x)[0]
+    np.testing.assert_allclose(N(out_a2), N(out_b), rtol=0, atol=1e-6)
+    with torch.no_grad():  # a plain in-place update (optimiser step) as well
+        a.rgb_fc.bias.add_(0.25)
+        out_a3 = a(*x)[0]
+    np.testing.assert_allclose(N(out_a3)[:, :3], N(out_b)[:, :3] + 0.25, rtol=0, atol=1e-5)
+
+
+def test_gnt_grad_enabled_takes_the_autograd_path():
+    """with gradients enabled and trainable parameters (train_static_renderer=True) the fused kernels
+    -- which return tensors without history -- must step aside"""
+    from pgdvs_amd.models.gnt.models.transformer_network import GNT
+
+    torch.manual_seed(0)
+    net = GNT(netwidth=64, transformer_depth=1).to(DEV).eval()
+    x = _gnt_inputs()
+    out = net(*x)[0]
+    assert out.requires_grad
+    out[:, :3].sum().backward()
+    assert net.rgbfeat_fc[0].weight.grad is not None and float(net.rgbfeat_fc[0].weight.grad.abs().sum()) > 0
+    with torch.no_grad():
+        fused = net(*x)[0]
+    assert not fused.requires_grad
+    np.testing.assert_allclose(N(fused), N(out), rtol=1e-4, atol=2e-5)
+    for p in net.parameters():  # frozen parameters: nothing to differentiate, fused kernels again
+        p.requires_grad_(False)
+    assert not ops.needs_autograd(net, x[0])
+
+
+@pytest.mark.parametrize("S,V", [(ops.GNT_RAY_MAX_SAMPLES + 1, 4), (8, 65)])
+def test_gnt_shape_boundaries_are_loud_and_correct(S, V, monkeypatch):
+    """one past the fused kernels' limits (samples per ray / source views): the torch branch runs, says so,
+    raises under PGDVS_GNT_STRICT, and agrees with the fused result on the part both can compute"""
+    from pgdvs_amd.models.gnt.models.transformer_network import GNT
+
+    torch.manual_seed(0)
+    net = GNT(netwidth=64, transformer_depth=1).to(DEV).eval()
+    x = _gnt_inputs(R=3, S=S, V=V, seed=2)
+    ops._fallback_seen.clear()
+    with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = net(*x)[0]
+    msgs = [str(i.message) for i in w if "pgdvs_amd" in str(i.message)]
+    assert len(msgs) == 1 and ("pgdvs_gnt_ray_layer" in msgs[0] if S > ops.GNT_RAY_MAX_SAMPLES else "pgdvs_gnt_view_layer" in msgs[0]), msgs
+    monkeypatch.setenv("PGDVS_GNT_STRICT", "1")
+    from pgdvs_amd._lib import PgdvsHipError
+
+    with torch.no_grad(), pytest.raises(PgdvsHipError):
+        net(*x)
+    monkeypatch.delenv("PGDVS_GNT_STRICT")
+    # all-torch statement of the same forward
+    ops._GNT_VIEW_ENABLED = False
+    try:
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = net(*x)[0]
+    finally:
+        ops._GNT_VIEW_ENABLED = True
+    np.testing.assert_allclose(N(out), N(ref), rtol=1e-4, atol=3e-5)
+
+
+# ---------------------------------------------------------------- aggregation status word
+def test_checked_count_raises_on_error_status():
+    from pgdvs_amd._lib import PgdvsHipError
+
+    assert ops.checked_count(torch.tensor([5], device=DEV), "x") == 5
+    with pytest.raises(PgdvsHipError):
+        ops.checked_count(torch.tensor([-1], device=DEV), "x")
+
+
+def test_static_aggregation_with_views_in_flight():
+    """three aggregations in flight on their own streams beside a chip-filling kernel (the benchmark's
+    situation): ticketed tile ids make the ordered-offset look-back independent of dispatch order; the
+    status word stays clean and every cloud is the oracle's"""
+    v = synth.make_video(6, 270, 480, seed=21)  # 16 tiles of 8192 pixels
+    rg, de, mk = T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]).view(torch.uint8)
+    o = orc.aggregate_static_pcl(v["rgbs"], v["depths"], v["dyn_masks"], v["K3s"], v["c2ws"])
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(3)]
+    filler = torch.randn(4096, 4096, device=DEV)
+    results = []
+    for it in range(12):
+        s = streams[it % 3]
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            results.append(ops.static_aggregate(rg, de, mk, v["K3s"], v["c2ws"]))
+        filler = filler @ filler * 1e-4  # keeps CUs busy on the default stream
+    torch.cuda.synchronize()
+    for cloud, cnt in results:
+        n = ops.checked_count(cnt, "pgdvs_static_aggregate")
+        assert n == o.shape[0]
+        assert np.array_equal(N(cloud[:n]).view(np.uint32), o.view(np.uint32))
+
+
+def test_points_raster_rejects_more_than_2e31_list_entries():
+    from pgdvs_amd import _lib
+    from pgdvs_amd._lib import PgdvsHipError
+
+    lib = _lib.load()
+    assert lib.pgdvs_points_raster_workspace_bytes(1 << 30, 1080, 1920, 0.5) == -4  # PGDVS_ERR_UNSUPPORTED
+    with pytest.raises(PgdvsHipError):
+        ops._ws(-4, DEV)
+
+
+def test_points_raster_device_count_is_clamped_to_capacity():
+    """a device-side count larger than the rows the workspace was sized for must not be trusted"""
+    rng = np.random.default_rng(0)
+    H, W, n = 40, 56, 500
+    pts = np.concatenate([rng.uniform(-0.5, 0.5, (n, 2)), rng.uniform(1.0, 2.0, (n, 1)), rng.random((n, 3))], 1).astype(np.float32)
+    cam = ops.cam_prep(T(synth.flat_cam(H, W, np.array([[50.0, 0, W / 2], [0, 50.0, H / 2], [0, 0, 1]]), np.eye(4)).astype(np.float32)))
+    ref = ops.points_raster(T(pts), T(pts)[:, 3:], cam, 0.05, 3, H, W, want_fragments=True)
+    big = ops.points_raster(T(pts), T(pts)[:, 3:], cam, 0.05, 3, H, W, want_fragments=True,
+                            n_points_dev=torch.tensor([10 * n], dtype=torch.int64, device=DEV))
+    neg = ops.points_raster(T(pts), T(pts)[:, 3:], cam, 0.05, 3, H, W, want_fragments=True,
+                            n_points_dev=torch.tensor([-1], dtype=torch.int64, device=DEV))
+    assert torch.equal(ref["idx"], big["idx"]) and torch.equal(ref["rgb"], big["rgb"])
+    assert int((neg["idx"] >= 0).sum()) == 0 and float(neg["mask"].sum()) == 0.0
+
+
+# ---------------------------------------------------------------- BASELINE.json configurations at their stated sizes
+def _renderer(static="geo", **over):
+    from pgdvs_amd.instantiate import load_config
+    from pgdvs_amd.renderers.pgdvs_renderer import PGDVSRenderer
+
+    cfg = load_config(static_renderer=static)
+    rc = cfg.engine.engine_cfg.render_cfg
+    for k, v in over.items():
+        rc[k] = v
+    return PGDVSRenderer(cfg, render_cfg=rc, softsplat_metric_abs_alpha=100.0).to(DEV).eval(), rc
+
+
+def _aggregate_and_check(v, S, H, W):
+    """A12 at this size: HIP cloud == oracle cloud, row for row and bit for bit (point ids are the
+    rasteriser's tie-break, so order matters)"""
+    cloud, cnt = ops.static_aggregate(T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]), v["K3s"], v["c2ws"], capacity=S * H * W)
+    o_cloud = orc.aggregate_static_pcl(v["rgbs"], v["depths"], v["dyn_masks"], v["K3s"], v["c2ws"])
+    n = ops.checked_count(cnt, "pgdvs_static_aggregate")
+    assert n == o_cloud.shape[0]
+    assert np.array_equal(N(cloud[:n]).view(np.uint32), o_cloud.view(np.uint32))
+    return cloud, cnt, o_cloud
+
+
+def _windows(H, W, dyn_mask, size=64):
+    """four size x size pixel windows: image corner, image centre, bottom-right edge, and one centred on
+    dynamic content (the static render there shows what the dynamic splat composites over)"""
+    ys, xs = np.nonzero(dyn_mask)
+    cy, cx = (int(ys.mean()), int(xs.mean())) if ys.size else (H // 3, W // 3)
+    clampw = lambda y, x: (max(0, min(H - size, y)), max(0, min(W - size, x)))  # noqa: E731
+    return [clampw(0, 0), clampw(H // 2 - size // 2, W // 2 - size // 2), clampw(H - size, W - size), clampw(cy - size // 2, cx - size // 2)]
+
+
+def _check_static_windows(cloud_np, flat_cam_tgt, H, W, radius, K, frag, img_chw, mask_hw, size=64, dyn_mask=None):
+    """HIP z-buffer fragments and composite on cropped windows against the oracle's naive rasteriser run
+    over ALL points for those pixels (O(window x N): seconds even at 1080p x 3.5 M points)"""
+    ndc = orc.points_to_ndc(cloud_np[:, :3], flat_cam_tgt, H, W)
+    hits = 0
+    for (y0, x0) in _windows(H, W, dyn_mask if dyn_mask is not None else np.zeros((H, W), bool), size):
+        y1, x1 = min(H, y0 + size), min(W, x0 + size)
+        idx, zbuf, d2 = orc.rasterize_points_window(ndc, H, W, radius, K, y0, y1, x0, x1)
+        assert np.array_equal(N(frag["idx"])[y0:y1, x0:x1], idx), (y0, x0)        # integer z-buffer index path: bit-exact
+        assert np.array_equal(N(frag["zbuf"])[y0:y1, x0:x1].view(np.uint32), zbuf.view(np.uint32)), (y0, x0)
+        assert np.array_equal(N(frag["dist2"])[y0:y1, x0:x1].view(np.uint32), d2.view(np.uint32)), (y0, x0)
+        img = orc.composite(idx, d2, radius, cloud_np[:, 3:])
+        ones = orc.composite(idx, d2, radius, None)
+        np.testing.assert_allclose(N(img_chw)[:, y0:y1, x0:x1], img.transpose(2, 0, 1), rtol=0, atol=1e-6)
+        assert np.array_equal(N(mask_hw)[y0:y1, x0:x1], (ones[..., 0] > 0).astype(np.float32))
+        hits += int((idx >= 0).sum())
+    assert hits > 0
+
+
+def _full_view_check(v, d, cloud, cnt, o_cloud, H, W, K, radius, remove_outlier=True, st_outlier=False, window=64):
+    """whole per-view path on HIP; the static image is pinned on windows against the full-cloud oracle
+    raster, then the oracle runs the dynamic branch + composite over the FULL frame on top of it"""
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=remove_outlier, st_render_pcl_pts_per_pixel=K, st_render_pcl_pt_radius=radius)
+    data = synth.to_torch(d, DEV)
+    data["st_pcl_rgb"], data["st_pcl_rgb_count"] = cloud[None], cnt
+    with torch.no_grad():
+        ret = model.forward(data, render_cfg=rc)
+    n = o_cloud.shape[0]
+    cam = ops.cam_prep(data["flat_cam_tgt"][0])
+    frag = ops.points_raster(cloud[:n], cloud[:n, 3:], cam, radius, K, H, W, want_fragments=True, rgb_planar=True)
+    assert torch.equal(frag["rgb"], ret["geo_static_rgb"][0]) and torch.equal(frag["mask"], ret["geo_static_mask"][0, 0])
+    _check_static_windows(o_cloud, d["flat_cam_tgt"][0], H, W, radius, K, frag, ret["geo_static_rgb"][0], ret["geo_static_mask"][0, 0],
+                          size=window, dyn_mask=d["dyn_mask_src_temporal"][0, 0, ..., 0] > 0)
+    od = dict(d)
+    od["rgb_gnt"] = N(ret["geo_static_rgb"]).transpose(0, 2, 3, 1)  # the (window-pinned) static image, [B,H,W,3]
+    o = orc.render_view(od, dict(rc), static_noise=d["static_noise"], alpha=100.0)
+    assert np.array_equal(N(ret["render_dyn_mask"]), o["render_dyn_mask"])
+    assert float(ret["render_dyn_mask"].mean()) > 0.03
+    for k in ["render_dyn_rgb", "combined_rgb"]:
+        np.testing.assert_allclose(N(ret[k]), o[k], rtol=0, atol=1e-4, err_msg=k)
+    assert float(np.mean((N(ret["combined_rgb"]) - o["combined_rgb"]) ** 2)) < 1e-8  # >= 80 dB
+    return ret
+
+
+def test_config_c1_256x256_4_frames_vs_oracle():
+    """BASELINE.json configs[0] at its stated size: single 256 x 256 target view, 4 source frames -- every
+    stage against the CPU oracle over the full frame (naive O(pixels x points) rasteriser included)"""
+    H, W, S = 256, 256, 4
+    v = synth.make_video(S, H, W, seed=1234)
+    d = synth.make_view(v, 1, frac=0.4, seed=5)
+    cloud, cnt, o_cloud = _aggregate_and_check(v, S, H, W)
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=True, st_render_pcl_pts_per_pixel=3)
+    data = synth.to_torch(d, DEV)
+    data["st_pcl_rgb"], data["st_pcl_rgb_count"] = cloud[None], cnt
+    with torch.no_grad():
+        ret = model.forward(data, render_cfg=rc)
+    od = dict(d)
+    od["st_pcl_rgb"] = o_cloud[None]
+    o = orc.render_view(od, dict(rc), static_noise=d["static_noise"], alpha=100.0)
+    assert np.array_equal(N(ret["geo_static_mask"]), o["geo_static_mask"])
+    assert np.array_equal(N(ret["render_dyn_mask"]), o["render_dyn_mask"])
+    for k in ["geo_static_rgb", "render_dyn_rgb", "combined_rgb", "combined_rgb_static", "combined_rgb_dyn"]:
+        np.testing.assert_allclose(N(ret[k]), o[k], rtol=0, atol=1e-4, err_msg=k)
+    frag = ops.points_raster(cloud[:o_cloud.shape[0]], None, ops.cam_prep(data["flat_cam_tgt"][0]), rc.st_render_pcl_pt_radius, 3, H, W,
+                             want_fragments=True, want_rgb=False)
+    idx, zbuf, d2 = orc.rasterize_points(o_cloud[:, :3], d["flat_cam_tgt"][0], H, W, rc.st_render_pcl_pt_radius, 3)
+    assert np.array_equal(N(frag["idx"]), idx) and np.array_equal(N(frag["zbuf"]).view(np.uint32), zbuf.view(np.uint32))
+    assert np.array_equal(N(frag["dist2"]).view(np.uint32), d2.view(np.uint32))
+
+
+def test_config_c3_1080p_24_frames_vs_oracle():
+    """BASELINE.json configs[2] -- the benchmark's own workload (1080p, 24 source frames, ~3.5 M static
+    points, ~310 k kNN queries) -- end to end: aggregated cloud bit-exact and in order; z-buffer fragments
+    bit-exact on four 64 x 64 windows (one over dynamic content) against the oracle rasterising ALL points
+    for those pixels; dynamic splat (outlier filter on: brute-force kNN in the oracle) + composite over
+    the full frame within 1e-4"""
+    H, W, S = 1080, 1920, 24
+    v = synth.make_video(S, H, W, seed=1234)
+    d = synth.make_view(v, 7, frac=0.4, seed=5)
+    cloud, cnt, o_cloud = _aggregate_and_check(v, S, H, W)
+    assert 1.2 * H * W < o_cloud.shape[0] < 3.0 * H * W
+    _full_view_check(v, d, cloud, cnt, o_cloud, H, W, 3, 0.01)
+
+
+def test_config_c4_nvidia_288x550_rank_slice_vs_oracle():
+    """BASELINE.json configs[3]: NVIDIA-Dynamic-Scenes-sized sequence (24 frames at 288 x 550), the views one
+    rank of eight renders (DistributedSampler slice of the 12 x 24 = 288 target views), with the settings of
+    the reference's pure-geometry benchmark `st_cvd_pcl_clean_dy_cvd_pcl_clean` (scripts/benchmark.sh:90-106:
+    st_pcl_remove_outlier=true, knn 50, std_thres 0.2, dyn_pcl_remove_outlier=true, radius 0.01, 3 points
+    per pixel) -- full frame against the oracle, statistical filter of the static cloud included"""
+    from pgdvs_amd.dist import shard_indices
+
+    H, W, S = 288, 550, 24
+    v = synth.make_video(S, H, W, seed=77)
+    cloud, cnt, o_cloud = _aggregate_and_check(v, S, H, W)
+    mine = shard_indices(12 * 24, rank=3, world=8)
+    assert len(mine) == 36 and mine[:3] == [3, 11, 19]
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=True, st_pcl_remove_outlier=True, st_pcl_outlier_knn=50,
+                          st_pcl_outlier_std_thres=0.2, st_render_pcl_pt_radius=0.01, st_render_pcl_pts_per_pixel=3)
+    for view in mine[:2]:  # (time, camera) of the view: frame = view // 12; two views keep the oracle time in seconds
+        i = min(view // 12, S - 2)
+        d = synth.make_view(v, i, frac=0.25 + 0.05 * (view % 12) / 12, seed=view)
+        data = synth.to_torch(d, DEV)
+        data["st_pcl_rgb"], data["st_pcl_rgb_count"] = cloud[None], cnt
+        with torch.no_grad():
+            ret = model.forward(data, render_cfg=rc)
+        od = dict(d)
+        od["st_pcl_rgb"] = o_cloud[None]
+        o = orc.render_view(od, dict(rc), static_noise=d["static_noise"], alpha=100.0)
+        assert np.array_equal(N(ret["geo_static_mask"]), o["geo_static_mask"])
+        assert np.array_equal(N(ret["render_dyn_mask"]), o["render_dyn_mask"])
+        for k in ["geo_static_rgb", "render_dyn_rgb", "combined_rgb"]:
+            np.testing.assert_allclose(N(ret[k]), o[k], rtol=0, atol=1e-4, err_msg=f"view {view}: {k}")
+
+
+def test_config_c5_1080p_48_frames_vs_oracle():
+    """BASELINE.json configs[4]: 1080p, 48 source frames, dynamic-mask compositing (one rank's view): cloud
+    bit-exact vs the oracle at S = 48, fragments on windows, dynamic branch + composite over the full frame"""
+    H, W, S = 1080, 1920, 48
+    v = synth.make_video(S, H, W, seed=4321)
+    d = synth.make_view(v, 30, frac=0.6, seed=9)
+    cloud, cnt, o_cloud = _aggregate_and_check(v, S, H, W)
+    ret = _full_view_check(v, d, cloud, cnt, o_cloud, H, W, 3, 0.01, window=48)
+    m = N(ret["render_dyn_mask"])[0, 0] > 0
+    # dynamic-mask compositing: inside the mask the view shows the splat, outside the static render
+    np.testing.assert_array_equal(N(ret["combined_rgb"])[0][:, ~m], N(ret["geo_static_rgb"])[0][:, ~m])
+    np.testing.assert_array_equal(N(ret["combined_rgb"])[0][:, m], N(ret["render_dyn_rgb"])[0][:, m])

@@ -73,23 +73,38 @@ def make_video(S, H, W, seed=1234, dyn_frac=0.15):
     c0 = np.array([[0.30 * W, 0.60 * H], [0.66 * W, 0.45 * H]])
     v, u = np.mgrid[0:H, 0:W].astype(np.float64)
     centers = np.empty((S, 2, 2))
-    for i in range(S):
+
+    def frame(i):
         K3, c2w = frame_camera(i, S, H, W)
-        K3s[i], c2ws[i] = K3, c2w
         z, tex = _background(H, W, K3, c2w)
         m = np.zeros((H, W), bool)
+        cs = np.empty((2, 2))
         for j in range(2):
             c = c0[j] + vel * i
-            centers[i, j] = c
+            cs[j] = c
             du, dv = (u - c[0]) / rad, (v - c[1]) / rad
             disc = du * du + dv * dv < 1.0
             m |= disc
             z = np.where(disc, 1.0 + 0.08 * du + 0.05 * dv + 0.2 * j, z)
             obj = np.stack([0.6 + 0.3 * np.sin(4 * du + j), 0.4 + 0.3 * np.cos(3 * dv), 0.5 + 0.3 * np.sin(5 * du * dv + 1)], -1)
             tex = np.where(disc[..., None], obj, tex)
-        rgbs[i] = np.clip(tex + rng.normal(0, 0.01, tex.shape), 0, 1).astype(np.float32)
-        depths[i] = z.astype(np.float32)
-        masks[i] = m
+        return K3, c2w, z.astype(np.float32), tex, m, cs
+
+    # frames are independent except for the noise stream, which is drawn in frame order: the geometry
+    # (numpy ufuncs release the GIL) runs on a thread pool, a few frames ahead of the sequential part
+    import concurrent.futures
+    import os
+
+    workers = max(1, min(S, (os.cpu_count() or 1), 16))
+    with concurrent.futures.ThreadPoolExecutor(workers) as ex:
+        pending = {}
+        nxt = 0
+        for i in range(S):
+            while nxt < S and nxt < i + 2 * workers:
+                pending[nxt] = ex.submit(frame, nxt)
+                nxt += 1
+            K3s[i], c2ws[i], depths[i], tex, masks[i], centers[i] = pending.pop(i).result()
+            rgbs[i] = np.clip(tex + rng.normal(0, 0.01, tex.shape), 0, 1).astype(np.float32)
     return dict(rgbs=rgbs, depths=depths, dyn_masks=masks, K3s=K3s, c2ws=c2ws, centers=centers, vel=vel, rad=rad)
 
 

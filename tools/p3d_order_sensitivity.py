@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""How much can the unpinned part of row A9 matter?  pytorch3d's camera chain runs through torch.bmm
+and torch.inverse, whose float32 rounding differs between its own backends (sequential multiply/add vs
+fused multiply-add; float32 LAPACK inverse vs a correctly rounded one).  This tool pushes N random
+points (plus edge-grazing discs and exact z ties) through oracle/p3d_second.py in each flavour, feeds
+every NDC set to the same naive rasteriser on pixel windows and reports the disagreement of the z-buffer
+index and of the composited image against the closed-form oracle (oracle/pgdvs_oracle.c).
+usage: p3d_order_sensitivity.py [n_points] [out.json]      (CPU only)"""
+import json
+import pathlib
+import sys
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "ml-pgdvs_amd"))
+from oracle import oracle as orc  # noqa: E402
+from oracle import p3d_second as p3d  # noqa: E402
+from pgdvs_amd import synth  # noqa: E402
+
+
+def scene(n, H, W, seed=0):
+    """points on the synthetic height field seen by a generic (rotated, translated) camera; 2 % of them are
+    exact duplicates in z of another point (ties broken by index) and 2 % sit at a distance of exactly the
+    disc radius (to float32 rounding) from a pixel centre (edge-grazing)"""
+    rng = np.random.default_rng(seed)
+    K3, c2w = synth.frame_camera(5, 24, H, W)
+    fc = synth.flat_cam(H, W, K3, c2w)
+    u, v = rng.uniform(-20, W + 20, n), rng.uniform(-20, H + 20, n)
+    z = 2.5 + 0.5 * np.sin(0.01 * u) + 0.3 * np.cos(0.013 * v) + rng.normal(0, 0.02, n)
+    n_tie = n // 50
+    z[rng.integers(0, n, n_tie)] = z[rng.integers(0, n, n_tie)]
+    radius = 0.01
+    r_px = radius * min(H, W) / 2.0
+    n_edge = n // 50
+    e = rng.integers(0, n, n_edge)
+    ang = rng.uniform(0, 2 * np.pi, n_edge)
+    u[e] = np.floor(u[e]) + 0.5 + r_px * np.cos(ang)  # pixel centres are at i + 0.5 in OpenCV pixel units
+    v[e] = np.floor(v[e]) + 0.5 + r_px * np.sin(ang)
+    cam = np.stack([(u - K3[0, 2]) / K3[0, 0] * z, (v - K3[1, 2]) / K3[1, 1] * z, z], 1)
+    world = cam @ c2w[:3, :3].T + c2w[:3, 3]
+    return fc, world.astype(np.float32), rng.random((n, 3)).astype(np.float32), radius
+
+
+def measure(n=1_000_000, H=540, W=960, K=3, win=48, seed=0):
+    fc, world, feat, radius = scene(n, H, W, seed)
+    base = orc.points_to_ndc(world, fc, H, W)
+    flavours = {"seq_f64inv": ("seq", "f64"), "seq_f32inv": ("seq", "f32"), "fma_f64inv": ("fma", "f64"), "fma_f32inv": ("fma", "f32")}
+    windows = [(0, 0), (H // 2 - win // 2, W // 2 - win // 2), (H - win, W - win), (H // 3, 2 * W // 3)]
+    ref = [orc.rasterize_points_window(base, H, W, radius, K, y, y + win, x, x + win) for y, x in windows]
+    ref_img = [orc.composite(r[0], r[2], radius, feat) for r in ref]
+    out = {"points": n, "image": [H, W], "points_per_pixel": K, "radius_ndc": radius, "windows": len(windows), "window": win,
+           "entries_compared": int(len(windows) * win * win * K), "flavours": {}}
+    for name, (fl, inv) in flavours.items():
+        ndc = p3d.points_to_ndc(fc, world, flavour=fl, inverse=inv)
+        diff_bits = (ndc.view(np.uint32) != base.view(np.uint32))
+        n_idx = n_pix = 0
+        max_img = 0.0
+        for (y, x), r, ri in zip(windows, ref, ref_img):
+            idx, zb, d2 = orc.rasterize_points_window(ndc, H, W, radius, K, y, y + win, x, x + win)
+            n_idx += int((idx != r[0]).sum())
+            n_pix += int((idx != r[0]).any(-1).sum())
+            max_img = max(max_img, float(np.abs(orc.composite(idx, d2, radius, feat) - ri).max()))
+        out["flavours"][name] = {
+            "ndc_xy_bits_differ_frac": float(diff_bits[:, :2].any(1).mean()), "ndc_z_bits_differ_frac": float(diff_bits[:, 2].mean()),
+            "max_abs_ndc_xy_diff": float(np.abs(ndc[:, :2] - base[:, :2]).max()),
+            "idx_entries_differ": n_idx, "idx_entries_differ_frac": n_idx / out["entries_compared"],
+            "pixels_with_any_idx_difference": n_pix, "max_abs_image_diff": max_img}
+    return out
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    res = measure(n)
+    txt = json.dumps(res, indent=1)
+    print(txt)
+    if len(sys.argv) > 2:
+        pathlib.Path(sys.argv[2]).write_text(txt + "\n")

@@ -1,11 +1,18 @@
-"""Caller-side helpers that make end-to-end numbers comparable with the reference's evaluator
-(SURVEY.md 8f-1): the quantisation of predictions before metrics
-(pgdvs/engines/evaluator_pgdvs.py:52-77) and the masked PSNR
-(pgdvs/utils/training.py:281-313).  Metric plumbing only -- a few elementwise torch ops on
-the final images; nothing here is on the rendering hot path."""
+"""Caller-side harness that makes end-to-end numbers comparable with the reference's evaluator
+(SURVEY.md 8f-1): ``eval_step`` reproduces ``PGDVSEvaluator.eval_step``
+(pgdvs/engines/evaluator_pgdvs.py:26-188) around any renderer with the plugin contract -- to-device,
+``forward`` under no_grad, clamp -> NaN to 0 -> quantise, ground truth resized to the render size,
+the evaluator's three masked PSNRs (``obtain_quantitative_nvidia`` :190-283 with
+``calculate_psnr`` pgdvs/utils/training.py:281-313) and ONE packed reduce of the metric sums to rank 0
+(the reference issues one ``torch.distributed.reduce`` per key, :183-186).  LPIPS and SSIM need
+third-party networks / skimage and are out of scope: their keys are not produced.  A few elementwise
+torch ops on final images; nothing here is on the rendering hot path."""
 import math
+from collections import OrderedDict
 
 import torch
+
+from . import dist as pdist
 
 
 def quantize_like_evaluator(x: torch.Tensor) -> torch.Tensor:
@@ -25,3 +32,58 @@ def masked_psnr(img1: torch.Tensor, img2: torch.Tensor, mask: torch.Tensor) -> f
     if mse == 0:
         return 0
     return 10 * math.log10(1.0 / mse)
+
+
+def to_device(batch: dict, device) -> dict:
+    """``_to_gpu_func`` (pgdvs/engines/abstract.py:153-157): tensors move, everything else passes through"""
+    return {k: v.to(device) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
+
+
+METRIC_KEYS = ("psnr_full_combined", "psnr_dyn_combined", "psnr_static_combined")
+
+
+@torch.no_grad()
+def eval_step(model, data: dict, render_cfg, *, device=None, disable_tqdm=True, return_images=False):
+    """One evaluator step on a batch of target views.  ``data`` is the reference's data dict (row A0) plus
+    ``rgb_tgt[B,H,W,3]`` and ``eval_mask[B,H,W,3]`` (1 = dynamic region).  Returns the reference's
+    ``metric_dict`` restricted to the in-scope keys: ``eval/count`` (int64) and the per-key SUMS over the
+    batch (float32), reduced to rank 0 when a process group is up.  With ``return_images`` also the
+    quantised prediction / ground truth and the per-view values."""
+    device = device if device is not None else next(iter(v for v in data.values() if isinstance(v, torch.Tensor))).device
+    data_gpu = to_device(data, device)
+    model.eval()
+    n_batch = data["rgb_src_temporal"].shape[0]
+    ret = model.forward(data_gpu, render_cfg=render_cfg, disable_tqdm=disable_tqdm, for_debug=False)
+    pred = OrderedDict({"combined": ret["combined_rgb"].clamp(0.0, 1.0)})
+    for k in pred:
+        if torch.any(torch.isnan(pred[k])):
+            pred[k] = torch.nan_to_num(pred[k], nan=0.0)
+    rgb_gt = data_gpu["rgb_tgt"].permute(0, 3, 1, 2).clamp(0.0, 1.0)
+    eval_mask = data_gpu["eval_mask"].permute(0, 3, 1, 2)
+    # quantise first, as if the images had been written to disk and read back (:70-77)
+    rgb_gt = (rgb_gt * 255).byte().float() / 255.0
+    for k in pred:
+        pred[k] = (pred[k] * 255).byte().float() / 255.0
+    _, _, rh, rw = pred["combined"].shape
+    if rgb_gt.shape[2] != rh or rgb_gt.shape[3] != rw:  # render_stride != 1 (:80-92)
+        rgb_gt = torch.nn.functional.interpolate(rgb_gt, size=(rh, rw), mode="bicubic", antialias=True, align_corners=True)
+        eval_mask = torch.nn.functional.interpolate(eval_mask, size=(rh, rw), mode="nearest")
+        eval_mask = (eval_mask > 0).float()
+    per_view = {k: [] for k in METRIC_KEYS}
+    for i_b in range(n_batch):
+        p, g = pred["combined"][i_b].to(rgb_gt.device), rgb_gt[i_b]
+        m_dyn = eval_mask[i_b]
+        # calculate_psnr asserts on [0,1] inputs; a bicubically resized ground truth can overshoot, as upstream
+        per_view["psnr_full_combined"].append(masked_psnr(g, p, torch.ones_like(g)))
+        per_view["psnr_dyn_combined"].append(masked_psnr(g, p, m_dyn))
+        per_view["psnr_static_combined"].append(masked_psnr(g, p, 1.0 - m_dyn))
+    # one packed reduce instead of one collective per key: [count, sums...] in float64 on the device
+    packed = torch.tensor([float(n_batch)] + [float(torch.tensor(per_view[k], dtype=torch.float32).sum()) for k in METRIC_KEYS],
+                          dtype=torch.float64, device=rgb_gt.device)
+    packed = pdist.reduce_metrics(packed, dst=0)
+    metric = {"eval/count": packed[:1].round().to(torch.int64)}
+    for j, k in enumerate(METRIC_KEYS):
+        metric[f"eval/{k}"] = packed[1 + j].to(torch.float32)
+    if return_images:
+        return metric, {"pred": pred["combined"], "gt": rgb_gt, "eval_mask": eval_mask, "per_view": per_view, "ret": ret}
+    return metric

@@ -332,3 +332,39 @@ def test_config_c5_1080p_48_frames_vs_oracle():
     # dynamic-mask compositing: inside the mask the view shows the splat, outside the static render
     np.testing.assert_array_equal(N(ret["combined_rgb"])[0][:, ~m], N(ret["geo_static_rgb"])[0][:, ~m])
     np.testing.assert_array_equal(N(ret["combined_rgb"])[0][:, m], N(ret["render_dyn_rgb"])[0][:, m])
+
+
+# ---------------------------------------------------------------- evaluator-shaped caller (row 8f-1)
+def test_eval_step_drives_the_hip_renderer():
+    """pgdvs_amd.harness.eval_step (the reference evaluator's step) around the HIP PGDVSRenderer: host-side
+    data dict in, device transfer, forward, quantisation, masked PSNRs.  Ground truth = the oracle's image of
+    the same view plus a known offset, so the expected PSNRs follow from the oracle alone."""
+    from pgdvs_amd.datasets.static_aggregation import aggregate_static_pcl
+    from pgdvs_amd.harness import eval_step, masked_psnr, quantize_like_evaluator
+
+    H, W, S = 72, 128, 4
+    v = synth.make_video(S, H, W, seed=21)
+    d = synth.make_view(v, 1, seed=3)
+    cloud = aggregate_static_pcl(T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]), v["K3s"], v["c2ws"])
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=True, dyn_pcl_outlier_knn=20, st_render_pcl_pts_per_pixel=3,
+                          st_render_pcl_pt_radius=0.02)
+    od = dict(d)
+    od["st_pcl_rgb"] = N(cloud)[None]
+    o = orc.render_view(od, dict(rc), static_noise=d["static_noise"], alpha=100.0)
+    gt = np.clip(o["combined_rgb"].transpose(0, 2, 3, 1) + 0.1, 0, 1).astype(np.float32)   # [B,H,W,3]
+    dyn = np.repeat(o["render_dyn_mask"].transpose(0, 2, 3, 1), 3, axis=-1).astype(np.float32)
+    data = {k: torch.from_numpy(np.ascontiguousarray(x)) for k, x in d.items()}                # HOST tensors, as a DataLoader yields
+    data["st_pcl_rgb"] = cloud[None].cpu()
+    data["rgb_tgt"], data["eval_mask"] = torch.from_numpy(gt), torch.from_numpy(dyn)
+    data["misc"] = [{"scene_id": "synthetic", "tgt_frame_id": 1, "tgt_cam_id": 0}]
+    md, extra = eval_step(model, data, rc, device=DEV, return_images=True)
+    assert int(md["eval/count"]) == 1 and md["eval/count"].device.type == "cuda"
+    pq = quantize_like_evaluator(torch.from_numpy(o["combined_rgb"][0]))
+    gq = quantize_like_evaluator(torch.from_numpy(gt[0]).permute(2, 0, 1))
+    # quantised predictions: the HIP image is within 1e-4 of the oracle's, so at most a handful of 8-bit steps differ
+    assert float((extra["pred"][0].cpu() != pq).float().mean()) < 2e-3
+    m = torch.from_numpy(dyn[0]).permute(2, 0, 1)
+    for key, mask in (("psnr_full_combined", torch.ones_like(m)), ("psnr_dyn_combined", m), ("psnr_static_combined", 1 - m)):
+        want = masked_psnr(gq, pq, mask)
+        assert abs(float(md[f"eval/{key}"]) - want) < 0.02, (key, float(md[f"eval/{key}"]), want)
+    assert 19.0 < float(md["eval/psnr_full_combined"]) < 21.5  # a 0.1 offset is ~20 dB

@@ -110,6 +110,20 @@ for kw in ({}, dict(n_steps=3, like=torch.empty(1, 3, 2, 2)), dict(n_steps=2, li
         assert (ag.stack is not None) == bool(kw)
     else:
         assert stack is None
+# evaluator-shaped step on every rank: the metric sums arrive on rank 0 through ONE packed reduce
+from pgdvs_amd.harness import eval_step
+class Fake(torch.nn.Module):
+    def forward(self, data_gpu, render_cfg=None, disable_tqdm=True, for_debug=False):
+        return {"combined_rgb": torch.full((2, 3, 4, 6), 0.25 * (rank + 1))}
+d = {"rgb_src_temporal": torch.zeros(2, 2, 4, 6, 3), "rgb_tgt": torch.full((2, 4, 6, 3), 0.5), "eval_mask": torch.zeros(2, 4, 6, 3)}
+md = eval_step(Fake(), d, None, device="cpu")
+if rank == 0:
+    import math
+    q = lambda x: float((torch.tensor(x) * 255).byte().float() / 255.0)
+    # (rank 1 predicts the ground truth exactly: the reference's PSNR is 0 for identical images)
+    want = sum(2 * 10 * math.log10(1.0 / (q(0.5) - q(0.25 * (r + 1))) ** 2) for r in range(world) if q(0.5) != q(0.25 * (r + 1)))
+    assert int(md["eval/count"]) == 2 * world and abs(float(md["eval/psnr_full_combined"]) - want) < 1e-3, (md, want)
+    assert float(md["eval/psnr_dyn_combined"]) == 0.0
 if rank == 0:
     assert out.shape == (n_views, 3, 4, 6), out.shape
     assert [int(out[i, 0, 0, 0]) for i in range(n_views)] == list(range(n_views))
@@ -204,6 +218,33 @@ def test_harness_quantisation_and_psnr_vs_reference(golden_dir):
     m = torch.from_numpy(g["mask"])
     assert abs(masked_psnr(pq, gq, m) - float(g["psnr"])) < 1e-9
     assert masked_psnr(gq, gq, m) == float(g["psnr_same"]) == 0
+
+
+def test_harness_eval_step_vs_reference_eval_step(golden_dir):
+    """pgdvs_amd.harness.eval_step against vectors produced by the reference's own PGDVSEvaluator.eval_step
+    (tests/golden/make_golden_harness.py) around a stand-in model: same clamp / NaN / quantisation / resize of
+    the ground truth / masked PSNR sums and count"""
+    import numpy as np
+
+    from pgdvs_amd.harness import METRIC_KEYS, eval_step
+
+    g = dict(np.load(golden_dir / "harness_eval_step.npz"))
+    for tag in ("same", "strided"):
+        pred = torch.from_numpy(g[f"{tag}_pred"])
+
+        class Fake(torch.nn.Module):
+            def forward(self, data_gpu, render_cfg=None, disable_tqdm=True, for_debug=False):
+                assert render_cfg == "rc" and for_debug is False
+                return {"combined_rgb": pred}
+
+        B, H, W, _ = g[f"{tag}_gt"].shape
+        data = {"rgb_src_temporal": torch.zeros(B, 2, H, W, 3), "rgb_tgt": torch.from_numpy(g[f"{tag}_gt"]),
+                "eval_mask": torch.from_numpy(g[f"{tag}_mask"]), "misc": [{}] * B}
+        md = eval_step(Fake(), data, "rc", device="cpu")
+        assert int(md["eval/count"]) == int(g[f"{tag}_metric__eval__count"][0]) == B
+        for k in METRIC_KEYS:
+            assert md[f"eval/{k}"].dtype == torch.float32
+            np.testing.assert_allclose(float(md[f"eval/{k}"]), float(g[f"{tag}_metric__eval__{k}"]), rtol=1e-6, err_msg=f"{tag} {k}")
 
 
 # ---------------------------------------------------------------- on-disk formats -> data dict (8f-3)

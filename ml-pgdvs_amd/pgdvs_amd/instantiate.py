@@ -45,20 +45,46 @@ def instantiate(cfg, *args, **kwargs):
     return cls(*args, **params)
 
 
-def load_config(static_renderer="gnt", overrides=None):
-    """Compose the config surface of the reference (configs/pgdvs.yaml defaults list):
-    _basic + model + static_renderer + engine.render_cfg, from pgdvs_amd/configs/*.yaml."""
+def _resolve(node, root):
+    """the `${a.b}` interpolations of the config files (OmegaConf syntax), whole-value references only"""
+    if isinstance(node, dict):
+        return {k: _resolve(v, root) for k, v in node.items()}
+    if isinstance(node, list):
+        return [_resolve(v, root) for v in node]
+    if isinstance(node, str) and node.startswith("${") and node.endswith("}") and node.count("${") == 1:
+        cur = root
+        for k in node[2:-1].split("."):
+            if not isinstance(cur, dict) or k not in cur:
+                return node  # e.g. ${hydra.job.name}: left for Hydra
+            cur = cur[k]
+        return _resolve(cur, root)
+    return node
+
+
+def load_config(static_renderer=None, overrides=None, **groups):
+    """Compose the config surface like Hydra does for the reference (configs/pgdvs.yaml): the defaults list of
+    pgdvs_amd/configs/pgdvs.yaml (_basic + engine + model + static_renderer + tracker + dataset), group choices
+    overridable by keyword (``static_renderer="geo"``, ``engine="visualizer_pgdvs"``, ``tracker="tapnet"``),
+    then dotted ``overrides``; ``${...}`` references to config keys are resolved."""
     import pathlib
     import yaml
 
     root = pathlib.Path(__file__).resolve().parent / "configs"
-    cfg = yaml.safe_load((root / "_basic.yaml").read_text())
-    cfg["model"] = yaml.safe_load((root / "model" / "pgdvs_renderer.yaml").read_text())
-    sr = yaml.safe_load((root / "static_renderer" / f"{static_renderer}.yaml").read_text()) or {"_target_": None}
-    cfg["static_renderer"] = sr
-    cfg["tracker"] = {}
-    cfg["engine"] = yaml.safe_load((root / "engine" / "evaluator_pgdvs.yaml").read_text())
-    cfg = AttrDict.wrap(cfg)
+    top = yaml.safe_load((root / "pgdvs.yaml").read_text())
+    if static_renderer is not None:
+        groups["static_renderer"] = static_renderer
+    cfg = {}
+    for entry in top["defaults"]:
+        if entry == "_self_":
+            continue
+        if isinstance(entry, str):
+            cfg.update(yaml.safe_load((root / f"{entry}.yaml").read_text()) or {})
+            continue
+        (group, choice), = entry.items()
+        choice = groups.pop(group, choice)
+        cfg[group] = yaml.safe_load((root / group / f"{choice}.yaml").read_text()) or {"_target_": None}
+    assert not groups, f"unknown config groups {sorted(groups)}"
+    cfg = AttrDict.wrap(_resolve(cfg, cfg))
     for dotted, v in (overrides or {}).items():
         node = cfg
         keys = dotted.split(".")

@@ -346,6 +346,42 @@ def test_mono_dataset_items_vs_reference(golden_dir, tmp_path):
             assert torch.equal(item[f"static_rgb_src_{sfx}"], item[f"rgb_src_{sfx}"] * (1 - m))
 
 
+def test_config_surface_groups_and_combined_dataset(nvidia_tree):
+    """every group of the reference's config tree exists in the mirror (configs/pgdvs.yaml defaults list,
+    engine/{evaluator,visualizer}_pgdvs, dataset/combined, tracker/{dummy,tapnet,cotracker}); the dataset group
+    instantiates the mirror's CombinedDataset over the mirrored loaders (configs/dataset/combined.yaml)"""
+    from pgdvs_amd.datasets.combined import CombinedDataset, dataset_class
+    from pgdvs_amd.datasets.nvidia_eval import NvidiaDynEvaluationDataset
+    from pgdvs_amd.instantiate import instantiate, load_config
+
+    cfg = load_config()
+    assert cfg.static_renderer._target_ == "pgdvs_amd.models.gnt.renderer.BaseRenderer" and cfg.tracker._target_ is None
+    assert cfg.engine._target_ == "pgdvs.engines.evaluator_pgdvs.PGDVSEvaluator"  # engines stay the reference's
+    assert load_config(engine="visualizer_pgdvs").engine.engine_cfg.render_cfg == cfg.engine.engine_cfg.render_cfg
+    assert load_config(tracker="tapnet").tracker.query_chunk_size == load_config(tracker="cotracker").tracker.query_chunk_size == 4096
+    ds_cfg = cfg.dataset
+    assert ds_cfg._target_ == "pgdvs_amd.datasets.combined.CombinedDataset"
+    assert ds_cfg.max_hw == -1 and ds_cfg.rgb_range == "0_1"                      # ${dataset_max_hw}, ${rgb_range}
+    assert ds_cfg.dataset_specifics.nvidia_vis.vis_bt_max_disp == 64              # ${vis_specifics.vis_bt_max_disp}
+    assert dataset_class("nvidia_eval") is NvidiaDynEvaluationDataset
+    with pytest.raises(KeyError):
+        dataset_class("no_such_dataset")
+    NT, root = nvidia_tree
+    spec = dict(ds_cfg.dataset_specifics.nvidia_eval)
+    spec.update(scene_ids=[NT.SCENE], raw_data_dir="raw", depth_data_dir="depths", mask_data_dir="masks", flow_data_dir="flows",
+                n_src_views_spatial=4, n_src_views_temporal_track_one_side=2)
+    spec.pop("use_zoe_depth"), spec.pop("zoe_depth_data_path")
+    node = dict(ds_cfg)
+    node.update(data_root=root, dataset_specifics={"nvidia_eval": spec})
+    ds = instantiate(node, mode="eval")
+    assert isinstance(ds, CombinedDataset) and len(ds) == NT.F * NT.N_CAMS
+    direct = ds.datasets["nvidia_eval"][7]
+    item = ds[7]
+    assert item["misc"] == direct["misc"] and torch.equal(item["flat_cam_tgt"], direct["flat_cam_tgt"])
+    with pytest.raises(IndexError):
+        ds[len(ds)]
+
+
 def test_nvidia_frame_selection_rules():
     from pgdvs_amd.datasets.nvidia_eval import select_temporal_frames
 

@@ -73,10 +73,17 @@ class AsyncImageGather:
             if self.on and dist.get_rank() == dst:
                 self.stack = torch.empty((n_steps, dist.get_world_size()) + tuple(like.shape), dtype=like.dtype, device=like.device)
 
+    def slot(self, j: int | None = None):
+        """The preallocated local buffer of step ``j`` (default: the next one), or None.  A renderer that
+        writes its image straight into it (``data["_combined_rgb_out"]``) makes ``submit`` copy-free."""
+        j = len(self.keep) if j is None else j
+        return self.local[j] if (self.local is not None and j < self.local.shape[0]) else None
+
     def submit(self, img: torch.Tensor) -> None:
         j = len(self.keep)
         if self.local is not None and j < self.local.shape[0] and tuple(img.shape) == tuple(self.local.shape[1:]):
-            self.local[j].copy_(img)  # on the caller's current stream, like the gather below
+            if img.data_ptr() != self.local[j].data_ptr():  # not rendered in place
+                self.local[j].copy_(img)  # on the caller's current stream, like the gather below
             img = self.local[j]
         else:
             img = img.contiguous()

@@ -274,15 +274,27 @@ def softsplat_bwd(ten_in, ten_flow, grad_out, need_in: bool = True, need_flow: b
     return gi, gf
 
 
-def dyn_splat_composite(rgb1, rgb2, flow12, flow_1_to_tgt, valid_mask, noise, alpha, static_rgb):
-    """Returns planar (render_dyn_rgb[3,H,W], render_dyn_mask[H,W], combined, combined_static, combined_dyn)."""
+def dyn_splat_composite(rgb1, rgb2, flow12, flow_1_to_tgt, valid_mask, noise, alpha, static_rgb, out_combined=None):
+    """Returns planar (render_dyn_rgb[3,H,W], render_dyn_mask[H,W], combined, combined_static, combined_dyn).
+    ``out_combined``: optional caller-owned contiguous [3,H,W] fp32 buffer the kernel writes the composite into
+    (e.g. a slice of the caller's image stack: no copy afterwards)."""
     r1 = _req(rgb1, torch.float32, "rgb1")
     H, W = r1.shape[0], r1.shape[1]
     dev = r1.device
     dyn_rgb = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     dyn_mask = torch.empty((H, W), dtype=torch.float32, device=dev)
     st = _req(static_rgb, torch.float32, "static_rgb") if static_rgb is not None else None
-    comb = torch.empty((3, 3, H, W), dtype=torch.float32, device=dev) if st is not None else None
+    comb = None
+    if st is not None:
+        if out_combined is not None:
+            if not (out_combined.is_cuda and out_combined.dtype == torch.float32 and out_combined.is_contiguous()
+                    and tuple(out_combined.shape) == (3, H, W)):
+                raise PgdvsHipError(f"out_combined: expected a contiguous fp32 GPU tensor [3,{H},{W}], got {tuple(out_combined.shape)}")
+            two = torch.empty((2, 3, H, W), dtype=torch.float32, device=dev)
+            comb = (out_combined, two[0], two[1])
+        else:
+            three = torch.empty((3, 3, H, W), dtype=torch.float32, device=dev)
+            comb = (three[0], three[1], three[2])
     nz = _req(noise, torch.float32, "noise") if noise is not None else None
     lib = _lib.load()
     ws = _ws(lib.pgdvs_dyn_splat_workspace_bytes(H, W), dev)

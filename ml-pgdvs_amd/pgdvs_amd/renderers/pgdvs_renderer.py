@@ -116,7 +116,10 @@ class PGDVSRenderer(PGDVSBaseRenderer):
                 n_points_dev=None if counts is None else counts[i_b:i_b + 1], planar=True)
             static_rgb.append(tmp_rgb)
             static_mask.append(tmp_mask)
-        ret_dict = {"geo_static_rgb": torch.stack(static_rgb, 0), "geo_static_mask": torch.stack(static_mask, 0)}
+        if len(static_rgb) == 1:  # a view, not a 25 MB copy
+            ret_dict = {"geo_static_rgb": static_rgb[0][None], "geo_static_mask": static_mask[0][None]}
+        else:
+            ret_dict = {"geo_static_rgb": torch.stack(static_rgb, 0), "geo_static_mask": torch.stack(static_mask, 0)}
         return ret_dict["geo_static_rgb"], ret_dict
 
     def forward_st_gnt(self, *, data, ray_batch, render_cfg, disable_tqdm=True):

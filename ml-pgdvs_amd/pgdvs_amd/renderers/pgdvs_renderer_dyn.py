@@ -169,13 +169,17 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
                 noise = torch.randn((n_b, 3, orig_h, orig_w), dtype=torch.float32, device=dev)
 
         dyn_rgbs, dyn_masks, combs = [], [], []
+        # optional caller-owned output [B,3,H,W] for combined_rgb (a slice of the caller's image stack): the
+        # splat epilogue writes the composite there, so no copy follows the render
+        out_comb = data.get("_combined_rgb_out", None)
         for i_b in range(n_b):
             flow_1_to_tgt, valid_mask, info = prepared["items"][i_b]
             if dyn_type == "softsplat":
                 rgb, mask, c, cs, cd = ops.dyn_splat_composite(
                     data["rgb_src_temporal"][i_b, 0], data["rgb_src_temporal"][i_b, 1], data["flow_fwd"][i_b],
                     flow_1_to_tgt, valid_mask, noise[i_b], self.softsplat_metric_abs_alpha,
-                    static_rgb[i_b] if fuse_static else None)
+                    static_rgb[i_b] if fuse_static else None,
+                    out_combined=out_comb[i_b] if (fuse_static and out_comb is not None) else None)
                 if fuse_static:
                     combs.append((c, cs, cd))
             elif dyn_type == "mesh":
@@ -226,7 +230,7 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
         }
         if fuse_static:
             st = (lambda k: torch.stack([c[k] for c in combs], 0)) if n_b > 1 else (lambda k: combs[0][k][None])
-            info_dict["combined_rgb"] = st(0)
+            info_dict["combined_rgb"] = out_comb if out_comb is not None else st(0)
             info_dict["combined_rgb_static"] = st(1)
             info_dict["combined_rgb_dyn"] = st(2)
         return render_dyn_rgb_final, render_dyn_mask_final, info_dict

@@ -6,20 +6,27 @@
 // the static pixels that the cloud accumulated from frames < i does not already cover
 // (integer-truncated projection occupancy), so frames are processed in order; inside a
 // frame everything is data-parallel.  Two launches per frame:
-//   mark   : project the accumulated cloud (fp64, as numpy does) and stamp occ[row,col] with
-//            the frame index (no clearing between frames).  Reads a packed xyz copy of the
-//            cloud (12 B/point instead of the 24 B rows); the fp64 quotients only feed a
-//            truncation and a bounds test, so they are formed with a refined reciprocal and
-//            the exact division runs only when the quotient is within rounding distance of an
-//            integer -- decisions stay identical to correctly rounded division.
 //   select : one pass over the frame's pixels that counts the selected ones (static && not
-//            stamped), turns the per-tile counts into ordered offsets inside the same launch
+//            occupied), turns the per-tile counts into ordered offsets inside the same launch
 //            (tagged 8-byte count granules gathered from all predecessor tiles, dynamic tile
 //            tickets for forward progress) and appends the unprojected (xyz,rgb) rows in
 //            row-major pixel order -- the order numpy's boolean indexing produces (point ids
 //            matter: the rasteriser breaks z ties by id).
+//   push   : the points frame i just appended are projected into EVERY later frame and stamp
+//            that frame's own occupancy map (one byte per pixel and frame, zeroed per call), so no
+//            point is ever projected into the same frame twice and the cloud is not re-read per
+//            frame.  Frame 0's launch carries ~3/4 of all projections and fills the chip; the later
+//            ones are a few microseconds each.
+//            numpy projects in fp64 (no z>0 test, no epsilon, closed bounds, astype(int)
+//            truncation).  Decisions only change where a quotient crosses an integer, so a cheap
+//            evaluation decides whenever its rigorous error bound keeps the quotient away from
+//            every integer: first in fp32 (12 FMAs, v_rcp_f32; bound ~2e-3 px), the ~1 % it cannot
+//            decide are parked in an LDS queue and re-evaluated densely in fp64 (screening form,
+//            bound ~1e-9 px), and the one in ~1e9 still open takes the reference operation order
+//            with correctly rounded divisions.
 // No host synchronisation: the running point counts live on the device.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -42,6 +49,12 @@ struct ProjF64 {
   double M[12];
   double tol_scale;
   int screen;  // affine w2c and finite matrices
+  // fp32 screening form of the same M: |s_k - S_k| <= e32[k] * max(|x|,|y|,|z|,1) for the fp32 FMA
+  // evaluation s_k of row k (4.5 x 2^-24 x the row sum of |M|: entries rounded to fp32, three fused
+  // multiply-adds), with the fp64 form's own tolerance folded in
+  float M32[12];
+  float e32[3];
+  int screen32;
 };
 
 // Decides `q >= 0 && q <= hi` and trunc(q) for q = a / b (correctly rounded fp64 division,
@@ -71,8 +84,9 @@ __device__ __forceinline__ bool trunc_div_in_range(double a, double b, double r,
 // per-frame projection constants live in the workspace (written by agg_params_kernel): the
 // marking kernel keeps only the screening form of its frames in registers and reads the
 // reference form through this pointer in the rare doubtful case
+constexpr int kProjChunk = 6;  // (kernel arguments are limited to 4 KB)
 struct ProjChunk {
-  ProjF64 p[8];
+  ProjF64 p[kProjChunk];
 };
 
 __global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, int first, int n) {
@@ -84,8 +98,7 @@ __global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, int fi
 // _compute_pcl_proj_mask, nvidia_eval_pure_geo.py:257-277 in the reference operation order (no
 // z>0 test, no epsilon, closed bounds, astype(int) truncation)
 __device__ __attribute__((noinline)) void mark_reference_order(const ProjF64 *__restrict__ pj, double x, double y,
-                                                               double z, int H, int W, int frame,
-                                                               uint16_t *__restrict__ occ) {
+                                                               double z, int H, int W, uint8_t *__restrict__ occ) {
   double vc[4];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -123,68 +136,140 @@ __device__ __attribute__((noinline)) void mark_reference_order(const ProjF64 *__
   const double rz = refined_rcp(pp[2]);
   if (!trunc_div_in_range(pp[1], pp[2], rz, H - 1, row)) return;
   if (!trunc_div_in_range(pp[0], pp[2], rz, W - 1, col)) return;
-  occ[(int64_t)row * W + col] = (uint16_t)frame;
+  occ[(int64_t)row * W + col] = 1;
 }
 
-// Stamps, for NF consecutive frames f0 .. f0+NF-1, the pixels hit by the points [*begin, *end)
-// of the accumulated cloud.  The kernel is bound by reading the cloud (each pass re-reads up to
-// 42 MB out of the Infinity Cache), so two frames share one pass over the bulk of the points.
-template <int NF>
-__global__ void __launch_bounds__(256)
-agg_mark_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ begin_p,
-                const int64_t *__restrict__ end_p, const ProjF64 *__restrict__ proj, int f0, int H, int W,
-                uint16_t *__restrict__ occ0, uint16_t *__restrict__ occ1) {
-  const int64_t begin = begin_p ? *begin_p : 0;
-  const int64_t n = *end_p;
-  double M[NF][12], tscale[NF];
-  bool screen[NF];
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-#pragma unroll
-    for (int k = 0; k < 12; ++k) M[f][k] = proj[f0 + f].M[k];
-    tscale[f] = proj[f0 + f].tol_scale;
-    screen[f] = proj[f0 + f].screen != 0;
-  }
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // a thread walks several points (grid-stride): the next point's load is issued before the
-  // current point's fp64 operations
-  float nx = 0.0f, ny = 0.0f, nz = 0.0f;
-  if (i < n) {
-    nx = xyz[i * 3 + 0];
-    ny = xyz[i * 3 + 1];
-    nz = xyz[i * 3 + 2];
-  }
-  for (; i < n; i += stride) {
-    const double x = (double)nx, y = (double)ny, z = (double)nz;
-    if (i + stride < n) {
-      nx = xyz[(i + stride) * 3 + 0];
-      ny = xyz[(i + stride) * 3 + 1];
-      nz = xyz[(i + stride) * 3 + 2];
-    }
+// fp64 decision for one (point, frame): the screening form M = K3 . w2c decides unless a quotient lies
+// within its rounding distance of an integer; then the reference operation order does
+__device__ __attribute__((noinline)) void mark_fp64(const ProjF64 *__restrict__ pj, float xf, float yf, float zf, int H,
+                                                    int W, uint8_t *__restrict__ occ) {
+  const double x = (double)xf, y = (double)yf, z = (double)zf;
+  if (pj->screen) {
+    const double *M = pj->M;
     const double amax = fmax(fmax(fabs(x), fabs(y)), fmax(fabs(z), 1.0));
+    const double s0 = __builtin_fma(M[0], x, __builtin_fma(M[1], y, __builtin_fma(M[2], z, M[3])));
+    const double s1 = __builtin_fma(M[4], x, __builtin_fma(M[5], y, __builtin_fma(M[6], z, M[7])));
+    const double s2 = __builtin_fma(M[8], x, __builtin_fma(M[9], y, __builtin_fma(M[10], z, M[11])));
+    const double r = refined_rcp(s2);
+    const double qx = s0 * r, qy = s1 * r;
+    const double tol = pj->tol_scale * amax * fabs(r);
+    const double fx = floor(qx), fy = floor(qy);
+    const double dx = fmin(qx - fx, (fx + 1.0) - qx), dy = fmin(qy - fy, (fy + 1.0) - qy);
+    // (false for NaN / inf as well: those take the reference path)
+    if (dx > tol * (1.0 + fabs(qx)) && dy > tol * (1.0 + fabs(qy))) {
+      if (qy >= 0.0 && qy <= (double)(H - 1) && qx >= 0.0 && qx <= (double)(W - 1)) occ[(int64_t)(int)qy * W + (int)qx] = 1;
+      return;
+    }
+  }
+  mark_reference_order(pj, x, y, z, H, W, occ);
+}
+
+// the fp32 screening constants of one frame, copied out of its ProjF64 record
+struct PushConsts {
+  float M[12];
+  float e[3];
+  int screen32;
+};
+__device__ __forceinline__ PushConsts load_push_consts(const ProjF64 *__restrict__ pj) {
+  PushConsts c;
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      uint16_t *occ = f == 0 ? occ0 : occ1;
-      const int frame = f0 + f;
-      bool decided = false;
-      if (screen[f]) {
-        const double s0 = __builtin_fma(M[f][0], x, __builtin_fma(M[f][1], y, __builtin_fma(M[f][2], z, M[f][3])));
-        const double s1 = __builtin_fma(M[f][4], x, __builtin_fma(M[f][5], y, __builtin_fma(M[f][6], z, M[f][7])));
-        const double s2 = __builtin_fma(M[f][8], x, __builtin_fma(M[f][9], y, __builtin_fma(M[f][10], z, M[f][11])));
-        const double r = refined_rcp(s2);
-        const double qx = s0 * r, qy = s1 * r;
-        const double tol = tscale[f] * amax * fabs(r);
-        const double fx = floor(qx), fy = floor(qy);
-        const double dx = fmin(qx - fx, (fx + 1.0) - qx), dy = fmin(qy - fy, (fy + 1.0) - qy);
-        // (false for NaN / inf as well: those take the reference path)
-        if (dx > tol * (1.0 + fabs(qx)) && dy > tol * (1.0 + fabs(qy))) {
-          if (qy >= 0.0 && qy <= (double)(H - 1) && qx >= 0.0 && qx <= (double)(W - 1))
-            occ[(int64_t)(int)qy * W + (int)qx] = (uint16_t)frame;
-          decided = true;
+  for (int k = 0; k < 12; ++k) c.M[k] = pj->M32[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) c.e[k] = pj->e32[k];
+  c.screen32 = pj->screen32;
+  return c;
+}
+
+constexpr int kPushThreads = 256;
+constexpr int kPushQueue = 1024;  // points with frames the fp32 form could not decide, queued per workgroup
+constexpr int kPushMaxFpg = 32;    // frames per workgroup row (one bit each in a queue entry)
+
+// Projects the points [cnts[src], cnts[src+1]) -- what frame `src` appended -- into the frames
+// f_lo + blockIdx.y * fpg ... (at most fpg of them, below f_hi) and stamps their occupancy maps
+// occ[f][P].  One thread per point, the frame loop inside (per-frame constants are wave-uniform:
+// scalar loads).
+__global__ void __launch_bounds__(kPushThreads)
+agg_push_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ cnts, int src,
+                const ProjF64 *__restrict__ proj, int f_lo, int f_hi, int fpg, int H, int W,
+                uint8_t *__restrict__ occ_all) {
+  __shared__ uint4 s_q[kPushQueue];
+  __shared__ int s_qn;
+  const int64_t begin = cnts[src], end = cnts[src + 1];
+  const int fa = f_lo + (int)blockIdx.y * fpg;
+  const int fb = fa + fpg < f_hi ? fa + fpg : f_hi;
+  if (fa >= fb || begin >= end) return;
+  const int64_t P = (int64_t)H * W;
+  const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+  if (threadIdx.x == 0) s_qn = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * kPushThreads;
+  // whole workgroups stay in the loop so that the queue can be drained between rounds
+  for (int64_t i0 = begin + (int64_t)blockIdx.x * kPushThreads; i0 < end; i0 += stride) {
+    const int64_t i = i0 + threadIdx.x;
+    const bool live = i < end;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (live) {
+      x = xyz[i * 3 + 0];
+      y = xyz[i * 3 + 1];
+      z = xyz[i * 3 + 2];
+    }
+    const float amax = fmaxf(fmaxf(fabsf(x), fabsf(y)), fmaxf(fabsf(z), 1.0f));
+    unsigned dmask = 0;
+    // (the constants of frame f+1 are requested while frame f is evaluated: scalar loads, wave-uniform)
+    PushConsts c = load_push_consts(proj + fa);
+    for (int f = fa; f < fb; ++f) {
+      const PushConsts cn = load_push_consts(proj + (f + 1 < fb ? f + 1 : f));
+      const float *M = c.M;
+      const float s0 = __builtin_fmaf(M[0], x, __builtin_fmaf(M[1], y, __builtin_fmaf(M[2], z, M[3])));
+      const float s1 = __builtin_fmaf(M[4], x, __builtin_fmaf(M[5], y, __builtin_fmaf(M[6], z, M[7])));
+      const float s2 = __builtin_fmaf(M[8], x, __builtin_fmaf(M[9], y, __builtin_fmaf(M[10], z, M[11])));
+      const float r = __builtin_amdgcn_rcpf(s2);  // v_rcp_f32: 1 ulp
+      const float qx = s0 * r, qy = s1 * r;
+      // |q~ - q_ref| <= (E_row + (|q~| + 1) E_2) |r| + 2^-22 |q~|, E_k = e32[k] amax (see ProjF64)
+      const float ar = fabsf(r) * amax * 1.001f;
+      const float tx = (c.e[0] + (fabsf(qx) + 1.0f) * c.e[2]) * ar + fabsf(qx) * 2.5e-7f;
+      const float ty = (c.e[1] + (fabsf(qy) + 1.0f) * c.e[2]) * ar + fabsf(qy) * 2.5e-7f;
+      const float fx = floorf(qx), fy = floorf(qy);
+      const float dx = fminf(qx - fx, (fx + 1.0f) - qx), dy = fminf(qy - fy, (fy + 1.0f) - qy);
+      // straight-line mask logic (bitwise: no short-circuit branches); every comparison is false for NaN
+      const bool small = (tx < 0.25f) & (ty < 0.25f) & (c.screen32 != 0);
+      const bool outside = (qx < -0.5f) | (qx > wm1 + 0.5f) | (qy < -0.5f) | (qy > hm1 + 0.5f);  // by more than the bound
+      const bool clear = (dx > tx) & (dy > ty);
+      const bool inr = (qx >= 0.0f) & (qx <= wm1) & (qy >= 0.0f) & (qy <= hm1);
+      if (live & small & !outside & clear & inr) occ_all[(int64_t)f * P + (int64_t)(int)qy * W + (int)qx] = 1;
+      const bool doubt = live & !(small & (outside | clear));
+      c = cn;
+      dmask |= (doubt ? 1u : 0u) << (f - fa);
+    }
+    // the (point, frame) pairs the fp32 form could not decide: one queue entry per point with a frame bitmask
+    if (dmask != 0) {
+      const int slot = atomicAdd(&s_qn, 1);
+      if (slot < kPushQueue) {
+        s_q[slot] = make_uint4((unsigned)(i & 0xffffffffll), (unsigned)(i >> 32), dmask, 0u);
+      } else {  // queue full (degenerate views): decide in place
+        for (unsigned m = dmask; m; m &= m - 1) {
+          const int f = fa + __builtin_ctz(m);
+          mark_fp64(proj + f, x, y, z, H, W, occ_all + (int64_t)f * P);
         }
       }
-      if (!decided) mark_reference_order(proj + frame, x, y, z, H, W, frame, occ);
+    }
+    // drain when the next round could overflow the queue (every thread adds at most one entry per round)
+    __syncthreads();
+    const int qn = s_qn < kPushQueue ? s_qn : kPushQueue;
+    const bool last = i0 + stride >= end;
+    if (last || qn + kPushThreads > kPushQueue) {
+      for (int e = threadIdx.x; e < qn; e += kPushThreads) {
+        const uint4 q = s_q[e];
+        const int64_t pi = (int64_t)q.x | ((int64_t)q.y << 32);
+        const float px = xyz[pi * 3 + 0], py = xyz[pi * 3 + 1], pz = xyz[pi * 3 + 2];
+        for (unsigned m = q.z; m; m &= m - 1) {
+          const int f = fa + __builtin_ctz(m);
+          mark_fp64(proj + f, px, py, pz, H, W, occ_all + (int64_t)f * P);
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_qn = 0;
+      __syncthreads();
     }
   }
 }
@@ -201,7 +286,7 @@ __device__ __forceinline__ unsigned long long sel_desc(int tag, int status, long
 
 struct SelArgs {
   const uint8_t *dyn_mask;   // frame's mask [P]
-  const uint16_t *occ;       // [P]
+  const uint8_t *occ;        // this frame's occupancy map [P], written by the earlier frames' push launches
   const float *depth;        // frame's depth [P]
   const float *rgb;          // frame's colours [P,3]
   float *cloud;              // [capacity,6]
@@ -223,14 +308,17 @@ __device__ __forceinline__ unsigned sel_flags16(const SelArgs &a, int base) {
     const unsigned mw[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
     for (int k = 0; k < 16; ++k) flags |= (((mw[k >> 2] >> ((k & 3) * 8)) & 0xffu) == 0u ? 1u : 0u) << k;
-    if (a.frame > 0) {
-      const uint4 o0 = *reinterpret_cast<const uint4 *>(a.occ + base);
-      const uint4 o1 = *reinterpret_cast<const uint4 *>(a.occ + base + 8);
-      const unsigned ow[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+    if (a.frame > 0 && ((reinterpret_cast<uintptr_t>(a.occ + base) & 15) == 0)) {
+      const uint4 o = *reinterpret_cast<const uint4 *>(a.occ + base);
+      const unsigned ow[4] = {o.x, o.y, o.z, o.w};
       unsigned stamped = 0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k)
-        stamped |= (((ow[k >> 1] >> ((k & 1) * 16)) & 0xffffu) == (unsigned)a.frame ? 1u : 0u) << k;
+      for (int k = 0; k < 16; ++k) stamped |= (((ow[k >> 2] >> ((k & 3) * 8)) & 0xffu) != 0u ? 1u : 0u) << k;
+      flags &= ~stamped;
+    } else if (a.frame > 0) {
+      unsigned stamped = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) stamped |= (a.occ[base + k] != 0 ? 1u : 0u) << k;
       flags &= ~stamped;
     }
   } else {
@@ -238,7 +326,7 @@ __device__ __forceinline__ unsigned sel_flags16(const SelArgs &a, int base) {
       const int p = base + k;
       if (p >= a.P) break;
       bool st = a.dyn_mask[p] == 0;
-      if (a.frame > 0) st = st && a.occ[p] != (uint16_t)a.frame;
+      if (a.frame > 0) st = st && a.occ[p] == 0;
       flags |= (st ? 1u : 0u) << k;
     }
   }
@@ -395,9 +483,8 @@ struct AggWs {
   int64_t *cnts;
   int32_t *ticket, *error;
   unsigned long long *desc;
-  uint16_t *occ;
+  uint8_t *occ;  // [S][P] one occupancy byte per (frame, pixel), zeroed per call
   float *xyz;
-  uint16_t *occ2;
   ProjF64 *proj;
   int64_t total_bytes;
 };
@@ -419,12 +506,10 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   off += align_up(tiles * 8, 16);
   w.state_bytes = off;
   off = align_up(off, 256);
-  w.occ = reinterpret_cast<uint16_t *>(p + off);
-  off += align_up(P * 2 + 32, 256);
+  w.occ = reinterpret_cast<uint8_t *>(p + off);
+  off += align_up((int64_t)S * P + 32, 256);
   w.xyz = reinterpret_cast<float *>(p + off);
   off += align_up((capacity > 0 ? capacity : 1) * 12, 256);
-  w.occ2 = reinterpret_cast<uint16_t *>(p + off);  // directly behind... (own region: odd frames)
-  off += align_up(P * 2 + 32, 256);
   w.proj = reinterpret_cast<ProjF64 *>(p + off);
   off += align_up((int64_t)S * (int64_t)sizeof(ProjF64), 256);
   w.total_bytes = off;
@@ -458,8 +543,7 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
   hipStream_t st = as_stream(stream);
   const int64_t P = (int64_t)H * W;
   hipError_t e = hipMemsetAsync(ws.state, 0, (size_t)ws.state_bytes, st);
-  if (e == hipSuccess) e = fill_async(ws.occ, 0, (size_t)P * 2, st);
-  if (e == hipSuccess) e = fill_async(ws.occ2, 0, (size_t)P * 2, st);
+  if (e == hipSuccess && S > 1) e = fill_async(ws.occ + P, 0, (size_t)(S - 1) * (size_t)P, st);  // (frame 0 has no map)
   if (e != hipSuccess) {
     set_error("static_aggregate memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
@@ -471,7 +555,7 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
     for (int i = 0; i < S; ++i) {
       const double *K3 = K3s_host + (size_t)i * 9;
       const double *c2w = c2ws_host + (size_t)i * 16;
-      ProjF64 &pj = chunk.p[i % 8];
+      ProjF64 &pj = chunk.p[i % kProjChunk];
       for (int k = 0; k < 9; ++k) pj.K3[k] = K3[k];
       if (inv_f64(c2w, pj.w2c, 4) != 0) {
         set_error("pgdvs_static_aggregate: singular c2w for frame %d", i);
@@ -498,6 +582,23 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
         }
         pj.tol_scale = 64.0 * 1.1102230246251565e-16 * rmax;
         pj.screen = pj.affine && finite && rmax > 0.0;
+        // fp32 form: entries rounded to fp32 (2^-24 relative each) + three fused multiply-adds whose
+        // partial sums are bounded by the row sum x amax (3 x 2^-24): 4 x 2^-24 in total, taken as 4.5;
+        // the fp64 form's own distance to the reference order (tol_scale) is folded in, and the
+        // float conversions round up
+        bool ok32 = pj.screen != 0;
+        for (int k = 0; k < 12; ++k) {
+          pj.M32[k] = (float)pj.M[k];
+          ok32 = ok32 && std::isfinite(pj.M32[k]);
+        }
+        for (int r = 0; r < 3; ++r) {
+          double rowsum = 0.0;
+          for (int c = 0; c < 4; ++c) rowsum += fabs(pj.M[r * 4 + c]);
+          const double e = (4.5 * 5.9604644775390625e-08 * rowsum + pj.tol_scale) * 1.000001;
+          pj.e32[r] = nextafterf((float)e, INFINITY);
+          ok32 = ok32 && std::isfinite(pj.e32[r]);
+        }
+        pj.screen32 = ok32 ? 1 : 0;
       }
       // rays use K and c2w cast to fp32 (torch.FloatTensor, nvidia_eval.py:841-842)
       float flat[34];
@@ -511,8 +612,8 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
         set_error("pgdvs_static_aggregate: singular intrinsics for frame %d", i);
         return PGDVS_ERR_INVALID;
       }
-      if (i % 8 == 7 || i == S - 1) {
-        const int first = i - i % 8, cnt = i % 8 + 1;
+      if (i % kProjChunk == kProjChunk - 1 || i == S - 1) {
+        const int first = i - i % kProjChunk, cnt = i % kProjChunk + 1;
         PGDVS_LAUNCH("agg_params", agg_params_kernel, dim3(1), dim3(256), 0, st, chunk, ws.proj, first, cnt);
       }
     }
@@ -521,7 +622,7 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
   auto select = [&](int i) {
     SelArgs a;
     a.dyn_mask = dyn_masks + (size_t)i * P;
-    a.occ = (i & 1) ? ws.occ2 : ws.occ;
+    a.occ = ws.occ + (size_t)i * (size_t)P;
     a.depth = depths + (size_t)i * P;
     a.rgb = rgbs + (size_t)i * P * 3;
     a.cloud = out;
@@ -537,25 +638,21 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
     a.tiles = tiles;
     PGDVS_LAUNCH("agg_select", agg_select_kernel, dim3(tiles), dim3(kSelThreads), 0, st, a, cams[(size_t)i]);
   };
-  // cnts[i] = points in the cloud before frame i.  Frames are handled in pairs: one pass over the
-  // points known before frame i stamps the occupancy of frames i AND i+1 (even frames use occ, odd
-  // ones occ2), frame i is selected, then only ITS new points are stamped into frame i+1.
-  select(0);
-  for (int i = 1; i < S; i += 2) {
-    uint16_t *occ_i = (i & 1) ? ws.occ2 : ws.occ, *occ_n = (i & 1) ? ws.occ : ws.occ2;
-    if (i + 1 < S) {
-      PGDVS_LAUNCH("agg_mark", agg_mark_kernel<2>, dim3(4096), dim3(256), 0, st, (const float *)ws.xyz,
-                   (const int64_t *)nullptr, (const int64_t *)(ws.cnts + i), (const ProjF64 *)ws.proj, i, H, W, occ_i, occ_n);
-    } else {
-      PGDVS_LAUNCH("agg_mark", agg_mark_kernel<1>, dim3(2048), dim3(256), 0, st, (const float *)ws.xyz,
-                   (const int64_t *)nullptr, (const int64_t *)(ws.cnts + i), (const ProjF64 *)ws.proj, i, H, W, occ_i, occ_i);
-    }
+  // cnts[i] = points in the cloud before frame i.  After frame i is selected, the points it appended are
+  // pushed into the occupancy maps of all later frames; frame i+1's selection reads its own map.
+  // Frame 0 appends every static pixel (~P points x S-1 frames: the chip-filling launch); later frames
+  // append a few per cent of that, so their launches are small (the count is device-side: the grid is an
+  // upper bound walked by a grid-stride loop).
+  static const int fpg_env = getenv("PGDVS_AGG_FPG") ? atoi(getenv("PGDVS_AGG_FPG")) : 0;
+  const int fpg = fpg_env > 0 ? (fpg_env < kPushMaxFpg ? fpg_env : kPushMaxFpg) : 8;  // frames per workgroup row: the point is re-read once per 8 frames
+  for (int i = 0; i < S; ++i) {
     select(i);
     if (i + 1 < S) {
-      PGDVS_LAUNCH("agg_mark_new", agg_mark_kernel<1>, dim3(256), dim3(256), 0, st, (const float *)ws.xyz,
-                   (const int64_t *)(ws.cnts + i), (const int64_t *)(ws.cnts + i + 1), (const ProjF64 *)ws.proj, i + 1, H,
-                   W, occ_n, occ_n);
-      select(i + 1);
+      const int groups = (int)cdiv(S - 1 - i, fpg);
+      const int64_t want = i == 0 ? cdiv(P, kPushThreads) : cdiv(P, 8 * kPushThreads);
+      const unsigned gx = (unsigned)(want < 1024 ? (want > 0 ? want : 1) : 1024);
+      PGDVS_LAUNCH(i == 0 ? "agg_push0" : "agg_push", agg_push_kernel, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
+                   (const float *)ws.xyz, (const int64_t *)ws.cnts, i, (const ProjF64 *)ws.proj, i + 1, S, fpg, H, W, ws.occ);
     }
   }
   PGDVS_LAUNCH("agg_finalize", agg_finalize_kernel, dim3(1), dim3(64), 0, st, (const int64_t *)ws.cnts,

@@ -337,6 +337,7 @@ def main():
             dist.barrier(device_ids=[local_rank])
 
     host_enqueue = [0.0]
+    host_wait = [0.0]  # part of host_enqueue spent blocked on the run-ahead bound (the GPU is behind)
     mem_probe = {}
 
     def timed(n_steps, profile):
@@ -350,6 +351,7 @@ def main():
                                  if os.environ.get("PGDVS_BENCH_MEM") else None)
         t0 = time.perf_counter()
         done = []
+        host_wait[0] = 0.0
         for j in range(n_steps):
             # bounded run-ahead: the host enqueues a view in ~0.7 ms and the GPU renders one in ~1.2, so an
             # unbounded loop gets tens of views ahead, and every view enqueued but not yet executed pins the
@@ -357,7 +359,9 @@ def main():
             # another stream used back before that stream's work has run): the pool then grows by
             # hipMalloc calls in the middle of the timed region, each of which drains the pipeline
             if len(done) >= args.run_ahead:
+                w0 = time.perf_counter()
                 done[j - args.run_ahead].synchronize()
+                host_wait[0] += time.perf_counter() - w0
             # per-kernel HIP events need real launches; one view at a time, so that a kernel's
             # duration is its own and not the queueing behind the other lanes' kernels
             img, cnt, main = step(j, eager=profile, lane=0 if profile else None, out=gather.slot())
@@ -493,6 +497,7 @@ def main():
                 print(f"  new segment {x['total_size'] / 1e6:9.1f} MB on {names.get(x['stream'], x['stream'])}: blocks "
                       + ", ".join(f"{b['size'] / 1e6:.1f}{'*' if b['state'] == 'active_allocated' else ''}" for b in x["blocks"][:8]), file=sys.stderr)
     host_ms = host_enqueue[0] / args.steps * 1e3
+    host_wait_ms = host_wait[0] / args.steps * 1e3
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     per_rank_s = [elapsed]
     if world > 1:
@@ -696,7 +701,7 @@ def main():
         out = {
             "metric": "novel-view frames/s at 1080p x 24 src frames; achieved HBM GB/s vs gfx950 peak",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "latency_ms": latency_ms, "host_enqueue_ms_per_step": round(host_ms, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "latency_ms": latency_ms, "host_enqueue_ms_per_step": round(host_ms, 3), "host_blocked_on_gpu_ms_per_step": round(host_wait_ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{W}x{H} target view, {S} source frames resident in HBM: static aggregation (A12) + "

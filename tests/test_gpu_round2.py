@@ -370,3 +370,25 @@ def test_eval_step_drives_the_hip_renderer():
         want = masked_psnr(gq, pq, mask)
         assert abs(float(md[f"eval/{key}"]) - want) < 0.02, (key, float(md[f"eval/{key}"]), want)
     assert 19.0 < float(md["eval/psnr_full_combined"]) < 21.5  # a 0.1 offset is ~20 dB
+
+
+# ---------------------------------------------------------------- rasteriser: list growth paths
+@pytest.mark.parametrize("n,spread,K", [(3000, 0.02, 3), (12000, 0.01, 3), (9000, 0.0, 2)])
+def test_points_raster_crowded_tiles_vs_oracle(n, spread, K):
+    """tile lists beyond the sorted path's LDS capacity (2560 entries: general path), far beyond it, and
+    thousands of points at one and the same depth (one z-bucket: the exact-rank pass hands over to the
+    general path) -- all bit-exact vs the oracle"""
+    rng = np.random.default_rng(n)
+    H, W = 40, 56
+    xy = rng.normal(0.0, 0.05, (n, 2))
+    z = 2.0 + rng.normal(0.0, spread, n) if spread > 0 else np.full(n, 2.0)
+    pts = np.concatenate([xy * z[:, None], z[:, None]], 1).astype(np.float32)
+    feat = rng.random((n, 3)).astype(np.float32)
+    fc = synth.flat_cam(H, W, np.array([[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]]), np.eye(4))
+    r = ops.points_raster(T(pts), T(feat), ops.cam_prep(T(fc)), 0.06, K, H, W, want_fragments=True)
+    idx, zbuf, d2 = orc.rasterize_points(pts, fc, H, W, 0.06, K)
+    assert (idx >= 0).mean() > 0.03 and int(N(r["idx"]).max()) > n // 2
+    assert np.array_equal(N(r["idx"]), idx)
+    assert np.array_equal(N(r["zbuf"]).view(np.uint32), zbuf.view(np.uint32))
+    assert np.array_equal(N(r["dist2"]).view(np.uint32), d2.view(np.uint32))
+    np.testing.assert_allclose(N(r["rgb"]), orc.composite(idx, d2, 0.06, feat), rtol=0, atol=1e-6)

@@ -36,9 +36,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 def measured_traffic(kernel, H, W, S):
     """HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same
-    command (profiles/r01_hbm_traffic.json, made by tools/make_profile_summary.py); None when
+    command (profiles/r02_hbm_traffic.json, made by tools/make_profile_summary.py); None when
     the workload differs from the profiled one."""
-    f = ROOT / "profiles" / "r01_hbm_traffic.json"
+    f = ROOT / "profiles" / "r02_hbm_traffic.json"
     if not f.exists() or (H, W, S) != (1080, 1920, 24):
         return None
     import re
@@ -47,6 +47,14 @@ def measured_traffic(kernel, H, W, S):
         if re.sub(r"<.*>", "", name).replace("_kernel", "") == kernel:
             return v["hbm_bytes_per_launch"]
     return None
+
+
+def measured_view_traffic(H, W, S):
+    """HBM bytes per view of all kernels together, from the same profile (None for other workloads)"""
+    f = ROOT / "profiles" / "r02_hbm_traffic.json"
+    if not f.exists() or (H, W, S) != (1080, 1920, 24):
+        return None
+    return json.loads(f.read_text()).get("total_hbm_bytes_per_view")
 
 
 def parse():
@@ -152,15 +160,17 @@ def algorithmic_bytes(name, H, W, S, n_static, n_dyn, K):
     """Algorithmic HBM bytes of ONE launch of kernel `name` (kernel table):
     reference fp32 layouts, every input read once and every output written once."""
     P = H * W
-    avg_acc = n_static * 0.5 if S > 1 else 0  # mean accumulated-cloud size seen by agg_mark
+    n0 = min(n_static, P)  # frame 0 appends (nearly) every static pixel; the later frames share the rest
     table = {
-        "agg_mark": 12 * (n_static * (S - 1) / max(S, 1)) if S > 1 else 0,  # xyz of the accumulated cloud (upper bound: final size)
-        "agg_select": 3 * P + (n_static / S) * (4 + 12 + 24 + 12),  # mask + occupancy; depth, rgb -> cloud row + xyz copy
+        # A12: new points read once (packed xyz, 12 B) and one occupancy byte stamped per later frame
+        "agg_push0": n0 * (12 + (S - 1)) if S > 1 else 0,
+        "agg_push": ((n_static - n0) / max(S - 1, 1)) * (12 + (S - 1) / 2.0) if S > 1 else 0,
+        "agg_select": 2 * P + (n_static / S) * (4 + 12 + 24 + 12),  # mask + occupancy bytes; depth, rgb -> cloud row + xyz copy
         "compact_count": P,
         "compact_scatter": P + 4 * P * 0.5,
         "raster_project_count": n_static * (12 + 16),
-        "raster_fill": n_static * (16 + 4 * 2.8),
-        "raster_tile": n_static * 2.8 * 20 + P * 16 + P * K * 12,
+        "raster_fill": n_static * (16 + 16 * 2.8),   # ndc in, 16-byte list entries out (2.8 tiles per point at this radius)
+        "raster_tile": n_static * 2.8 * 16 + P * 16 + P * K * 12,
         "dyn_warp": P * (4 + 1 + 1) + n_dyn * (8 + 4 + 12 + 4 + 4 * 12 + 24),
         "project_flow_dense": P * (1 + 12) + n_dyn * 12,
         "dyn_splat_scatter": P * (12 + 8 + 8 + 4 + 12 + 4 * 12) + P * 4 * 4 + n_dyn * 4 * 4 * 5,
@@ -173,7 +183,6 @@ def algorithmic_bytes(name, H, W, S, n_static, n_dyn, K):
         "gather_rows": n_dyn * (4 + 12 + 12),
         "scatter_keep": n_dyn * 6,
     }
-    del avg_acc
     return float(table.get(name, 0.0))
 
 
@@ -542,7 +551,7 @@ def main():
                         "event_bracket_overhead_ms": round(float(lib.pgdvs_prof_overhead_ms()), 5),
                         "note": ("dominant kernel by time per view (HIP events on the launch stream, one view at a time, the "
                                  "empty-launch bracket cost subtracted); "
-                                 + ("a VALU-bound search kernel, not an HBM stream" if dom in ("raster_tile", "grid_query", "grid_query_tpq")
+                                 + ("a VALU-bound search kernel, not an HBM stream" if dom in ("raster_tile", "grid_query", "grid_query_tpq", "agg_push0")
                                     else "a short kernel launched once per source frame, bound by its dependent global round trips "
                                          "(tile counts -> ordered offsets -> append), not by bandwidth")
                                  + " (DESIGN.md section 4); the whole path's figure is roofline_path")}
@@ -666,26 +675,53 @@ def main():
         torch.manual_seed(0)
         net = GNT(netwidth=64, transformer_depth=8).to(dev).eval()
         Rg, Sg, Vg = args.gnt_rays, 256, S
+        # A13 feeds A14 with REAL projections: a chunk of this view's target rays is sampled along the ray and
+        # projected into the S resident source frames (pgdvs_gnt_gather: rgb + 32-channel feature rows, ray
+        # differences, in-bounds / dynamic masks); the feature maps are random (the ResUNet is a torch/MIOpen row)
         g = torch.Generator(device=dev).manual_seed(1)
-        rgb_feat = torch.randn(Rg, Sg, Vg, 35, device=dev, generator=g)
-        rd = torch.randn(Rg, Sg, Vg, 4, device=dev, generator=g)
-        mk = (torch.rand(Rg, Sg, Vg, 1, device=dev, generator=g) < 0.8).float()
-        pts = torch.randn(Rg, Sg, 3, device=dev, generator=g)
-        rdir = torch.randn(Rg, 3, device=dev, generator=g)
+        v0 = views[0]
+        cam_t = ops.cam_prep(v0["flat_cam_tgt"][0])
+        cams_s = ops.cam_prep(torch.stack([torch.from_numpy(synth.flat_cam(H, W, K3s[i], c2ws[i])) for i in range(S)]).to(dev))
+        ro, rd, _, _ = ops.get_rays(cam_t, H, W, 1)
+        pick = torch.randperm(H * W, device=dev, generator=g)[:Rg].sort().values
+        ro, rd = ro[pick].contiguous(), rd[pick].contiguous()
+        featmaps = torch.randn(S, (H + 3) // 4, (W + 3) // 4, 32, device=dev, generator=g)
+        inv_masks = T(video["dyn_masks"].astype(np.float32))
+        drange = torch.tensor([[0.8, 5.0]], device=dev)
+
+        def gnt_chunk():
+            gg = ops.gnt_gather(ro, rd, drange, Sg, True, cam_t, cams_s, rgbs, featmaps, inv_masks)
+            out = net(gg["rgb_feat"], gg["ray_diff"], gg["mask"], gg["pts"], rd, ret_view_entropy=True, ret_view_std=True)
+            return gg, out
+
         with torch.no_grad():
-            net(rgb_feat, rd, mk, pts, rdir, ret_view_entropy=True, ret_view_std=True)
+            gg, _ = gnt_chunk()
             torch.cuda.synchronize()
+            valid_frac = float(gg["mask"].mean())
+            e0, e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t_gather = t_net = 0.0
             g0 = time.perf_counter()
             for _ in range(3):
-                net(rgb_feat, rd, mk, pts, rdir, ret_view_entropy=True, ret_view_std=True)
-            torch.cuda.synchronize()
+                e0.record()
+                gg = ops.gnt_gather(ro, rd, drange, Sg, True, cam_t, cams_s, rgbs, featmaps, inv_masks)
+                e1.record()
+                net(gg["rgb_feat"], gg["ray_diff"], gg["mask"], gg["pts"], rd, ret_view_entropy=True, ret_view_std=True)
+                e2.record()
+                torch.cuda.synchronize()
+                t_gather += e0.elapsed_time(e1) / 3
+                t_net += e1.elapsed_time(e2) / 3
         gdt = (time.perf_counter() - g0) / 3
         gflop = 2.0 * Rg * Sg * (1048064 + 84416 * Vg)
+        gather_bytes = Rg * Sg * Vg * (4 * 35 * 4 + (44 + 4 * 32))  # 4 bilinear corners x 35 channels read, one row written
         gnt = {"rays": Rg, "samples_per_ray": Sg, "views": Vg, "layers": 8, "ms_per_chunk": round(gdt * 1e3, 2),
-               "tflops": round(gflop / gdt / 1e12, 2), "peak_tflops_fp32_mfma": 157.3,
-               "frac_of_peak": round(gflop / gdt / 157.3e12, 4), "dtype": "f32 (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)",
+               "ms_gather_A13": round(t_gather, 3), "ms_transformer_A14": round(t_net, 3),
+               "tflops": round(gflop / gdt / 1e12, 2), "tflops_A14_alone": round(gflop / (t_net * 1e-3) / 1e12, 2),
+               "peak_tflops_fp32_mfma": 157.3, "frac_of_peak": round(gflop / gdt / 157.3e12, 4),
+               "gather_alg_GBps": round(gather_bytes / (t_gather * 1e-3) / 1e9, 1), "valid_projection_fraction": round(valid_frac, 3),
+               "dtype": "f32 (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)",
                "est_seconds_per_1080p_frame": round(gdt * (H * W / Rg), 1),
-               "note": "GNT.forward incl. view entropy/std side outputs; synthetic gathered features"}
+               "note": "pgdvs_gnt_gather (real projections of target-ray samples into the resident source frames, dynamic masks "
+                       "applied) + GNT.forward incl. view entropy/std side outputs; FLOPs counted for A14 only, time for both"}
         # The whole renderer with the GNT static renderer at the reference's own benchmark setting
         # (NVIDIA Dynamic Scenes: 288 x 550 targets, 10 spatial + 2 temporal source views, 256 samples
         # per ray, chunks of 1024 rays).  Informational, never `value`.
@@ -719,7 +755,7 @@ def main():
             # bytes(S,P) = (20 S + 120) H W algorithmic bytes per novel view x views per second per GPU
             "roofline_path": {"bound": "hbm", "achieved": round(alg_total * fps / 1e9 / max(world, 1), 2), "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": round(alg_total * fps / 1e9 / max(world, 1) / HBM_PEAK_GBS, 5),
-                              "alg_bytes_per_view": alg_total,
+                              "alg_bytes_per_view": alg_total, "traffic_bytes_per_view": measured_view_traffic(H, W, S),
                               "note": "all kernels of a view; the path is bound by search / z-buffer / fp64 re-projection work, "
                                       "not by streaming its inputs (DESIGN.md section 4)"},
             "cpu_baseline": cpu_baseline, "gnt": gnt, "variants": variants, "kernels": kernels,

@@ -57,6 +57,17 @@ for k in sorted(set(fetch) | set(write)):
     wk, n2 = write.get(k, (0.0, 0))
     traffic[k] = {"launches_profiled": max(n, n2), "FETCH_SIZE_KB_raw": round(fk, 1), "WRITE_SIZE_KB_raw": round(wk, 1),
                   "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024)}
-json.dump({"command": cmd, "note": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 FETCH_SIZE correction)",
+# per view: launches per view from the kernel-trace pass (one raster_tile launch = one view)
+calls = {n: c for n, c, _, _, _ in rows}
+views = max([c for n, c in calls.items() if n.startswith("raster_tile_kernel")] or [0])
+total = 0
+if views:
+    for k, v in traffic.items():
+        v["launches_per_view"] = round(calls.get(k, v["launches_profiled"]) / views, 2)
+        v["hbm_bytes_per_view"] = int(v["hbm_bytes_per_launch"] * calls.get(k, v["launches_profiled"]) / views)
+        total += v["hbm_bytes_per_view"]
+json.dump({"command": cmd, "note": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 FETCH_SIZE correction); per view = x launches "
+                                   "per view of the kernel-trace pass of the same command",
+           "views_profiled": views, "total_hbm_bytes_per_view": total,
            "kernels": traffic}, open(out / f"{tag}_hbm_traffic.json", "w"), indent=1)
 print("wrote", out / f"{tag}_kernel_stats.csv", out / f"{tag}_hbm_traffic.json")

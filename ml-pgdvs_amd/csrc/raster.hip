@@ -271,6 +271,7 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
   const float bx_lo = pix_to_ndc(W - 1 - (qx0 + 7), W, range_x) - margin;
   const float by_hi = pix_to_ndc(H - 1 - qy0, H, range_y) + margin;
   const float by_lo = pix_to_ndc(H - 1 - (qy0 + 7), H, range_y) - margin;
+  const float qx_hi = bx_hi - margin, qx_lo = bx_lo + margin, qy_hi = by_hi - margin, qy_lo = by_lo + margin;
   int64_t beg = offsets[tile], end = offsets[tile + 1];
   if (end > list_capacity) end = list_capacity;
   const int64_t n64 = end > beg ? end - beg : 0;
@@ -436,7 +437,10 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
         if (__ballot(inside && key[K - 1] == __builtin_inff()) == 0ull) break;
         const int e = base + lane;
         const float2 c = s_xy[e < n ? e : 0];
-        const bool in = e < n && c.x >= bx_lo && c.x <= bx_hi && c.y >= by_lo && c.y <= by_hi;
+        // the disc must reach the rectangle of the quadrant's pixel centres (distance of its centre to the
+        // rectangle, with the same rounding margin as the box): drops the corners of the expanded box
+        const float ex = fmaxf(fmaxf(qx_lo - c.x, c.x - qx_hi), 0.0f), ey = fmaxf(fmaxf(qy_lo - c.y, c.y - qy_hi), 0.0f);
+        const bool in = e < n && ex * ex + ey * ey <= margin * margin;
         const unsigned long long mask = __ballot(in);
         if (!mask) continue;
         const int cnt = (int)__popcll(mask);

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256)
 raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_host,
                             const int64_t *__restrict__ n_dev, const float *__restrict__ cam,
                             float radius, int H, int W, int ntx, int nty,
-                            float4 *__restrict__ ndc4, int32_t *__restrict__ tile_count) {
+                            int32_t *__restrict__ tile_count) {
   // a device-side count never exceeds the rows the caller sized the workspace for (and a
   // negative one -- the aggregation's error status -- renders nothing)
   int64_t n = n_dev ? *n_dev : n_host;
@@ -109,7 +109,6 @@ raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, i
     if (i < n) {
       const float *X = pts + i * pts_stride;
       float3 p = point_to_ndc(rc, X[0], X[1], X[2]);
-      ndc4[i] = make_float4(p.x, p.y, p.z, 0.0f);
       b = tile_box(rc, p, radius, H, W, ntx, nty);
     }
     int nx = wave_max_i32_scalar(b.tx1 - b.tx0 + 1), ny = wave_max_i32_scalar(b.ty1 - b.ty0 + 1);
@@ -152,9 +151,9 @@ raster_scan_kernel(const int32_t *__restrict__ counts, int n, int32_t *__restric
 }
 
 __global__ void __launch_bounds__(256)
-raster_fill_kernel(int64_t n_host, const int64_t *__restrict__ n_dev,
+raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_host, const int64_t *__restrict__ n_dev,
                    const float *__restrict__ cam, float radius, int H, int W, int ntx, int nty,
-                   const float4 *__restrict__ ndc4, const int32_t *__restrict__ offsets,
+                   const int32_t *__restrict__ offsets,
                    int32_t *__restrict__ cursor, float4 *__restrict__ lists,
                    int64_t list_capacity) {
   // a device-side count never exceeds the rows the caller sized the workspace for (and a
@@ -169,8 +168,11 @@ raster_fill_kernel(int64_t n_host, const int64_t *__restrict__ n_dev,
     b.tx0 = 1; b.tx1 = 0; b.ty0 = 1; b.ty1 = 0;
     float4 ent = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) {
-      float4 q = ndc4[i];
-      b = tile_box(rc, make_float3(q.x, q.y, q.z), radius, H, W, ntx, nty);
+      // projected again rather than kept: the same instructions on the same inputs as in the counting pass
+      // give the same tile box, and 32 bytes per point of intermediate traffic disappear
+      const float *X = pts + i * pts_stride;
+      const float3 q = point_to_ndc(rc, X[0], X[1], X[2]);
+      b = tile_box(rc, q, radius, H, W, ntx, nty);
       // -0.0 -> +0.0 once, so that the z bits order like the values
       ent = make_float4(q.x, q.y, __int_as_float((int)i), q.z + 0.0f);
     }
@@ -598,7 +600,6 @@ static int64_t max_tiles_per_point(float radius, int H, int W) {
 }
 
 struct RasterWs {
-  float4 *ndc4;
   int32_t *tile_count, *cursor, *offsets;
   float4 *lists;  // 16-byte entries (x_ndc, y_ndc, id, z)
   int64_t list_capacity;
@@ -610,8 +611,6 @@ static RasterWs raster_ws_layout(void *base, int64_t n, int H, int W, float radi
   int64_t ntiles = cdiv(W, kTile) * cdiv(H, kTile);
   char *p = reinterpret_cast<char *>(base);
   int64_t off = 0;
-  w.ndc4 = reinterpret_cast<float4 *>(p + off);
-  off += align_up((n > 0 ? n : 1) * 16, 256);
   w.tile_count = reinterpret_cast<int32_t *>(p + off);
   off += align_up(ntiles * 4, 256);
   w.cursor = reinterpret_cast<int32_t *>(p + off);
@@ -684,15 +683,13 @@ PGDVS_API int pgdvs_points_raster(const float *pts, int64_t pts_stride, const fl
   if (n_points > 0) {
     unsigned g = (unsigned)(cdiv(n_points, 256) < 4096 ? cdiv(n_points, 256) : 4096);
     PGDVS_LAUNCH("raster_project_count", raster_project_count_kernel, dim3(g), dim3(256), 0, st, pts, pts_stride,
-                       n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.ndc4,
-                       ws.tile_count);
+                       n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count);
   }
   PGDVS_LAUNCH("raster_scan", raster_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_count, ntiles, ws.offsets);
   if (n_points > 0) {
     unsigned g = (unsigned)(cdiv(n_points, 256) < 4096 ? cdiv(n_points, 256) : 4096);
-    PGDVS_LAUNCH("raster_fill", raster_fill_kernel, dim3(g), dim3(256), 0, st, n_points, n_points_dev, cam_tgt,
-                       radius, H, W, ntx, nty, ws.ndc4, ws.offsets, ws.cursor, ws.lists,
-                       ws.list_capacity);
+    PGDVS_LAUNCH("raster_fill", raster_fill_kernel, dim3(g), dim3(256), 0, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
+                       radius, H, W, ntx, nty, ws.offsets, ws.cursor, ws.lists, ws.list_capacity);
   }
   const int tiles_per_xcd = (int)cdiv(ntiles, 8);
   dim3 grid(8 * tiles_per_xcd);

@@ -220,9 +220,9 @@ struct TopK {
   }
 };
 
-constexpr int kSortCap = 2560;       // list entries the sorted path holds in LDS (52 KB with the rest: 3 workgroups per CU)
+constexpr int kSortCap = 2048;       // list entries the sorted path holds in LDS (52 KB with the rest: 3 workgroups per CU)
 constexpr int kSortPerThread = kSortCap / 256;
-constexpr int kSortBuckets = 2048;   // monotone z-buckets of the distribution pass
+constexpr int kSortBuckets = 1024;   // monotone z-buckets of the distribution pass
 constexpr int kSortMaxBucket = 64;   // more entries than this in one bucket (equal depths): general path
 // ranks are carried as floats (exact below 2^24; +inf = empty slot) so that v_med3_f32 applies
 
@@ -236,7 +236,7 @@ __device__ __forceinline__ void rank_insert(float (&key)[K], float r) {
 }
 
 template <int K>
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, 4)
 raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__ offsets, int64_t list_capacity,
                    const float *__restrict__ feat, int64_t feat_stride, float radius, int H, int W,
                    int ntx, int nty, int tiles_per_xcd, int64_t *__restrict__ idx_out,
@@ -244,8 +244,11 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
                    float *__restrict__ rgb_out, int rgb_planar, float *__restrict__ mask_out) {
   __shared__ float2 s_xy[kSortCap];         // rank order: NDC x, y (general path: staging of 256 entries)
   __shared__ uint2 s_kz[kSortCap];          // bucket order: (z bits, id); after ranking, rank order: (id, z bits)
-  __shared__ unsigned s_cnt[kSortBuckets];  // bucket counts, then bucket starts
   __shared__ float4 s_wave[4][68];          // per-wave strip of culled points (+ padding)
+  // bucket counts, then bucket starts: dead before the walk begins, so they share the strips' storage
+  unsigned *s_cnt = reinterpret_cast<unsigned *>(&s_wave[0][0]);
+  static_assert(kSortBuckets * 4 <= 4 * 68 * 16, "the counters alias the strips");
+  static_assert(kSortCap * 16 + 4 * 68 * 16 + 128 <= 40960, "four workgroups per CU");
   __shared__ unsigned s_red[12];
   __shared__ int s_flag;
   // XCD-aware mapping: blocks b, b+8, ... share an XCD -> give them a contiguous tile band
@@ -402,9 +405,17 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
             const unsigned bs = s_cnt[b], be = b + 1u < (unsigned)kSortBuckets ? s_cnt[b + 1u] : (unsigned)n;
             const uint2 me = s_kz[p];
             unsigned r = bs;
-            for (unsigned j = bs; j < be; ++j) {
-              const uint2 o = s_kz[j];
-              r += (o.x < me.x) | ((o.x == me.x) & (o.y < me.y)) ? 1u : 0u;
+            // buckets hold 0-2 entries: the first four are read together (independent LDS reads), a
+            // longer bucket finishes in a loop
+            uint2 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = s_kz[bs + j < (unsigned)n ? bs + j : (unsigned)n - 1u];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              r += (bs + j < be) & ((o[j].x < me.x) | ((o[j].x == me.x) & (o[j].y < me.y))) ? 1u : 0u;
+            for (unsigned j = bs + 4u; j < be; ++j) {
+              const uint2 oj = s_kz[j];
+              r += (oj.x < me.x) | ((oj.x == me.x) & (oj.y < me.y)) ? 1u : 0u;
             }
             pos[k] = r;
           }
@@ -451,16 +462,21 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
         // same wave writes and reads: LDS ops of one wave complete in order; keep the compiler
         // from moving the reads above the writes
         __builtin_amdgcn_wave_barrier();
-        for (int j = 0; j < cnt; j += 4) {
-          float4 p[4];
+        float4 p[4], pn[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) p[u] = strip[j + u];
+        for (int u = 0; u < 4; ++u) p[u] = strip[u];
+        for (int j = 0; j < cnt; j += 4) {
+          // the next four entries are requested before these four are evaluated
+#pragma unroll
+          for (int u = 0; u < 4; ++u) pn[u] = strip[(j + 4 + u) & 63];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const float dx = p[u].x - xf, dy = p[u].y - yf;
             const float d2 = dx * dx + dy * dy;
             rank_insert<K>(key, d2 < r2 ? p[u].z : __builtin_inff());
           }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) p[u] = pn[u];
         }
         __builtin_amdgcn_wave_barrier();
       }

@@ -5,7 +5,7 @@ fused multiply-add; float32 LAPACK inverse vs a correctly rounded one).  This to
 points (plus edge-grazing discs and exact z ties) through oracle/p3d_second.py in each flavour, feeds
 every NDC set to the same naive rasteriser on pixel windows and reports the disagreement of the z-buffer
 index and of the composited image against the closed-form oracle (oracle/pgdvs_oracle.c).
-usage: p3d_order_sensitivity.py [n_points] [out.json]      (CPU only)"""
+usage: python tests/p3d_order_sensitivity.py [n_points] [out.json]      (CPU only; test infrastructure: imports oracle/)"""
 import json
 import pathlib
 import sys

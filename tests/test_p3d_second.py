@@ -60,8 +60,8 @@ def test_backend_accumulation_order_sensitivity_is_small_and_measured():
     """pytorch3d's own backends (sequential vs fused multiply-add in torch.bmm) on 150 k points with edge-grazing
     discs and exact z ties: ~40 % of the NDC coordinates change in the last bit, the z-buffer index on a few
     1e-4 of the entries at most.  That is the size of the hole `parity unpinned` leaves for A9; the full
-    10^6-point run is profiles/r02_p3d_order_sensitivity.json (tools/p3d_order_sensitivity.py)."""
-    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent / "tools"))
+    10^6-point run is profiles/r02_p3d_order_sensitivity.json (tests/p3d_order_sensitivity.py)."""
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent))
     import p3d_order_sensitivity as S
 
     r = S.measure(n=150_000, win=32)

@@ -12,7 +12,6 @@ import numpy as np
 R0 = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(R0 / "ml-pgdvs_amd"))
 sys.path.insert(0, str(R0 / "tools"))
-sys.path.insert(0, str(R0))
 import torch  # noqa: E402
 
 from fast_video import bench_cloud  # noqa: E402
@@ -20,16 +19,16 @@ from pgdvs_amd import ops  # noqa: E402
 
 K, RADIUS, H, W = 3, 0.01, 1080, 1920
 cloud, v, fc = bench_cloud()
-cam = ops.cam_prep(torch.from_numpy(fc).cuda())
-# NDC of all points the way the kernels compute it (tools: fp32 torch, good enough for statistics)
-c = cam.cpu().numpy()
-from oracle import oracle as orc  # noqa: E402
-
-ndc = orc.points_to_ndc(cloud[:, :3].cpu().numpy(), fc, H, W)
+# pixel-index coordinates of all points (pixel i centred at i, as pytorch3d's +0.5 centres in OpenCV pixel
+# units) and view depth: plain pinhole projection in float64 -- statistics only, no parity claim
+fcn = np.asarray(fc, np.float64)
+K4, c2w = fcn[2:18].reshape(4, 4), fcn[18:34].reshape(4, 4)
+w2c = np.linalg.inv(c2w)
+Xc = cloud[:, :3].cpu().numpy().astype(np.float64) @ w2c[:3, :3].T + w2c[:3, 3]
+z = Xc[:, 2]
+px = K4[0, 0] * Xc[:, 0] / z + K4[0, 2] - 0.5
+py = K4[1, 1] * Xc[:, 1] / z + K4[1, 2] - 0.5
 s = min(H, W) / 2.0
-px = (W / 2.0) - ndc[:, 0] * s - 0.5   # pixel-index coordinates (pixel i centred at i)
-py = (H / 2.0) - ndc[:, 1] * s - 0.5
-z = ndc[:, 2]
 rpx = RADIUS * s
 rng = np.random.default_rng(0)
 tiles = [(int(rng.integers(4, H // 16 - 4)), int(rng.integers(4, W // 16 - 4))) for _ in range(40)]

@@ -559,7 +559,7 @@ def main():
     # ---------------- latency of ONE view (nothing else in flight): the throughput above comes from overlapping
     # `inflight` independent views; this is the time a single view takes from first launch to last kernel
     latency_ms = None
-    if rank == 0:
+    if True:  # (every rank, so that all ranks reach the end of the run together; rank 0 reports its own)
         torch.cuda.synchronize()
         lat = []
         for j in range(12):
@@ -762,6 +762,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 

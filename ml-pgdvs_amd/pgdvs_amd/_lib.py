@@ -84,6 +84,12 @@ def load() -> C.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` from the repo root "
             "(needs hipcc). There is no CPU fallback for the product path."
         )
+    # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be the ONE runtime of the
+    # process: loaded first, the dynamic loader binds this library's libamdhip64 references to it.  Loaded
+    # second (after /opt/rocm's copy came in through this library), torch's streams and allocations live in a
+    # different runtime instance than our launches ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
+
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

@@ -168,8 +168,8 @@ def algorithmic_bytes(name, H, W, S, n_static, n_dyn, K):
         "agg_select": 2 * P + (n_static / S) * (4 + 12 + 24 + 12),  # mask + occupancy bytes; depth, rgb -> cloud row + xyz copy
         "compact_count": P,
         "compact_scatter": P + 4 * P * 0.5,
-        "raster_project_count": n_static * (12 + 16),
-        "raster_fill": n_static * (16 + 16 * 2.8),   # ndc in, 16-byte list entries out (2.8 tiles per point at this radius)
+        "raster_project_count": n_static * 12,       # xyz in, tile counters only
+        "raster_fill": n_static * (12 + 16 * 2.8),   # xyz in, 16-byte list entries out (2.8 tiles per point at this radius)
         "raster_tile": n_static * 2.8 * 16 + P * 16 + P * K * 12,
         "dyn_warp": P * (4 + 1 + 1) + n_dyn * (8 + 4 + 12 + 4 + 4 * 12 + 24),
         "project_flow_dense": P * (1 + 12) + n_dyn * 12,

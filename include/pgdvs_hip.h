@@ -188,7 +188,9 @@ int pgdvs_dyn_splat_composite(int H, int W, const float *rgb1, const float *rgb2
  * and render_dyn_pcl (pgdvs/renderers/pgdvs_renderer_dyn.py:671-724).
  *   points: xyz at pts[i*pts_stride..+3), features at feat[i*feat_stride..+3)
  *   n_points: host count; n_points_dev (nullable): device int64 count that overrides
- *   it (n_points is then the capacity)
+ *   it (n_points is then the capacity: a larger or negative device count is clamped to [0, n_points]).
+ *   Returns PGDVS_ERR_UNSUPPORTED (and the workspace query a negative size) when n_points times the
+ *   tiles a disc of this radius can touch reaches 2^31 list entries.
  *   outputs (any may be NULL): idx[H,W,K] int64 (-1 pad), zbuf[H,W,K] (-1 pad),
  *   dist2[H,W,K] (-1 pad), rgb ([H,W,3] if rgb_planar == 0, [3,H,W] otherwise),
  *   mask[H,W] ((ones-render) > 0 as 0/1 floats).  K (points_per_pixel) in [1, 8]. */
@@ -204,7 +206,10 @@ int pgdvs_points_raster(const float *pts, int64_t pts_stride, const float *feat,
  * pgdvs/datasets/nvidia_eval.py:840-847, pgdvs/datasets/base.py:507-546).
  *   rgbs[S,H,W,3] in [0,1]; depths[S,H,W]; dyn_masks[S,H,W] u8 (non-zero = dynamic)
  *   K3s: HOST double[S,9]; c2ws: HOST double[S,16]   (float64 numpy upstream)
- *   out[capacity,6] (xyz,rgb) in the reference's order; count_out: device int64. */
+ *   out[capacity,6] (xyz,rgb) in the reference's order; count_out: device int64 = the number
+ *   of rows written, or -1 if the kernels' internal ordering protocol reported an error (the rows are
+ *   then not valid; pgdvs_points_raster treats a negative device count as 0).
+ *   The workspace holds one occupancy byte per (frame, pixel): S*H*W bytes + 12 bytes per row. */
 int64_t pgdvs_static_aggregate_workspace_bytes(int S, int H, int W, int64_t capacity);
 int pgdvs_static_aggregate(const float *rgbs, const float *depths, const uint8_t *dyn_masks,
                            const double *K3s_host, const double *c2ws_host, int S, int H, int W,

@@ -392,3 +392,52 @@ def test_points_raster_crowded_tiles_vs_oracle(n, spread, K):
     assert np.array_equal(N(r["zbuf"]).view(np.uint32), zbuf.view(np.uint32))
     assert np.array_equal(N(r["dist2"]).view(np.uint32), d2.view(np.uint32))
     np.testing.assert_allclose(N(r["rgb"]), orc.composite(idx, d2, 0.06, feat), rtol=0, atol=1e-6)
+
+
+# ---------------------------------------------------------------- A12: where the projection bounds are tight
+@pytest.mark.parametrize("motion", ["static", "tiny_shift", "integer_shift", "roll", "projective_K", "behind", "far"])
+def test_static_aggregation_degenerate_camera_motions_vs_oracle(motion):
+    """camera motions that put re-projected points exactly on (or within rounding of) pixel boundaries: a static
+    camera (every point re-projects to x.000.. / x.999..: the fp32 screening form can decide nothing, the fp64 form
+    little, the reference operation order decides), a 1e-7 shift, a shift by whole pixels at constant depth, an
+    in-plane roll, and intrinsics with a skew term (K not of the sparse form) -- occupancy decisions identical to
+    numpy's fp64 projection, cloud bit-exact and in order"""
+    from pgdvs_amd.datasets.static_aggregation import aggregate_static_pcl
+
+    S, H, W = 5, 61, 83
+    v = synth.make_video(S, H, W, seed=33)
+    K3s, c2ws, depths = v["K3s"].copy(), v["c2ws"].copy(), v["depths"].copy()
+    for i in range(S):
+        c2ws[i] = c2ws[0]
+        K3s[i] = K3s[0]
+    if motion == "tiny_shift":
+        for i in range(S):
+            c2ws[i, 0, 3] += 1e-7 * i
+    elif motion == "integer_shift":
+        depths[:] = 2.0  # fronto-parallel plane: a translation of d/f per pixel shifts the image by whole pixels
+        for i in range(S):
+            c2ws[i, 0, 3] += 3 * i * 2.0 / K3s[0, 0, 0]
+    elif motion == "roll":
+        for i in range(S):
+            a = 0.01 * i
+            R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+            c2ws[i, :3, :3] = c2ws[0, :3, :3] @ R
+    elif motion == "behind":
+        for i in range(1, S, 2):  # odd frames look the other way: the cloud lies behind them (no z > 0 test upstream)
+            a = np.deg2rad(170.0)
+            R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+            c2ws[i, :3, :3] = c2ws[0, :3, :3] @ R
+    elif motion == "far":
+        depths *= 4000.0  # coordinates of ~1e4: the error bounds scale with max(|x|,|y|,|z|)
+        for i in range(S):
+            c2ws[i, 0, 3] += 25.0 * i
+    elif motion == "projective_K":
+        for i in range(S):
+            K3s[i, 0, 1] = 0.3 * i  # skew
+            c2ws[i, 0, 3] += 0.01 * i
+    st = N(aggregate_static_pcl(T(v["rgbs"]), T(depths), T(v["dyn_masks"]), K3s, c2ws))
+    o = orc.aggregate_static_pcl(v["rgbs"], depths, v["dyn_masks"], K3s, c2ws)
+    assert st.shape == o.shape, (st.shape, o.shape)
+    assert np.array_equal(st.view(np.uint32), o.view(np.uint32))
+    if motion == "static":  # dedup is total where the frames agree: only what differs between frames is added
+        assert st.shape[0] < 2.2 * H * W

@@ -249,6 +249,7 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
   unsigned *s_cnt = reinterpret_cast<unsigned *>(&s_wave[0][0]);
   static_assert(kSortBuckets * 4 <= 4 * 68 * 16, "the counters alias the strips");
   static_assert(kSortCap * 16 + 4 * 68 * 16 + 128 <= 40960, "four workgroups per CU");
+  static_assert(kSortCap % 256 == 0, "every thread owns kSortCap / 256 entries");
   __shared__ unsigned s_red[12];
   __shared__ int s_flag;
   // XCD-aware mapping: blocks b, b+8, ... share an XCD -> give them a contiguous tile band

@@ -129,9 +129,13 @@ __device__ __forceinline__ float linspace_pm1(int i, int steps) {
 // pixel none of whose corners is flagged, before its backwarp, exponential and 16 atomics (the
 // L2 atomic rate, ~270 G/s, is what bounds the scatter).  Identical results for finite inputs (a
 // non-finite static colour no longer turns an untouched target pixel into NaN).
+// The same set is the only place where the accumulators are ever READ (the finish kernel writes the
+// static composite elsewhere without looking at them), so only its pixels are zeroed -- here, by whoever
+// flags them (idempotent) -- instead of 20 bytes per pixel of memset; what the scatter adds onto the
+// uninitialised accumulators of unflagged pixels is never looked at.
 __global__ void __launch_bounds__(256)
 dyn_splat_flag_kernel(int H, int W, const float *__restrict__ flow_1_to_tgt,
-                      const float *__restrict__ valid_mask, uint8_t *__restrict__ flags) {
+                      const float *__restrict__ valid_mask, uint8_t *__restrict__ flags, float *__restrict__ acc) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int P = H * W;
   if (p >= P) return;
@@ -140,7 +144,11 @@ dyn_splat_flag_kernel(int H, int W, const float *__restrict__ flow_1_to_tgt,
   SplatCorners c = splat_corners(x, y, flow_1_to_tgt[p], flow_1_to_tgt[(size_t)P + p], H, W);
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (c.idx[k] >= 0) flags[c.idx[k]] = 1;
+    if (c.idx[k] >= 0) {
+      flags[c.idx[k]] = 1;
+#pragma unroll
+      for (int pl = 0; pl < 5; ++pl) acc[(size_t)pl * P + c.idx[k]] = 0.0f;
+    }
 }
 
 // acc planes: 0..2 rgb*e, 3 e, 4 mask*e
@@ -266,19 +274,23 @@ dyn_splat_scatter_kernel(int H, int W, const float *__restrict__ rgb1,
 // normalise, threshold, mask and composite (pgdvs_renderer_dyn.py:200-202,
 // pgdvs_renderer.py:169-178)
 __global__ void __launch_bounds__(256)
-dyn_splat_finish_kernel(int P, const float *__restrict__ acc, const float *__restrict__ static_rgb,
+dyn_splat_finish_kernel(int P, const float *__restrict__ acc, const uint8_t *__restrict__ flags,
+                        const float *__restrict__ static_rgb,
                         float *__restrict__ dyn_rgb, float *__restrict__ dyn_mask,
                         float *__restrict__ comb, float *__restrict__ comb_st,
                         float *__restrict__ comb_dy) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
-  float nrm = acc[(size_t)3 * P + p] + 0.0000001f;
-  float mk = acc[(size_t)4 * P + p] / nrm;
+  // a pixel no dynamic source pixel reaches has splatted mask 0 -> below the 1e-3 threshold -> (.) * 0:
+  // its accumulators (never initialised) are not read
+  const bool live = flags[p] != 0;
+  float nrm = live ? acc[(size_t)3 * P + p] + 0.0000001f : 1.0f;
+  float mk = live ? acc[(size_t)4 * P + p] / nrm : 0.0f;
   float dm = mk > 1e-3f ? 1.0f : 0.0f;
   dyn_mask[p] = dm;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    float v = (acc[(size_t)k * P + p] / nrm) * dm;
+    float v = live ? (acc[(size_t)k * P + p] / nrm) * dm : 0.0f;
     dyn_rgb[(size_t)k * P + p] = v;
     if (static_rgb) {
       float a = (1.0f - dm) * static_rgb[(size_t)k * P + p];
@@ -422,18 +434,18 @@ PGDVS_API int pgdvs_dyn_splat_composite(int H, int W, const float *rgb1, const f
   const int P = H * W;
   float *acc = reinterpret_cast<float *>(workspace);
   uint8_t *flags = reinterpret_cast<uint8_t *>(acc + (size_t)5 * P);
-  hipError_t e = fill_async(acc, 0, (size_t)5 * P * sizeof(float) + (size_t)P, st);
+  hipError_t e = fill_async(flags, 0, (size_t)P, st);  // (the accumulators are zeroed where they will be read)
   if (e != hipSuccess) {
     set_error("dyn_splat memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
   }
   dim3 grid((unsigned)cdiv(P, 256)), block(256);
   PGDVS_LAUNCH("dyn_splat_flag", dyn_splat_flag_kernel, grid, block, 0, st, H, W, flow_1_to_tgt, valid_dyn_mask_1,
-               flags);
+               flags, acc);
   const dim3 tgrid((unsigned)cdiv(W, kSplatTile), (unsigned)cdiv(H, kSplatTile));
   PGDVS_LAUNCH("dyn_splat_scatter", dyn_splat_scatter_kernel, tgrid, block, 0, st, H, W, rgb1, rgb2, flow12,
                      flow_1_to_tgt, valid_dyn_mask_1, noise, alpha, acc, (const uint8_t *)flags);
-  PGDVS_LAUNCH("dyn_splat_finish", dyn_splat_finish_kernel, grid, block, 0, st, P, acc, static_rgb,
+  PGDVS_LAUNCH("dyn_splat_finish", dyn_splat_finish_kernel, grid, block, 0, st, P, acc, (const uint8_t *)flags, static_rgb,
                      render_dyn_rgb, render_dyn_mask, combined, combined_static, combined_dyn);
   return check_launch("dyn_splat_composite");
 }

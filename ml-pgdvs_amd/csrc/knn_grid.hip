@@ -341,17 +341,29 @@ grid_scan_apply_kernel(const int32_t *__restrict__ in, const GridParams *__restr
   }
 }
 
+// slot of this lane inside its cell, counting the cell's (already scanned) count DOWN: no second
+// counter array to zero.  The order inside a cell is arbitrary either way (the results do not
+// depend on it: only sorted distance values are consumed).
+__device__ __forceinline__ int wave_cell_take(int32_t *__restrict__ remaining, int c) {
+  const int lane = threadIdx.x & 63;
+  RunInfo r = wave_runs(c);
+  int base = 0;
+  if (r.is_leader && c >= 0) base = atomicSub(&remaining[c], r.length) - r.length;
+  base = __shfl(base, r.leader, 64);
+  return base + (lane - r.leader);
+}
+
 __global__ void __launch_bounds__(256)
 grid_fill_kernel(const float *__restrict__ pts, const GridParams *__restrict__ gp,
                  const int32_t *__restrict__ cell_of, const int32_t *__restrict__ cell_start,
-                 int32_t *__restrict__ cursor, float4 *__restrict__ sorted,
+                 int32_t *__restrict__ cell_count, float4 *__restrict__ sorted,
                  const int32_t *__restrict__ gate) {
   if (gate && *gate == 0) return;
   const int n = gp->n;
   const int n_round = (n + 63) / 64 * 64;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
     const int c = i < n ? cell_of[i] : -1;
-    const int slot = wave_tile_reserve(cursor, c);
+    const int slot = wave_cell_take(cell_count, c);
     if (i < n)
       sorted[cell_start[c] + slot] = make_float4(pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2],
                                                  __int_as_float(i));
@@ -959,7 +971,7 @@ struct GridWs {
   unsigned *bbox;
   unsigned long long *sumsq;
   GridParams *gp;
-  int32_t *cell_count, *cursor, *cell_start, *block_sums, *cell_of;
+  int32_t *cell_count, *cell_start, *block_sums, *cell_of;
   float4 *sorted;
   int32_t *fb_count, *fb_list;
   int32_t *open_count, *open_list;  // queries the thread-per-query pass left to the ring search
@@ -968,7 +980,7 @@ struct GridWs {
   int32_t *stats;  // [16] ring histogram, filled only when PGDVS_KNN_STATS=1 (diagnostics)
   // second level
   GridParams *gp2;
-  int32_t *cell_count2, *cursor2, *cell_start2, *block_sums2;
+  int32_t *cell_count2, *cell_start2, *block_sums2;
   float4 *sorted2;
   int32_t *fb2_count, *fb2_list;
   float *fb2_bound;
@@ -995,8 +1007,6 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   off += 256;
   w.cell_count = reinterpret_cast<int32_t *>(p + off);
   off += align_up(((int64_t)kGridMaxCells + 1) * 4, 256);
-  w.cursor = reinterpret_cast<int32_t *>(p + off);
-  off += align_up(((int64_t)kGridMaxCells + 1) * 4, 256);
   w.cell_start = reinterpret_cast<int32_t *>(p + off);
   off += align_up(((int64_t)kGridMaxCells + 1) * 4, 256);
   w.block_sums = reinterpret_cast<int32_t *>(p + off);
@@ -1017,8 +1027,6 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   w.gp2 = reinterpret_cast<GridParams *>(p + off);
   off += 256;
   w.cell_count2 = reinterpret_cast<int32_t *>(p + off);
-  off += align_up(((int64_t)kCoarseMaxCells + 1) * 4, 256);
-  w.cursor2 = reinterpret_cast<int32_t *>(p + off);
   off += align_up(((int64_t)kCoarseMaxCells + 1) * 4, 256);
   w.cell_start2 = reinterpret_cast<int32_t *>(p + off);
   off += align_up(((int64_t)kCoarseMaxCells + 1) * 4, 256);
@@ -1081,7 +1089,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   PGDVS_LAUNCH("grid_params", grid_params_kernel, dim3(1), dim3(64), 0, st, ws.bbox, count,
                (const unsigned long long *)ws.sumsq, ws.gp, target);
   PGDVS_LAUNCH("grid_zero", grid_zero_kernel, dim3(2048), dim3(256), 0, st, ws.gp, ws.cell_count,
-               ws.cursor);
+               (int32_t *)nullptr);
   PGDVS_LAUNCH("grid_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
                ws.cell_count, (const int32_t *)nullptr);
   const int nb = kGridMaxCells / kScanTile;
@@ -1091,7 +1099,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   PGDVS_LAUNCH("grid_scan_apply", grid_scan_apply_kernel, dim3(nb), dim3(1024), 0, st, ws.cell_count, ws.gp,
                ws.block_sums, ws.cell_start);
   PGDVS_LAUNCH("grid_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
-               ws.cell_start, ws.cursor, ws.sorted, (const int32_t *)nullptr);
+               ws.cell_start, ws.cell_count, ws.sorted, (const int32_t *)nullptr);
   const char *env = getenv("PGDVS_KNN_STATS");
   int32_t *stats = (env && env[0] == '1') ? ws.stats : nullptr;
   const unsigned gq = (unsigned)(cdiv(nq_cap, 4) < 256 * 8 ? (cdiv(nq_cap, 4) > 0 ? cdiv(nq_cap, 4) : 1) : 256 * 8);
@@ -1130,7 +1138,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   const int nb2 = kCoarseMaxCells / kScanTile;
   PGDVS_LAUNCH("grid2_params", grid_params_coarse_kernel, dim3(1), dim3(64), 0, st, ws.gp, ws.bbox, ws.gp2,
                kCoarseScale, kCoarseMaxCells);
-  PGDVS_LAUNCH("grid2_zero", grid_zero_kernel, dim3(256), dim3(256), 0, st, ws.gp2, ws.cell_count2, ws.cursor2);
+  PGDVS_LAUNCH("grid2_zero", grid_zero_kernel, dim3(256), dim3(256), 0, st, ws.gp2, ws.cell_count2, (int32_t *)nullptr);
   PGDVS_LAUNCH("grid2_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp2, ws.cell_of,
                ws.cell_count2, (const int32_t *)ws.fb_count);
   PGDVS_LAUNCH("grid2_scan", grid_scan_blocks_kernel, dim3(nb2), dim3(1024), 0, st, ws.cell_count2, ws.gp2,
@@ -1139,7 +1147,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   PGDVS_LAUNCH("grid2_scan", grid_scan_apply_kernel, dim3(nb2), dim3(1024), 0, st, ws.cell_count2, ws.gp2,
                ws.block_sums2, ws.cell_start2);
   PGDVS_LAUNCH("grid2_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp2, ws.cell_of,
-               ws.cell_start2, ws.cursor2, ws.sorted2, (const int32_t *)ws.fb_count);
+               ws.cell_start2, ws.cell_count2, ws.sorted2, (const int32_t *)ws.fb_count);
   QuerySrc qs2 = qs;
   qs2.list = ws.fb_list;
   qs2.list_count = ws.fb_count;

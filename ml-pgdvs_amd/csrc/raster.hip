@@ -11,13 +11,14 @@
 // 256-thread workgroup per tile.  Selection uses the total order (z, id), which is also
 // pytorch3d's priority-queue order, so idx/zbuf/dist2 do not depend on list order.
 //   sorted path (a tile's list fits the LDS capacity -- the normal case): the workgroup sorts its
-//     list by (z, id) in LDS -- one distribution pass into 2048 monotone z-buckets, exact ranks
+//     list by (z, id) in LDS -- one distribution pass into 1024 monotone z-buckets, exact ranks
 //     inside a bucket by counting -- and a point's RANK becomes its 32-bit key.  Every wavefront
-//     (one 8x8 quadrant, pixel per lane) then walks the sorted list front to back: box cull with a
-//     ballot, per-pixel disc test, and a branch-free insertion of the rank into the pixel's K
-//     smallest (v_min_u32 + K-1 v_med3_u32: 8 vector instructions per tested point for K=3, no
-//     divergence), leaving as soon as every pixel of the quadrant holds K points: nothing behind
-//     can matter.  (Measured before this form, per wavefront at 1080p x 3.5 M points: 292 tested
+//     (one 8x8 quadrant, pixel per lane) then walks the sorted list front to back: cull by the
+//     distance of the disc centre to the quadrant's rectangle of pixel centres (ballot), per-pixel
+//     disc test, and a branch-free insertion of the rank (carried as a float) into the pixel's K
+//     smallest (K v_med3_f32: 8 vector instructions per tested point for K=3, no divergence),
+//     leaving as soon as every pixel of the quadrant holds K points: nothing behind can matter.
+//     2048 entries x 16 bytes + the strips = 37 KB of LDS: four workgroups per CU.  (Measured before this form, per wavefront at 1080p x 3.5 M points: 292 tested
 //     points of which 167 diverged into a 13-instruction 64-bit insertion, 1130 staged entries; in
 //     sorted order 228 are tested and 541 staged.)
 //   general path (longer lists, or > 64 equal-depth points in one bucket): lists staged through
@@ -406,7 +407,7 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
             const unsigned bs = s_cnt[b], be = b + 1u < (unsigned)kSortBuckets ? s_cnt[b + 1u] : (unsigned)n;
             const uint2 me = s_kz[p];
             unsigned r = bs;
-            // buckets hold 0-2 entries: the first four are read together (independent LDS reads), a
+            // buckets hold 0-3 entries: the first four are read together (independent LDS reads), a
             // longer bucket finishes in a loop
             uint2 o[4];
 #pragma unroll

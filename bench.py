@@ -71,8 +71,12 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel pass")
     ap.add_argument("--pts-per-pixel", type=int, default=3)
     ap.add_argument("--no-outlier", action="store_true", help="dyn_pcl_remove_outlier=false (YAML default)")
-    ap.add_argument("--inflight", type=int, default=3,
-                    help="independent target views rendered concurrently, each on its own pair of HIP streams")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="independent target views rendered concurrently, each on its own HIP stream; 0 (default): "
+                         "measured during warm-up among 3, 6 and 7 (the best count is not monotone: 4 and 8 lose 15 %%)")
+    ap.add_argument("--side-stream", action="store_true",
+                    help="throughput runs: give every lane a second stream for the dynamic-branch geometry (round 1's "
+                         "arrangement, best with --inflight 3); default: one stream per lane")
     ap.add_argument("--stream-pool", type=int, default=0, help="experiment: lanes draw their (main, side) streams from a pool of this many")
     ap.add_argument("--lane-priorities", default="", help="experiment: stream priorities, main/side per lane, e.g. -1,-1,0,0,0,0")
     ap.add_argument("--run-ahead", type=int, default=6, help="views the host may have enqueued beyond the last finished one")
@@ -265,8 +269,11 @@ def main():
     # Views are independent (the reference shards them over ranks): `inflight` of them are kept
     # in flight per GPU, each on its own (main, side) stream pair, so one view's launch-bound
     # chains fill the gaps of another's.  Every view still runs the complete path.
-    n_lanes = max(1, args.inflight)
-    args.run_ahead = max(args.run_ahead, n_lanes + 1)  # the bound must leave every lane a view to work on
+    lane_candidates = (3, 6, 7)
+    auto_lanes = args.inflight <= 0
+    n_lanes = max(lane_candidates) if auto_lanes else max(1, args.inflight)
+    base_run_ahead = args.run_ahead
+    args.run_ahead = max(base_run_ahead, n_lanes + 1)  # the bound must leave every lane a view to work on
     if args.stream_pool > 0 and n_lanes > 1:
         pool = [torch.cuda.Stream(device=dev) for _ in range(args.stream_pool)]
         lanes = [(pool[(2 * i) % len(pool)], pool[(2 * i + 1) % len(pool)]) for i in range(n_lanes)]
@@ -274,17 +281,24 @@ def main():
         pr = [int(x) for x in args.lane_priorities.split(",")]
         lanes = [(torch.cuda.Stream(device=dev, priority=pr[(2 * i) % len(pr)]), torch.cuda.Stream(device=dev, priority=pr[(2 * i + 1) % len(pr)]))
                  for i in range(n_lanes)]
-    else:
+    elif args.side_stream or os.environ.get("PGDVS_BENCH_PAIRED_STREAMS"):
         lanes = [(torch.cuda.Stream(device=dev) if n_lanes > 1 else None, torch.cuda.Stream(device=dev)) for _ in range(n_lanes)]
+    else:
+        # one stream per lane; a single side stream (lane 0's, for the latency measurement) is created last
+        mains = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
+        side0 = torch.cuda.Stream(device=dev)
+        lanes = [(mains[i], side0 if i == 0 else None) for i in range(n_lanes)]
 
-    def render_view(data, side, out=None):
-        """the whole per-view path: A12 + A9 on the current stream, A1-A5 on `side`, A6-A8 + A11;
-        `out` [1,3,H,W]: the caller's slot for the final image (written by the splat epilogue itself)"""
+    def render_view(data, side, out=None, use_side=None):
+        """the whole per-view path: A12 + A9 on the current stream, A1-A5 on `side` (or on the current stream
+        as well), A6-A8 + A11; `out` [1,3,H,W]: the caller's slot for the final image (written by the splat
+        epilogue itself)"""
         data = dict(data)
+        use_side = args.side_stream if use_side is None else use_side
         if out is not None:
             data["_combined_rgb_out"] = out
         # dynamic-branch geometry on a side stream, overlapping the static aggregation + raster
-        data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=side)
+        data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=side if use_side else None)
         cloud, cnt = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=cap)
         data["st_pcl_rgb"] = cloud[None]
         data["st_pcl_rgb_count"] = cnt
@@ -292,12 +306,12 @@ def main():
             ret = model.forward(data, render_cfg=rc, disable_tqdm=True)
         return ret["combined_rgb"], cnt
 
-    def step_eager(j, lane=None, out=None):
+    def step_eager(j, lane=None, out=None, use_side=None):
         main, side = lanes[(j % n_lanes) if lane is None else lane]
         if main is not None:
             main.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
-            img, cnt = render_view(views[(j + rank) % n_views], side, out)
+            img, cnt = render_view(views[(j + rank) % n_views], side, out, use_side)
         return img, cnt, main
 
     # One captured HIP graph per lane (pgdvs_amd.runtime.GraphedRender): per view the host copies
@@ -432,6 +446,23 @@ def main():
         del g
         torch.cuda.synchronize()
         barrier()
+    lanes_note = f"{n_lanes} (--inflight)"
+    if auto_lanes:
+        # How many views in flight?  Measured, not guessed: throughput is not monotone in the lane count on this
+        # runtime (3: 907, 4: 799, 5: 858, 6: 914, 7: 955, 8: 873, 11: 968 frames/s on one box), so a few counts are
+        # timed through the same loop as the headline (a rehearsal first: every lane's allocator pool must exist)
+        trial = {}
+        for k in lane_candidates:
+            n_lanes = k
+            args.run_ahead = max(base_run_ahead, k + 1)
+            timed(2 * k, profile=False)
+            trial[k] = timed(6 * k, profile=False)[0] / (6 * k)
+        tt = torch.tensor([trial[k] for k in lane_candidates], dtype=torch.float64, device=dev)
+        if world > 1:  # every rank must take the same count
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        n_lanes = lane_candidates[int(torch.argmin(tt).item())]
+        args.run_ahead = max(base_run_ahead, n_lanes + 1)
+        lanes_note = "auto: " + ", ".join(f"{k} lanes {float(tt[i]) * 1e3:.3f} ms/view" for i, k in enumerate(lane_candidates)) + f" -> {n_lanes}"
     if args.launch == "auto":
         # Eager launches or graph replay?  Measured, not guessed: a few views each way during warm-up.
         # Eager costs the host ~0.7 ms per view when it is idle -- below the ~1.3 ms the GPU needs -- but
@@ -500,7 +531,8 @@ def main():
         for i, (m, sd) in enumerate(lanes):
             if m is not None:
                 names[m.cuda_stream] = f"lane{i}.main"
-            names[sd.cuda_stream] = f"lane{i}.side"
+            if sd is not None:
+                names[sd.cuda_stream] = f"lane{i}.side"
         for x in torch.cuda.memory_snapshot():
             if (x["address"], x["total_size"]) not in seg0:
                 print(f"  new segment {x['total_size'] / 1e6:9.1f} MB on {names.get(x['stream'], x['stream'])}: blocks "
@@ -564,7 +596,7 @@ def main():
         lat = []
         for j in range(12):
             l0 = time.perf_counter()
-            step_eager(j, 0)
+            step_eager(j, 0, use_side=True)  # (lowest latency: the two branches of the view side by side)
             join_lanes()
             torch.cuda.synchronize()
             lat.append((time.perf_counter() - l0) * 1e3)
@@ -580,19 +612,29 @@ def main():
         cloud_c, cnt_c = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=cap)
 
         def step_cached(j):
-            data = dict(views[j % n_views])
-            data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=lanes[0][1])
-            data["st_pcl_rgb"], data["st_pcl_rgb_count"] = cloud_c[None], cnt_c
-            with torch.no_grad():
-                return model.forward(data, render_cfg=rc, disable_tqdm=True)["combined_rgb"]
+            main, side = lanes[j % n_lanes]
+            if main is not None:
+                main.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
+                data = dict(views[j % n_views])
+                data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=side if args.side_stream else None)
+                data["st_pcl_rgb"], data["st_pcl_rgb_count"] = cloud_c[None], cnt_c
+                with torch.no_grad():
+                    return model.forward(data, render_cfg=rc, disable_tqdm=True)["combined_rgb"]
 
-        for j in range(2):
+        # same arrangement as the headline (views round-robin over the lanes), bounded run-ahead by lane reuse
+        for j in range(n_lanes):
             step_cached(j)
+        join_lanes()
         torch.cuda.synchronize()
         v0 = time.perf_counter()
-        nv = min(args.steps, 10)
+        nv = max(min(args.steps, 40), n_lanes)
         for j in range(nv):
             step_cached(j)
+            if j % (2 * n_lanes) == 2 * n_lanes - 1:
+                join_lanes()
+                torch.cuda.synchronize()
+        join_lanes()
         torch.cuda.synchronize()
         variants = {"static_cloud_aggregated_once_per_scene": {
             "frames_per_s": round(nv / (time.perf_counter() - v0), 2), "steps": nv,
@@ -743,7 +785,7 @@ def main():
                 "workload": f"{W}x{H} target view, {S} source frames resident in HBM: static aggregation (A12) + "
                             f"point z-buffer raster K={K} (A9) + flow-warped dynamic splat (A1-A8, outlier filter "
                             f"{'on' if not args.no_outlier else 'off'}) + composite (A11)",
-                "views_in_flight": (len(graphs) if graphs else n_lanes), "host_run_ahead_views": args.run_ahead, "memory": mem_note, "launch": graph_note, "height": H, "width": W, "src_frames": S, "static_points": n_static, "dyn_pixels": n_dyn,
+                "views_in_flight": (len(graphs) if graphs else n_lanes), "views_in_flight_choice": lanes_note, "host_run_ahead_views": args.run_ahead, "memory": mem_note, "launch": graph_note, "height": H, "width": W, "src_frames": S, "static_points": n_static, "dyn_pixels": n_dyn,
                 "parallelism": f"frames sharded over {world} GPU(s), RCCL gather of the image stack" if world > 1 else "1 GPU",
                 "per_rank_frames_per_s": [round(args.steps / x, 2) for x in per_rank_s],
                 "gather_bytes_to_rank0": int(3 * H * W * 4 * args.steps * (world - 1)),

@@ -381,6 +381,10 @@ __global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamB
   const int tag = a.frame + 1;
   if (tid == 0)
     __hip_atomic_store(&a.desc[tile], sel_desc(tag, 1, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // a tile that selects nothing appends nothing: it needs no offset and leaves at once instead of polling
+  // beside the other views' kernels (in the later frames most tiles are like this); the last tile stays to
+  // record the new cloud size
+  if (total == 0 && tile != a.tiles - 1) return;
   long long part = 0;
   for (int j = tid; j < tile; j += kSelThreads) {
     unsigned spins = 0;

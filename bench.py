@@ -573,7 +573,12 @@ def main():
                     "launches_per_step": calls / n_prof, "avg_ms": round(avg_ms, 5),
                     "ms_per_step": round(total_ms / n_prof, 4),
                     "alg_GBps": round(ab / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 and ab > 0 else None}
-            dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+            # dominant kernel = most time per view; among kernels within 10 % of the maximum (the tile raster and the
+            # kNN thread-per-query pass are a coin flip) the one that moves the most algorithmic bytes, for which an HBM
+            # roofline says something -- the kNN pass reads 6 MB and is a pure VALU search
+            top = max(v["ms_per_step"] for v in kernels.values())
+            near = [k for k, v in kernels.items() if v["ms_per_step"] >= 0.9 * top]
+            dom = max(near, key=lambda k: algorithmic_bytes(k, H, W, S, n_static, n_dyn, K))
             ab = algorithmic_bytes(dom, H, W, S, n_static, n_dyn, K)
             ach = ab / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -180,6 +180,63 @@ __device__ __forceinline__ PushConsts load_push_consts(const ProjF64 *__restrict
   return c;
 }
 
+// One row of the cloud from pixel p of a frame: unprojection exactly as _compute_pcl (fp32, fixed operation
+// order), (xyz, rgb) to the cloud and the packed xyz copy; returns the point.  Shared by the selection of
+// frame 0 (which appends in place) and by the push launches of the later frames (which append the pixels
+// their frame's selection listed).
+struct AppendSrc {
+  const float *depth;  // frame's depth [P]
+  const float *rgb;    // frame's colours [P,3]
+  float *cloud;        // [capacity,6]
+  float *xyz;          // [capacity,3]
+  int P, W;
+};
+struct f3 { float x, y, z; };  // 12-byte loads / stores in one instruction
+
+__device__ __forceinline__ f3 append_row(const AppendSrc &a, const CamBlock &cam, int p, int64_t pos, bool write) {
+  // row / column of the pixel: float reciprocal + one correction step (exact for P < 2^24),
+  // integer division otherwise
+  int r, col;
+  if (a.P < (1 << 24)) {
+    r = (int)(((float)p + 0.5f) * (1.0f / (float)a.W));
+    col = p - r * a.W;
+    if (col < 0) {
+      --r;
+      col += a.W;
+    } else if (col >= a.W) {
+      ++r;
+      col -= a.W;
+    }
+  } else {
+    r = p / a.W;
+    col = p - r * a.W;
+  }
+  const float u = (float)col, v = (float)r;
+  const float d = a.depth[p];
+  float X[3];
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    float dir = cam.v[PGDVS_CAM_M + ax * 3 + 0] * u;
+    dir = dir + cam.v[PGDVS_CAM_M + ax * 3 + 1] * v;
+    dir = dir + cam.v[PGDVS_CAM_M + ax * 3 + 2];
+    X[ax] = cam.v[PGDVS_CAM_O + ax] + dir * d;
+  }
+  f3 xq;
+  xq.x = X[0];
+  xq.y = X[1];
+  xq.z = X[2];
+  if (write) {
+    const f3 c = *reinterpret_cast<const f3 *>(a.rgb + (size_t)p * 3);
+    // a cloud row is 24 bytes at an 8-byte aligned address: three 8-byte stores
+    float2 *o = reinterpret_cast<float2 *>(a.cloud + pos * 6);
+    o[0] = make_float2(X[0], X[1]);
+    o[1] = make_float2(X[2], c.x);
+    o[2] = make_float2(c.y, c.z);
+    *reinterpret_cast<f3 *>(a.xyz + pos * 3) = xq;
+  }
+  return xq;
+}
+
 constexpr int kPushThreads = 256;
 constexpr int kPushQueue = 1024;  // points with frames the fp32 form could not decide, queued per workgroup
 constexpr int kPushMaxFpg = 32;    // frames per workgroup row (one bit each in a queue entry)
@@ -191,7 +248,7 @@ constexpr int kPushMaxFpg = 32;    // frames per workgroup row (one bit each in 
 __global__ void __launch_bounds__(kPushThreads)
 agg_push_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ cnts, int src,
                 const ProjF64 *__restrict__ proj, int f_lo, int f_hi, int fpg, int H, int W,
-                uint8_t *__restrict__ occ_all) {
+                uint8_t *__restrict__ occ_all, const int32_t *__restrict__ sel_pix, AppendSrc app, CamBlock cam) {
   __shared__ uint4 s_q[kPushQueue];
   __shared__ int s_qn;
   const int64_t begin = cnts[src], end = cnts[src + 1];
@@ -203,8 +260,11 @@ agg_push_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ cnts,
   // frame groups side by side (gridDim.y covers them; a smaller gridDim.y walks them one after the other:
   // tried for frame 0 so that all workgroups stamp the same <= fpg maps at a time -- 98 us against 81 us,
   // and the same 4.8 bytes written per stamp)
-  for (int fa = f_lo + (int)blockIdx.y * fpg; fa < f_hi; fa += (int)gridDim.y * fpg) {
-  const int fb = fa + fpg < f_hi ? fa + fpg : f_hi;
+  // (with a deferred append, frame group 0 runs once even when there is no later frame to stamp)
+  bool first_iter = true;
+  for (int fa = f_lo + (int)blockIdx.y * fpg; fa < f_hi || (first_iter && sel_pix != nullptr && blockIdx.y == 0);
+       fa += (int)gridDim.y * fpg, first_iter = false) {
+  const int fb = fa >= f_hi ? fa : (fa + fpg < f_hi ? fa + fpg : f_hi);
   // XCD-aware order: workgroups b, b+8, ... share an XCD (and its L2), so each XCD walks one contiguous
   // eighth of the points -- a band of source rows whose stamps fall into a band of the maps.  Interleaved
   // 256-point chunks made neighbouring chunks (same row, adjacent columns) dirty the same 128-byte lines
@@ -220,7 +280,14 @@ agg_push_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ cnts,
     const int64_t i = i0 + threadIdx.x;
     const bool live = i < end;
     float x = 0.f, y = 0.f, z = 0.f;
-    if (live) {
+    if (live && sel_pix != nullptr) {
+      // deferred append: the frame's selection only listed its pixels (in cloud order); the row is built
+      // here, where the work is spread over the whole grid however the pixels cluster (frame group 0 writes)
+      const f3 X = append_row(app, cam, sel_pix[i - begin], i, blockIdx.y == 0 && first_iter);
+      x = X.x;
+      y = X.y;
+      z = X.z;
+    } else if (live) {
       x = xyz[i * 3 + 0];
       y = xyz[i * 3 + 1];
       z = xyz[i * 3 + 2];
@@ -253,11 +320,12 @@ agg_push_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ cnts,
       c = cn;
       dmask |= (doubt ? 1u : 0u) << (f - fa);
     }
-    // the (point, frame) pairs the fp32 form could not decide: one queue entry per point with a frame bitmask
+    // the (point, frame) pairs the fp32 form could not decide: one queue entry per point (the point itself and a
+    // frame bitmask)
     if (dmask != 0) {
       const int slot = atomicAdd(&s_qn, 1);
       if (slot < kPushQueue) {
-        s_q[slot] = make_uint4((unsigned)(i & 0xffffffffll), (unsigned)(i >> 32), dmask, 0u);
+        s_q[slot] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), dmask);
       } else {  // queue full (degenerate views): decide in place
         for (unsigned m = dmask; m; m &= m - 1) {
           const int f = fa + __builtin_ctz(m);
@@ -272,9 +340,8 @@ agg_push_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ cnts,
     if (last || qn + kPushThreads > kPushQueue) {
       for (int e = threadIdx.x; e < qn; e += kPushThreads) {
         const uint4 q = s_q[e];
-        const int64_t pi = (int64_t)q.x | ((int64_t)q.y << 32);
-        const float px = xyz[pi * 3 + 0], py = xyz[pi * 3 + 1], pz = xyz[pi * 3 + 2];
-        for (unsigned m = q.z; m; m &= m - 1) {
+        const float px = __uint_as_float(q.x), py = __uint_as_float(q.y), pz = __uint_as_float(q.z);
+        for (unsigned m = q.w; m; m &= m - 1) {
           const int f = fa + __builtin_ctz(m);
           mark_fp64(proj + f, px, py, pz, H, W, occ_all + (int64_t)f * P);
         }
@@ -308,6 +375,7 @@ struct SelArgs {
   unsigned long long *desc;  // [tiles]
   int32_t *ticket;           // [S]
   int32_t *error;            // set when a look-back spin gives up
+  int32_t *sel_pix;          // deferred append (frames >= 1): the selected pixels in cloud order, [P]
   int64_t capacity;
   int frame, P, W, tiles;
 };
@@ -432,57 +500,30 @@ __global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamB
     }
   }
   __syncthreads();
-  const float *__restrict__ depth = a.depth;
-  const float *__restrict__ rgb = a.rgb;
-  float *__restrict__ cloud = a.cloud;
-  float *__restrict__ xyz = a.xyz;
   const int64_t pos0 = cloud_base + s_excl;
   const int tile_px = tile * kSelTile;
-  const float inv_w = 1.0f / (float)a.W;
+  if (a.sel_pix != nullptr) {
+    // later frames: only the list of selected pixels, in cloud order; the rows are built by the frame's push
+    // launch, whose grid shares the work evenly (here a few tiles hold all of a disocclusion's pixels)
+    for (int e = tid; e < total; e += kSelThreads) {
+      const int64_t pos = pos0 + e;
+      if (pos >= a.capacity) break;
+      a.sel_pix[pos - cloud_base] = tile_px + (int)s_list[e];
+    }
+    return;
+  }
+  AppendSrc app;
+  app.depth = a.depth;
+  app.rgb = a.rgb;
+  app.cloud = a.cloud;
+  app.xyz = a.xyz;
+  app.P = a.P;
+  app.W = a.W;
 #pragma unroll 4
   for (int e = tid; e < total; e += kSelThreads) {
     const int64_t pos = pos0 + e;
     if (pos >= a.capacity) break;
-    const int p = tile_px + (int)s_list[e];
-    // row / column of the pixel: float reciprocal + one correction step (exact for P < 2^24),
-    // integer division otherwise
-    int r, col;
-    if (a.P < (1 << 24)) {
-      r = (int)(((float)p + 0.5f) * inv_w);
-      col = p - r * a.W;
-      if (col < 0) {
-        --r;
-        col += a.W;
-      } else if (col >= a.W) {
-        ++r;
-        col -= a.W;
-      }
-    } else {
-      r = p / a.W;
-      col = p - r * a.W;
-    }
-    const float u = (float)col, v = (float)r;
-    const float d = depth[p];
-    struct f3 { float x, y, z; };  // 12-byte loads / stores in one instruction
-    const f3 c = *reinterpret_cast<const f3 *>(rgb + (size_t)p * 3);
-    float X[3];
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-      float dir = cam.v[PGDVS_CAM_M + ax * 3 + 0] * u;
-      dir = dir + cam.v[PGDVS_CAM_M + ax * 3 + 1] * v;
-      dir = dir + cam.v[PGDVS_CAM_M + ax * 3 + 2];
-      X[ax] = cam.v[PGDVS_CAM_O + ax] + dir * d;
-    }
-    // a cloud row is 24 bytes at an 8-byte aligned address: three 8-byte stores
-    float2 *o = reinterpret_cast<float2 *>(cloud + pos * 6);
-    o[0] = make_float2(X[0], X[1]);
-    o[1] = make_float2(X[2], c.x);
-    o[2] = make_float2(c.y, c.z);
-    f3 xq;
-    xq.x = X[0];
-    xq.y = X[1];
-    xq.z = X[2];
-    *reinterpret_cast<f3 *>(xyz + pos * 3) = xq;
+    append_row(app, cam, tile_px + (int)s_list[e], pos, true);
   }
 }
 
@@ -501,6 +542,7 @@ struct AggWs {
   int32_t *ticket, *error;
   unsigned long long *desc;
   uint8_t *occ;  // [S][P] one occupancy byte per (frame, pixel), zeroed per call
+  int32_t *sel_pix;  // [P] the pixels the current frame selected, in cloud order
   float *xyz;
   ProjF64 *proj;
   int64_t total_bytes;
@@ -527,6 +569,8 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   off += align_up((int64_t)S * P + 32, 256);
   w.xyz = reinterpret_cast<float *>(p + off);
   off += align_up((capacity > 0 ? capacity : 1) * 12, 256);
+  w.sel_pix = reinterpret_cast<int32_t *>(p + off);
+  off += align_up(P * 4, 256);
   w.proj = reinterpret_cast<ProjF64 *>(p + off);
   off += align_up((int64_t)S * (int64_t)sizeof(ProjF64), 256);
   w.total_bytes = off;
@@ -648,6 +692,7 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
     a.desc = ws.desc;
     a.ticket = ws.ticket;
     a.error = ws.error;
+    a.sel_pix = i > 0 ? ws.sel_pix : nullptr;
     a.capacity = capacity;
     a.frame = i;
     a.P = (int)P;
@@ -664,12 +709,22 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
   const int fpg = fpg_env > 0 ? (fpg_env < kPushMaxFpg ? fpg_env : kPushMaxFpg) : 8;  // frames per workgroup row: the point is re-read once per 8 frames
   for (int i = 0; i < S; ++i) {
     select(i);
-    if (i + 1 < S) {
-      const int groups = (int)cdiv(S - 1 - i, fpg);
+    // frame 0 appended its rows itself and only stamps; a later frame's push also builds the rows of the
+    // pixels its selection listed -- for the last frame that is all it does
+    if (i + 1 < S || i > 0) {
+      const int groups = i + 1 < S ? (int)cdiv(S - 1 - i, fpg) : 1;
       const int64_t want = i == 0 ? cdiv(P, kPushThreads) : cdiv(P, 8 * kPushThreads);
       const unsigned gx = (unsigned)(want < 1024 ? (want > 8 ? (want + 7) / 8 * 8 : 8) : 1024);  // a multiple of 8: one share per XCD
+      AppendSrc app;
+      app.depth = depths + (size_t)i * P;
+      app.rgb = rgbs + (size_t)i * P * 3;
+      app.cloud = out;
+      app.xyz = ws.xyz;
+      app.P = (int)P;
+      app.W = W;
       PGDVS_LAUNCH(i == 0 ? "agg_push0" : "agg_push", agg_push_kernel, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
-                   (const float *)ws.xyz, (const int64_t *)ws.cnts, i, (const ProjF64 *)ws.proj, i + 1, S, fpg, H, W, ws.occ);
+                   (const float *)ws.xyz, (const int64_t *)ws.cnts, i, (const ProjF64 *)ws.proj, i + 1, S, fpg, H, W, ws.occ,
+                   (const int32_t *)(i > 0 ? ws.sel_pix : nullptr), app, cams[(size_t)i]);
     }
   }
   PGDVS_LAUNCH("agg_finalize", agg_finalize_kernel, dim3(1), dim3(64), 0, st, (const int64_t *)ws.cnts,

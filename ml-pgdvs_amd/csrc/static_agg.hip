@@ -712,8 +712,13 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
     // frame 0 appended its rows itself and only stamps; a later frame's push also builds the rows of the
     // pixels its selection listed -- for the last frame that is all it does
     if (i + 1 < S || i > 0) {
-      const int groups = i + 1 < S ? (int)cdiv(S - 1 - i, fpg) : 1;
-      const int64_t want = i == 0 ? cdiv(P, kPushThreads) : cdiv(P, 8 * kPushThreads);
+      // (frame 0: 8 frames per workgroup row, the points are read three times; the small launches are latency
+      // chains, shorter with 4 frames per row)
+      const int fpg_i = i == 0 ? fpg : (fpg > 4 ? 4 : fpg);
+      const int groups = i + 1 < S ? (int)cdiv(S - 1 - i, fpg_i) : 1;
+      // (later frames append a few per cent of P: 256 workgroups walk whatever there is; a grid sized for the worst
+      // case spent its time dispatching workgroups that leave at once)
+      const int64_t want = i == 0 ? cdiv(P, kPushThreads) : (cdiv(P, 8 * kPushThreads) < 256 ? cdiv(P, 8 * kPushThreads) : 256);
       const unsigned gx = (unsigned)(want < 1024 ? (want > 8 ? (want + 7) / 8 * 8 : 8) : 1024);  // a multiple of 8: one share per XCD
       AppendSrc app;
       app.depth = depths + (size_t)i * P;
@@ -723,7 +728,7 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
       app.P = (int)P;
       app.W = W;
       PGDVS_LAUNCH(i == 0 ? "agg_push0" : "agg_push", agg_push_kernel, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
-                   (const float *)ws.xyz, (const int64_t *)ws.cnts, i, (const ProjF64 *)ws.proj, i + 1, S, fpg, H, W, ws.occ,
+                   (const float *)ws.xyz, (const int64_t *)ws.cnts, i, (const ProjF64 *)ws.proj, i + 1, S, fpg_i, H, W, ws.occ,
                    (const int32_t *)(i > 0 ? ws.sel_pix : nullptr), app, cams[(size_t)i]);
     }
   }

@@ -6,14 +6,105 @@
 namespace pgdvs {
 
 // ---------------------------------------------------------------------------
-__global__ void cam_prep_kernel(const float *__restrict__ flat_cams, int n,
-                                float *__restrict__ blocks) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// Gauss-Jordan inverse of an N x N matrix (N <= 4) with partial pivoting, one COLUMN of the augmented
+// matrix [A | I] per lane (lanes 0 .. 2N-1 of a wavefront; pivot values and multipliers are broadcast).
+// Every element goes through exactly the operations of the serial inv_f64 (common.h, = the oracle's), in
+// the same order, so the results agree bit for bit; a single thread walking the 4 x 8 array needed ~7 us for
+// the two inverses of a camera, mostly dependent fp64 divisions.  Returns false for a singular matrix.
+template <int N>
+__device__ __forceinline__ bool inv_f64_wave(double (&m)[N], int lane) {
+  // m[r] = element (r, lane) of the augmented matrix
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    // column c lives on lane c: pivot row = first row >= c with the largest magnitude
+    double colv[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) colv[r] = __shfl(m[r], c, 64);
+    int piv = c;
+    double best = fabs(colv[c]);
+#pragma unroll
+    for (int r = c + 1; r < N; ++r) {
+      const double v = fabs(colv[r]);
+      if (v > best) {
+        best = v;
+        piv = r;
+      }
+    }
+    if (best == 0.0) ok = false;
+    // swap rows c and piv (uniform over the wavefront)
+#pragma unroll
+    for (int r = c + 1; r < N; ++r)
+      if (r == piv) {
+        const double t = m[c];
+        m[c] = m[r];
+        m[r] = t;
+        const double tc = colv[c];
+        colv[c] = colv[r];
+        colv[r] = tc;
+      }
+    const double d = colv[c];
+    m[c] = m[c] / d;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      if (r == c) continue;
+      const double f = colv[r];
+      if (f == 0.0) continue;
+      m[r] = m[r] - f * m[c];
+    }
+  }
+  return ok;
+}
+
+// one wavefront per camera: flat_cam[34] -> camera block (same values as cam_block_from_flat)
+__global__ void __launch_bounds__(64) cam_prep_kernel(const float *__restrict__ flat_cams, int n,
+                                                      float *__restrict__ blocks) {
+  const int i = blockIdx.x, lane = threadIdx.x;
   if (i >= n) return;
-  float fc[34], blk[PGDVS_CAM_BLOCK];
-  for (int k = 0; k < 34; ++k) fc[k] = flat_cams[i * 34 + k];
-  cam_block_from_flat(fc, blk);
-  for (int k = 0; k < PGDVS_CAM_BLOCK; ++k) blocks[i * PGDVS_CAM_BLOCK + k] = blk[k];
+  const float *fc = flat_cams + (size_t)i * 34;
+  const float *K = fc + 2, *c2w = fc + 18;
+  float *blk = blocks + (size_t)i * PGDVS_CAM_BLOCK;
+  __shared__ float s_kinv[9], s_w2c[16];
+  // K[:3,:3]^-1: lanes 0..5 hold the columns of [K3 | I]
+  double a3[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) a3[r] = lane < 3 ? (double)K[r * 4 + lane] : (lane - 3 == r ? 1.0 : 0.0);
+  const bool ok3 = inv_f64_wave<3>(a3, lane);
+  // c2w^-1: lanes 0..7 hold the columns of [c2w | I]
+  double a4[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) a4[r] = lane < 4 ? (double)c2w[r * 4 + (lane & 3)] : (lane - 4 == r ? 1.0 : 0.0);
+  const bool ok4 = inv_f64_wave<4>(a4, lane);
+  const bool bad = !(ok3 && ok4);
+  if (lane >= 3 && lane < 6)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) s_kinv[r * 3 + (lane - 3)] = bad ? __builtin_nanf("") : (float)a3[r];
+  if (lane >= 4 && lane < 8)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_w2c[r * 4 + (lane - 4)] = bad ? __builtin_nanf("") : (float)a4[r];
+  __syncthreads();
+  // derived matrices: fp32 products in a fixed left-to-right order (no FMA contraction in this library)
+  if (lane < 9) {
+    const int r = lane / 3, c = lane - r * 3;
+    blk[PGDVS_CAM_KINV + lane] = s_kinv[lane];
+    float v = c2w[r * 4 + 0] * s_kinv[0 * 3 + c];
+    v = v + c2w[r * 4 + 1] * s_kinv[1 * 3 + c];
+    v = v + c2w[r * 4 + 2] * s_kinv[2 * 3 + c];
+    blk[PGDVS_CAM_M + lane] = v;
+    blk[PGDVS_CAM_R + lane] = c2w[r * 4 + c];
+  }
+  if (lane < 3) blk[PGDVS_CAM_O + lane] = c2w[lane * 4 + 3];
+  if (lane < 16) {
+    const int r = lane >> 2, c = lane & 3;
+    float v = K[r * 4 + 0] * s_w2c[0 * 4 + c];
+    v = v + K[r * 4 + 1] * s_w2c[1 * 4 + c];
+    v = v + K[r * 4 + 2] * s_w2c[2 * 4 + c];
+    v = v + K[r * 4 + 3] * s_w2c[3 * 4 + c];
+    blk[PGDVS_CAM_P + lane] = v;
+    blk[PGDVS_CAM_W2C + lane] = s_w2c[lane];
+    blk[PGDVS_CAM_K + lane] = K[lane];
+  }
+  if (lane < 2) blk[PGDVS_CAM_HW + lane] = fc[lane];
 }
 
 // A1 -- pgdvs_renderer_base.py:17-57
@@ -261,7 +352,7 @@ PGDVS_API int pgdvs_cam_prep(const float *flat_cams, int n, float *cam_blocks,
                              pgdvs_stream_t stream) {
   PGDVS_REQUIRE(flat_cams && cam_blocks && n >= 0, "pgdvs_cam_prep: bad arguments");
   if (n == 0) return PGDVS_OK;
-  PGDVS_LAUNCH("cam_prep", cam_prep_kernel, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, as_stream(stream),
+  PGDVS_LAUNCH("cam_prep", cam_prep_kernel, dim3((unsigned)n), dim3(64), 0, as_stream(stream),
                      flat_cams, n, cam_blocks);
   return check_launch("cam_prep");
 }

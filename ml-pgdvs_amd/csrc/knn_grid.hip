@@ -29,6 +29,7 @@ constexpr int kRingCap = 24;
 // searches are no longer hidden behind the bulk: hand them to the coarse grid after a few rings.
 constexpr int kRingCapAfterTpq = 3;
 constexpr float kTargetPerCellDefault = 24.0f;
+constexpr float kTrialCoarser = 4.0f;
 
 struct GridParams {
   float mn[3];
@@ -1077,9 +1078,11 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   const char *etc = getenv("PGDVS_KNN_PER_CELL");  // tuning knob (any value gives exact results)
   const float target = etc && atof(etc) >= 1.0 ? (float)atof(etc) : kTargetPerCellDefault * (float)(K + 1) / 51.0f;
   PGDVS_LAUNCH("grid_bbox", grid_bbox_kernel, dim3(gbb), dim3(256), 0, st, pts, count, ws.bbox);
-  // trial grid from the bounding box, measure the occupancy, then the final grid
+  // trial grid from the bounding box, measure the occupancy, then the final grid.  The trial aims at
+  // kTrialCoarser times the occupancy (cells twice as wide on a surface): an eighth of the cells to zero
+  // and to read back, and the surface scaling of pass 1 extrapolates over a factor of two only
   PGDVS_LAUNCH("grid_params", grid_params_kernel, dim3(1), dim3(64), 0, st, ws.bbox, count,
-               (const unsigned long long *)nullptr, ws.gp, target);
+               (const unsigned long long *)nullptr, ws.gp, target * kTrialCoarser);
   PGDVS_LAUNCH("grid_zero", grid_zero_kernel, dim3(2048), dim3(256), 0, st, ws.gp, ws.cell_count,
                (int32_t *)nullptr);
   PGDVS_LAUNCH("grid_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,

@@ -47,7 +47,7 @@ __device__ __forceinline__ float ord2f(unsigned u) {
   return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
-// bbox[0..2] = min (ordered-uint), bbox[3..5] = max.  Launched with few blocks: six
+// bbox[0..2] = ~min (ordered-uint, complemented so that an all-zero block is the empty box), bbox[3..5] = max.  Launched with few blocks: six
 // atomics per block.
 __global__ void __launch_bounds__(256)
 grid_bbox_kernel(const float *__restrict__ pts, const int32_t *__restrict__ count,
@@ -82,7 +82,7 @@ grid_bbox_kernel(const float *__restrict__ pts, const int32_t *__restrict__ coun
     int a = threadIdx.x;
     float lo = fminf(fminf(s_mn[0][a], s_mn[1][a]), fminf(s_mn[2][a], s_mn[3][a]));
     float hi = fmaxf(fmaxf(s_mx[0][a], s_mx[1][a]), fmaxf(s_mx[2][a], s_mx[3][a]));
-    atomicMin(&bbox[a], f2ord(lo));
+    atomicMax(&bbox[a], ~f2ord(lo));
     atomicMax(&bbox[3 + a], f2ord(hi));
   }
 }
@@ -99,7 +99,7 @@ __global__ void grid_params_kernel(const unsigned *__restrict__ bbox,
   const int n = *count;
   float mn[3], ext[3];
   for (int a = 0; a < 3; ++a) {
-    float lo = ord2f(bbox[a]), hi = ord2f(bbox[3 + a]);
+    float lo = ord2f(~bbox[a]), hi = ord2f(bbox[3 + a]);
     if (!(hi >= lo)) {  // no finite point
       lo = 0.0f;
       hi = 0.0f;
@@ -152,7 +152,7 @@ __global__ void grid_params_coarse_kernel(const GridParams *__restrict__ fine, c
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float ext[3];
   for (int a = 0; a < 3; ++a) {
-    float lo = ord2f(bbox[a]), hi = ord2f(bbox[3 + a]);
+    float lo = ord2f(~bbox[a]), hi = ord2f(bbox[3 + a]);
     if (!(hi >= lo)) {
       lo = 0.0f;
       hi = 0.0f;
@@ -995,8 +995,8 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   GridWs w;
   char *p = reinterpret_cast<char *>(base);
   int64_t off = 0;
-  // one 256-byte state block, initialised by two memsets per call: bbox min (0xff), then zeros
-  // for bbox max, sumsq, the ring histogram and the open-query counters of both levels
+  // one 256-byte state block, zeroed by one memset per call: complemented bbox min, bbox max, sumsq,
+  // the ring histogram and the open-query counters of both levels
   w.bbox = reinterpret_cast<unsigned *>(p + off);
   w.sumsq = reinterpret_cast<unsigned long long *>(p + off + 64);
   w.stats = reinterpret_cast<int32_t *>(p + off + 128);
@@ -1066,9 +1066,8 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
     set_error("knn_grid: workspace too small");
     return PGDVS_ERR_WORKSPACE;
   }
-  // bbox init: min <- 0xffffffff, max <- 0 in the order-preserving uint encoding
-  hipError_t e = hipMemsetAsync(ws.bbox, 0xff, 3 * sizeof(unsigned), st);
-  if (e == hipSuccess) e = hipMemsetAsync(ws.bbox + 3, 0x00, 256 - 3 * sizeof(unsigned), st);  // max, sumsq, stats, counters
+  // empty box: ~min = 0 and max = 0 in the order-preserving uint encoding
+  hipError_t e = hipMemsetAsync(ws.bbox, 0x00, 256, st);  // ~min, max, sumsq, stats, counters
   if (e != hipSuccess) {
     set_error("knn_grid memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;

@@ -214,7 +214,8 @@ struct RunInfo {
 
 __device__ __forceinline__ RunInfo wave_runs(int t) {
   const int lane = threadIdx.x & 63;
-  int prev = __shfl_up(t, 1, 64);
+  // wave_shr:1 -- lane i reads lane i-1 through the DPP path (no LDS round trip); lane 0 is a leader anyway
+  int prev = __builtin_amdgcn_update_dpp(t, t, 0x138, 0xf, 0xf, false);
   bool lead = lane == 0 || prev != t;
   unsigned long long L = __ballot(lead);
   RunInfo r;

@@ -92,24 +92,54 @@ __device__ __forceinline__ int wave_max_i32_scalar(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-__global__ void __launch_bounds__(256)
+// Binning, pass 1: entries per tile.  A workgroup takes one contiguous chunk of the cloud (a few rows of
+// one source frame: a few hundred tiles) and counts into an LDS table first, so that a tile costs the
+// chunk one global atomic instead of one per run of lanes.  Images with more tiles than the table holds
+// count straight into global memory.
+constexpr int kBinSlots = 16384;  // 64 KB of LDS counters: up to 2048 x 2048 pixels
+constexpr int kBinThreads = 1024;
+
+__device__ __forceinline__ void wave_tile_count_lds(int *s_tab, int t) {
+  RunInfo r = wave_runs(t);
+  if (r.is_leader && t >= 0) atomicAdd(&s_tab[t], r.length);
+}
+
+__global__ void __launch_bounds__(kBinThreads)
 raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_host,
                             const int64_t *__restrict__ n_dev, const float *__restrict__ cam,
                             float radius, int H, int W, int ntx, int nty,
                             int32_t *__restrict__ tile_count) {
+  extern __shared__ int s_tab[];  // one counter per tile (none when the image has more tiles than kBinSlots)
   // a device-side count never exceeds the rows the caller sized the workspace for (and a
   // negative one -- the aggregation's error status -- renders nothing)
   int64_t n = n_dev ? *n_dev : n_host;
   n = n > n_host ? n_host : (n < 0 ? 0 : n);
   RasterCam rc = make_raster_cam(cam, H, W);
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t n_round = (n + 63) / 64 * 64;  // keep whole wavefronts in the loop
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+  const int ntiles = ntx * nty;
+  const bool local = ntiles <= kBinSlots;
+  if (local) {
+    for (int t = threadIdx.x; t < ntiles; t += kBinThreads) s_tab[t] = 0;
+    __syncthreads();
+  }
+  const int64_t chunk = ((n + gridDim.x - 1) / gridDim.x + 63) / 64 * 64;  // whole wavefronts stay in the loop
+  const int64_t lo = (int64_t)blockIdx.x * chunk;
+  const int64_t hi = lo + chunk;
+  // the next point's coordinates are requested before this one's counters are touched
+  float nxt[3] = {0.0f, 0.0f, 0.0f};
+  if (lo + threadIdx.x < n) {
+    const float *X = pts + (lo + threadIdx.x) * pts_stride;
+    nxt[0] = X[0]; nxt[1] = X[1]; nxt[2] = X[2];
+  }
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kBinThreads) {
+    const float cur[3] = {nxt[0], nxt[1], nxt[2]};
+    if (i + kBinThreads < hi && i + kBinThreads < n) {
+      const float *X = pts + (i + kBinThreads) * pts_stride;
+      nxt[0] = X[0]; nxt[1] = X[1]; nxt[2] = X[2];
+    }
     TileBox b;
     b.tx0 = 1; b.tx1 = 0; b.ty0 = 1; b.ty1 = 0;
     if (i < n) {
-      const float *X = pts + i * pts_stride;
-      float3 p = point_to_ndc(rc, X[0], X[1], X[2]);
+      float3 p = point_to_ndc(rc, cur[0], cur[1], cur[2]);
       b = tile_box(rc, p, radius, H, W, ntx, nty);
     }
     int nx = wave_max_i32_scalar(b.tx1 - b.tx0 + 1), ny = wave_max_i32_scalar(b.ty1 - b.ty0 + 1);
@@ -117,8 +147,18 @@ raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, i
       for (int jx = 0; jx < nx; ++jx) {
         int tx = b.tx0 + jx, ty = b.ty0 + jy;
         int t = (tx <= b.tx1 && ty <= b.ty1) ? ty * ntx + tx : -1;
-        wave_tile_count(tile_count, t);
+        if (local)
+          wave_tile_count_lds(s_tab, t);
+        else
+          wave_tile_count(tile_count, t);
       }
+  }
+  if (local) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < ntiles; t += kBinThreads) {
+      const int v = s_tab[t];
+      if (v) __hip_atomic_fetch_add(&tile_count[t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -151,43 +191,143 @@ raster_scan_kernel(const int32_t *__restrict__ counts, int n, int32_t *__restric
   if (threadIdx.x == 0) offsets[n] = carry;
 }
 
-__global__ void __launch_bounds__(256)
+// Binning, pass 2: the list entries.  Per chunk of kFillThreads * kFillPer points a workgroup hands every
+// (point, tile) pair its rank among the chunk's entries of that tile from the LDS table (ranks kept in
+// registers), reserves one contiguous range per tile it touched with a single global atomic, and writes the
+// entries at range start + rank: a chunk's entries of one tile are adjacent in the list (whole-line writes
+// instead of 16-byte appends interleaved between workgroups).
+constexpr int kFillPer = 8;
+constexpr int kFillThreads = 256;
+constexpr int kFillMaxSpan = 2;  // tile box sides kept in registers; wider boxes (large radii) take the slow path
+
+__device__ __forceinline__ int wave_tile_reserve_lds(int *s_tab, int t) {
+  const int lane = threadIdx.x & 63;
+  RunInfo r = wave_runs(t);
+  int base = 0;
+  if (r.is_leader && t >= 0) base = atomicAdd(&s_tab[t], r.length);
+  base = __shfl(base, r.leader, 64);
+  return base + (lane - r.leader);
+}
+
+__global__ void __launch_bounds__(kFillThreads)
 raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_host, const int64_t *__restrict__ n_dev,
                    const float *__restrict__ cam, float radius, int H, int W, int ntx, int nty,
                    const int32_t *__restrict__ offsets,
                    int32_t *__restrict__ cursor, float4 *__restrict__ lists,
                    int64_t list_capacity) {
+  extern __shared__ int s_tab[];  // one counter per tile (none on the slow path)
   // a device-side count never exceeds the rows the caller sized the workspace for (and a
   // negative one -- the aggregation's error status -- renders nothing)
   int64_t n = n_dev ? *n_dev : n_host;
   n = n > n_host ? n_host : (n < 0 ? 0 : n);
   RasterCam rc = make_raster_cam(cam, H, W);
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t n_round = (n + 63) / 64 * 64;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-    TileBox b;
-    b.tx0 = 1; b.tx1 = 0; b.ty0 = 1; b.ty1 = 0;
-    float4 ent = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n) {
-      // projected again rather than kept: the same instructions on the same inputs as in the counting pass
-      // give the same tile box, and 32 bytes per point of intermediate traffic disappear
-      const float *X = pts + i * pts_stride;
-      const float3 q = point_to_ndc(rc, X[0], X[1], X[2]);
-      b = tile_box(rc, q, radius, H, W, ntx, nty);
-      // -0.0 -> +0.0 once, so that the z bits order like the values
-      ent = make_float4(q.x, q.y, __int_as_float((int)i), q.z + 0.0f);
+  const int ntiles = ntx * nty;
+  // tile boxes of at most 2 x 2 tiles (disc diameter + margins within one tile side) and a table that holds
+  // every tile: otherwise the entries are appended one run of lanes at a time
+  const float rpx = radius * (float)W / rc.range_x + 0.0625f, rpy = radius * (float)H / rc.range_y + 0.0625f;
+  const bool local = ntiles <= kBinSlots && 2.0f * rpx + 2.0f < (float)kTile && 2.0f * rpy + 2.0f < (float)kTile;
+  constexpr int64_t kChunk = (int64_t)kFillThreads * kFillPer;
+  for (int64_t c0 = (int64_t)blockIdx.x * kChunk; c0 < n; c0 += (int64_t)gridDim.x * kChunk) {
+    int t0[kFillPer], span[kFillPer];
+    float ex[kFillPer], ey[kFillPer], ez[kFillPer];
+    // all loads of the chunk first (the LDS atomics below would otherwise fence them one behind the other);
+    // projected again rather than read back: the same instructions on the same inputs as in the counting
+    // pass give the same tile box, and 32 bytes per point of intermediate traffic disappear
+#pragma unroll
+    for (int u = 0; u < kFillPer; ++u) {
+      const int64_t i = c0 + (int64_t)u * kFillThreads + threadIdx.x;
+      const float *X = pts + (i < n ? i : n - 1) * pts_stride;
+      ex[u] = X[0];
+      ey[u] = X[1];
+      ez[u] = X[2];
     }
-    int nx = wave_max_i32_scalar(b.tx1 - b.tx0 + 1), ny = wave_max_i32_scalar(b.ty1 - b.ty0 + 1);
-    for (int jy = 0; jy < ny; ++jy)
-      for (int jx = 0; jx < nx; ++jx) {
-        int tx = b.tx0 + jx, ty = b.ty0 + jy;
-        int t = (tx <= b.tx1 && ty <= b.ty1) ? ty * ntx + tx : -1;
-        int slot = wave_tile_reserve(cursor, t);
-        if (t >= 0) {
-          int64_t pos = (int64_t)offsets[t] + slot;
-          if (pos < list_capacity) lists[pos] = ent;
+    if (local) {
+      for (int t = threadIdx.x; t < ntiles; t += kFillThreads) s_tab[t] = 0;
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < kFillPer; ++u) {
+      const int64_t i = c0 + (int64_t)u * kFillThreads + threadIdx.x;
+      TileBox b;
+      b.tx0 = 1; b.tx1 = 0; b.ty0 = 1; b.ty1 = 0;
+      if (i < n) {
+        const float3 q = point_to_ndc(rc, ex[u], ey[u], ez[u]);
+        b = tile_box(rc, q, radius, H, W, ntx, nty);
+        ex[u] = q.x;
+        ey[u] = q.y;
+        ez[u] = q.z + 0.0f;  // -0.0 -> +0.0 once, so that the z bits order like the values
+      }
+      t0[u] = b.ty0 * ntx + b.tx0;
+      span[u] = (b.tx1 - b.tx0 + 1) | ((b.ty1 - b.ty0 + 1) << 16);  // (0, 0) for a point that touches no tile
+    }
+    if (local) {
+      unsigned rank[kFillPer][kFillMaxSpan];  // two 16-bit ranks per word: [u][jy] holds jx = 0, 1
+#pragma unroll
+      for (int u = 0; u < kFillPer; ++u) {
+        const int nx = wave_max_i32_scalar(span[u] & 0xffff), ny = wave_max_i32_scalar(span[u] >> 16);
+#pragma unroll
+        for (int jy = 0; jy < kFillMaxSpan; ++jy) {
+          rank[u][jy] = 0;
+#pragma unroll
+          for (int jx = 0; jx < kFillMaxSpan; ++jx) {
+            if (jy >= ny || jx >= nx) continue;  // uniform
+            const int t = (jx < (span[u] & 0xffff) && jy < (span[u] >> 16)) ? t0[u] + jy * ntx + jx : -1;
+            rank[u][jy] |= ((unsigned)wave_tile_reserve_lds(s_tab, t) & 0xffffu) << (16 * jx);  // < kChunk <= 65536
+          }
         }
       }
+      static_assert(kChunk <= 65536, "ranks are packed in 16 bits");
+      __syncthreads();
+      // one global atomic per tile the chunk touched; the requests of a thread go out back to back
+      for (int tb = threadIdx.x; tb < ntiles; tb += kFillThreads * 4) {
+        int v[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int t = tb + k * kFillThreads;
+          v[k] = t < ntiles ? s_tab[t] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int t = tb + k * kFillThreads;
+          r[k] = v[k] ? offsets[t] + atomicAdd(&cursor[t], v[k]) : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (v[k]) s_tab[tb + k * kFillThreads] = r[k];  // list position of this chunk's first entry of the tile
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < kFillPer; ++u) {
+        const int64_t i = c0 + (int64_t)u * kFillThreads + threadIdx.x;
+        const float4 ent = make_float4(ex[u], ey[u], __int_as_float((int)i), ez[u]);
+#pragma unroll
+        for (int jy = 0; jy < kFillMaxSpan; ++jy)
+#pragma unroll
+          for (int jx = 0; jx < kFillMaxSpan; ++jx)
+            if (jx < (span[u] & 0xffff) && jy < (span[u] >> 16)) {
+              const int t = t0[u] + jy * ntx + jx;
+              const int64_t pos = (int64_t)s_tab[t] + (int)((rank[u][jy] >> (16 * jx)) & 0xffffu);
+              if (pos < list_capacity) lists[pos] = ent;
+            }
+      }
+      __syncthreads();  // the table is zeroed again for the next chunk
+    } else {
+#pragma unroll
+      for (int u = 0; u < kFillPer; ++u) {
+        const int64_t i = c0 + (int64_t)u * kFillThreads + threadIdx.x;
+        const float4 ent = make_float4(ex[u], ey[u], __int_as_float((int)i), ez[u]);
+        const int nx = wave_max_i32_scalar(span[u] & 0xffff), ny = wave_max_i32_scalar(span[u] >> 16);
+        for (int jy = 0; jy < ny; ++jy)
+          for (int jx = 0; jx < nx; ++jx) {
+            const int t = (jx < (span[u] & 0xffff) && jy < (span[u] >> 16)) ? t0[u] + jy * ntx + jx : -1;
+            const int slot = wave_tile_reserve(cursor, t);
+            if (t >= 0) {
+              const int64_t pos = (int64_t)offsets[t] + slot;
+              if (pos < list_capacity) lists[pos] = ent;
+            }
+          }
+      }
+    }
   }
 }
 
@@ -698,15 +838,17 @@ PGDVS_API int pgdvs_points_raster(const float *pts, int64_t pts_stride, const fl
     set_error("points_raster memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
   }
+  const size_t lds = ntiles <= kBinSlots ? (size_t)ntiles * 4 : 4;  // the binning kernels' table of tile counters
   if (n_points > 0) {
-    unsigned g = (unsigned)(cdiv(n_points, 256) < 4096 ? cdiv(n_points, 256) : 4096);
-    PGDVS_LAUNCH("raster_project_count", raster_project_count_kernel, dim3(g), dim3(256), 0, st, pts, pts_stride,
+    unsigned g = (unsigned)(cdiv(n_points, kBinThreads) < 512 ? cdiv(n_points, kBinThreads) : 512);
+    PGDVS_LAUNCH("raster_project_count", raster_project_count_kernel, dim3(g), dim3(kBinThreads), lds, st, pts, pts_stride,
                        n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count);
   }
   PGDVS_LAUNCH("raster_scan", raster_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_count, ntiles, ws.offsets);
   if (n_points > 0) {
-    unsigned g = (unsigned)(cdiv(n_points, 256) < 4096 ? cdiv(n_points, 256) : 4096);
-    PGDVS_LAUNCH("raster_fill", raster_fill_kernel, dim3(g), dim3(256), 0, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
+    const int64_t chunks = cdiv(n_points, (int64_t)kFillThreads * kFillPer);
+    unsigned g = (unsigned)(chunks < 4096 ? chunks : 4096);
+    PGDVS_LAUNCH("raster_fill", raster_fill_kernel, dim3(g), dim3(kFillThreads), lds, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
                        radius, H, W, ntx, nty, ws.offsets, ws.cursor, ws.lists, ws.list_capacity);
   }
   const int tiles_per_xcd = (int)cdiv(ntiles, 8);

@@ -237,7 +237,11 @@ __device__ __forceinline__ f3 append_row(const AppendSrc &a, const CamBlock &cam
   return xq;
 }
 
+constexpr int kSelThreads = 512;
+constexpr int kSelItems = 16;
+constexpr int kSelTile = kSelThreads * kSelItems;
 constexpr int kPushThreads = 256;
+constexpr int kPushMaxTiles = 2048;  // selection tiles a push workgroup can scan itself (16.7 M pixels); more: ordered selection
 constexpr int kPushQueue = 1024;  // points with frames the fp32 form could not decide, queued per workgroup
 constexpr int kPushMaxFpg = 32;    // frames per workgroup row (one bit each in a queue entry)
 
@@ -246,12 +250,50 @@ constexpr int kPushMaxFpg = 32;    // frames per workgroup row (one bit each in 
 // occ[f][P].  One thread per point, the frame loop inside (per-frame constants are wave-uniform:
 // scalar loads).
 __global__ void __launch_bounds__(kPushThreads)
-agg_push_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ cnts, int src,
+agg_push_kernel(const float *__restrict__ xyz, int64_t *cnts, int src,
                 const ProjF64 *__restrict__ proj, int f_lo, int f_hi, int fpg, int H, int W,
-                uint8_t *__restrict__ occ_all, const int32_t *__restrict__ sel_pix, AppendSrc app, CamBlock cam) {
+                uint8_t *__restrict__ occ_all, const int32_t *__restrict__ sel_pix,
+                const int32_t *__restrict__ tile_cnt, int tiles, int64_t capacity, AppendSrc app, CamBlock cam) {
   __shared__ uint4 s_q[kPushQueue];
   __shared__ int s_qn;
-  const int64_t begin = cnts[src], end = cnts[src + 1];
+  __shared__ int s_pref[kPushMaxTiles + 1];  // listed selection: pixels selected before each tile of the frame
+  __shared__ int s_wsum[kPushThreads / kWave];
+  int64_t begin = cnts[src], end;
+  if (tile_cnt != nullptr) {
+    // The frame's selection left its pixels tile by tile (slots [t * kSelTile, +tile_cnt[t]) of sel_pix) and the
+    // tile counts: every workgroup scans the counts itself (tiles <= kPushMaxTiles, a few hundred at 1080p)
+    // instead of the selection waiting for its predecessors' counts.  Point j of the frame is pixel
+    // sel_pix[t * kSelTile + j - s_pref[t]] of the tile t whose range holds j.
+    constexpr int kPer = kPushMaxTiles / kPushThreads;
+    int v[kPer], run = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int t = (int)threadIdx.x * kPer + k;
+      v[k] = t < tiles ? tile_cnt[t] : 0;
+      run += v[k];
+    }
+    int x = run;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off, 64);
+      if ((int)(threadIdx.x & 63) >= off) x += y;
+    }
+    if ((threadIdx.x & 63) == 63) s_wsum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    int excl = x - run;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) excl += s_wsum[w];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      s_pref[threadIdx.x * kPer + k] = excl;
+      excl += v[k];
+    }
+    if (threadIdx.x == kPushThreads - 1) s_pref[kPushMaxTiles] = excl;
+    __syncthreads();
+    end = begin + s_pref[kPushMaxTiles];
+    end = end > capacity ? capacity : end;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) cnts[src + 1] = end;  // read by the next frame's launches
+  } else {
+    end = cnts[src + 1];
+  }
   if (begin >= end) return;
   const int64_t P = (int64_t)H * W;
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
@@ -283,7 +325,16 @@ agg_push_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ cnts,
     if (live && sel_pix != nullptr) {
       // deferred append: the frame's selection only listed its pixels (in cloud order); the row is built
       // here, where the work is spread over the whole grid however the pixels cluster (frame group 0 writes)
-      const f3 X = append_row(app, cam, sel_pix[i - begin], i, blockIdx.y == 0 && first_iter);
+      int slot = (int)(i - begin);
+      if (tile_cnt != nullptr) {  // the tile whose range holds point `slot`: the last t with s_pref[t] <= slot
+        int lo = 0, hi = tiles - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (s_pref[mid] <= slot) lo = mid; else hi = mid - 1;
+        }
+        slot = lo * kSelTile + (slot - s_pref[lo]);
+      }
+      const f3 X = append_row(app, cam, sel_pix[slot], i, blockIdx.y == 0 && first_iter);
       x = X.x;
       y = X.y;
       z = X.z;
@@ -354,9 +405,6 @@ agg_push_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ cnts,
   }
 }
 
-constexpr int kSelThreads = 512;
-constexpr int kSelItems = 16;
-constexpr int kSelTile = kSelThreads * kSelItems;
 constexpr unsigned kSelSpinLimit = 1u << 22;
 
 // tile count granule: [63:48] frame tag, [47:46] status (unused, 1), [45:0] value
@@ -376,6 +424,7 @@ struct SelArgs {
   int32_t *ticket;           // [S]
   int32_t *error;            // set when a look-back spin gives up
   int32_t *sel_pix;          // deferred append (frames >= 1): the selected pixels in cloud order, [P]
+  int32_t *tile_cnt;         // listed selection (agg_select_list_kernel): selected pixels per tile, [tiles]
   int64_t capacity;
   int frame, P, W, tiles;
 };
@@ -527,6 +576,47 @@ __global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamB
   }
 }
 
+// Selection of a later frame without any ordering inside the launch: tile t leaves its selected pixels (row-major)
+// in its own slots sel_pix[t * kSelTile ...] and its count in tile_cnt[t]; the frame's push launch, which builds
+// the rows anyway, turns the counts into offsets.  No ticket, no predecessor counts to wait for: the launch is
+// one read of the mask and the map (the frames after the first select a few per cent of their pixels).
+__global__ void __launch_bounds__(kSelThreads) agg_select_list_kernel(SelArgs a) {
+  __shared__ int wave_sums[kSelThreads / kWave];
+  __shared__ uint16_t s_list[kSelTile];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x;
+  const int base = tile * kSelTile + tid * kSelItems;
+  const unsigned flags = base < a.P ? sel_flags16(a, base) : 0u;
+  const int c = __popc(flags);
+  int x = c;
+  for (int off = 1; off < 64; off <<= 1) {
+    int y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wave_sums[wave] = x;
+  __syncthreads();
+  int wave_off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kSelThreads / kWave; ++w) {
+    if (w < wave) wave_off += wave_sums[w];
+    total += wave_sums[w];
+  }
+  if (tid == 0) a.tile_cnt[tile] = total;
+  if (total == 0) return;
+  {
+    int slot = wave_off + x - c;
+    unsigned f = flags;
+    while (f) {
+      const int k = __builtin_ctz(f);
+      f &= f - 1;
+      s_list[slot++] = (uint16_t)(tid * kSelItems + k);
+    }
+  }
+  __syncthreads();
+  const int tile_px = tile * kSelTile;
+  for (int e = tid; e < total; e += kSelThreads) a.sel_pix[tile_px + e] = tile_px + (int)s_list[e];
+}
+
 // the count the caller sees: the cloud size, or -1 when a look-back spin gave up in any frame
 // (the cloud is then not trustworthy; hosts that read the count raise, see ops.static_aggregate)
 __global__ void agg_finalize_kernel(const int64_t *__restrict__ cnts, const int32_t *__restrict__ error, int S,
@@ -541,6 +631,7 @@ struct AggWs {
   int64_t *cnts;
   int32_t *ticket, *error;
   unsigned long long *desc;
+  int32_t *tile_cnt;  // [tiles] listed selection of the current frame
   uint8_t *occ;  // [S][P] one occupancy byte per (frame, pixel), zeroed per call
   int32_t *sel_pix;  // [P] the pixels the current frame selected, in cloud order
   float *xyz;
@@ -563,6 +654,8 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   off += 16;
   w.desc = reinterpret_cast<unsigned long long *>(p + off);
   off += align_up(tiles * 8, 16);
+  w.tile_cnt = reinterpret_cast<int32_t *>(p + off);
+  off += align_up(tiles * 4, 16);
   w.state_bytes = off;
   off = align_up(off, 256);
   w.occ = reinterpret_cast<uint8_t *>(p + off);
@@ -680,6 +773,10 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
     }
   }
   const int tiles = (int)cdiv(P, kSelTile);
+  // frames >= 1: listed selection (offsets made by the push launch) unless the image has more tiles than a push
+  // workgroup scans, or PGDVS_AGG_ORDERED=1 asks for the ordered selection (tests run both)
+  static const bool ordered_env = getenv("PGDVS_AGG_ORDERED") && getenv("PGDVS_AGG_ORDERED")[0] == '1';
+  const bool listed = tiles <= kPushMaxTiles && !ordered_env;
   auto select = [&](int i) {
     SelArgs a;
     a.dyn_mask = dyn_masks + (size_t)i * P;
@@ -693,12 +790,17 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
     a.ticket = ws.ticket;
     a.error = ws.error;
     a.sel_pix = i > 0 ? ws.sel_pix : nullptr;
+    a.tile_cnt = ws.tile_cnt;
     a.capacity = capacity;
     a.frame = i;
     a.P = (int)P;
     a.W = W;
     a.tiles = tiles;
-    PGDVS_LAUNCH("agg_select", agg_select_kernel, dim3(tiles), dim3(kSelThreads), 0, st, a, cams[(size_t)i]);
+    if (i > 0 && listed) {
+      PGDVS_LAUNCH("agg_select", agg_select_list_kernel, dim3(tiles), dim3(kSelThreads), 0, st, a);
+    } else {
+      PGDVS_LAUNCH("agg_select", agg_select_kernel, dim3(tiles), dim3(kSelThreads), 0, st, a, cams[(size_t)i]);
+    }
   };
   // cnts[i] = points in the cloud before frame i.  After frame i is selected, the points it appended are
   // pushed into the occupancy maps of all later frames; frame i+1's selection reads its own map.
@@ -728,8 +830,9 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
       app.P = (int)P;
       app.W = W;
       PGDVS_LAUNCH(i == 0 ? "agg_push0" : "agg_push", agg_push_kernel, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
-                   (const float *)ws.xyz, (const int64_t *)ws.cnts, i, (const ProjF64 *)ws.proj, i + 1, S, fpg_i, H, W, ws.occ,
-                   (const int32_t *)(i > 0 ? ws.sel_pix : nullptr), app, cams[(size_t)i]);
+                   (const float *)ws.xyz, ws.cnts, i, (const ProjF64 *)ws.proj, i + 1, S, fpg_i, H, W, ws.occ,
+                   (const int32_t *)(i > 0 ? ws.sel_pix : nullptr), (const int32_t *)(i > 0 && listed ? ws.tile_cnt : nullptr),
+                   tiles, capacity, app, cams[(size_t)i]);
     }
   }
   PGDVS_LAUNCH("agg_finalize", agg_finalize_kernel, dim3(1), dim3(64), 0, st, (const int64_t *)ws.cnts,

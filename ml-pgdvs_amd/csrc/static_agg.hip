@@ -11,7 +11,9 @@
 //            (tagged 8-byte count granules gathered from all predecessor tiles, dynamic tile
 //            tickets for forward progress) and appends the unprojected (xyz,rgb) rows in
 //            row-major pixel order -- the order numpy's boolean indexing produces (point ids
-//            matter: the rasteriser breaks z ties by id).
+//            matter: the rasteriser breaks z ties by id).  Frames >= 1 (a few per cent of the pixels
+//            each, 2(S-1) launches of pure latency) only leave tile-local pixel lists and counts
+//            (agg_select_list_kernel); their push launch makes the offsets and builds the rows.
 //   push   : the points frame i just appended are projected into EVERY later frame and stamp
 //            that frame's own occupancy map (one byte per pixel and frame, zeroed per call), so no
 //            point is ever projected into the same frame twice and the cloud is not re-read per

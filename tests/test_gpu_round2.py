@@ -125,6 +125,25 @@ def test_checked_count_raises_on_error_status():
         ops.checked_count(torch.tensor([-1], device=DEV), "x")
 
 
+def test_static_aggregation_ordered_selection_path():
+    """frames >= 1 normally take the listed selection (offsets made by the push launch); images with more than
+    2048 selection tiles (> 16.7 M pixels) take the ordered selection instead.  PGDVS_AGG_ORDERED=1 forces that
+    path (read once per process, hence the child process) through the same bit-exact aggregation tests."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, PGDVS_AGG_ORDERED="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(here, "test_gpu_parity.py"), "-k",
+                        "static_aggregation_shapes_vs_oracle or static_aggregation_vs_reference_golden or "
+                        "static_aggregation_capacity_clamp"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_static_aggregation_with_views_in_flight():
     """three aggregations in flight on their own streams beside a chip-filling kernel (the benchmark's
     situation): ticketed tile ids make the ordered-offset look-back independent of dispatch order; the

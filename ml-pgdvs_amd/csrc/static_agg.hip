@@ -244,21 +244,26 @@ constexpr int kSelItems = 16;
 constexpr int kSelTile = kSelThreads * kSelItems;
 constexpr int kPushThreads = 256;
 constexpr int kPushMaxTiles = 2048;  // selection tiles a push workgroup can scan itself (16.7 M pixels); more: ordered selection
-constexpr int kPushQueue = 1024;  // points with frames the fp32 form could not decide, queued per workgroup
+// points with frames the fp32 form could not decide, queued per workgroup: 1024 entries for frame 0's chip-filling
+// launch (drained every fourth round); 512 (every second round) for the later frames, whose launches are a few
+// rounds long and fit into the LDS the other views' rasteriser workgroups leave free (12 KB per CU)
+constexpr int kPushQueue = 1024;
+constexpr int kPushQueueSmall = 512;
 constexpr int kPushMaxFpg = 32;    // frames per workgroup row (one bit each in a queue entry)
 
 // Projects the points [cnts[src], cnts[src+1]) -- what frame `src` appended -- into the frames
 // f_lo + blockIdx.y * fpg ... (at most fpg of them, below f_hi) and stamps their occupancy maps
 // occ[f][P].  One thread per point, the frame loop inside (per-frame constants are wave-uniform:
 // scalar loads).
+template <int kQueue>
 __global__ void __launch_bounds__(kPushThreads)
 agg_push_kernel(const float *__restrict__ xyz, int64_t *cnts, int src,
                 const ProjF64 *__restrict__ proj, int f_lo, int f_hi, int fpg, int H, int W,
                 uint8_t *__restrict__ occ_all, const int32_t *__restrict__ sel_pix,
                 const int32_t *__restrict__ tile_cnt, int tiles, int64_t capacity, AppendSrc app, CamBlock cam) {
-  __shared__ uint4 s_q[kPushQueue];
+  __shared__ uint4 s_q[kQueue];
   __shared__ int s_qn;
-  __shared__ int s_pref[kPushMaxTiles + 1];  // listed selection: pixels selected before each tile of the frame
+  extern __shared__ int s_pref[];  // listed selection: pixels selected before each tile of the frame, [tiles + 1]
   __shared__ int s_wsum[kPushThreads / kWave];
   int64_t begin = cnts[src], end;
   if (tile_cnt != nullptr) {
@@ -285,12 +290,12 @@ agg_push_kernel(const float *__restrict__ xyz, int64_t *cnts, int src,
     for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) excl += s_wsum[w];
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-      s_pref[threadIdx.x * kPer + k] = excl;
+      const int t = (int)threadIdx.x * kPer + k;
+      if (t <= tiles) s_pref[t] = excl;  // (the tiles behind the last one count nothing: s_pref[tiles] = total)
       excl += v[k];
     }
-    if (threadIdx.x == kPushThreads - 1) s_pref[kPushMaxTiles] = excl;
     __syncthreads();
-    end = begin + s_pref[kPushMaxTiles];
+    end = begin + s_pref[tiles];
     end = end > capacity ? capacity : end;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) cnts[src + 1] = end;  // read by the next frame's launches
   } else {
@@ -377,7 +382,7 @@ agg_push_kernel(const float *__restrict__ xyz, int64_t *cnts, int src,
     // frame bitmask)
     if (dmask != 0) {
       const int slot = atomicAdd(&s_qn, 1);
-      if (slot < kPushQueue) {
+      if (slot < kQueue) {
         s_q[slot] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), dmask);
       } else {  // queue full (degenerate views): decide in place
         for (unsigned m = dmask; m; m &= m - 1) {
@@ -388,9 +393,9 @@ agg_push_kernel(const float *__restrict__ xyz, int64_t *cnts, int src,
     }
     // drain when the next round could overflow the queue (every thread adds at most one entry per round)
     __syncthreads();
-    const int qn = s_qn < kPushQueue ? s_qn : kPushQueue;
+    const int qn = s_qn < kQueue ? s_qn : kQueue;
     const bool last = ch + c_step >= c_hi;
-    if (last || qn + kPushThreads > kPushQueue) {
+    if (last || qn + kPushThreads > kQueue) {
       for (int e = threadIdx.x; e < qn; e += kPushThreads) {
         const uint4 q = s_q[e];
         const float px = __uint_as_float(q.x), py = __uint_as_float(q.y), pz = __uint_as_float(q.z);
@@ -584,7 +589,6 @@ __global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamB
 // one read of the mask and the map (the frames after the first select a few per cent of their pixels).
 __global__ void __launch_bounds__(kSelThreads) agg_select_list_kernel(SelArgs a) {
   __shared__ int wave_sums[kSelThreads / kWave];
-  __shared__ uint16_t s_list[kSelTile];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x;
   const int base = tile * kSelTile + tid * kSelItems;
@@ -604,19 +608,15 @@ __global__ void __launch_bounds__(kSelThreads) agg_select_list_kernel(SelArgs a)
     total += wave_sums[w];
   }
   if (tid == 0) a.tile_cnt[tile] = total;
-  if (total == 0) return;
-  {
-    int slot = wave_off + x - c;
-    unsigned f = flags;
-    while (f) {
-      const int k = __builtin_ctz(f);
-      f &= f - 1;
-      s_list[slot++] = (uint16_t)(tid * kSelItems + k);
-    }
+  // straight from the registers into the tile's slots (a few per cent of the pixels; no LDS list, so that the
+  // launch fits beside the other views' rasteriser workgroups)
+  int32_t *dst = a.sel_pix + tile * kSelTile + wave_off + x - c;
+  unsigned f = flags;
+  while (f) {
+    const int k = __builtin_ctz(f);
+    f &= f - 1;
+    *dst++ = base + k;
   }
-  __syncthreads();
-  const int tile_px = tile * kSelTile;
-  for (int e = tid; e < total; e += kSelThreads) a.sel_pix[tile_px + e] = tile_px + (int)s_list[e];
 }
 
 // the count the caller sees: the cloud size, or -1 when a look-back spin gave up in any frame
@@ -831,10 +831,17 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
       app.xyz = ws.xyz;
       app.P = (int)P;
       app.W = W;
-      PGDVS_LAUNCH(i == 0 ? "agg_push0" : "agg_push", agg_push_kernel, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
-                   (const float *)ws.xyz, ws.cnts, i, (const ProjF64 *)ws.proj, i + 1, S, fpg_i, H, W, ws.occ,
-                   (const int32_t *)(i > 0 ? ws.sel_pix : nullptr), (const int32_t *)(i > 0 && listed ? ws.tile_cnt : nullptr),
-                   tiles, capacity, app, cams[(size_t)i]);
+      if (i == 0) {
+        PGDVS_LAUNCH("agg_push0", agg_push_kernel<kPushQueue>, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
+                     (const float *)ws.xyz, ws.cnts, i, (const ProjF64 *)ws.proj, i + 1, S, fpg_i, H, W, ws.occ,
+                     (const int32_t *)nullptr, (const int32_t *)nullptr, tiles, capacity, app, cams[(size_t)i]);
+      } else {
+        const size_t lds = listed ? ((size_t)tiles + 1) * 4 : 0;
+        PGDVS_LAUNCH("agg_push", agg_push_kernel<kPushQueueSmall>, dim3(gx, (unsigned)groups), dim3(kPushThreads), lds, st,
+                     (const float *)ws.xyz, ws.cnts, i, (const ProjF64 *)ws.proj, i + 1, S, fpg_i, H, W, ws.occ,
+                     (const int32_t *)ws.sel_pix, (const int32_t *)(listed ? ws.tile_cnt : nullptr), tiles, capacity, app,
+                     cams[(size_t)i]);
+      }
     }
   }
   PGDVS_LAUNCH("agg_finalize", agg_finalize_kernel, dim3(1), dim3(64), 0, st, (const int64_t *)ws.cnts,

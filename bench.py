@@ -299,9 +299,10 @@ def main():
             data["_combined_rgb_out"] = out
         # dynamic-branch geometry on a side stream, overlapping the static aggregation + raster
         data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=side if use_side else None)
-        cloud, cnt = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=cap)
+        cloud, cnt, xyz = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=cap, return_xyz=True)
         data["st_pcl_rgb"] = cloud[None]
         data["st_pcl_rgb_count"] = cnt
+        data["st_pcl_xyz"] = xyz[None]  # the packed coordinates: the rasteriser's binning reads 12 bytes per point, not 24
         with torch.no_grad():
             ret = model.forward(data, render_cfg=rc, disable_tqdm=True)
         return ret["combined_rgb"], cnt
@@ -614,7 +615,7 @@ def main():
     # (nvidia_eval_pure_geo.py:166-178) and only renders per target view
     variants = None
     if rank == 0 and world == 1 and not args.no_kernel_timing:
-        cloud_c, cnt_c = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=cap)
+        cloud_c, cnt_c, xyz_c = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=cap, return_xyz=True)
 
         def step_cached(j):
             main, side = lanes[j % n_lanes]
@@ -623,7 +624,7 @@ def main():
             with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
                 data = dict(views[j % n_views])
                 data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=side if args.side_stream else None)
-                data["st_pcl_rgb"], data["st_pcl_rgb_count"] = cloud_c[None], cnt_c
+                data["st_pcl_rgb"], data["st_pcl_rgb_count"], data["st_pcl_xyz"] = cloud_c[None], cnt_c, xyz_c[None]
                 with torch.no_grad():
                     return model.forward(data, render_cfg=rc, disable_tqdm=True)["combined_rgb"]
 

@@ -215,6 +215,13 @@ int pgdvs_static_aggregate(const float *rgbs, const float *depths, const uint8_t
                            const double *K3s_host, const double *c2ws_host, int S, int H, int W,
                            float *out, int64_t capacity, int64_t *count_out, void *workspace,
                            int64_t workspace_bytes, pgdvs_stream_t stream);
+/* The same, and xyz_out[capacity,3] receives the coordinates alone (12 bytes per point): pass it as `pts` with
+ * pts_stride 3 (and out + 3 with stride 6 as `feat`) to pgdvs_points_raster, whose binning passes then read half
+ * the bytes.  Same workspace size. */
+int pgdvs_static_aggregate_packed(const float *rgbs, const float *depths, const uint8_t *dyn_masks,
+                                  const double *K3s_host, const double *c2ws_host, int S, int H, int W,
+                                  float *out, float *xyz_out, int64_t capacity, int64_t *count_out,
+                                  void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream);
 
 /* ---- GNT static renderer ---------------------------------------------------- */
 /* A13: ray sampling + Projector.compute (pgdvs/models/gnt/ray_sampler.py:59-123,

@@ -681,11 +681,36 @@ PGDVS_API int64_t pgdvs_static_aggregate_workspace_bytes(int S, int H, int W, in
   return agg_ws_layout(nullptr, S, H, W, capacity).total_bytes;
 }
 
+static int static_aggregate_impl(const float *rgbs, const float *depths, const uint8_t *dyn_masks,
+                                 const double *K3s_host, const double *c2ws_host, int S, int H, int W, float *out,
+                                 float *xyz_out, int64_t capacity, int64_t *count_out, void *workspace,
+                                 int64_t workspace_bytes, pgdvs_stream_t stream);
+
 PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
                                      const uint8_t *dyn_masks, const double *K3s_host,
                                      const double *c2ws_host, int S, int H, int W, float *out,
                                      int64_t capacity, int64_t *count_out, void *workspace,
                                      int64_t workspace_bytes, pgdvs_stream_t stream) {
+  return static_aggregate_impl(rgbs, depths, dyn_masks, K3s_host, c2ws_host, S, H, W, out, nullptr, capacity, count_out,
+                               workspace, workspace_bytes, stream);
+}
+
+// The same aggregation; the packed coordinates the push launches work from ([capacity,3], 12 bytes per point)
+// are kept in caller storage: the rasteriser's binning passes read them instead of the 24-byte rows.
+PGDVS_API int pgdvs_static_aggregate_packed(const float *rgbs, const float *depths,
+                                            const uint8_t *dyn_masks, const double *K3s_host,
+                                            const double *c2ws_host, int S, int H, int W, float *out, float *xyz_out,
+                                            int64_t capacity, int64_t *count_out, void *workspace,
+                                            int64_t workspace_bytes, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(xyz_out, "pgdvs_static_aggregate_packed: null pointer");
+  return static_aggregate_impl(rgbs, depths, dyn_masks, K3s_host, c2ws_host, S, H, W, out, xyz_out, capacity, count_out,
+                               workspace, workspace_bytes, stream);
+}
+
+static int static_aggregate_impl(const float *rgbs, const float *depths, const uint8_t *dyn_masks,
+                                 const double *K3s_host, const double *c2ws_host, int S, int H, int W, float *out,
+                                 float *xyz_out, int64_t capacity, int64_t *count_out, void *workspace,
+                                 int64_t workspace_bytes, pgdvs_stream_t stream) {
   PGDVS_REQUIRE(rgbs && depths && dyn_masks && K3s_host && c2ws_host && out && count_out,
                 "pgdvs_static_aggregate: null pointer");
   PGDVS_REQUIRE(S > 0 && S < 65535 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31) && capacity > 0 &&
@@ -696,6 +721,7 @@ PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
     set_error("pgdvs_static_aggregate: workspace too small");
     return PGDVS_ERR_WORKSPACE;
   }
+  if (xyz_out) ws.xyz = xyz_out;
   hipStream_t st = as_stream(stream);
   const int64_t P = (int64_t)H * W;
   hipError_t e = hipMemsetAsync(ws.state, 0, (size_t)ws.state_bytes, st);

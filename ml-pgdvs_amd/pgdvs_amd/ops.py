@@ -352,9 +352,10 @@ def mesh_render(cam_tgt, keep, pcl, rgb, H: int, W: int, want_faces: bool = Fals
     return out
 
 
-def static_aggregate(rgbs, depths, dyn_masks, K3s, c2ws, capacity: int | None = None):
+def static_aggregate(rgbs, depths, dyn_masks, K3s, c2ws, capacity: int | None = None, return_xyz: bool = False):
     """rgbs[S,H,W,3] fp32 in [0,1]; depths[S,H,W]; dyn_masks[S,H,W] bool/uint8 (GPU tensors);
-    K3s[S,3,3], c2ws[S,4,4] float64 numpy (host).  -> (cloud[capacity,6], count[int64 dev])."""
+    K3s[S,3,3], c2ws[S,4,4] float64 numpy (host).  -> (cloud[capacity,6], count[int64 dev]) and, with
+    ``return_xyz``, the packed coordinates [capacity,3] (``data["st_pcl_xyz"]`` for the renderer)."""
     r = _req(rgbs, torch.float32, "rgbs")
     d = _req(depths, torch.float32, "depths")
     m = _req(dyn_masks.contiguous().view(torch.uint8) if dyn_masks.dtype == torch.bool else dyn_masks, torch.uint8, "dyn_masks")
@@ -366,6 +367,12 @@ def static_aggregate(rgbs, depths, dyn_masks, K3s, c2ws, capacity: int | None = 
     cnt = torch.empty(1, dtype=torch.int64, device=r.device)
     lib = _lib.load()
     ws = _ws(lib.pgdvs_static_aggregate_workspace_bytes(S, H, W, cap), r.device)
+    if return_xyz:
+        xyz = torch.empty((cap, 3), dtype=torch.float32, device=r.device)
+        check(lib.pgdvs_static_aggregate_packed(
+            _ptr(r), _ptr(d), _ptr(m), K3.ctypes.data_as(C.c_void_p), c2w.ctypes.data_as(C.c_void_p), S, H, W,
+            _ptr(out), _ptr(xyz), cap, _ptr(cnt), _ptr(ws), ws.numel(), _stream()), "pgdvs_static_aggregate_packed")
+        return out, cnt, xyz
     check(lib.pgdvs_static_aggregate(
         _ptr(r), _ptr(d), _ptr(m), K3.ctypes.data_as(C.c_void_p), c2w.ctypes.data_as(C.c_void_p), S, H, W,
         _ptr(out), cap, _ptr(cnt), _ptr(ws), ws.numel(), _stream()), "pgdvs_static_aggregate")

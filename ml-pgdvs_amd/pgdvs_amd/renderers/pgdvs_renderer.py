@@ -109,11 +109,13 @@ class PGDVSRenderer(PGDVSBaseRenderer):
         """:182-201"""
         static_rgb, static_mask = [], []
         counts = data.get("st_pcl_rgb_count", None)  # optional device counts [B] (int64)
+        xyz = data.get("st_pcl_xyz", None)  # optional packed coordinates [B,#pt,3] (ops.static_aggregate(return_xyz=True))
         for i_b in range(data["flat_cam_tgt"].shape[0]):
             tmp_rgb, tmp_mask = self.static_renderer(
                 tgt_h=ray_batch["render_h"], tgt_w=ray_batch["render_w"], flat_tgt_cam=data["flat_cam_tgt"][i_b],
                 st_pcl_rgb=data["st_pcl_rgb"][i_b], render_cfg=render_cfg,
-                n_points_dev=None if counts is None else counts[i_b:i_b + 1], planar=True)
+                n_points_dev=None if counts is None else counts[i_b:i_b + 1], planar=True,
+                st_pcl_xyz=None if xyz is None else xyz[i_b])
             static_rgb.append(tmp_rgb)
             static_mask.append(tmp_mask)
         if len(static_rgb) == 1:  # a view, not a 25 MB copy

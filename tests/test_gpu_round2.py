@@ -125,6 +125,36 @@ def test_checked_count_raises_on_error_status():
         ops.checked_count(torch.tensor([-1], device=DEV), "x")
 
 
+def test_static_aggregation_packed_xyz_and_raster_from_it():
+    """pgdvs_static_aggregate_packed: same cloud, plus the coordinates alone; the rasteriser fed with the packed
+    coordinates (stride 3) and the colours of the rows (stride 6) gives the same fragments bit for bit, through
+    ops and through the renderer's optional ``st_pcl_xyz``"""
+    from types import SimpleNamespace
+
+    from pgdvs_amd.renderers.st_geo_renderer import StaticGeoPointRenderer
+
+    v = synth.make_video(4, 72, 128, seed=5)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    args = (T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]).view(torch.uint8), v["K3s"], v["c2ws"])
+    cloud, cnt = ops.static_aggregate(*args)
+    cloud2, cnt2, xyz = ops.static_aggregate(*args, return_xyz=True)
+    n = int(cnt.item())
+    assert int(cnt2.item()) == n and torch.equal(cloud[:n], cloud2[:n]) and torch.equal(xyz[:n], cloud[:n, :3])
+    d = synth.make_view(v, 1, seed=3)
+    fc = T(d["flat_cam_tgt"][0])
+    cam = ops.cam_prep(fc)
+    a = ops.points_raster(cloud, cloud[:, 3:], cam, 0.01, 3, 72, 128, n_points_dev=cnt, want_fragments=True)
+    b = ops.points_raster(xyz, cloud[:, 3:], cam, 0.01, 3, 72, 128, n_points_dev=cnt, want_fragments=True)
+    for k in ("idx", "zbuf", "dist2", "rgb", "mask"):
+        assert torch.equal(a[k], b[k]), k
+    rc = SimpleNamespace(st_pcl_remove_outlier=False, st_render_pcl_pt_radius=0.01, st_render_pcl_pts_per_pixel=3)
+    ren = StaticGeoPointRenderer()
+    r0 = ren(tgt_h=72, tgt_w=128, flat_tgt_cam=fc, st_pcl_rgb=cloud, render_cfg=rc, n_points_dev=cnt, planar=True)
+    r1 = ren(tgt_h=72, tgt_w=128, flat_tgt_cam=fc, st_pcl_rgb=cloud, render_cfg=rc, n_points_dev=cnt, planar=True,
+             st_pcl_xyz=xyz)
+    assert torch.equal(r0[0], r1[0]) and torch.equal(r0[1], r1[1])
+
+
 def test_static_aggregation_ordered_selection_path():
     """frames >= 1 normally take the listed selection (offsets made by the push launch); images with more than
     2048 selection tiles (> 16.7 M pixels) take the ordered selection instead.  PGDVS_AGG_ORDERED=1 forces that

@@ -125,6 +125,62 @@ def test_checked_count_raises_on_error_status():
         ops.checked_count(torch.tensor([-1], device=DEV), "x")
 
 
+@pytest.mark.parametrize("H,W,n,K,radius", [(96, 128, 600, 3, 0.2), (130, 70, 900, 2, 0.35)])
+def test_points_raster_large_radius_binning_path(H, W, n, K, radius):
+    """discs wider than a tile side: the tile box of a point exceeds 2 x 2 tiles, so the binning passes leave the
+    LDS-table form (ranks in registers) for the per-run global appends"""
+    rng = np.random.default_rng(H + W + n)
+    fc = synth.flat_cam(H, W, *synth.frame_camera(1, 4, H, W))
+    pts = np.concatenate([rng.uniform(-1.4, 1.4, (n, 2)), rng.uniform(0.3, 3.0, (n, 1))], 1).astype(np.float32)
+    pts[: n // 6, 2] = pts[n // 6: 2 * (n // 6), 2][: n // 6]  # depth ties -> (z, id) order
+    rgb = rng.random((n, 3), dtype=np.float32)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    cloud = T(np.concatenate([pts, rgb], 1))
+    r = ops.points_raster(cloud, cloud[:, 3:], ops.cam_prep(T(fc)), radius, K, H, W, want_fragments=True)
+    idx, zbuf, d2 = orc.rasterize_points(pts, fc, H, W, radius, K)
+    assert (idx >= 0).mean() > 0.5
+    assert np.array_equal(N(r["idx"]), idx)
+    assert np.array_equal(N(r["zbuf"]).view(np.uint32), zbuf.view(np.uint32))
+    assert np.array_equal(N(r["dist2"]).view(np.uint32), d2.view(np.uint32))
+    np.testing.assert_allclose(N(r["rgb"]), orc.composite(idx, d2, radius, rgb), rtol=0, atol=1e-6)
+
+
+def test_points_raster_more_tiles_than_the_binning_table():
+    """2064 x 2064 pixels = 129 x 129 tiles > 16 384 LDS counters: the binning passes count and append through
+    global memory; fragments checked on windows against the oracle's naive rasteriser over all points"""
+    H = W = 2064
+    n, K, radius = 6000, 3, 0.004
+    rng = np.random.default_rng(77)
+    fc = synth.flat_cam(H, W, *synth.frame_camera(1, 4, H, W))
+    z = rng.uniform(0.8, 3.0, (n, 1))
+    pts = np.concatenate([rng.uniform(-0.62, 0.62, (n, 2)) * z, z], 1).astype(np.float32)
+    # clusters inside the checked windows so that they hold many (and overlapping) discs
+    for k, (cy, cx) in enumerate([(0.55, 0.55), (0.0, 0.0), (-0.55, -0.55)]):
+        m = slice(k * 1500, (k + 1) * 1500)
+        pts[m, 0] = (cx + rng.uniform(-0.03, 0.03, 1500)) * pts[m, 2]
+        pts[m, 1] = (cy + rng.uniform(-0.03, 0.03, 1500)) * pts[m, 2]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    cloud = T(np.concatenate([pts, rng.random((n, 3), dtype=np.float32)], 1))
+    r = ops.points_raster(cloud, cloud[:, 3:], ops.cam_prep(T(fc)), radius, K, H, W, want_fragments=True)
+    ndc = orc.points_to_ndc(pts, fc, H, W)
+    gi = N(r["idx"])
+    hits = 0
+    ys, xs = np.nonzero((gi[..., 0] >= 0))
+    assert ys.size > 1000
+    # windows around covered pixels spread over the image (first, middle, last in raster order) + a corner
+    picks = [(int(ys[i]), int(xs[i])) for i in (0, ys.size // 3, ys.size // 2, 2 * ys.size // 3, ys.size - 1)] + [(0, 0)]
+    for (cy, cx) in picks:
+        y0, x0 = max(0, min(H - 96, cy - 48)), max(0, min(W - 96, cx - 48))
+        idx, zbuf, d2 = orc.rasterize_points_window(ndc, H, W, radius, K, y0, y0 + 96, x0, x0 + 96)
+        assert np.array_equal(gi[y0:y0 + 96, x0:x0 + 96], idx), (y0, x0)
+        assert np.array_equal(N(r["zbuf"])[y0:y0 + 96, x0:x0 + 96].view(np.uint32), zbuf.view(np.uint32)), (y0, x0)
+        assert np.array_equal(N(r["dist2"])[y0:y0 + 96, x0:x0 + 96].view(np.uint32), d2.view(np.uint32)), (y0, x0)
+        hits += int((idx >= 0).sum())
+    assert hits > 500
+    # every covered pixel of the whole image names a point whose disc really covers it (cheap global sanity)
+    assert int((gi >= n).sum()) == 0
+
+
 def test_static_aggregation_packed_xyz_and_raster_from_it():
     """pgdvs_static_aggregate_packed: same cloud, plus the coordinates alone; the rasteriser fed with the packed
     coordinates (stride 3) and the colours of the rows (stride 6) gives the same fragments bit for bit, through

@@ -9,6 +9,8 @@
 // change the multiset of the K+1 smallest values.  Queries that do not terminate within
 // kRingCap rings (isolated outliers) repeat the search on a second-level grid with
 // kCoarseScale-times larger cells; the few still open after that are scanned exhaustively.
+// The first-level grid's cell -> points index is sparse (CellIndex: a bit per cell, ranks per 64 cells, starts of
+// the occupied cells only): a depth-map cloud occupies ~0.15 % of the cells of its bounding box.
 //
 // Self-queries first go through a THREAD-per-query pass over the 3x3x3 block of their cell
 // (grid_query_tpq_kernel, below); what that leaves open, and cross-set queries, use:
@@ -235,15 +237,156 @@ grid_count_kernel(const float *__restrict__ pts, const GridParams *__restrict__ 
   }
 }
 
-// exclusive scan of cell_count[0 .. ncells) -> cell_start[0 .. ncells]; ncells is a device
-// value, blocks beyond it exit at once
+// Start offset of a cell's points in the cell-sorted array.
+//   dense : start[c], one int per cell (second-level grid, <= 256 K cells).
+//   sparse: the first-level grid of a depth-map cloud has ~9 M cells of which 0.15 % hold points, so the dense
+//           table cost 36 MB of zeroing and two 36 MB scan passes per call.  Instead: one bit per cell, per 64
+//           cells a 16-byte word {bits, rank = occupied cells before the word}, and start[j] for the j-th
+//           occupied cell only.  start(c) = start[rank + popcount(bits below c)]: an empty cell gets the start of
+//           the next occupied one, which is what the exclusive scan over all cells gave.  Two dependent loads
+//           instead of one, 2 MB of table instead of 72.
+struct CellIndex {
+  const int32_t *start;
+  const uint4 *tab;  // nullptr = dense
+  __device__ __forceinline__ int at(int c) const {
+    if (tab == nullptr) return start[c];
+    const uint4 w = tab[c >> 6];
+    const unsigned long long bits = ((unsigned long long)w.y << 32) | (unsigned long long)w.x;
+    const int j = (int)w.z + __popcll(bits & ((1ull << (c & 63)) - 1ull));
+    return start[j];
+  }
+};
+
+constexpr int kTabWords = (kGridMaxCells >> 6) + 1;  // (+1: cell index ncells, one past the last cell, is looked up too)
+constexpr int kRankWordsPerBlock = 4096;
+
+// zero the words of the bit table that cover cells [0, ncells] and the per-occupied-cell counters
+__global__ void __launch_bounds__(256)
+grid_tab_zero_kernel(const GridParams *__restrict__ gp, uint4 *__restrict__ tab, int32_t *__restrict__ occ_count) {
+  const int nw = (gp->ncells >> 6) + 1;
+  const int nc = gp->n < gp->ncells ? gp->n : gp->ncells;  // occupied cells <= min(points, cells)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += gridDim.x * blockDim.x) tab[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nc; i += gridDim.x * blockDim.x) occ_count[i] = 0;
+}
+
+// cell of every point; its bit in the table (one atomic per run of lanes that share a cell)
+__global__ void __launch_bounds__(256)
+grid_mark_kernel(const float *__restrict__ pts, const GridParams *__restrict__ gp, int32_t *__restrict__ cell_of,
+                 uint4 *__restrict__ tab) {
+  const GridParams g = *gp;
+  const int n_round = (g.n + 63) / 64 * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+    int c = -1;
+    if (i < g.n) {
+      int cx = cell_coord(pts[(size_t)i * 3 + 0], g.mn[0], g.inv_h, g.G[0]);
+      int cy = cell_coord(pts[(size_t)i * 3 + 1], g.mn[1], g.inv_h, g.G[1]);
+      int cz = cell_coord(pts[(size_t)i * 3 + 2], g.mn[2], g.inv_h, g.G[2]);
+      c = (cz * g.G[1] + cy) * g.G[0] + cx;
+      cell_of[i] = c;
+    }
+    const RunInfo r = wave_runs(c);
+    if (r.is_leader && c >= 0)
+      atomicOr(reinterpret_cast<unsigned long long *>(&tab[c >> 6]), 1ull << (c & 63));
+  }
+}
+
+// rank of every table word = occupied cells before it.  Two launches: bits per workgroup of kRankWordsPerBlock
+// words, then every workgroup sums the (<= 65) totals before its own and scans its words.  (One launch in which a
+// workgroup counted the bits of all words before its own itself took 25 us: the last workgroup's 1 MB walk.)
+__device__ __forceinline__ int tab_word_bits(const uint4 *__restrict__ tab, int w) {
+  const uint2 b = *reinterpret_cast<const uint2 *>(&tab[w]);
+  return __popc(b.x) + __popc(b.y);
+}
+
+__global__ void __launch_bounds__(1024)
+grid_rank_totals_kernel(const GridParams *__restrict__ gp, const uint4 *__restrict__ tab, int32_t *__restrict__ totals) {
+  __shared__ int ws[16];
+  const int nw = (gp->ncells >> 6) + 1;
+  const int w0 = blockIdx.x * kRankWordsPerBlock;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int s = 0;
+  if (w0 < nw) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int w = w0 + k * 1024 + tid;
+      if (w < nw) s += tab_word_bits(tab, w);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) ws[wave] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += ws[w];
+    totals[blockIdx.x] = t;
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+grid_rank_kernel(const GridParams *__restrict__ gp, uint4 *__restrict__ tab, const int32_t *__restrict__ totals,
+                 int32_t *__restrict__ nocc_out) {
+  __shared__ int ws[16];
+  const int nw = (gp->ncells >> 6) + 1;
+  const int w0 = blockIdx.x * kRankWordsPerBlock;
+  if (w0 >= nw) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the workgroups before this one (at most kTabWords / kRankWordsPerBlock + 1 = 65 totals: two per lane)
+  int pre = 0;
+  for (int b = lane; b < (int)blockIdx.x; b += 64) pre += totals[b];
+  for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
+  int c[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int w = w0 + tid * 4 + k;
+    c[k] = w < nw ? tab_word_bits(tab, w) : 0;
+    s += c[k];
+  }
+  int x = s;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) ws[wave] = x;
+  __syncthreads();
+  int run = pre + x - s;
+  for (int w = 0; w < wave; ++w) run += ws[w];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int w = w0 + tid * 4 + k;
+    if (w < nw) tab[w].z = (unsigned)run;
+    run += c[k];
+    if (w == nw - 1) *nocc_out = run;  // occupied cells in total
+  }
+}
+
+// points per occupied cell: cell_of[i] becomes the cell's index among the occupied ones
+__global__ void __launch_bounds__(256)
+grid_occ_count_kernel(const GridParams *__restrict__ gp, int32_t *__restrict__ cell_of, const uint4 *__restrict__ tab,
+                      int32_t *__restrict__ occ_count) {
+  const int n = gp->n;
+  const int n_round = (n + 63) / 64 * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+    int j = -1;
+    if (i < n) {
+      const int c = cell_of[i];
+      const uint4 w = tab[c >> 6];
+      const unsigned long long bits = ((unsigned long long)w.y << 32) | (unsigned long long)w.x;
+      j = (int)w.z + __popcll(bits & ((1ull << (c & 63)) - 1ull));
+      cell_of[i] = j;
+    }
+    wave_tile_count(occ_count, j);
+  }
+}
+
+// exclusive scan of in[0 .. n) -> out[0 .. n]; n = *n_ptr is a device value (the cells of a dense grid, or the
+// occupied cells of the sparse one), blocks beyond it exit at once
 constexpr int kScanItems = 16;
 constexpr int kScanTile = 1024 * kScanItems;
 __global__ void __launch_bounds__(1024)
-grid_scan_blocks_kernel(const int32_t *__restrict__ in, const GridParams *__restrict__ gp,
+grid_scan_blocks_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ n_ptr,
                         int32_t *__restrict__ block_sums) {
   __shared__ int ws[16];
-  const int n = gp->ncells;
+  const int n = *n_ptr;
   int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
   int s = 0;
   if (blockIdx.x * kScanTile < n) {
@@ -286,10 +429,10 @@ grid_scan_sums_kernel(int32_t *__restrict__ block_sums, int nb) {
 }
 
 __global__ void __launch_bounds__(1024)
-grid_scan_apply_kernel(const int32_t *__restrict__ in, const GridParams *__restrict__ gp,
+grid_scan_apply_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ n_ptr,
                        const int32_t *__restrict__ block_sums, int32_t *__restrict__ out) {
   __shared__ int ws[16];
-  const int n = gp->ncells;
+  const int n = *n_ptr;
   if (blockIdx.x * kScanTile > n) return;
   int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
   int v[kScanItems];
@@ -359,6 +502,8 @@ grid_fill_kernel(const float *__restrict__ pts, const GridParams *__restrict__ g
                  const int32_t *__restrict__ cell_of, const int32_t *__restrict__ cell_start,
                  int32_t *__restrict__ cell_count, float4 *__restrict__ sorted,
                  const int32_t *__restrict__ gate) {
+  // (cell_of holds whatever indexes cell_start / cell_count: the cell id of a dense grid, the occupied-cell
+  // index of the sparse one)
   if (gate && *gate == 0) return;
   const int n = gp->n;
   const int n_round = (n + 63) / 64 * 64;
@@ -561,7 +706,7 @@ __device__ __forceinline__ float box_axis_dist2(float q, float mn, float h, int 
 
 __device__ __forceinline__ void
 grid_query_body(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted,
-                const int32_t *__restrict__ cell_start, int KK, QuerySrc qs, float *__restrict__ avg_out,
+                const CellIndex cell_start, int KK, QuerySrc qs, float *__restrict__ avg_out,
                 int32_t *__restrict__ stats, int ring_cap, int32_t *__restrict__ fb_count,
                 int32_t *__restrict__ fb_list, float *__restrict__ fb_bound) {
   const GridParams g = *gp;
@@ -617,18 +762,18 @@ grid_query_body(const GridParams *__restrict__ gp, const float4 *__restrict__ so
           if (outer) {
             int x0 = cx - r < 0 ? 0 : cx - r;
             int x1 = cx + r >= g.G[0] ? g.G[0] - 1 : cx + r;
-            s0 = cell_start[row + x0];
-            e0 = cell_start[row + x1 + 1];
+            s0 = cell_start.at(row + x0);
+            e0 = cell_start.at(row + x1 + 1);
             bd0 = byz + box_axis_dist2(qx, g.mn[0], g.h, x0, x1, g.G[0]);
           } else {
             if (cx - r >= 0) {
-              s0 = cell_start[row + cx - r];
-              e0 = cell_start[row + cx - r + 1];
+              s0 = cell_start.at(row + cx - r);
+              e0 = cell_start.at(row + cx - r + 1);
               bd0 = byz + box_axis_dist2(qx, g.mn[0], g.h, cx - r, cx - r, g.G[0]);
             }
             if (cx + r < g.G[0]) {
-              s1 = cell_start[row + cx + r];
-              e1 = cell_start[row + cx + r + 1];
+              s1 = cell_start.at(row + cx + r);
+              e1 = cell_start.at(row + cx + r + 1);
               bd1 = byz + box_axis_dist2(qx, g.mn[0], g.h, cx + r, cx + r, g.G[0]);
             }
           }
@@ -719,7 +864,7 @@ __device__ __forceinline__ void tpq_insert(float (&a)[KK], float c) {
 template <int KK>
 __global__ void __launch_bounds__(256, 5)
 grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted,
-                      const int32_t *__restrict__ cell_start, int first_col, float *__restrict__ avg_out,
+                      const CellIndex cell_start, int first_col, float *__restrict__ avg_out,
                       int32_t *__restrict__ open_count, int32_t *__restrict__ open_list) {
   __shared__ int2 s_run[9][256];
   __shared__ float s_bd[9][256];
@@ -749,8 +894,8 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
       float bd = 0.0f;
       if (live && z >= 0 && z < g.G[2] && y >= 0 && y < g.G[1]) {
         const int row = (z * g.G[1] + y) * g.G[0];
-        se.x = cell_start[row + x0];
-        se.y = cell_start[row + x1 + 1];
+        se.x = cell_start.at(row + x0);
+        se.y = cell_start.at(row + x1 + 1);
         bd = bx + box_axis_dist2(qy, g.mn[1], g.h, y, y, g.G[1]) + box_axis_dist2(qz, g.mn[2], g.h, z, z, g.G[2]);
       }
       s_run[k][tid] = se;
@@ -861,7 +1006,7 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
 // same search, two kernel symbols so that profiles keep them apart
 __global__ void __launch_bounds__(256)
 grid_query_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted,
-                  const int32_t *__restrict__ cell_start, int KK, QuerySrc qs, float *__restrict__ avg_out,
+                  const CellIndex cell_start, int KK, QuerySrc qs, float *__restrict__ avg_out,
                   int32_t *__restrict__ stats, int ring_cap, int32_t *__restrict__ fb_count,
                   int32_t *__restrict__ fb_list, float *__restrict__ fb_bound) {
   grid_query_body(gp, sorted, cell_start, KK, qs, avg_out, stats, ring_cap, fb_count, fb_list, fb_bound);
@@ -869,7 +1014,7 @@ grid_query_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ 
 
 __global__ void __launch_bounds__(256)
 grid2_query_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted,
-                   const int32_t *__restrict__ cell_start, int KK, QuerySrc qs, float *__restrict__ avg_out,
+                   const CellIndex cell_start, int KK, QuerySrc qs, float *__restrict__ avg_out,
                    int32_t *__restrict__ stats, int ring_cap, int32_t *__restrict__ fb_count,
                    int32_t *__restrict__ fb_list, float *__restrict__ fb_bound) {
   grid_query_body(gp, sorted, cell_start, KK, qs, avg_out, stats, ring_cap, fb_count, fb_list, fb_bound);
@@ -972,7 +1117,9 @@ struct GridWs {
   unsigned *bbox;
   unsigned long long *sumsq;
   GridParams *gp;
-  int32_t *cell_count, *cell_start, *block_sums, *cell_of;
+  int32_t *cell_count, *block_sums, *cell_of;  // cell_count: the dense counters of the TRIAL grid only
+  uint4 *tab;                                   // first-level grid: bit table with ranks (CellIndex)
+  int32_t *occ_count, *occ_start, *nocc;        // points per occupied cell, their starts, the number of occupied cells
   float4 *sorted;
   int32_t *fb_count, *fb_list;
   int32_t *open_count, *open_list;  // queries the thread-per-query pass left to the ring search
@@ -1003,13 +1150,21 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   w.fb_count = reinterpret_cast<int32_t *>(p + off + 192);
   w.fb2_count = reinterpret_cast<int32_t *>(p + off + 196);
   w.open_count = reinterpret_cast<int32_t *>(p + off + 200);
+  w.nocc = reinterpret_cast<int32_t *>(p + off + 204);
   off += 256;
   w.gp = reinterpret_cast<GridParams *>(p + off);
   off += 256;
   w.cell_count = reinterpret_cast<int32_t *>(p + off);
   off += align_up(((int64_t)kGridMaxCells + 1) * 4, 256);
-  w.cell_start = reinterpret_cast<int32_t *>(p + off);
-  off += align_up(((int64_t)kGridMaxCells + 1) * 4, 256);
+  w.tab = reinterpret_cast<uint4 *>(p + off);
+  off += align_up((int64_t)kTabWords * 16, 256);
+  {  // occupied cells <= min(points, cells)
+    const int64_t occ_cap = (capacity < kGridMaxCells ? (capacity > 0 ? capacity : 1) : (int64_t)kGridMaxCells) + 2;
+    w.occ_count = reinterpret_cast<int32_t *>(p + off);
+    off += align_up(occ_cap * 4, 256);
+    w.occ_start = reinterpret_cast<int32_t *>(p + off);
+    off += align_up(occ_cap * 4, 256);
+  }
   w.block_sums = reinterpret_cast<int32_t *>(p + off);
   off += align_up((int64_t)(kGridMaxCells / kScanTile) * 4, 256);
   w.cell_of = reinterpret_cast<int32_t *>(p + off);
@@ -1090,18 +1245,27 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
                ws.gp, ws.sumsq);
   PGDVS_LAUNCH("grid_params", grid_params_kernel, dim3(1), dim3(64), 0, st, ws.bbox, count,
                (const unsigned long long *)ws.sumsq, ws.gp, target);
-  PGDVS_LAUNCH("grid_zero", grid_zero_kernel, dim3(2048), dim3(256), 0, st, ws.gp, ws.cell_count,
-               (int32_t *)nullptr);
-  PGDVS_LAUNCH("grid_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
-               ws.cell_count, (const int32_t *)nullptr);
-  const int nb = kGridMaxCells / kScanTile;
-  PGDVS_LAUNCH("grid_scan_blocks", grid_scan_blocks_kernel, dim3(nb), dim3(1024), 0, st, ws.cell_count, ws.gp,
-               ws.block_sums);
+  // the final grid as a sparse cell index (CellIndex): bit table, ranks, points per occupied cell, their starts
+  PGDVS_LAUNCH("grid_tab_zero", grid_tab_zero_kernel, dim3(512), dim3(256), 0, st, ws.gp, ws.tab, ws.occ_count);
+  PGDVS_LAUNCH("grid_mark", grid_mark_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of, ws.tab);
+  const unsigned nrb = (unsigned)cdiv(kTabWords, kRankWordsPerBlock);
+  PGDVS_LAUNCH("grid_rank", grid_rank_totals_kernel, dim3(nrb), dim3(1024), 0, st, ws.gp, (const uint4 *)ws.tab, ws.block_sums);
+  PGDVS_LAUNCH("grid_rank", grid_rank_kernel, dim3(nrb), dim3(1024), 0, st, ws.gp, ws.tab, (const int32_t *)ws.block_sums,
+               ws.nocc);
+  PGDVS_LAUNCH("grid_occ_count", grid_occ_count_kernel, dim3(gpts), dim3(256), 0, st, ws.gp, ws.cell_of,
+               (const uint4 *)ws.tab, ws.occ_count);
+  const int64_t occ_cap = capacity < kGridMaxCells ? capacity : (int64_t)kGridMaxCells;
+  const int nb = (int)cdiv(occ_cap + 1, kScanTile);  // (<= kGridMaxCells / kScanTile = 1024: one pass over the block sums)
+  PGDVS_LAUNCH("grid_scan_blocks", grid_scan_blocks_kernel, dim3(nb), dim3(1024), 0, st, ws.occ_count,
+               (const int32_t *)ws.nocc, ws.block_sums);
   PGDVS_LAUNCH("grid_scan_sums", grid_scan_sums_kernel, dim3(1), dim3(1024), 0, st, ws.block_sums, nb);
-  PGDVS_LAUNCH("grid_scan_apply", grid_scan_apply_kernel, dim3(nb), dim3(1024), 0, st, ws.cell_count, ws.gp,
-               ws.block_sums, ws.cell_start);
+  PGDVS_LAUNCH("grid_scan_apply", grid_scan_apply_kernel, dim3(nb), dim3(1024), 0, st, ws.occ_count,
+               (const int32_t *)ws.nocc, ws.block_sums, ws.occ_start);
   PGDVS_LAUNCH("grid_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
-               ws.cell_start, ws.cell_count, ws.sorted, (const int32_t *)nullptr);
+               ws.occ_start, ws.occ_count, ws.sorted, (const int32_t *)nullptr);
+  CellIndex ci;
+  ci.start = ws.occ_start;
+  ci.tab = ws.tab;
   const char *env = getenv("PGDVS_KNN_STATS");
   int32_t *stats = (env && env[0] == '1') ? ws.stats : nullptr;
   const unsigned gq = (unsigned)(cdiv(nq_cap, 4) < 256 * 8 ? (cdiv(nq_cap, 4) > 0 ? cdiv(nq_cap, 4) : 1) : 256 * 8);
@@ -1113,7 +1277,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
 #define PGDVS_TPQ_CASE(N)                                                                                        \
   case N:                                                                                                        \
     PGDVS_LAUNCH("grid_query_tpq", grid_query_tpq_kernel<N>, dim3(gt), dim3(256), 0, st, ws.gp, ws.sorted,      \
-                 ws.cell_start, qs.first_col, avg_out, ws.open_count, ws.open_list);                             \
+                 ci, qs.first_col, avg_out, ws.open_count, ws.open_list);                                        \
     break;
       PGDVS_TPQ_CASE(5)
       PGDVS_TPQ_CASE(9)
@@ -1131,7 +1295,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
     qs1.list_count = ws.open_count;
   }
   PGDVS_LAUNCH("grid_query", grid_query_kernel, dim3(tpq ? (gq < 256 ? gq : 256) : gq), dim3(256), 0, st, ws.gp,
-               ws.sorted, ws.cell_start, KK, qs1, avg_out, stats, tpq ? kRingCapAfterTpq : kRingCap, ws.fb_count, ws.fb_list,
+               ws.sorted, ci, KK, qs1, avg_out, stats, tpq ? kRingCapAfterTpq : kRingCap, ws.fb_count, ws.fb_list,
                ws.fb_bound);
   // Second level: the queries still open after kRingCap rings (isolated points, far from
   // everything in units of the cell size) repeat the ring search on a grid with
@@ -1143,19 +1307,22 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   PGDVS_LAUNCH("grid2_zero", grid_zero_kernel, dim3(256), dim3(256), 0, st, ws.gp2, ws.cell_count2, (int32_t *)nullptr);
   PGDVS_LAUNCH("grid2_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp2, ws.cell_of,
                ws.cell_count2, (const int32_t *)ws.fb_count);
-  PGDVS_LAUNCH("grid2_scan", grid_scan_blocks_kernel, dim3(nb2), dim3(1024), 0, st, ws.cell_count2, ws.gp2,
+  PGDVS_LAUNCH("grid2_scan", grid_scan_blocks_kernel, dim3(nb2), dim3(1024), 0, st, ws.cell_count2, (const int32_t *)&ws.gp2->ncells,
                ws.block_sums2);
   PGDVS_LAUNCH("grid2_scan", grid_scan_sums_kernel, dim3(1), dim3(1024), 0, st, ws.block_sums2, nb2);
-  PGDVS_LAUNCH("grid2_scan", grid_scan_apply_kernel, dim3(nb2), dim3(1024), 0, st, ws.cell_count2, ws.gp2,
+  PGDVS_LAUNCH("grid2_scan", grid_scan_apply_kernel, dim3(nb2), dim3(1024), 0, st, ws.cell_count2, (const int32_t *)&ws.gp2->ncells,
                ws.block_sums2, ws.cell_start2);
   PGDVS_LAUNCH("grid2_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp2, ws.cell_of,
                ws.cell_start2, ws.cell_count2, ws.sorted2, (const int32_t *)ws.fb_count);
+  CellIndex ci2;  // the coarse grid stays dense (<= 256 K cells)
+  ci2.start = ws.cell_start2;
+  ci2.tab = nullptr;
   QuerySrc qs2 = qs;
   qs2.list = ws.fb_list;
   qs2.list_count = ws.fb_count;
   qs2.qsorted = ws.sorted;
   PGDVS_LAUNCH("grid2_query", grid2_query_kernel, dim3(gq < 1024 ? gq : 1024), dim3(256), 0, st, ws.gp2, ws.sorted2,
-               ws.cell_start2, KK, qs2, avg_out, (int32_t *)nullptr, kRingCap, ws.fb2_count, ws.fb2_list,
+               ci2, KK, qs2, avg_out, (int32_t *)nullptr, kRingCap, ws.fb2_count, ws.fb2_list,
                ws.fb2_bound);
   // exhaustive scan for what is left (rare)
   PGDVS_LAUNCH("grid_fallback", grid_fallback_kernel, dim3(4096), dim3(256), 0, st, ws.gp, ws.sorted, KK,

@@ -162,31 +162,42 @@ raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, i
   }
 }
 
-// single-block exclusive scan: offsets[i] = sum_{j<i} counts[j], offsets[n] = total
+// single-block exclusive scan: offsets[i] = sum_{j<i} counts[j], offsets[n] = total.  Eight consecutive counts
+// per thread (1080p: 8160 tiles = one round, one barrier pair)
 __global__ void __launch_bounds__(1024)
 raster_scan_kernel(const int32_t *__restrict__ counts, int n, int32_t *__restrict__ offsets) {
   __shared__ int wave_sums[1024 / kWave];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int start = 0; start < n; start += 1024) {
-    int i = start + threadIdx.x;
-    int v = i < n ? counts[i] : 0;
-    int x = v;
-    for (int off = 1; off < 64; off <<= 1) {
-      int y = __shfl_up(x, off, 64);
-      if ((threadIdx.x & 63) >= off) x += y;
+  constexpr int kPer = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int carry = 0;  // (every thread keeps its own copy)
+  for (int start = 0; start < n; start += 1024 * kPer) {
+    const int i0 = start + (int)threadIdx.x * kPer;
+    int v[kPer], s = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      v[k] = i0 + k < n ? counts[i0 + k] : 0;
+      s += v[k];
     }
-    int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 63) wave_sums[wave] = x;
+    int x = s;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_sums[wave] = x;
     __syncthreads();
-    int wave_off = 0;
-    for (int w = 0; w < wave; ++w) wave_off += wave_sums[w];
-    int incl = carry + wave_off + x;
-    if (i < n) offsets[i] = incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry = incl;
-    __syncthreads();
+    int run = carry + x - s, total = 0;
+#pragma unroll
+    for (int w = 0; w < 1024 / kWave; ++w) {
+      if (w < wave) run += wave_sums[w];
+      total += wave_sums[w];
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      if (i0 + k < n) offsets[i0 + k] = run;
+      run += v[k];
+    }
+    carry += total;
+    __syncthreads();  // wave_sums is rewritten by the next round
   }
   if (threadIdx.x == 0) offsets[n] = carry;
 }

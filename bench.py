@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--no-outlier", action="store_true", help="dyn_pcl_remove_outlier=false (YAML default)")
     ap.add_argument("--inflight", type=int, default=0,
                     help="independent target views rendered concurrently, each on its own HIP stream; 0 (default): "
-                         "measured during warm-up among 3, 6 and 7 (the best count is not monotone: 4 and 8 lose 15 %%)")
+                         "measured during warm-up among 3, 7 and 11 (the best count is not monotone: 4 and 8 lose 10-15 %%)")
     ap.add_argument("--side-stream", action="store_true",
                     help="throughput runs: give every lane a second stream for the dynamic-branch geometry (round 1's "
                          "arrangement, best with --inflight 3); default: one stream per lane")
@@ -269,7 +269,7 @@ def main():
     # Views are independent (the reference shards them over ranks): `inflight` of them are kept
     # in flight per GPU, each on its own (main, side) stream pair, so one view's launch-bound
     # chains fill the gaps of another's.  Every view still runs the complete path.
-    lane_candidates = (3, 6, 7)
+    lane_candidates = (3, 7, 11)
     auto_lanes = args.inflight <= 0
     n_lanes = max(lane_candidates) if auto_lanes else max(1, args.inflight)
     base_run_ahead = args.run_ahead
@@ -450,7 +450,8 @@ def main():
     lanes_note = f"{n_lanes} (--inflight)"
     if auto_lanes:
         # How many views in flight?  Measured, not guessed: throughput is not monotone in the lane count on this
-        # runtime (3: 907, 4: 799, 5: 858, 6: 914, 7: 955, 8: 873, 11: 968 frames/s on one box), so a few counts are
+        # runtime (3: 907, 4: 799, 5: 858, 6: 914, 7: 955, 8: 873, 11: 968 frames/s on one box; later in round 2
+        # 4: 885, 5: 928, 7: 1009, 8: 934, 9: 994, 10: 1021, 11: 1028, 13: 995), so a few counts are
         # timed through the same loop as the headline (a rehearsal first: every lane's allocator pool must exist)
         trial = {}
         for k in lane_candidates:

@@ -60,9 +60,10 @@ def measured_view_traffic(H, W, S):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed views per rank (filling and draining eleven lanes costs a few views: 60 steps measure 1028 frames/s where 200 measure 1076 and 1500 measure 1081)")
     ap.add_argument("--graph-lanes", type=int, default=2, help="views in flight when replaying HIP graphs")
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--frames", type=int, default=24)

@@ -546,3 +546,35 @@ def test_static_aggregation_degenerate_camera_motions_vs_oracle(motion):
     assert np.array_equal(st.view(np.uint32), o.view(np.uint32))
     if motion == "static":  # dedup is total where the frames agree: only what differs between frames is added
         assert st.shape[0] < 2.2 * H * W
+
+
+def test_bench_line_contract_small_workload():
+    """`bench.py` end to end on the GPU at a small size: one JSON line with the driver's fields, the roofline object
+    and the CPU baseline (timed oracle), and the HIP-vs-oracle check of configs[0] inside it"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--height", "96", "--width", "160", "--frames", "4",
+                        "--steps", "12", "--warmup", "3", "--gnt-rays", "0"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    b = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in b, k
+    assert b["n_gpus"] == 1 and b["steps"] == 12 and b["warmup"] == 3 and b["value"] > 0 and b["higher_is_better"] is True
+    assert b["vs_baseline"] is None and b["scaling"] == "weak" and b["data"] == "synthetic" and "workload" in b["config"]
+    assert abs(b["value"] - 1e3 / b["ms_per_step"]) / b["value"] < 0.02
+    rf = b["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = b["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    assert cb["hip_vs_oracle_configs0"]["differing_8bit_values"] == 0

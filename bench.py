@@ -83,7 +83,8 @@ def parse():
     ap.add_argument("--run-ahead", type=int, default=6, help="views the host may have enqueued beyond the last finished one")
     ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
                     help="eager: enqueue every kernel of every view from Python; graph: replay one captured HIP graph "
-                         "per lane; auto: eager unless the host turns out to be the bottleneck during warm-up")
+                         "per lane (--graph-lanes of them, no lane probe); auto: eager, and with "
+                         "PGDVS_BENCH_HOST_BOUND_RATIO=0.85 a replay probe when the host is the bottleneck during warm-up")
     ap.add_argument("--gnt-rays", type=int, default=1024, help="rays of the GNT sub-benchmark chunk (0 = skip)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: exercise the launcher, the view sharding, the per-step gather and the timing "
@@ -272,6 +273,8 @@ def main():
     # chains fill the gaps of another's.  Every view still runs the complete path.
     lane_candidates = (3, 7, 11)
     auto_lanes = args.inflight <= 0
+    if auto_lanes and args.launch == "graph":  # replay: one graph per lane, no lane probe through the graphs
+        auto_lanes, args.inflight = False, max(1, args.graph_lanes)
     n_lanes = max(lane_candidates) if auto_lanes else max(1, args.inflight)
     base_run_ahead = args.run_ahead
     args.run_ahead = max(base_run_ahead, n_lanes + 1)  # the bound must leave every lane a view to work on
@@ -486,7 +489,12 @@ def main():
         # replay can only win when the host is the limit: its enqueue time then fills (nearly) the whole
         # wall time of the probe.  Otherwise no graph is built at all -- building them leaves the process
         # in a state in which eager launches measure ~2 % slower (825-831 against 840-849 frames/s).
-        host_bound = th_e > float(os.environ.get("PGDVS_BENCH_HOST_BOUND_RATIO", "0.85")) * t_eager  # (0 forces the replay probe)
+        # The replay probe is opt-in (PGDVS_BENCH_HOST_BOUND_RATIO, e.g. 0.85; 0 forces it): on a healthy host replay
+        # loses (1.22 against 1.01 ms per view), and graphs are one more thing that can go wrong inside a measurement
+        # (a lane probe run THROUGH graphs built before it faulted on replay: --launch graph now skips that probe;
+        # tools/graph_check.py replays every op of the path on its own).
+        ratio = os.environ.get("PGDVS_BENCH_HOST_BOUND_RATIO")
+        host_bound = ratio is not None and th_e > float(ratio) * t_eager
         if world > 1:
             hb = torch.tensor([1.0 if host_bound else 0.0], dtype=torch.float64, device=dev)
             dist.all_reduce(hb, op=dist.ReduceOp.MAX)
@@ -505,7 +513,8 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
             t_eager, t_graph = float(tt[0].item()) / world, float(tt[1].item()) / world
         probe_note = (f"auto: eager {t_eager / n_try * 1e3:.2f} ms/view with {th_e / n_try * 1e3:.2f} ms of host enqueue, "
-                      + (f"graph replay {t_graph / n_try * 1e3:.2f} ms/view" if host_bound else "host not the limit: no graphs built"))
+                      + (f"graph replay {t_graph / n_try * 1e3:.2f} ms/view" if host_bound else
+                         ("host not the limit: no graphs built" if ratio is not None else "graph replay is opt-in: no graphs built")))
         if graphs is not None and t_graph < 0.97 * t_eager:
             graph_note += f" ({probe_note})"
         else:

@@ -104,19 +104,21 @@ __device__ __forceinline__ void wave_tile_count_lds(int *s_tab, int t) {
   if (r.is_leader && t >= 0) atomicAdd(&s_tab[t], r.length);
 }
 
+// (kSlots: 8192 covers 1080p and gives five workgroups of the fill pass per CU; 16384 for larger images)
+template <int kSlots>
 __global__ void __launch_bounds__(kBinThreads)
 raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_host,
                             const int64_t *__restrict__ n_dev, const float *__restrict__ cam,
                             float radius, int H, int W, int ntx, int nty,
                             int32_t *__restrict__ tile_count) {
-  extern __shared__ int s_tab[];  // one counter per tile (none when the image has more tiles than kBinSlots)
+  __shared__ int s_tab[kSlots];  // one counter per tile (unused when the image has more tiles)
   // a device-side count never exceeds the rows the caller sized the workspace for (and a
   // negative one -- the aggregation's error status -- renders nothing)
   int64_t n = n_dev ? *n_dev : n_host;
   n = n > n_host ? n_host : (n < 0 ? 0 : n);
   RasterCam rc = make_raster_cam(cam, H, W);
   const int ntiles = ntx * nty;
-  const bool local = ntiles <= kBinSlots;
+  const bool local = ntiles <= kSlots;
   if (local) {
     for (int t = threadIdx.x; t < ntiles; t += kBinThreads) s_tab[t] = 0;
     __syncthreads();
@@ -220,13 +222,14 @@ __device__ __forceinline__ int wave_tile_reserve_lds(int *s_tab, int t) {
   return base + (lane - r.leader);
 }
 
+template <int kSlots>
 __global__ void __launch_bounds__(kFillThreads)
 raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_host, const int64_t *__restrict__ n_dev,
                    const float *__restrict__ cam, float radius, int H, int W, int ntx, int nty,
                    const int32_t *__restrict__ offsets,
                    int32_t *__restrict__ cursor, float4 *__restrict__ lists,
                    int64_t list_capacity) {
-  extern __shared__ int s_tab[];  // one counter per tile (none on the slow path)
+  __shared__ int s_tab[kSlots];  // one counter per tile (unused on the slow path)
   // a device-side count never exceeds the rows the caller sized the workspace for (and a
   // negative one -- the aggregation's error status -- renders nothing)
   int64_t n = n_dev ? *n_dev : n_host;
@@ -236,7 +239,7 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
   // tile boxes of at most 2 x 2 tiles (disc diameter + margins within one tile side) and a table that holds
   // every tile: otherwise the entries are appended one run of lanes at a time
   const float rpx = radius * (float)W / rc.range_x + 0.0625f, rpy = radius * (float)H / rc.range_y + 0.0625f;
-  const bool local = ntiles <= kBinSlots && 2.0f * rpx + 2.0f < (float)kTile && 2.0f * rpy + 2.0f < (float)kTile;
+  const bool local = ntiles <= kSlots && 2.0f * rpx + 2.0f < (float)kTile && 2.0f * rpy + 2.0f < (float)kTile;
   constexpr int64_t kChunk = (int64_t)kFillThreads * kFillPer;
   for (int64_t c0 = (int64_t)blockIdx.x * kChunk; c0 < n; c0 += (int64_t)gridDim.x * kChunk) {
     int t0[kFillPer], span[kFillPer];
@@ -849,18 +852,28 @@ PGDVS_API int pgdvs_points_raster(const float *pts, int64_t pts_stride, const fl
     set_error("points_raster memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
   }
-  const size_t lds = ntiles <= kBinSlots ? (size_t)ntiles * 4 : 4;  // the binning kernels' table of tile counters
+  const bool small_table = ntiles <= kBinSlots / 2;  // the binning kernels' table of tile counters: 32 KB or 64 KB
   if (n_points > 0) {
     unsigned g = (unsigned)(cdiv(n_points, kBinThreads) < 512 ? cdiv(n_points, kBinThreads) : 512);
-    PGDVS_LAUNCH("raster_project_count", raster_project_count_kernel, dim3(g), dim3(kBinThreads), lds, st, pts, pts_stride,
-                       n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count);
+    if (small_table) {
+      PGDVS_LAUNCH("raster_project_count", raster_project_count_kernel<kBinSlots / 2>, dim3(g), dim3(kBinThreads), 0, st, pts,
+                   pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count);
+    } else {
+      PGDVS_LAUNCH("raster_project_count", raster_project_count_kernel<kBinSlots>, dim3(g), dim3(kBinThreads), 0, st, pts,
+                   pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count);
+    }
   }
   PGDVS_LAUNCH("raster_scan", raster_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_count, ntiles, ws.offsets);
   if (n_points > 0) {
     const int64_t chunks = cdiv(n_points, (int64_t)kFillThreads * kFillPer);
     unsigned g = (unsigned)(chunks < 4096 ? chunks : 4096);
-    PGDVS_LAUNCH("raster_fill", raster_fill_kernel, dim3(g), dim3(kFillThreads), lds, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
+    if (small_table) {
+      PGDVS_LAUNCH("raster_fill", raster_fill_kernel<kBinSlots / 2>, dim3(g), dim3(kFillThreads), 0, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
                        radius, H, W, ntx, nty, ws.offsets, ws.cursor, ws.lists, ws.list_capacity);
+    } else {
+      PGDVS_LAUNCH("raster_fill", raster_fill_kernel<kBinSlots>, dim3(g), dim3(kFillThreads), 0, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
+                       radius, H, W, ntx, nty, ws.offsets, ws.cursor, ws.lists, ws.list_capacity);
+    }
   }
   const int tiles_per_xcd = (int)cdiv(ntiles, 8);
   dim3 grid(8 * tiles_per_xcd);

@@ -246,7 +246,7 @@ constexpr int kPushThreads = 256;
 constexpr int kPushMaxTiles = 2048;  // selection tiles a push workgroup can scan itself (16.7 M pixels); more: ordered selection
 // points with frames the fp32 form could not decide, queued per workgroup: 1024 entries for frame 0's chip-filling
 // launch (drained every fourth round); 512 (every second round) for the later frames, whose launches are a few
-// rounds long and fit into the LDS the other views' rasteriser workgroups leave free (12 KB per CU)
+// rounds long
 constexpr int kPushQueue = 1024;
 constexpr int kPushQueueSmall = 512;
 constexpr int kPushMaxFpg = 32;    // frames per workgroup row (one bit each in a queue entry)
@@ -263,7 +263,7 @@ agg_push_kernel(const float *__restrict__ xyz, int64_t *cnts, int src,
                 const int32_t *__restrict__ tile_cnt, int tiles, int64_t capacity, AppendSrc app, CamBlock cam) {
   __shared__ uint4 s_q[kQueue];
   __shared__ int s_qn;
-  extern __shared__ int s_pref[];  // listed selection: pixels selected before each tile of the frame, [tiles + 1]
+  __shared__ int s_pref[kPushMaxTiles + 1];  // listed selection: pixels selected before each tile of the frame
   __shared__ int s_wsum[kPushThreads / kWave];
   int64_t begin = cnts[src], end;
   if (tile_cnt != nullptr) {
@@ -862,8 +862,7 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
                      (const float *)ws.xyz, ws.cnts, i, (const ProjF64 *)ws.proj, i + 1, S, fpg_i, H, W, ws.occ,
                      (const int32_t *)nullptr, (const int32_t *)nullptr, tiles, capacity, app, cams[(size_t)i]);
       } else {
-        const size_t lds = listed ? ((size_t)tiles + 1) * 4 : 0;
-        PGDVS_LAUNCH("agg_push", agg_push_kernel<kPushQueueSmall>, dim3(gx, (unsigned)groups), dim3(kPushThreads), lds, st,
+        PGDVS_LAUNCH("agg_push", agg_push_kernel<kPushQueueSmall>, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
                      (const float *)ws.xyz, ws.cnts, i, (const ProjF64 *)ws.proj, i + 1, S, fpg_i, H, W, ws.occ,
                      (const int32_t *)ws.sel_pix, (const int32_t *)(listed ? ws.tile_cnt : nullptr), tiles, capacity, app,
                      cams[(size_t)i]);

@@ -62,7 +62,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200,
                     help="timed views per rank (filling and draining eleven lanes costs a few views: 60 steps measure 1028 frames/s where 200 measure 1076 and 1500 measure 1081)")
-    ap.add_argument("--graph-lanes", type=int, default=2, help="views in flight when replaying HIP graphs")
+    ap.add_argument("--graph-lanes", type=int, default=7,
+                    help="views in flight when replaying HIP graphs (2: 853, 4: 885, 7: 1000, 11: 1017 frames/s; eager: 1055-1075)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
@@ -329,8 +330,7 @@ def main():
         try:
             from pgdvs_amd.runtime import GraphedRender
 
-            # (replay runs best with two views in flight -- 741 vs 671 frames/s with three: the
-            # captured fork/join structure already keeps both of a view's branches busy)
+            # (one graph per lane; with single-stream lanes replay gains from more of them like eager launches do)
             graphs = [GraphedRender(lambda d, side=side: render_view(d, side), views[0],
                                     stream=main if main is not None else torch.cuda.Stream(device=dev))
                       for main, side in lanes[:max(1, min(n_lanes, args.graph_lanes))]]

@@ -84,8 +84,8 @@ def parse():
     ap.add_argument("--run-ahead", type=int, default=6, help="views the host may have enqueued beyond the last finished one")
     ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
                     help="eager: enqueue every kernel of every view from Python; graph: replay one captured HIP graph "
-                         "per lane (--graph-lanes of them, no lane probe); auto: eager, and with "
-                         "PGDVS_BENCH_HOST_BOUND_RATIO=0.85 a replay probe when the host is the bottleneck during warm-up")
+                         "per lane (--graph-lanes of them, no lane probe); auto: eager unless the host turns out to be "
+                         "the bottleneck during warm-up (then a replay probe decides)")
     ap.add_argument("--gnt-rays", type=int, default=1024, help="rays of the GNT sub-benchmark chunk (0 = skip)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: exercise the launcher, the view sharding, the per-step gather and the timing "
@@ -489,12 +489,11 @@ def main():
         # replay can only win when the host is the limit: its enqueue time then fills (nearly) the whole
         # wall time of the probe.  Otherwise no graph is built at all -- building them leaves the process
         # in a state in which eager launches measure ~2 % slower (825-831 against 840-849 frames/s).
-        # The replay probe is opt-in (PGDVS_BENCH_HOST_BOUND_RATIO, e.g. 0.85; 0 forces it): on a healthy host replay
-        # loses (1.22 against 1.01 ms per view), and graphs are one more thing that can go wrong inside a measurement
-        # (a lane probe run THROUGH graphs built before it faulted on replay: --launch graph now skips that probe;
-        # tools/graph_check.py replays every op of the path on its own).
-        ratio = os.environ.get("PGDVS_BENCH_HOST_BOUND_RATIO")
-        host_bound = ratio is not None and th_e > float(ratio) * t_eager
+        # (PGDVS_BENCH_HOST_BOUND_RATIO: 0 forces the replay probe, 2 switches it off.  A lane probe run THROUGH
+        # graphs built before it faulted on replay: graphs are only built here, after the lane count is settled, and
+        # --launch graph skips the lane probe; tools/graph_check.py replays every op of the path on its own.)
+        ratio = os.environ.get("PGDVS_BENCH_HOST_BOUND_RATIO", "0.85")
+        host_bound = th_e > float(ratio) * t_eager
         if world > 1:
             hb = torch.tensor([1.0 if host_bound else 0.0], dtype=torch.float64, device=dev)
             dist.all_reduce(hb, op=dist.ReduceOp.MAX)
@@ -514,7 +513,7 @@ def main():
             t_eager, t_graph = float(tt[0].item()) / world, float(tt[1].item()) / world
         probe_note = (f"auto: eager {t_eager / n_try * 1e3:.2f} ms/view with {th_e / n_try * 1e3:.2f} ms of host enqueue, "
                       + (f"graph replay {t_graph / n_try * 1e3:.2f} ms/view" if host_bound else
-                         ("host not the limit: no graphs built" if ratio is not None else "graph replay is opt-in: no graphs built")))
+                         "host not the limit: no graphs built"))
         if graphs is not None and t_graph < 0.97 * t_eager:
             graph_note += f" ({probe_note})"
         else:

@@ -238,11 +238,19 @@ def main():
     if args.dry_run:
         return dry_main(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    # test hook (tests/test_gpu_round2.py): every rank on GPU 0 with gloo moving the device tensors, so that the
+    # N-rank code of this file (lane agreement, per-step gather, max-over-ranks timing) runs on a 1-GPU box
+    shared_gpu_test = os.environ.get("PGDVS_BENCH_SHARED_GPU_TEST") == "1"
+    if shared_gpu_test:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if shared_gpu_test:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == args.gpus, f"world size {dist.get_world_size()} != --gpus {args.gpus}"
 
     from pgdvs_amd import _lib, dist as pdist, ops, synth

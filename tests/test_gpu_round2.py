@@ -578,3 +578,34 @@ def test_bench_line_contract_small_workload():
         assert k in cb, k
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
     assert cb["hip_vs_oracle_configs0"]["differing_8bit_values"] == 0
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """the N-rank code of bench.py's real main (lane count agreed through an all-reduce, per-step asynchronous
+    gather of the images to rank 0, barrier + max-over-ranks timing, per-rank rates) with two ranks sharing this
+    box's GPU: PGDVS_BENCH_SHARED_GPU_TEST=1 puts every rank on GPU 0 and lets gloo move the device tensors (RCCL
+    refuses two ranks on one device); launched the way the driver launches N > 1"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PGDVS_BENCH_SHARED_GPU_TEST="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--height", "96",
+                        "--width", "160", "--frames", "4", "--steps", "10", "--warmup", "3", "--gnt-rays", "0",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]  # rank 0 alone prints
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["steps"] == 10 and b["scaling"] == "weak" and b["value"] > 0
+    per_rank = b["config"]["per_rank_frames_per_s"]
+    assert len(per_rank) == 2 and all(x > 0 for x in per_rank)
+    assert b["config"]["gather_bytes_to_rank0"] == 3 * 96 * 160 * 4 * 10
+    assert abs(b["value"] - 2 * 1e3 / b["ms_per_step"]) / b["value"] < 0.02  # whole-job rate: both ranks' views / max time

@@ -86,10 +86,11 @@ __device__ __forceinline__ bool trunc_div_in_range(double a, double b, double r,
 // per-frame projection constants live in the workspace (written by agg_params_kernel): the
 // marking kernel keeps only the screening form of its frames in registers and reads the
 // reference form through this pointer in the rare doubtful case
-constexpr int kProjChunk = 6;  // (kernel arguments are limited to 4 KB)
+constexpr int kProjChunk = 10;  // (kernel arguments are limited to 4 KB)
 struct ProjChunk {
   ProjF64 p[kProjChunk];
 };
+static_assert(sizeof(ProjChunk) + 32 <= 4096, "agg_params_kernel's arguments");
 
 __global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, int first, int n) {
   const int words = (int)(sizeof(ProjF64) / 4);

@@ -1289,13 +1289,15 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
         tpq = false;
     }
   }
+  const char *erc = getenv("PGDVS_KNN_RING_CAP");  // tuning knob (any value >= 1 gives exact results)
+  const int ring_cap_after_tpq = erc && atoi(erc) >= 1 ? atoi(erc) : kRingCapAfterTpq;
   QuerySrc qs1 = qs;
   if (tpq) {  // the ring search only sees what the first pass left open
     qs1.list = ws.open_list;
     qs1.list_count = ws.open_count;
   }
   PGDVS_LAUNCH("grid_query", grid_query_kernel, dim3(tpq ? (gq < 256 ? gq : 256) : gq), dim3(256), 0, st, ws.gp,
-               ws.sorted, ci, KK, qs1, avg_out, stats, tpq ? kRingCapAfterTpq : kRingCap, ws.fb_count, ws.fb_list,
+               ws.sorted, ci, KK, qs1, avg_out, stats, tpq ? ring_cap_after_tpq : kRingCap, ws.fb_count, ws.fb_list,
                ws.fb_bound);
   // Second level: the queries still open after kRingCap rings (isolated points, far from
   // everything in units of the cell size) repeat the ring search on a grid with

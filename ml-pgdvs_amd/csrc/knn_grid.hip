@@ -1296,7 +1296,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
     qs1.list = ws.open_list;
     qs1.list_count = ws.open_count;
   }
-  PGDVS_LAUNCH("grid_query", grid_query_kernel, dim3(tpq ? (gq < 256 ? gq : 256) : gq), dim3(256), 0, st, ws.gp,
+  PGDVS_LAUNCH("grid_query", grid_query_kernel, dim3(tpq ? (gq < 512 ? gq : 512) : gq), dim3(256), 0, st, ws.gp,
                ws.sorted, ci, KK, qs1, avg_out, stats, tpq ? ring_cap_after_tpq : kRingCap, ws.fb_count, ws.fb_list,
                ws.fb_bound);
   // Second level: the queries still open after kRingCap rings (isolated points, far from

@@ -54,6 +54,8 @@ struct ProjF64 {
   // fp32 screening form of the same M: |s_k - S_k| <= e32[k] * max(|x|,|y|,|z|,1) for the fp32 FMA
   // evaluation s_k of row k (4.5 x 2^-24 x the row sum of |M|: entries rounded to fp32, three fused
   // multiply-adds), with the fp64 form's own tolerance folded in
+  // (stored with rows 0 and 1 interleaved -- M00 M10 M01 M11 M02 M12 M03 M13, then row 2 -- so that one scalar load
+  // leaves the pairs of the two-wide FMAs in aligned SGPR pairs)
   float M32[12];
   float e32[3];
   int screen32;
@@ -168,8 +170,9 @@ __device__ __attribute__((noinline)) void mark_fp64(const ProjF64 *__restrict__ 
 }
 
 // the fp32 screening constants of one frame, copied out of its ProjF64 record
+typedef float f2v __attribute__((ext_vector_type(2)));
 struct PushConsts {
-  float M[12];
+  float M[12];  // in ProjF64::M32's order: (row 0, row 1) column pairs, then row 2
   float e[3];
   int screen32;
 };
@@ -353,13 +356,15 @@ agg_push_kernel(const float *__restrict__ xyz, int64_t *cnts, int src,
     }
     const float amax = fmaxf(fmaxf(fabsf(x), fabsf(y)), fmaxf(fabsf(z), 1.0f));
     unsigned dmask = 0;
-    // (the constants of frame f+1 are requested while frame f is evaluated: scalar loads, wave-uniform)
-    PushConsts c = load_push_consts(proj + fa);
-    for (int f = fa; f < fb; ++f) {
-      const PushConsts cn = load_push_consts(proj + (f + 1 < fb ? f + 1 : f));
+    // One frame: fp32 screening of the projection, stamp or doubt bit.
+    auto frame = [&](const int f, const PushConsts &c) {
       const float *M = c.M;
-      const float s0 = __builtin_fmaf(M[0], x, __builtin_fmaf(M[1], y, __builtin_fmaf(M[2], z, M[3])));
-      const float s1 = __builtin_fmaf(M[4], x, __builtin_fmaf(M[5], y, __builtin_fmaf(M[6], z, M[7])));
+      // rows 0 and 1 as one two-wide FMA chain (v_pk_fma_f32 on the SGPR pairs as loaded: the scalar unit, one per
+      // CU, was as busy as the vector pipes re-pairing the constants); the same three fused multiply-adds per row
+      const f2v p0 = {M[0], M[1]}, p1 = {M[2], M[3]}, p2 = {M[4], M[5]}, p3 = {M[6], M[7]};
+      const f2v xx = {x, x}, yy = {y, y}, zz = {z, z};
+      const f2v s01 = __builtin_elementwise_fma(p0, xx, __builtin_elementwise_fma(p1, yy, __builtin_elementwise_fma(p2, zz, p3)));
+      const float s0 = s01.x, s1 = s01.y;
       const float s2 = __builtin_fmaf(M[8], x, __builtin_fmaf(M[9], y, __builtin_fmaf(M[10], z, M[11])));
       const float r = __builtin_amdgcn_rcpf(s2);  // v_rcp_f32: 1 ulp
       const float qx = s0 * r, qy = s1 * r;
@@ -376,8 +381,19 @@ agg_push_kernel(const float *__restrict__ xyz, int64_t *cnts, int src,
       const bool inr = (qx >= 0.0f) & (qx <= wm1) & (qy >= 0.0f) & (qy <= hm1);
       if (live & small & !outside & clear & inr) occ_all[(int64_t)f * P + (int64_t)(int)qy * W + (int)qx] = 1;
       const bool doubt = live & !(small & (outside | clear));
-      c = cn;
       dmask |= (doubt ? 1u : 0u) << (f - fa);
+    };
+    // Two frames per trip with two sets of constants: each set is requested (scalar loads, wave-uniform) while the
+    // other frame is evaluated and lands in its own registers -- a single set renamed per frame cost ~14 scalar
+    // moves per projection.
+    PushConsts ca = load_push_consts(proj + fa);
+    for (int f = fa; f < fb; f += 2) {
+      const PushConsts cb = load_push_consts(proj + (f + 1 < fb ? f + 1 : f));
+      frame(f, ca);
+      if (f + 1 < fb) {
+        ca = load_push_consts(proj + (f + 2 < fb ? f + 2 : f + 1));
+        frame(f + 1, cb);
+      }
     }
     // the (point, frame) pairs the fp32 form could not decide: one queue entry per point (the point itself and a
     // frame bitmask)
@@ -771,8 +787,10 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
         // float conversions round up
         bool ok32 = pj.screen != 0;
         for (int k = 0; k < 12; ++k) {
-          pj.M32[k] = (float)pj.M[k];
-          ok32 = ok32 && std::isfinite(pj.M32[k]);
+          // k = row * 4 + column -> interleaved position of rows 0 / 1, row 2 behind them
+          const int pos = k < 8 ? (k & 3) * 2 + (k >> 2) : k;
+          pj.M32[pos] = (float)pj.M[k];
+          ok32 = ok32 && std::isfinite(pj.M32[pos]);
         }
         for (int r = 0; r < 3; ++r) {
           double rowsum = 0.0;

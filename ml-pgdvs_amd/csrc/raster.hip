@@ -92,6 +92,12 @@ __device__ __forceinline__ int wave_max_i32_scalar(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// the tile box of every point spans at most 2 x 2 tiles: disc diameter + the margins of tile_box within one tile side
+__device__ __forceinline__ bool tile_box_within_2x2(const RasterCam &rc, float radius, int H, int W) {
+  const float rpx = radius * (float)W / rc.range_x + 0.0625f, rpy = radius * (float)H / rc.range_y + 0.0625f;
+  return 2.0f * rpx + 2.0f < (float)kTile && 2.0f * rpy + 2.0f < (float)kTile;
+}
+
 // Binning, pass 1: entries per tile.  A workgroup takes one contiguous chunk of the cloud (a few rows of
 // one source frame: a few hundred tiles) and counts into an LDS table first, so that a tile costs the
 // chunk one global atomic instead of one per run of lanes.  Images with more tiles than the table holds
@@ -119,6 +125,7 @@ raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, i
   RasterCam rc = make_raster_cam(cam, H, W);
   const int ntiles = ntx * nty;
   const bool local = ntiles <= kSlots;
+  const bool box2 = tile_box_within_2x2(rc, radius, H, W);
   if (local) {
     for (int t = threadIdx.x; t < ntiles; t += kBinThreads) s_tab[t] = 0;
     __syncthreads();
@@ -144,7 +151,13 @@ raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, i
       float3 p = point_to_ndc(rc, cur[0], cur[1], cur[2]);
       b = tile_box(rc, p, radius, H, W, ntx, nty);
     }
-    int nx = wave_max_i32_scalar(b.tx1 - b.tx0 + 1), ny = wave_max_i32_scalar(b.ty1 - b.ty0 + 1);
+    // (a disc narrower than a tile side touches at most 2 x 2 tiles: four fixed rounds instead of two wave-wide
+    // maxima -- 2 x 26 instructions, as many as the projection -- to find the round count)
+    int nx = 2, ny = 2;
+    if (!box2) {
+      nx = wave_max_i32_scalar(b.tx1 - b.tx0 + 1);
+      ny = wave_max_i32_scalar(b.ty1 - b.ty0 + 1);
+    }
     for (int jy = 0; jy < ny; ++jy)
       for (int jx = 0; jx < nx; ++jx) {
         int tx = b.tx0 + jx, ty = b.ty0 + jy;
@@ -238,8 +251,7 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
   const int ntiles = ntx * nty;
   // tile boxes of at most 2 x 2 tiles (disc diameter + margins within one tile side) and a table that holds
   // every tile: otherwise the entries are appended one run of lanes at a time
-  const float rpx = radius * (float)W / rc.range_x + 0.0625f, rpy = radius * (float)H / rc.range_y + 0.0625f;
-  const bool local = ntiles <= kSlots && 2.0f * rpx + 2.0f < (float)kTile && 2.0f * rpy + 2.0f < (float)kTile;
+  const bool local = ntiles <= kSlots && tile_box_within_2x2(rc, radius, H, W);
   constexpr int64_t kChunk = (int64_t)kFillThreads * kFillPer;
   for (int64_t c0 = (int64_t)blockIdx.x * kChunk; c0 < n; c0 += (int64_t)gridDim.x * kChunk) {
     int t0[kFillPer], span[kFillPer];
@@ -278,13 +290,11 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
       unsigned rank[kFillPer][kFillMaxSpan];  // two 16-bit ranks per word: [u][jy] holds jx = 0, 1
 #pragma unroll
       for (int u = 0; u < kFillPer; ++u) {
-        const int nx = wave_max_i32_scalar(span[u] & 0xffff), ny = wave_max_i32_scalar(span[u] >> 16);
 #pragma unroll
         for (int jy = 0; jy < kFillMaxSpan; ++jy) {
           rank[u][jy] = 0;
 #pragma unroll
           for (int jx = 0; jx < kFillMaxSpan; ++jx) {
-            if (jy >= ny || jx >= nx) continue;  // uniform
             const int t = (jx < (span[u] & 0xffff) && jy < (span[u] >> 16)) ? t0[u] + jy * ntx + jx : -1;
             rank[u][jy] |= ((unsigned)wave_tile_reserve_lds(s_tab, t) & 0xffffu) << (16 * jx);  // < kChunk <= 65536
           }

@@ -397,7 +397,9 @@ template <int K>
 __device__ __forceinline__ void rank_insert(float (&key)[K], float r) {
 #pragma unroll
   for (int k = K - 1; k > 0; --k) key[k] = __builtin_amdgcn_fmed3f(key[k - 1], key[k], r);
-  key[0] = __builtin_amdgcn_fmed3f(key[0], r, -__builtin_inff());  // min without the NaN canonicalisation of fminf
+  // min(key[0], r) as ONE instruction: fminf -- and the median with -inf, which LLVM folds into it -- first
+  // canonicalises both operands (v_max_f32 x, x); neither is ever NaN here (ranks or +inf)
+  asm("v_min_f32 %0, %1, %2" : "=v"(key[0]) : "v"(key[0]), "v"(r));
 }
 
 template <int K>

@@ -858,7 +858,9 @@ template <int KK>
 __device__ __forceinline__ void tpq_insert(float (&a)[KK], float c) {
 #pragma unroll
   for (int i = KK - 1; i > 0; --i) a[i] = __builtin_amdgcn_fmed3f(a[i - 1], a[i], c);
-  a[0] = __builtin_fminf(a[0], c);
+  // (one instruction: fminf canonicalises both operands first; neither is NaN here -- a NaN distance never passes
+  // the `d < mx` test that feeds the queue)
+  asm("v_min_f32 %0, %1, %2" : "=v"(a[0]) : "v"(a[0]), "v"(c));
 }
 
 template <int KK>

@@ -912,7 +912,11 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
 #pragma unroll
   for (int u = 0; u < kTpqQueue; ++u) qd[u] = __builtin_inff();
   int qc = 0;
-  int k = -1, j = 0, e = 0;
+  int k = -1;
+  // the lane's current run as BYTE offsets into `sorted` (16 bytes per point; the host takes this pass only below
+  // 2^27 points): the load then takes scalar base + 32-bit vector offset as it stands -- no sign extension, no
+  // 64-bit shift-add per candidate
+  unsigned j = 0u, e = 0u;
   // Two candidate buffers: each half-step requests a candidate into one buffer -- for every lane,
   // unconditionally, from a clamped index, so that no exec-masked move forces a wait right
   // behind the load -- and evaluates the candidate the previous half-step requested into the
@@ -925,13 +929,13 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
       ++k;
       if (k < 9) {
         const int2 se = s_run[k][tid];
-        j = se.x;
-        e = s_bd[k][tid] < mx ? se.y : se.x;  // no point of the run can enter the list: skip it
+        j = (unsigned)se.x * 16u;
+        e = s_bd[k][tid] < mx ? (unsigned)se.y * 16u : j;  // no point of the run can enter the list: skip it
       }
     }
     v_issue = j < e;
-    c_issue = sorted[v_issue ? j : 0];
-    j += v_issue ? 1 : 0;
+    c_issue = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sorted) + (size_t)(v_issue ? j : 0u));
+    j += v_issue ? 16u : 0u;
     if (v_use) {
       const float d = dist2(qx, qy, qz, c_use);
       if (d < mx) {  // (stale threshold: a candidate that no longer qualifies lands beyond column K)
@@ -1272,7 +1276,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   int32_t *stats = (env && env[0] == '1') ? ws.stats : nullptr;
   const unsigned gq = (unsigned)(cdiv(nq_cap, 4) < 256 * 8 ? (cdiv(nq_cap, 4) > 0 ? cdiv(nq_cap, 4) : 1) : 256 * 8);
   const char *no_tpq = getenv("PGDVS_KNN_NO_TPQ");  // diagnostics: force the wavefront-per-query search
-  bool tpq = qpts == nullptr && !(no_tpq && no_tpq[0] == '1');
+  bool tpq = qpts == nullptr && !(no_tpq && no_tpq[0] == '1') && capacity < (1ll << 27);  // (32-bit byte offsets)
   if (tpq) {
     const unsigned gt = (unsigned)(cdiv(capacity, 256) < 2560 ? (cdiv(capacity, 256) > 0 ? cdiv(capacity, 256) : 1) : 2560);
     switch (KK) {

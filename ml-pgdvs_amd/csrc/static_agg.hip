@@ -5,20 +5,26 @@
 // Upstream this is single-threaded numpy at dataset construction.  Frame i may only add
 // the static pixels that the cloud accumulated from frames < i does not already cover
 // (integer-truncated projection occupancy), so frames are processed in order; inside a
-// frame everything is data-parallel.  Two launches per frame:
-//   select : one pass over the frame's pixels that counts the selected ones (static && not
-//            occupied), turns the per-tile counts into ordered offsets inside the same launch
-//            (tagged 8-byte count granules gathered from all predecessor tiles, dynamic tile
-//            tickets for forward progress) and appends the unprojected (xyz,rgb) rows in
-//            row-major pixel order -- the order numpy's boolean indexing produces (point ids
-//            matter: the rasteriser breaks z ties by id).  Frames >= 1 (a few per cent of the pixels
-//            each, 2(S-1) launches of pure latency) only leave tile-local pixel lists and counts
-//            (agg_select_list_kernel); their push launch makes the offsets and builds the rows.
-//   push   : the points frame i just appended are projected into EVERY later frame and stamp
-//            that frame's own occupancy map (one byte per pixel and frame, zeroed per call), so no
-//            point is ever projected into the same frame twice and the cloud is not re-read per
-//            frame.  Frame 0's launch carries ~3/4 of all projections and fills the chip; the later
-//            ones are a few microseconds each.
+// frame everything is data-parallel.
+//   frame 0  : `select` appends every static pixel (count, ordered offsets inside the launch: tagged
+//            8-byte count granules gathered from all predecessor tiles, dynamic tile tickets for forward
+//            progress; rows in row-major pixel order -- the order numpy's boolean indexing produces; point
+//            ids matter: the rasteriser breaks z ties by id), `push0` projects those points ONCE into every
+//            later frame and stamps that frame's own occupancy map (one byte per pixel and frame, zeroed
+//            per call).  This launch carries ~3/4 of all projections and fills the chip.
+//   step i   : ONE launch per later frame (i = 1 .. S-1), a latency chain of S-1 links: a workgroup reads its
+//            share of the frame's mask and of the frame's own occupancy map (complete: every earlier frame has
+//            stamped it), lists the selected pixels in LDS, leaves their selection BITS for the end, unprojects
+//            them and stamps the maps of the frames behind.  Neither order nor offsets exist inside the chain
+//            (round 2: a selection launch that listed the pixels tile by tile + a push launch that scanned the
+//            tile counts, built the rows and stamped: 3 + 11 us per frame; now 7.6):
+//   rows     : at the end the selection bits of all later frames are counted per (frame, tile) and ONE
+//            chip-filling launch builds their rows in the reference's order.
+//            (Tried first: candidate bits cleared by memory-side atomic AND instead of occupancy bytes -- an eighth
+//            of the map bytes, but a wavefront's 64 clears fall on scattered dwords of one or two bit rows, and
+//            the atomic units take such an instruction lane by lane: 88 us per link.)
+//   (PGDVS_AGG_ORDERED=1 keeps round 2's chain -- per frame an ordered selection and a byte-stamping push
+//   that also builds the rows -- as an independent second implementation for the tests.)
 //            numpy projects in fp64 (no z>0 test, no epsilon, closed bounds, astype(int)
 //            truncation).  Decisions only change where a quotient crosses an integer, so a cheap
 //            evaluation decides whenever its rigorous error bound keeps the quotient away from
@@ -94,16 +100,30 @@ struct ProjChunk {
 };
 static_assert(sizeof(ProjChunk) + 32 <= 4096, "agg_params_kernel's arguments");
 
-__global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, int first, int n) {
+struct PushConsts;
+__global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, float *__restrict__ pc32, int first, int n) {
   const int words = (int)(sizeof(ProjF64) / 4);
   for (int k = threadIdx.x; k < n * words; k += blockDim.x)
     reinterpret_cast<uint32_t *>(dst + first)[k] = reinterpret_cast<const uint32_t *>(&c.p[0])[k];
+  // the fp32 screening record (PushConsts: M32[12], e32[3], pad), 16 floats per frame
+  for (int k = threadIdx.x; k < n * 16; k += blockDim.x) {
+    const ProjF64 &pj = c.p[k >> 4];
+    const int j = k & 15;
+    pc32[(size_t)(first + (k >> 4)) * 16 + j] = j < 12 ? pj.M32[j] : (j < 15 ? (pj.screen32 ? pj.e32[j - 12] : INFINITY) : 0.0f);
+  }
 }
 
 // _compute_pcl_proj_mask, nvidia_eval_pure_geo.py:257-277 in the reference operation order (no
 // z>0 test, no epsilon, closed bounds, astype(int) truncation)
+// How a decided projection marks pixel q = row * W + col of frame f.
+struct ByteStamp {  // one occupancy byte per (frame, pixel): frame 0's chip-filling push (coalesced byte stores)
+  uint8_t *occ_all;
+  int64_t P;
+  __device__ __forceinline__ void operator()(int f, int q) const { occ_all[(int64_t)f * P + q] = 1; }
+};
+template <class Stamp>
 __device__ __attribute__((noinline)) void mark_reference_order(const ProjF64 *__restrict__ pj, double x, double y,
-                                                               double z, int H, int W, uint8_t *__restrict__ occ) {
+                                                               double z, int H, int W, int f, const Stamp &stamp) {
   double vc[4];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -141,13 +161,14 @@ __device__ __attribute__((noinline)) void mark_reference_order(const ProjF64 *__
   const double rz = refined_rcp(pp[2]);
   if (!trunc_div_in_range(pp[1], pp[2], rz, H - 1, row)) return;
   if (!trunc_div_in_range(pp[0], pp[2], rz, W - 1, col)) return;
-  occ[(int64_t)row * W + col] = 1;
+  stamp(f, row * W + col);
 }
 
 // fp64 decision for one (point, frame): the screening form M = K3 . w2c decides unless a quotient lies
 // within its rounding distance of an integer; then the reference operation order does
+template <class Stamp>
 __device__ __attribute__((noinline)) void mark_fp64(const ProjF64 *__restrict__ pj, float xf, float yf, float zf, int H,
-                                                    int W, uint8_t *__restrict__ occ) {
+                                                    int W, int f, const Stamp &stamp) {
   const double x = (double)xf, y = (double)yf, z = (double)zf;
   if (pj->screen) {
     const double *M = pj->M;
@@ -162,29 +183,21 @@ __device__ __attribute__((noinline)) void mark_fp64(const ProjF64 *__restrict__ 
     const double dx = fmin(qx - fx, (fx + 1.0) - qx), dy = fmin(qy - fy, (fy + 1.0) - qy);
     // (false for NaN / inf as well: those take the reference path)
     if (dx > tol * (1.0 + fabs(qx)) && dy > tol * (1.0 + fabs(qy))) {
-      if (qy >= 0.0 && qy <= (double)(H - 1) && qx >= 0.0 && qx <= (double)(W - 1)) occ[(int64_t)(int)qy * W + (int)qx] = 1;
+      if (qy >= 0.0 && qy <= (double)(H - 1) && qx >= 0.0 && qx <= (double)(W - 1)) stamp(f, (int)qy * W + (int)qx);
       return;
     }
   }
-  mark_reference_order(pj, x, y, z, H, W, occ);
+  mark_reference_order(pj, x, y, z, H, W, f, stamp);
 }
 
-// the fp32 screening constants of one frame, copied out of its ProjF64 record
+// the fp32 screening constants of one frame: a 64-byte record of its own (one s_load_dwordx16, indexed by a shift)
 typedef float f2v __attribute__((ext_vector_type(2)));
 struct PushConsts {
   float M[12];  // in ProjF64::M32's order: (row 0, row 1) column pairs, then row 2
-  float e[3];
-  int screen32;
+  float e[3];   // +inf when the frame has no fp32 screening form: every projection is then undecided
+  float pad;
 };
-__device__ __forceinline__ PushConsts load_push_consts(const ProjF64 *__restrict__ pj) {
-  PushConsts c;
-#pragma unroll
-  for (int k = 0; k < 12; ++k) c.M[k] = pj->M32[k];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) c.e[k] = pj->e32[k];
-  c.screen32 = pj->screen32;
-  return c;
-}
+static_assert(sizeof(PushConsts) == 64, "PushConsts");
 
 // One row of the cloud from pixel p of a frame: unprojection exactly as _compute_pcl (fp32, fixed operation
 // order), (xyz, rgb) to the cloud and the packed xyz copy; returns the point.  Shared by the selection of
@@ -247,7 +260,6 @@ constexpr int kSelThreads = 512;
 constexpr int kSelItems = 16;
 constexpr int kSelTile = kSelThreads * kSelItems;
 constexpr int kPushThreads = 256;
-constexpr int kPushMaxTiles = 2048;  // selection tiles a push workgroup can scan itself (16.7 M pixels); more: ordered selection
 // points with frames the fp32 form could not decide, queued per workgroup: 1024 entries for frame 0's chip-filling
 // launch (drained every fourth round); 512 (every second round) for the later frames, whose launches are a few
 // rounds long
@@ -255,58 +267,121 @@ constexpr int kPushQueue = 1024;
 constexpr int kPushQueueSmall = 512;
 constexpr int kPushMaxFpg = 32;    // frames per workgroup row (one bit each in a queue entry)
 
+// One point against the frames [fa, fb): fp32 screening of each projection, stamp where it decides; returns the
+// bitmask (bit f - fa) of the frames it could not decide (lanes that are not `live`: all bits).  Per-frame constants
+// are wave-uniform scalar loads.
+//   q~ = (M32 X)_k / (M32 X)_2 differs from the reference's fp64 value by at most t_k (see ProjF64).  With
+//   ts = 1/4 - (tx + ty), A = min(dx - tx, dy - ty) (dx, dy: distance of q~ to the nearest integer) and
+//   mi = min(qx, W-1 - qx, qy, H-1 - qy):   stamp  <=>  ts > 0 and A > 0 and mi >= 0        (in range, both sure)
+//                                          decided <=>  ts > 0 and (A > 0 or mi < -1/2)    (else: fp64)
+//   ts > 0 implies that every quantity is finite (NaN / inf coordinates, a zero denominator: ts is NaN or -inf and
+//   every comparison false), and the subtractions keep the sign of the comparisons they replace exactly.
+//   The decisions are arithmetic (min / max on the vector unit) with four comparisons at the end: written as twelve
+//   comparisons combined in scalar registers the loop spent 42 scalar against 50 vector instructions per frame, and
+//   the scalar unit -- one per CU for four SIMDs -- set the pace of frame 0's launch (38 M scalar wave-instructions
+//   = 62 of its 72 us).
+template <class Stamp>
+__device__ __forceinline__ unsigned screen_frames(const PushConsts *__restrict__ pc, const int fa, const int fb,
+                                                  const bool live, float x, float y, float z, const float wm1,
+                                                  const float hm1, const int W, const Stamp &stamp) {
+  if (!live) x = y = z = __builtin_nanf("");  // decides nothing, stamps nothing
+  const float amax = fmaxf(fmaxf(fabsf(x), fabsf(y)), fmaxf(fabsf(z), 1.0f));
+  unsigned dmask = 0;
+  auto frame = [&](const int f, const PushConsts &c) {
+    const float *M = c.M;
+    // rows 0 and 1 as one two-wide FMA chain (v_pk_fma_f32 on the SGPR pairs as loaded); the same three fused
+    // multiply-adds per row
+    const f2v p0 = {M[0], M[1]}, p1 = {M[2], M[3]}, p2 = {M[4], M[5]}, p3 = {M[6], M[7]};
+    const f2v xx = {x, x}, yy = {y, y}, zz = {z, z};
+    const f2v s01 = __builtin_elementwise_fma(p0, xx, __builtin_elementwise_fma(p1, yy, __builtin_elementwise_fma(p2, zz, p3)));
+    const float s0 = s01.x, s1 = s01.y;
+    const float s2 = __builtin_fmaf(M[8], x, __builtin_fmaf(M[9], y, __builtin_fmaf(M[10], z, M[11])));
+    const float r = __builtin_amdgcn_rcpf(s2);  // v_rcp_f32: 1 ulp
+    const float qx = s0 * r, qy = s1 * r;
+    // |q~ - q_ref| <= (E_row + (|q~| + 1) E_2) |r| + 2^-22 |q~|, E_k = e32[k] amax (see ProjF64)
+    const float ar = fabsf(r) * amax * 1.001f;
+    const float tx = (c.e[0] + (fabsf(qx) + 1.0f) * c.e[2]) * ar + fabsf(qx) * 2.5e-7f;
+    const float ty = (c.e[1] + (fabsf(qy) + 1.0f) * c.e[2]) * ar + fabsf(qy) * 2.5e-7f;
+    const float fx = floorf(qx), fy = floorf(qy);
+    const float dx = fminf(qx - fx, (fx + 1.0f) - qx), dy = fminf(qy - fy, (fy + 1.0f) - qy);
+    const float ts = 0.25f - (tx + ty);
+    const float A = fminf(dx - tx, dy - ty);
+    const float mi = fminf(fminf(qx, wm1 - qx), fminf(qy, hm1 - qy));
+    const float B = fmaxf(A, -0.5f - mi);
+    const bool sure = ts > 0.0f;
+    if (sure & (A > 0.0f) & (mi >= 0.0f)) stamp(f, (int)qy * W + (int)qx);
+    dmask |= ((sure & (B > 0.0f)) ? 0u : 1u) << (f - fa);
+  };
+  // Two frames per trip with two sets of constants: each set is requested (scalar loads, wave-uniform) while the
+  // other frame is evaluated and lands in its own registers -- a single set renamed per frame cost ~14 scalar
+  // moves per projection.
+  // (the record array has two spare entries behind the last frame: the requests ahead need no clamping)
+  const PushConsts *p = pc + fa;
+  PushConsts ca = p[0];
+  for (int f = fa; f < fb; f += 2, p += 2) {
+    const PushConsts cb = p[1];
+    frame(f, ca);
+    if (f + 1 < fb) {
+      ca = p[2];
+      frame(f + 1, cb);
+    }
+  }
+  return live ? dmask : 0u;
+}
+
+// The (point, frame) pairs the fp32 form could not decide: one LDS queue entry per point (the point itself and a
+// frame bitmask), drained densely through the fp64 forms when the next round could overflow the queue (every
+// thread adds at most one entry per round) and after the last round.  Called by every thread of the workgroup.
+template <int kQueue, int kThreads, class Stamp>
+__device__ __forceinline__ void queue_doubtful(uint4 *s_q, int *s_qn, const unsigned dmask, const float x, const float y,
+                                               const float z, const int fa, const bool last,
+                                               const ProjF64 *__restrict__ proj, const int H, const int W, const Stamp &stamp) {
+  if (dmask != 0) {
+    const int slot = atomicAdd(s_qn, 1);
+    if (slot < kQueue) {
+      s_q[slot] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), dmask);
+    } else {  // queue full (degenerate views): decide in place
+      for (unsigned m = dmask; m; m &= m - 1) {
+        const int f = fa + __builtin_ctz(m);
+        mark_fp64(proj + f, x, y, z, H, W, f, stamp);
+      }
+    }
+  }
+  __syncthreads();
+  const int qn = *s_qn < kQueue ? *s_qn : kQueue;
+  // every wavefront has read the count before any of them can add to it again (next round): the decision to
+  // drain -- and with it the barriers inside -- is the same on all of them
+  __syncthreads();
+  if (last || qn + kThreads > kQueue) {
+    for (int e = threadIdx.x; e < qn; e += kThreads) {
+      const uint4 q = s_q[e];
+      const float px = __uint_as_float(q.x), py = __uint_as_float(q.y), pz = __uint_as_float(q.z);
+      for (unsigned m = q.w; m; m &= m - 1) {
+        const int f = fa + __builtin_ctz(m);
+        mark_fp64(proj + f, px, py, pz, H, W, f, stamp);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *s_qn = 0;
+    __syncthreads();
+  }
+}
+
 // Projects the points [cnts[src], cnts[src+1]) -- what frame `src` appended -- into the frames
 // f_lo + blockIdx.y * fpg ... (at most fpg of them, below f_hi) and stamps their occupancy maps
-// occ[f][P].  One thread per point, the frame loop inside (per-frame constants are wave-uniform:
-// scalar loads).
+// occ[f][P].  One thread per point, the frame loop inside.  Frame 0's launch (the chip-filling one) on the
+// default path; with PGDVS_AGG_ORDERED=1 every frame's, and then a later frame's launch also builds the rows of
+// the pixels its ordered selection listed in sel_pix (cloud order).
 template <int kQueue>
 __global__ void __launch_bounds__(kPushThreads)
-agg_push_kernel(const float *__restrict__ xyz, int64_t *cnts, int src,
-                const ProjF64 *__restrict__ proj, int f_lo, int f_hi, int fpg, int H, int W,
-                uint8_t *__restrict__ occ_all, const int32_t *__restrict__ sel_pix,
-                const int32_t *__restrict__ tile_cnt, int tiles, int64_t capacity, AppendSrc app, CamBlock cam) {
+agg_push_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ cnts, int src,
+                const ProjF64 *__restrict__ proj, const PushConsts *__restrict__ pc, int f_lo, int f_hi, int fpg, int H, int W,
+                uint8_t *__restrict__ occ_all, const int32_t *__restrict__ sel_pix, AppendSrc app, CamBlock cam) {
   __shared__ uint4 s_q[kQueue];
   __shared__ int s_qn;
-  __shared__ int s_pref[kPushMaxTiles + 1];  // listed selection: pixels selected before each tile of the frame
-  __shared__ int s_wsum[kPushThreads / kWave];
-  int64_t begin = cnts[src], end;
-  if (tile_cnt != nullptr) {
-    // The frame's selection left its pixels tile by tile (slots [t * kSelTile, +tile_cnt[t]) of sel_pix) and the
-    // tile counts: every workgroup scans the counts itself (tiles <= kPushMaxTiles, a few hundred at 1080p)
-    // instead of the selection waiting for its predecessors' counts.  Point j of the frame is pixel
-    // sel_pix[t * kSelTile + j - s_pref[t]] of the tile t whose range holds j.
-    constexpr int kPer = kPushMaxTiles / kPushThreads;
-    int v[kPer], run = 0;
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int t = (int)threadIdx.x * kPer + k;
-      v[k] = t < tiles ? tile_cnt[t] : 0;
-      run += v[k];
-    }
-    int x = run;
-    for (int off = 1; off < 64; off <<= 1) {
-      const int y = __shfl_up(x, off, 64);
-      if ((int)(threadIdx.x & 63) >= off) x += y;
-    }
-    if ((threadIdx.x & 63) == 63) s_wsum[threadIdx.x >> 6] = x;
-    __syncthreads();
-    int excl = x - run;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) excl += s_wsum[w];
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int t = (int)threadIdx.x * kPer + k;
-      if (t <= tiles) s_pref[t] = excl;  // (the tiles behind the last one count nothing: s_pref[tiles] = total)
-      excl += v[k];
-    }
-    __syncthreads();
-    end = begin + s_pref[tiles];
-    end = end > capacity ? capacity : end;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) cnts[src + 1] = end;  // read by the next frame's launches
-  } else {
-    end = cnts[src + 1];
-  }
+  const int64_t begin = cnts[src], end = cnts[src + 1];
   if (begin >= end) return;
-  const int64_t P = (int64_t)H * W;
+  const ByteStamp stamp{occ_all, (int64_t)H * W};
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
   if (threadIdx.x == 0) s_qn = 0;
   __syncthreads();
@@ -329,23 +404,13 @@ agg_push_kernel(const float *__restrict__ xyz, int64_t *cnts, int src,
   const int64_t c_step = gridDim.x >> 3 ? gridDim.x >> 3 : 1;
   // whole workgroups stay in the loop so that the queue can be drained between rounds
   for (int64_t ch = c_lo + (int64_t)(blockIdx.x >> 3); ch < c_hi; ch += c_step) {
-    const int64_t i0 = begin + ch * kPushThreads;
-    const int64_t i = i0 + threadIdx.x;
+    const int64_t i = begin + ch * kPushThreads + threadIdx.x;
     const bool live = i < end;
     float x = 0.f, y = 0.f, z = 0.f;
     if (live && sel_pix != nullptr) {
       // deferred append: the frame's selection only listed its pixels (in cloud order); the row is built
       // here, where the work is spread over the whole grid however the pixels cluster (frame group 0 writes)
-      int slot = (int)(i - begin);
-      if (tile_cnt != nullptr) {  // the tile whose range holds point `slot`: the last t with s_pref[t] <= slot
-        int lo = 0, hi = tiles - 1;
-        while (lo < hi) {
-          const int mid = (lo + hi + 1) >> 1;
-          if (s_pref[mid] <= slot) lo = mid; else hi = mid - 1;
-        }
-        slot = lo * kSelTile + (slot - s_pref[lo]);
-      }
-      const f3 X = append_row(app, cam, sel_pix[slot], i, blockIdx.y == 0 && first_iter);
+      const f3 X = append_row(app, cam, sel_pix[i - begin], i, blockIdx.y == 0 && first_iter);
       x = X.x;
       y = X.y;
       z = X.z;
@@ -354,79 +419,39 @@ agg_push_kernel(const float *__restrict__ xyz, int64_t *cnts, int src,
       y = xyz[i * 3 + 1];
       z = xyz[i * 3 + 2];
     }
-    const float amax = fmaxf(fmaxf(fabsf(x), fabsf(y)), fmaxf(fabsf(z), 1.0f));
     unsigned dmask = 0;
-    // One frame: fp32 screening of the projection, stamp or doubt bit.
-    auto frame = [&](const int f, const PushConsts &c) {
-      const float *M = c.M;
-      // rows 0 and 1 as one two-wide FMA chain (v_pk_fma_f32 on the SGPR pairs as loaded: the scalar unit, one per
-      // CU, was as busy as the vector pipes re-pairing the constants); the same three fused multiply-adds per row
-      const f2v p0 = {M[0], M[1]}, p1 = {M[2], M[3]}, p2 = {M[4], M[5]}, p3 = {M[6], M[7]};
-      const f2v xx = {x, x}, yy = {y, y}, zz = {z, z};
-      const f2v s01 = __builtin_elementwise_fma(p0, xx, __builtin_elementwise_fma(p1, yy, __builtin_elementwise_fma(p2, zz, p3)));
-      const float s0 = s01.x, s1 = s01.y;
-      const float s2 = __builtin_fmaf(M[8], x, __builtin_fmaf(M[9], y, __builtin_fmaf(M[10], z, M[11])));
-      const float r = __builtin_amdgcn_rcpf(s2);  // v_rcp_f32: 1 ulp
-      const float qx = s0 * r, qy = s1 * r;
-      // |q~ - q_ref| <= (E_row + (|q~| + 1) E_2) |r| + 2^-22 |q~|, E_k = e32[k] amax (see ProjF64)
-      const float ar = fabsf(r) * amax * 1.001f;
-      const float tx = (c.e[0] + (fabsf(qx) + 1.0f) * c.e[2]) * ar + fabsf(qx) * 2.5e-7f;
-      const float ty = (c.e[1] + (fabsf(qy) + 1.0f) * c.e[2]) * ar + fabsf(qy) * 2.5e-7f;
-      const float fx = floorf(qx), fy = floorf(qy);
-      const float dx = fminf(qx - fx, (fx + 1.0f) - qx), dy = fminf(qy - fy, (fy + 1.0f) - qy);
-      // straight-line mask logic (bitwise: no short-circuit branches); every comparison is false for NaN
-      const bool small = (tx < 0.25f) & (ty < 0.25f) & (c.screen32 != 0);
-      const bool outside = (qx < -0.5f) | (qx > wm1 + 0.5f) | (qy < -0.5f) | (qy > hm1 + 0.5f);  // by more than the bound
-      const bool clear = (dx > tx) & (dy > ty);
-      const bool inr = (qx >= 0.0f) & (qx <= wm1) & (qy >= 0.0f) & (qy <= hm1);
-      if (live & small & !outside & clear & inr) occ_all[(int64_t)f * P + (int64_t)(int)qy * W + (int)qx] = 1;
-      const bool doubt = live & !(small & (outside | clear));
-      dmask |= (doubt ? 1u : 0u) << (f - fa);
-    };
-    // Two frames per trip with two sets of constants: each set is requested (scalar loads, wave-uniform) while the
-    // other frame is evaluated and lands in its own registers -- a single set renamed per frame cost ~14 scalar
-    // moves per projection.
-    PushConsts ca = load_push_consts(proj + fa);
-    for (int f = fa; f < fb; f += 2) {
-      const PushConsts cb = load_push_consts(proj + (f + 1 < fb ? f + 1 : f));
-      frame(f, ca);
-      if (f + 1 < fb) {
-        ca = load_push_consts(proj + (f + 2 < fb ? f + 2 : f + 1));
-        frame(f + 1, cb);
-      }
-    }
-    // the (point, frame) pairs the fp32 form could not decide: one queue entry per point (the point itself and a
-    // frame bitmask)
-    if (dmask != 0) {
-      const int slot = atomicAdd(&s_qn, 1);
-      if (slot < kQueue) {
-        s_q[slot] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), dmask);
-      } else {  // queue full (degenerate views): decide in place
-        for (unsigned m = dmask; m; m &= m - 1) {
-          const int f = fa + __builtin_ctz(m);
-          mark_fp64(proj + f, x, y, z, H, W, occ_all + (int64_t)f * P);
-        }
-      }
-    }
-    // drain when the next round could overflow the queue (every thread adds at most one entry per round)
-    __syncthreads();
-    const int qn = s_qn < kQueue ? s_qn : kQueue;
-    const bool last = ch + c_step >= c_hi;
-    if (last || qn + kPushThreads > kQueue) {
-      for (int e = threadIdx.x; e < qn; e += kPushThreads) {
-        const uint4 q = s_q[e];
-        const float px = __uint_as_float(q.x), py = __uint_as_float(q.y), pz = __uint_as_float(q.z);
-        for (unsigned m = q.w; m; m &= m - 1) {
-          const int f = fa + __builtin_ctz(m);
-          mark_fp64(proj + f, px, py, pz, H, W, occ_all + (int64_t)f * P);
-        }
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) s_qn = 0;
-      __syncthreads();
-    }
+    if (fa < fb) dmask = screen_frames(pc, fa, fb, live, x, y, z, wm1, hm1, W, stamp);
+    queue_doubtful<kQueue, kPushThreads>(s_q, &s_qn, dmask, x, y, z, fa, ch + c_step >= c_hi, proj, H, W, stamp);
   }
   }
+}
+
+// ---- the later frames: one `step` launch per frame, rows at the end -------------------------------------------------
+
+constexpr int kBitTileWords = kSelTile / 32;  // a tile of 8192 pixels = 256 words, one per thread
+constexpr int kStepThreads = 256;
+constexpr int kStepPx = 16;        // pixels per thread of a step launch
+constexpr int kStepChunkPx = 128;  // ... in chunks of 128 consecutive pixels (8 threads), dealt round-robin to the workgroups
+constexpr int kStepChunks = kStepThreads * kStepPx / kStepChunkPx;  // chunks per workgroup (32: 4096 pixels)
+
+// block-wide exclusive offset of `c` (256 threads) and the block total
+__device__ __forceinline__ int block_excl_256(const int c, int *s_wsum, int &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int x = c;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) s_wsum[wave] = x;
+  __syncthreads();
+  int wave_off = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) wave_off += s_wsum[w];
+    total += s_wsum[w];
+  }
+  return wave_off + x - c;
 }
 
 constexpr unsigned kSelSpinLimit = 1u << 22;
@@ -447,8 +472,7 @@ struct SelArgs {
   unsigned long long *desc;  // [tiles]
   int32_t *ticket;           // [S]
   int32_t *error;            // set when a look-back spin gives up
-  int32_t *sel_pix;          // deferred append (frames >= 1): the selected pixels in cloud order, [P]
-  int32_t *tile_cnt;         // listed selection (agg_select_list_kernel): selected pixels per tile, [tiles]
+  int32_t *sel_pix;          // deferred append (ordered chain, frames >= 1): the selected pixels in cloud order, [P]
   int64_t capacity;
   int frame, P, W, tiles;
 };
@@ -485,6 +509,19 @@ __device__ __forceinline__ unsigned sel_flags16(const SelArgs &a, int base) {
     }
   }
   return flags;
+}
+
+// one bit per byte of four dwords: bit k = (byte k is zero)
+__device__ __forceinline__ unsigned zero_bytes16(const uint4 v) {
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+  unsigned bits = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // high bit of every non-zero byte, gathered into four adjacent bits by one multiplication
+    const unsigned nz = ((((w[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[k]) >> 7) & 0x01010101u;
+    bits |= ((nz * 0x10204080u) >> 28) << (4 * k);
+  }
+  return ~bits & 0xffffu;
 }
 
 __global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamBlock cam) {
@@ -600,47 +637,177 @@ __global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamB
   }
 }
 
-// Selection of a later frame without any ordering inside the launch: tile t leaves its selected pixels (row-major)
-// in its own slots sel_pix[t * kSelTile ...] and its count in tile_cnt[t]; the frame's push launch, which builds
-// the rows anyway, turns the counts into offsets.  No ticket, no predecessor counts to wait for: the launch is
-// one read of the mask and the map (the frames after the first select a few per cent of their pixels).
-__global__ void __launch_bounds__(kSelThreads) agg_select_list_kernel(SelArgs a) {
-  __shared__ int wave_sums[kSelThreads / kWave];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x;
-  const int base = tile * kSelTile + tid * kSelItems;
-  const unsigned flags = base < a.P ? sel_flags16(a, base) : 0u;
-  const int c = __popc(flags);
-  int x = c;
-  for (int off = 1; off < 64; off <<= 1) {
-    int y = __shfl_up(x, off, 64);
-    if (lane >= off) x += y;
+// selection flags of 16 pixels of a later frame, both 16-byte loads in flight together (sel_flags16 waits for each in turn:
+// dependent round trips at the head of every chain link); selected = mask byte zero and map byte zero = (mask | map) zero
+__device__ __forceinline__ unsigned sel_flags16_pair(const SelArgs &a, const int64_t base) {
+  if (base + 16 <= a.P && (((reinterpret_cast<uintptr_t>(a.dyn_mask + base) | reinterpret_cast<uintptr_t>(a.occ + base)) & 15) == 0)) {
+    const uint4 m = *reinterpret_cast<const uint4 *>(a.dyn_mask + base);
+    const uint4 o = *reinterpret_cast<const uint4 *>(a.occ + base);
+    return zero_bytes16(make_uint4(m.x | o.x, m.y | o.y, m.z | o.z, m.w | o.w));
   }
-  if (lane == 63) wave_sums[wave] = x;
+  return base < a.P ? sel_flags16(a, (int)base) : 0u;
+}
+
+// One link of the chain: frame `src`'s selection = static and not stamped (tmp_st_mask & ~tmp_proj_mask, :224-245);
+// its own map is complete when the launch starts.  Workgroup b takes the 128-pixel chunks b, b + gridDim.x, ... (32 of
+// them, 16 pixels per thread: selected pixels cluster -- whole rows at an image border, bands around depth edges --
+// and chunks dealt round-robin give every workgroup the same sample of the image; with 64-word groups the slowest
+// workgroup ran 10+ rounds of the loop below and WAS the launch: 21 us), lists the selected pixels in LDS and leaves
+// their bits in sel[src] (row blockIdx.y == 0); every thread then unprojects its pixels (as _compute_pcl) and screens
+// them against the frames src + 1 + blockIdx.y * fpg ... like agg_push_kernel.  gridDim.x is a multiple of 8: the
+// workgroups (x, 0), (x, 1), ... land on one XCD and share its L2's copy of the chunk (the rows re-read the same 4 MB).
+// The last frame's launch only leaves its bits.
+template <int kQueue>
+__global__ void __launch_bounds__(kStepThreads)
+agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__ sel16, int64_t Wd, int src,
+                const ProjF64 *__restrict__ proj, const PushConsts *__restrict__ pc, int f_hi, int fpg, int H, int W,
+                AppendSrc app, CamBlock cam) {
+  __shared__ uint16_t s_list[kStepThreads * kStepPx];  // (thread << 4 | pixel) of every selected pixel, 8 KB
+  __shared__ uint4 s_q[kQueue];
+  __shared__ int s_qn;
+  __shared__ int s_wsum[4];
+  const int tid = threadIdx.x;
+  auto pixel_base = [&](const int t) {
+    return ((int64_t)blockIdx.x + (int64_t)(t >> 3) * gridDim.x) * kStepChunkPx + (t & 7) * kStepPx;
+  };
+  const int64_t base = pixel_base(tid);
+  const uint32_t bits = sel_flags16_pair(a, base);
+  if (blockIdx.y == 0 && base < Wd * 32) sel16[((int64_t)src * Wd * 32 + base) >> 4] = (uint16_t)bits;
+  const int fa = src + 1 + (int)blockIdx.y * fpg;
+  if (fa >= f_hi) return;
+  const int fb = fa + fpg < f_hi ? fa + fpg : f_hi;
+  int n;
+  int slot = block_excl_256(__popc(bits), s_wsum, n);
+  if (n == 0) return;
+  for (uint32_t m = bits; m; m &= m - 1) s_list[slot++] = (uint16_t)((tid << 4) | __builtin_ctz(m));
+  if (tid == 0) s_qn = 0;
   __syncthreads();
-  int wave_off = 0, total = 0;
+  const ByteStamp stamp{occ_all, (int64_t)H * W};
+  const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+  for (int e0 = 0; e0 < n; e0 += kStepThreads) {
+    const int e = e0 + tid;
+    const bool live = e < n;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (live) {
+      const int ent = s_list[e];
+      const f3 X = append_row(app, cam, (int)(pixel_base(ent >> 4) + (ent & 15)), 0, false);
+      x = X.x;
+      y = X.y;
+      z = X.z;
+    }
+    const unsigned dmask = screen_frames(pc, fa, fb, live, x, y, z, wm1, hm1, W, stamp);
+    queue_doubtful<kQueue, kStepThreads>(s_q, &s_qn, dmask, x, y, z, fa, e0 + kStepThreads >= n, proj, H, W, stamp);
+  }
+}
+
+// After the chain: selected pixels per (frame, tile of 8192 pixels), tile_cnt[f][t] (frames >= 1)
+__global__ void __launch_bounds__(kBitTileWords) agg_count_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles,
+                                                                  int32_t *__restrict__ tile_cnt) {
+  __shared__ int s_wsum[4];
+  const int f = 1 + (int)blockIdx.y;
+  int total;
+  block_excl_256(__popc(sel[(int64_t)f * Wd + (int64_t)blockIdx.x * kBitTileWords + threadIdx.x]), s_wsum, total);
+  if (threadIdx.x == 0) tile_cnt[(int64_t)f * tiles + blockIdx.x] = total;
+}
+
+// ... their running sum in (frame, tile) order: tile_off[u] = selected pixels of the later frames before entry u
+// (u = f * tiles + t, from u = tiles on); tile_off[S * tiles] = all of them.  One workgroup.
+__global__ void __launch_bounds__(1024) agg_scan_kernel(const int32_t *__restrict__ tile_cnt, int64_t *__restrict__ tile_off,
+                                                        int64_t lo, int64_t hi) {
+  __shared__ long long s_w[16];
+  __shared__ long long s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t u0 = lo; u0 < hi; u0 += 4096) {
+    const int64_t u = u0 + (int64_t)tid * 4;
+    int v[4];
 #pragma unroll
-  for (int w = 0; w < kSelThreads / kWave; ++w) {
-    if (w < wave) wave_off += wave_sums[w];
-    total += wave_sums[w];
+    for (int k = 0; k < 4; ++k) v[k] = u + k < hi ? tile_cnt[u + k] : 0;
+    long long x = (long long)v[0] + v[1] + v[2] + v[3];
+    const long long mine = x;
+    for (int off = 1; off < 64; off <<= 1) {
+      const long long y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    long long before = s_carry;
+    for (int q = 0; q < wave; ++q) before += s_w[q];
+    long long run = before + x - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (u + k < hi) tile_off[u + k] = run;
+      run += v[k];
+    }
+    __syncthreads();
+    if (tid == 1023) s_carry = run;
+    __syncthreads();
   }
-  if (tid == 0) a.tile_cnt[tile] = total;
-  // straight from the registers into the tile's slots (a few per cent of the pixels; no LDS list, so that the
-  // launch fits beside the other views' rasteriser workgroups)
-  int32_t *dst = a.sel_pix + tile * kSelTile + wave_off + x - c;
-  unsigned f = flags;
-  while (f) {
-    const int k = __builtin_ctz(f);
-    f &= f - 1;
-    *dst++ = base + k;
+  if (tid == 0) tile_off[hi] = s_carry;
+}
+
+// ... and their rows, in the reference's order (frame, then row-major pixel: tmp_pcl[tmp_st_mask] :247-251): tile (t, f)
+// starts behind frame 0's rows and everything counted before it.
+struct RowsArgs {
+  const float *depths;  // [S][P]
+  const float *rgbs;    // [S][P][3]
+  float *cloud;
+  float *xyz;
+  int64_t capacity;
+  int P, W;
+};
+__global__ void __launch_bounds__(kBitTileWords)
+agg_rows_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles, const int64_t *__restrict__ tile_off,
+                const int64_t *__restrict__ cnts, const CamBlock *__restrict__ cams, RowsArgs a) {
+  __shared__ uint16_t s_list[kSelTile];
+  __shared__ int s_wsum[4];
+  const int tid = threadIdx.x;
+  const int f = 1 + (int)blockIdx.y, t = (int)blockIdx.x;
+  const uint32_t bits = sel[(int64_t)f * Wd + (int64_t)t * kBitTileWords + tid];
+  int total;
+  int slot = block_excl_256(__popc(bits), s_wsum, total);
+  if (total == 0) return;
+  for (uint32_t m = bits; m; m &= m - 1) s_list[slot++] = (uint16_t)((tid << 5) | __builtin_ctz(m));
+  __syncthreads();
+  const int64_t pos0 = cnts[1] + tile_off[(int64_t)f * tiles + t];
+  AppendSrc app;
+  app.depth = a.depths + (size_t)f * (size_t)a.P;
+  app.rgb = a.rgbs + (size_t)f * (size_t)a.P * 3;
+  app.cloud = a.cloud;
+  app.xyz = a.xyz;
+  app.P = a.P;
+  app.W = a.W;
+  const CamBlock &cam = cams[f];
+  const int tile_px = t * kSelTile;
+#pragma unroll 4
+  for (int e = tid; e < total; e += kBitTileWords) {
+    const int64_t pos = pos0 + e;
+    if (pos >= a.capacity) break;
+    append_row(app, cam, tile_px + (int)s_list[e], pos, true);
   }
+}
+
+struct CamChunk {
+  CamBlock c[12];
+};
+static_assert(sizeof(CamChunk) + 32 <= 4096, "agg_cams_kernel's arguments");
+__global__ void agg_cams_kernel(CamChunk c, CamBlock *__restrict__ dst, int first, int n) {
+  const int words = (int)(sizeof(CamBlock) / 4);
+  for (int k = threadIdx.x; k < n * words; k += blockDim.x)
+    reinterpret_cast<uint32_t *>(dst + first)[k] = reinterpret_cast<const uint32_t *>(&c.c[0])[k];
 }
 
 // the count the caller sees: the cloud size, or -1 when a look-back spin gave up in any frame
 // (the cloud is then not trustworthy; hosts that read the count raise, see ops.static_aggregate)
-__global__ void agg_finalize_kernel(const int64_t *__restrict__ cnts, const int32_t *__restrict__ error, int S,
+// (total: the later frames' count behind frame 0's cnts[1]; null = cnts[S] as the ordered chain left it)
+__global__ void agg_finalize_kernel(const int64_t *__restrict__ cnts, const int32_t *__restrict__ error,
+                                    const int64_t *__restrict__ total, int S, int64_t capacity,
                                     int64_t *__restrict__ count_out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *count_out = *error ? -1 : cnts[S];
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const long long n = total != nullptr ? cnts[1] + *total : cnts[S];
+    *count_out = *error ? -1 : (n > capacity ? capacity : n);
+  }
 }
 
 struct AggWs {
@@ -650,11 +817,16 @@ struct AggWs {
   int64_t *cnts;
   int32_t *ticket, *error;
   unsigned long long *desc;
-  int32_t *tile_cnt;  // [tiles] listed selection of the current frame
+  int32_t *tile_cnt;   // [S][tiles] pixels the later frames selected per (frame, tile)
+  int64_t *tile_off;   // [S * tiles + 1] their running sum
   uint8_t *occ;  // [S][P] one occupancy byte per (frame, pixel), zeroed per call
-  int32_t *sel_pix;  // [P] the pixels the current frame selected, in cloud order
+  uint32_t *sel;  // [S][Wd] selection bits of the later frames (each written whole by its agg_step launch)
+  int64_t Wd;
+  int32_t *sel_pix;  // [P] ordered chain: the pixels the current frame selected, in cloud order
   float *xyz;
-  ProjF64 *proj;
+  ProjF64 *proj;   // [S]
+  PushConsts *pc32;  // [S + 2] fp32 screening records (two spare entries: see screen_frames)
+  CamBlock *cams;  // [S]
   int64_t total_bytes;
 };
 
@@ -673,18 +845,27 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   off += 16;
   w.desc = reinterpret_cast<unsigned long long *>(p + off);
   off += align_up(tiles * 8, 16);
-  w.tile_cnt = reinterpret_cast<int32_t *>(p + off);
-  off += align_up(tiles * 4, 16);
   w.state_bytes = off;
   off = align_up(off, 256);
+  w.tile_cnt = reinterpret_cast<int32_t *>(p + off);
+  off += align_up((int64_t)S * tiles * 4, 256);
+  w.tile_off = reinterpret_cast<int64_t *>(p + off);
+  off += align_up(((int64_t)S * tiles + 1) * 8, 256);
   w.occ = reinterpret_cast<uint8_t *>(p + off);
   off += align_up((int64_t)S * P + 32, 256);
+  w.Wd = tiles * kBitTileWords;
+  w.sel = reinterpret_cast<uint32_t *>(p + off);
+  off += align_up((int64_t)S * w.Wd * 4, 256);
   w.xyz = reinterpret_cast<float *>(p + off);
   off += align_up((capacity > 0 ? capacity : 1) * 12, 256);
   w.sel_pix = reinterpret_cast<int32_t *>(p + off);
   off += align_up(P * 4, 256);
   w.proj = reinterpret_cast<ProjF64 *>(p + off);
   off += align_up((int64_t)S * (int64_t)sizeof(ProjF64), 256);
+  w.pc32 = reinterpret_cast<PushConsts *>(p + off);
+  off += align_up((int64_t)(S + 2) * (int64_t)sizeof(PushConsts), 256);
+  w.cams = reinterpret_cast<CamBlock *>(p + off);
+  off += align_up((int64_t)S * (int64_t)sizeof(CamBlock), 256);
   w.total_bytes = off;
   return w;
 }
@@ -815,15 +996,16 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       }
       if (i % kProjChunk == kProjChunk - 1 || i == S - 1) {
         const int first = i - i % kProjChunk, cnt = i % kProjChunk + 1;
-        PGDVS_LAUNCH("agg_params", agg_params_kernel, dim3(1), dim3(256), 0, st, chunk, ws.proj, first, cnt);
+        PGDVS_LAUNCH("agg_params", agg_params_kernel, dim3(1), dim3(256), 0, st, chunk, ws.proj, reinterpret_cast<float *>(ws.pc32), first,
+                     cnt);
       }
     }
   }
   const int tiles = (int)cdiv(P, kSelTile);
-  // frames >= 1: listed selection (offsets made by the push launch) unless the image has more tiles than a push
-  // workgroup scans, or PGDVS_AGG_ORDERED=1 asks for the ordered selection (tests run both)
+  // PGDVS_AGG_ORDERED=1: round 2's chain for every frame (ordered selection + byte-stamping push that builds the rows),
+  // kept as a second implementation that the tests run the same bit-exact cases through
   static const bool ordered_env = getenv("PGDVS_AGG_ORDERED") && getenv("PGDVS_AGG_ORDERED")[0] == '1';
-  const bool listed = tiles <= kPushMaxTiles && !ordered_env;
+  const bool bit_chain = !ordered_env && S > 1;
   auto select = [&](int i) {
     SelArgs a;
     a.dyn_mask = dyn_masks + (size_t)i * P;
@@ -837,58 +1019,107 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
     a.ticket = ws.ticket;
     a.error = ws.error;
     a.sel_pix = i > 0 ? ws.sel_pix : nullptr;
-    a.tile_cnt = ws.tile_cnt;
     a.capacity = capacity;
     a.frame = i;
     a.P = (int)P;
     a.W = W;
     a.tiles = tiles;
-    if (i > 0 && listed) {
-      PGDVS_LAUNCH("agg_select", agg_select_list_kernel, dim3(tiles), dim3(kSelThreads), 0, st, a);
+    PGDVS_LAUNCH("agg_select", agg_select_kernel, dim3(tiles), dim3(kSelThreads), 0, st, a, cams[(size_t)i]);
+  };
+  auto frame_src = [&](int i) {
+    AppendSrc app;
+    app.depth = depths + (size_t)i * P;
+    app.rgb = rgbs + (size_t)i * P * 3;
+    app.cloud = out;
+    app.xyz = ws.xyz;
+    app.P = (int)P;
+    app.W = W;
+    return app;
+  };
+  // cnts[i] = points in the cloud before frame i.  Frame 0 appends every static pixel (~P points x S-1 frames: the
+  // chip-filling push launch, 8 frames per workgroup row so that the points are read three times).
+  static const int fpg_env = getenv("PGDVS_AGG_FPG") ? atoi(getenv("PGDVS_AGG_FPG")) : 0;
+  const int fpg = fpg_env > 0 ? (fpg_env < kPushMaxFpg ? fpg_env : kPushMaxFpg) : 8;
+  auto push = [&](int i) {
+    // (ordered chain: later frames append a few per cent of P and their launches are latency chains, shorter with 4
+    // frames per row; 256 workgroups walk whatever there is -- the count is device-side)
+    const int fpg_i = i == 0 ? fpg : (fpg > 4 ? 4 : fpg);
+    const int groups = i + 1 < S ? (int)cdiv(S - 1 - i, fpg_i) : 1;
+    const int64_t want = i == 0 ? cdiv(P, kPushThreads) : (cdiv(P, 8 * kPushThreads) < 256 ? cdiv(P, 8 * kPushThreads) : 256);
+    const unsigned gx = (unsigned)(want < 1024 ? (want > 8 ? (want + 7) / 8 * 8 : 8) : 1024);  // a multiple of 8: one share per XCD
+    if (i == 0) {
+      PGDVS_LAUNCH("agg_push0", agg_push_kernel<kPushQueue>, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
+                   (const float *)ws.xyz, (const int64_t *)ws.cnts, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, i + 1, S, fpg_i, H, W,
+                   ws.occ,
+                   (const int32_t *)nullptr, frame_src(i), cams[(size_t)i]);
     } else {
-      PGDVS_LAUNCH("agg_select", agg_select_kernel, dim3(tiles), dim3(kSelThreads), 0, st, a, cams[(size_t)i]);
+      PGDVS_LAUNCH("agg_push", agg_push_kernel<kPushQueueSmall>, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
+                   (const float *)ws.xyz, (const int64_t *)ws.cnts, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, i + 1, S, fpg_i, H, W,
+                   ws.occ,
+                   (const int32_t *)ws.sel_pix, frame_src(i), cams[(size_t)i]);
     }
   };
-  // cnts[i] = points in the cloud before frame i.  After frame i is selected, the points it appended are
-  // pushed into the occupancy maps of all later frames; frame i+1's selection reads its own map.
-  // Frame 0 appends every static pixel (~P points x S-1 frames: the chip-filling launch); later frames
-  // append a few per cent of that, so their launches are small (the count is device-side: the grid is an
-  // upper bound walked by a grid-stride loop).
-  static const int fpg_env = getenv("PGDVS_AGG_FPG") ? atoi(getenv("PGDVS_AGG_FPG")) : 0;
-  const int fpg = fpg_env > 0 ? (fpg_env < kPushMaxFpg ? fpg_env : kPushMaxFpg) : 8;  // frames per workgroup row: the point is re-read once per 8 frames
-  for (int i = 0; i < S; ++i) {
-    select(i);
-    // frame 0 appended its rows itself and only stamps; a later frame's push also builds the rows of the
-    // pixels its selection listed -- for the last frame that is all it does
-    if (i + 1 < S || i > 0) {
-      // (frame 0: 8 frames per workgroup row, the points are read three times; the small launches are latency
-      // chains, shorter with 4 frames per row)
-      const int fpg_i = i == 0 ? fpg : (fpg > 4 ? 4 : fpg);
-      const int groups = i + 1 < S ? (int)cdiv(S - 1 - i, fpg_i) : 1;
-      // (later frames append a few per cent of P: 256 workgroups walk whatever there is; a grid sized for the worst
-      // case spent its time dispatching workgroups that leave at once)
-      const int64_t want = i == 0 ? cdiv(P, kPushThreads) : (cdiv(P, 8 * kPushThreads) < 256 ? cdiv(P, 8 * kPushThreads) : 256);
-      const unsigned gx = (unsigned)(want < 1024 ? (want > 8 ? (want + 7) / 8 * 8 : 8) : 1024);  // a multiple of 8: one share per XCD
-      AppendSrc app;
-      app.depth = depths + (size_t)i * P;
-      app.rgb = rgbs + (size_t)i * P * 3;
-      app.cloud = out;
-      app.xyz = ws.xyz;
-      app.P = (int)P;
-      app.W = W;
-      if (i == 0) {
-        PGDVS_LAUNCH("agg_push0", agg_push_kernel<kPushQueue>, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
-                     (const float *)ws.xyz, ws.cnts, i, (const ProjF64 *)ws.proj, i + 1, S, fpg_i, H, W, ws.occ,
-                     (const int32_t *)nullptr, (const int32_t *)nullptr, tiles, capacity, app, cams[(size_t)i]);
-      } else {
-        PGDVS_LAUNCH("agg_push", agg_push_kernel<kPushQueueSmall>, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
-                     (const float *)ws.xyz, ws.cnts, i, (const ProjF64 *)ws.proj, i + 1, S, fpg_i, H, W, ws.occ,
-                     (const int32_t *)ws.sel_pix, (const int32_t *)(listed ? ws.tile_cnt : nullptr), tiles, capacity, app,
-                     cams[(size_t)i]);
+  if (!bit_chain) {
+    for (int i = 0; i < S; ++i) {
+      select(i);
+      // frame 0 appended its rows itself and only stamps; a later frame's push also builds the rows of the
+      // pixels its selection listed -- for the last frame that is all it does
+      if (i + 1 < S || i > 0) push(i);
+    }
+    PGDVS_LAUNCH("agg_finalize", agg_finalize_kernel, dim3(1), dim3(64), 0, st, (const int64_t *)ws.cnts,
+                 (const int32_t *)ws.error, (const int64_t *)nullptr, S, capacity, count_out);
+    return check_launch("static_aggregate");
+  }
+  {
+    CamChunk chunk;
+    const int per = (int)(sizeof(chunk.c) / sizeof(chunk.c[0]));
+    for (int i = 1; i < S; ++i) {  // (frame 0's block travels by value)
+      chunk.c[(i - 1) % per] = cams[(size_t)i];
+      if ((i - 1) % per == per - 1 || i == S - 1) {
+        const int cnt = (i - 1) % per + 1;
+        PGDVS_LAUNCH("agg_params", agg_cams_kernel, dim3(1), dim3(256), 0, st, chunk, ws.cams, i - cnt + 1, cnt);
       }
     }
   }
+  select(0);
+  push(0);
+  {
+    // 32 chunks of 128 pixels per workgroup, dealt round-robin; a multiple of 8 workgroups per row (see the kernel)
+    const unsigned gx = (unsigned)align_up(cdiv(ws.Wd * 32 / kStepChunkPx, kStepChunks), 8);
+    static const int sfpg_env = getenv("PGDVS_AGG_STEP_FPG") ? atoi(getenv("PGDVS_AGG_STEP_FPG")) : 0;
+    // frames per workgroup row: 2: 9.9, 3: 8.4, 4: 7.9, 6: 7.6, 8: 7.6 us per link at 1080p x 24 frames
+    const int sfpg = sfpg_env > 0 ? (sfpg_env < kPushMaxFpg ? sfpg_env : kPushMaxFpg) : 6;
+    for (int i = 1; i < S; ++i) {
+      SelArgs a;
+      a.dyn_mask = dyn_masks + (size_t)i * P;
+      a.occ = ws.occ + (size_t)i * (size_t)P;
+      a.frame = i;
+      a.P = (int)P;
+      a.W = W;
+      const unsigned gy = i + 1 < S ? (unsigned)cdiv(S - 1 - i, sfpg) : 1u;
+      PGDVS_LAUNCH("agg_step", agg_step_kernel<kPushQueueSmall>, dim3(gx, gy), dim3(kStepThreads), 0, st, a, ws.occ,
+                   reinterpret_cast<uint16_t *>(ws.sel), ws.Wd, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, sfpg, H, W,
+                   frame_src(i), cams[(size_t)i]);
+    }
+  }
+  PGDVS_LAUNCH("agg_count", agg_count_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,
+               (const uint32_t *)ws.sel, ws.Wd, tiles, ws.tile_cnt);
+  PGDVS_LAUNCH("agg_count", agg_scan_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)ws.tile_cnt, ws.tile_off, (int64_t)tiles,
+               (int64_t)S * tiles);
+  {
+    RowsArgs ra;
+    ra.depths = depths;
+    ra.rgbs = rgbs;
+    ra.cloud = out;
+    ra.xyz = ws.xyz;
+    ra.capacity = capacity;
+    ra.P = (int)P;
+    ra.W = W;
+    PGDVS_LAUNCH("agg_rows", agg_rows_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,
+                 (const uint32_t *)ws.sel, ws.Wd, tiles, (const int64_t *)ws.tile_off, (const int64_t *)ws.cnts,
+                 (const CamBlock *)ws.cams, ra);
+  }
   PGDVS_LAUNCH("agg_finalize", agg_finalize_kernel, dim3(1), dim3(64), 0, st, (const int64_t *)ws.cnts,
-               (const int32_t *)ws.error, S, count_out);
+               (const int32_t *)ws.error, (const int64_t *)(ws.tile_off + (int64_t)S * tiles), S, capacity, count_out);
   return check_launch("static_aggregate");
 }

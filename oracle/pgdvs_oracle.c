@@ -708,6 +708,87 @@ static void raster_points_window(const float *ndc, int64_t N, int H, int W, floa
   }
 }
 
+/* The same per-pixel lists from a POINT-major sweep, for full-size frames (the pixel-major loop above is
+ * O(pixels x points): hours at 1080p x 3.5 M points).  Same pix_to_ndc, same disc arithmetic
+ * (dx = x - xf; dy = y - yf; d2 = dx*dx + dy*dy; d2 < r2) and the same insertion rule, points visited in
+ * index order, so every pixel receives exactly the tests that pass in the naive loop, in the same order:
+ * a point is tried on a conservative pixel box (its disc's bounding box in pixel units, widened by two
+ * pixels against the rounding of the box itself; the test decides, the box only has to be a superset).
+ * Threads own bands of rows.  tests/test_oracle_golden.py proves it equal to the naive loop. */
+ORC_API void orc_raster_points_pointmajor(const float *ndc, int64_t N, int H, int W, float radius, int K,
+                                          int64_t *idx, float *zbuf, float *dist2) {
+  const float r2 = radius * radius;
+  const size_t P = (size_t)H * W;
+  int32_t *cnt = (int32_t *)calloc(P, sizeof(int32_t));
+  float *xf = (float *)malloc(sizeof(float) * (size_t)W);
+  float *yf = (float *)malloc(sizeof(float) * (size_t)H);
+  for (int xi = 0; xi < W; ++xi) xf[xi] = pix_to_ndc(W - 1 - xi, W, H);
+  for (int yi = 0; yi < H; ++yi) yf[yi] = pix_to_ndc(H - 1 - yi, H, W);
+  /* pixel index as a real-valued function of the NDC coordinate: ndc = -off + (range*(S-1-i) + off)/S */
+  const double rx = W > H ? 2.0 * (double)W / (double)H : 2.0, ry = H > W ? 2.0 * (double)H / (double)W : 2.0;
+  const double ox = rx / 2.0, oy = ry / 2.0;
+  const double rpx = (double)radius * (double)W / rx + 2.0, rpy = (double)radius * (double)H / ry + 2.0;
+#pragma omp parallel
+  {
+    const int T = omp_get_num_threads(), t = omp_get_thread_num();
+    const int ya = (int)((int64_t)H * t / T), yb = (int)((int64_t)H * (t + 1) / T);
+    for (int64_t p = 0; p < N && ya < yb; ++p) {
+      const float px = ndc[p * 3 + 0], py = ndc[p * 3 + 1], pz = ndc[p * 3 + 2];
+      if (pz < 0.0f) continue;
+      const double cy = (double)(H - 1) - (((double)py + oy) * (double)H - oy) / ry;
+      if (!(cy + rpy >= (double)ya && cy - rpy <= (double)(yb - 1))) continue;
+      const double cx = (double)(W - 1) - (((double)px + ox) * (double)W - ox) / rx;
+      if (!(cx + rpx >= 0.0 && cx - rpx <= (double)(W - 1))) continue;
+      int y0 = (int)floor(cy - rpy), y1 = (int)ceil(cy + rpy);
+      int x0 = (int)floor(cx - rpx), x1 = (int)ceil(cx + rpx);
+      y0 = y0 < ya ? ya : y0;
+      y1 = y1 > yb - 1 ? yb - 1 : y1;
+      x0 = x0 < 0 ? 0 : x0;
+      x1 = x1 > W - 1 ? W - 1 : x1;
+      for (int yi = y0; yi <= y1; ++yi) {
+        const float dy = py - yf[yi];
+        for (int xi = x0; xi <= x1; ++xi) {
+          const float dx = px - xf[xi];
+          const float d2 = dx * dx + dy * dy;
+          if (!(d2 < r2)) continue;
+          const size_t o = ((size_t)yi * W + xi) * K;
+          int c = cnt[(size_t)yi * W + xi];
+          int k;
+          if (c < K) {
+            k = c;
+            cnt[(size_t)yi * W + xi] = c + 1;
+          } else if (pz < zbuf[o + K - 1]) {
+            k = K - 1;
+          } else {
+            continue;
+          }
+          while (k > 0 && zbuf[o + k - 1] > pz) {
+            zbuf[o + k] = zbuf[o + k - 1];
+            idx[o + k] = idx[o + k - 1];
+            dist2[o + k] = dist2[o + k - 1];
+            --k;
+          }
+          zbuf[o + k] = pz;
+          idx[o + k] = p;
+          dist2[o + k] = d2;
+        }
+      }
+    }
+    for (int yi = ya; yi < yb; ++yi)
+      for (int xi = 0; xi < W; ++xi) {
+        const size_t o = ((size_t)yi * W + xi) * K;
+        for (int k = cnt[(size_t)yi * W + xi]; k < K; ++k) {
+          idx[o + k] = -1;
+          zbuf[o + k] = -1.0f;
+          dist2[o + k] = -1.0f;
+        }
+      }
+  }
+  free(cnt);
+  free(xf);
+  free(yf);
+}
+
 /* NormWeightedCompositor: weights = 1 - dist2/(r*r) (points/renderer.py),
  * t = max(sum_k w_k, 1e-4); out[c] = sum_k w_k * feat[idx_k][c] / t
  * (norm_weighted_sum_cpu.cpp).  feat[N, fstride] (first C used); out[H,W,C]. */

@@ -158,3 +158,35 @@ def test_softsplat_backward_vs_autograd_golden(golden_dir):
     np.testing.assert_allclose(gi, g["sum_grad_in"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(gf, g["sum_grad_flow"], rtol=0, atol=1e-5)
     assert np.all(gi[0, :, 0, :4] == 0) and np.all(gf[0, :, 0, :4] == 0)  # targets far outside the image
+
+
+# ---------------------------------------------------------------- A9: point-major evaluation == naive loop
+@pytest.mark.parametrize("H,W,K,radius", [(40, 64, 3, 0.05), (64, 40, 1, 0.03), (48, 48, 8, 0.08), (33, 57, 3, 0.2)])
+def test_pointmajor_raster_equals_naive(H, W, K, radius):
+    """orc_raster_points_pointmajor (the full-frame checker of the 1080p tests) returns the naive O(pixels x points)
+    loop's idx / zbuf / dist2 bit for bit: random clouds with exact z ties, points behind the camera, NaN / inf
+    coordinates, discs grazing pixel centres and points far outside the frame."""
+    rng = np.random.default_rng(H * 1000 + W)
+    N = 6000
+    ax, ay = (W / H, 1.0) if W > H else (1.0, H / W)
+    ndc = np.empty((N, 3), np.float32)
+    ndc[:, 0] = rng.uniform(-1.3 * ax, 1.3 * ax, N)
+    ndc[:, 1] = rng.uniform(-1.3 * ay, 1.3 * ay, N)
+    ndc[:, 2] = rng.uniform(0.5, 4.0, N)
+    ndc[rng.choice(N, 800, replace=False), 2] = np.float32(1.25)  # exact ties: the order among them is the index order
+    ndc[rng.choice(N, 200, replace=False), 2] = -0.5               # behind the camera
+    ndc[rng.choice(N, 20, replace=False), 2] = 0.0
+    bad = rng.choice(N, 30, replace=False)
+    ndc[bad[:10], 0] = np.nan
+    ndc[bad[10:20], 1] = np.inf
+    ndc[bad[20:], 2] = np.nan
+    # discs whose edge passes (nearly) through a pixel centre: centre + radius along x, nudged by a few ulp
+    xs = np.array([-(W / min(H, W)) + (2 * (W - 1 - x) + 1) / min(H, W) for x in range(W)], np.float32)
+    for j, i in enumerate(rng.choice(N, 300, replace=False)):
+        ndc[i, 0] = np.nextafter(np.float32(xs[j % W] + np.float32(radius)), np.float32(10 * (j % 3 - 1)))
+    ref = orc.rasterize_points_window(ndc, H, W, radius, K, 0, H, 0, W)
+    got = orc.rasterize_points_pointmajor(ndc, H, W, radius, K)
+    assert np.array_equal(ref[0], got[0])
+    assert np.array_equal(ref[1].view(np.uint32), got[1].view(np.uint32))
+    assert np.array_equal(ref[2].view(np.uint32), got[2].view(np.uint32))
+    assert (ref[0] >= 0).mean() > 0.3  # the case is not empty

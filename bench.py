@@ -34,27 +34,42 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def _traffic_profile():
+    """the committed rocprofv3 FETCH_SIZE / WRITE_SIZE summary of this same command (made by
+    tools/make_profile_summary.py from separate --pmc passes): newest round first"""
+    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+        f = ROOT / "profiles" / name
+        if f.exists():
+            return name, json.loads(f.read_text())
+    return None, None
+
+
 def measured_traffic(kernel, H, W, S):
-    """HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same
-    command (profiles/r02_hbm_traffic.json, made by tools/make_profile_summary.py); None when
-    the workload differs from the profiled one."""
-    f = ROOT / "profiles" / "r02_hbm_traffic.json"
-    if not f.exists() or (H, W, S) != (1080, 1920, 24):
+    """HBM bytes per launch of `kernel` from the committed profile (NOT measured in this run: counters need their
+    own rocprofv3 passes); None when the workload differs from the profiled one."""
+    name, prof = _traffic_profile()
+    if prof is None or (H, W, S) != (1080, 1920, 24):
         return None
     import re
-    ks = json.loads(f.read_text())["kernels"]
-    for name, v in ks.items():
-        if re.sub(r"<.*>", "", name).replace("_kernel", "") == kernel:
+    for k, v in prof["kernels"].items():
+        if re.sub(r"<.*>", "", k).replace("_kernel", "") == kernel:
             return v["hbm_bytes_per_launch"]
     return None
 
 
 def measured_view_traffic(H, W, S):
-    """HBM bytes per view of all kernels together, from the same profile (None for other workloads)"""
-    f = ROOT / "profiles" / "r02_hbm_traffic.json"
-    if not f.exists() or (H, W, S) != (1080, 1920, 24):
+    """HBM bytes per view of all kernels together, from the same committed profile (None for other workloads)"""
+    name, prof = _traffic_profile()
+    if prof is None or (H, W, S) != (1080, 1920, 24):
         return None
-    return json.loads(f.read_text()).get("total_hbm_bytes_per_view")
+    return prof.get("total_hbm_bytes_per_view")
+
+
+def pmc_instruction_profile():
+    """per-kernel instruction counters per launch (SQ_INSTS_VALU / SALU / LDS wave-instructions, busy and wait
+    cycles) from the committed rocprofv3 --pmc summary of this command, or {}"""
+    f = ROOT / "profiles" / "r03_pmc_instructions.json"
+    return json.loads(f.read_text()) if f.exists() else {}
 
 
 def parse():
@@ -171,8 +186,13 @@ def algorithmic_bytes(name, H, W, S, n_static, n_dyn, K):
     table = {
         # A12: new points read once (packed xyz, 12 B) and one occupancy byte stamped per later frame
         "agg_push0": n0 * (12 + (S - 1)) if S > 1 else 0,
-        "agg_push": ((n_static - n0) / max(S - 1, 1)) * (12 + (S - 1) / 2.0) if S > 1 else 0,
-        "agg_select": 2 * P + (n_static / S) * (4 + 12 + 24 + 12),  # mask + occupancy bytes; depth, rgb -> cloud row + xyz copy
+        # one later frame: mask + own occupancy map read, selection bits written, depth of the new points, one byte stamped
+        # per new point and later frame
+        "agg_step": 2 * P + P / 8 + ((n_static - n0) / max(S - 1, 1)) * (4 + (S - 1) / 2.0) if S > 1 else 0,
+        "agg_count": (S - 1) * P / 8,
+        # rows of all later frames: selection bits; depth, rgb -> cloud row + xyz copy
+        "agg_rows": (S - 1) * P / 8 + (n_static - n0) * (4 + 12 + 24 + 12),
+        "agg_select": P + n0 * (4 + 12 + 24 + 12),  # frame 0: mask; depth, rgb -> cloud row + xyz copy
         "compact_count": P,
         "compact_scatter": P + 4 * P * 0.5,
         "raster_project_count": n_static * 12,       # xyz in, tile counters only
@@ -268,6 +288,12 @@ def main():
     view_ids = [int(round(j * (S - 2) / max(n_views - 1, 1))) for j in range(n_views)]
     # each rank starts at a different view so that ranks do different work (frame sharding)
     views = [synth.to_torch(synth.make_view(video, i, frac=0.4, seed=5), dev) for i in view_ids]
+    # The timed views carry NO injected noise: like the reference (torch.randn_like per forward,
+    # pgdvs_renderer_dyn.py:177-182) every step draws its own -- in the splat kernel, where it is consumed.  One
+    # view keeps the synthetic generator's field for the checks that need two renders to agree.
+    check_view = dict(views[0])
+    for d_ in views:
+        d_.pop("static_noise", None)
 
     cfg = load_config(static_renderer="geo", overrides={
         "engine.engine_cfg.render_cfg.dyn_pcl_remove_outlier": not args.no_outlier,
@@ -470,13 +496,17 @@ def main():
             n_lanes = k
             args.run_ahead = max(base_run_ahead, k + 1)
             timed(2 * k, profile=False)
-            trial[k] = timed(6 * k, profile=False)[0] / (6 * k)
+            # as many views as the timed region will render (filling and draining k lanes is part of a short run:
+            # a count chosen on 6 k views overrated the deep pipelines for the driver's --steps 20), at most 6 k
+            n_probe = max(k, min(6 * k, args.steps))
+            trial[k] = timed(n_probe, profile=False)[0] / n_probe
         tt = torch.tensor([trial[k] for k in lane_candidates], dtype=torch.float64, device=dev)
         if world > 1:  # every rank must take the same count
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         n_lanes = lane_candidates[int(torch.argmin(tt).item())]
         args.run_ahead = max(base_run_ahead, n_lanes + 1)
-        lanes_note = "auto: " + ", ".join(f"{k} lanes {float(tt[i]) * 1e3:.3f} ms/view" for i, k in enumerate(lane_candidates)) + f" -> {n_lanes}"
+        lanes_note = ("auto (probed on min(6 k, --steps) views each): " + ", ".join(f"{k} lanes {float(tt[i]) * 1e3:.3f} ms/view" for i, k in enumerate(lane_candidates))
+                      + f" -> {n_lanes}")
     if args.launch == "auto":
         # Eager launches or graph replay?  Measured, not guessed: a few views each way during warm-up.
         # Eager costs the host ~0.7 ms per view when it is idle -- below the ~1.3 ms the GPU needs -- but
@@ -540,6 +570,13 @@ def main():
     elapsed, gathered, cnt = timed(args.steps, profile=False)
     gc.enable()
     ms0, ms1, seg0 = mem_probe["before"], mem_probe["after"], mem_probe["segments"]
+    # a short timed region (the driver's --steps 20) spends a visible share filling and draining the lanes: the
+    # steady-state rate of the same loop is reported beside it (never `value`)
+    steady = None
+    if args.steps < 100 and world == 1:
+        e2 = timed(200, profile=False)[0]
+        steady = {"frames_per_s": round(200 / e2, 2), "steps": 200,
+                  "note": "same loop and lane count over 200 views, measured right after the timed region; not the headline value"}
     mem_note = {"device_mallocs_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
                 "reserved_GB_peak": round(ms1.get("reserved_bytes.all.peak", 0) / 1e9, 2),
                 "allocated_GB_peak": round(ms1.get("allocated_bytes.all.peak", 0) / 1e9, 2)}
@@ -567,10 +604,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     n_static = int(cnt.item())
-    # concurrency must not change results: the timed run's first image == the warm-up image of the same view
-    if rank == 0 and gathered is not None:
+    # concurrency must not change results: the same view (fixed noise field) alone on one lane and on every lane at once
+    if True:
+        torch.cuda.synchronize()
+        main0, side0_ = lanes[0]
+        with torch.cuda.stream(main0) if main0 is not None else contextlib.nullcontext():
+            alone = render_view(check_view, side0_)[0].clone()
+        join_lanes()
+        torch.cuda.synchronize()
+        together = []
+        for li in range(n_lanes):
+            main, side = lanes[li]
+            if main is not None:
+                main.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
+                together.append(render_view(check_view, side)[0])
+        join_lanes()
+        torch.cuda.synchronize()
         # (the splat accumulates with float atomics, so the comparison is to rounding, not bit-exact)
-        assert torch.allclose(gathered[0], ref_img[0], rtol=0, atol=1e-5), "in-flight views disagree with the sequential result"
+        assert all(torch.allclose(t_, alone, rtol=0, atol=1e-5) for t_ in together), "in-flight views disagree with the sequential result"
+        del together
     n_dyn = int(views[0]["dyn_mask_src_temporal"][0, 0].sum().item())
 
     # ---------------- per-kernel durations with HIP events on the launch stream
@@ -601,8 +654,26 @@ def main():
             dom = max(near, key=lambda k: algorithmic_bytes(k, H, W, S, n_static, n_dyn, K))
             ab = algorithmic_bytes(dom, H, W, S, n_static, n_dyn, K)
             ach = ab / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+            # the binding limit of the co-dominant kernels is vector-instruction issue, not HBM: SQ_INSTS_VALU per
+            # launch from the committed --pmc summary x 2 cycles per wave64 instruction on a SIMD-32
+            # (MI355X_MICROARCH.md) / (1024 SIMDs x 2.4 GHz x this run's launch duration)
+            pmc = pmc_instruction_profile().get("kernels", {}) if (H, W, S) == (1080, 1920, 24) else {}
+            valu = {}
+            for k in near:
+                c = pmc.get(k)
+                if c and c.get("SQ_INSTS_VALU"):
+                    t_issue = c["SQ_INSTS_VALU"] * 2.0 / (1024 * 2.4e9)
+                    valu[k] = {"bound": "valu", "valu_wave_insts_per_launch": c["SQ_INSTS_VALU"],
+                               "salu_wave_insts_per_launch": c.get("SQ_INSTS_SALU"),
+                               "valu_issue_frac": round(t_issue / (kernels[k]["avg_ms"] * 1e-3), 4),
+                               "source": "profiles/r03_pmc_instructions.json (committed rocprofv3 --pmc pass of this command), "
+                                         "duration from this run"}
+            tprof_name, _ = _traffic_profile()
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dom, H, W, S),
+                        "traffic_source": (f"profiles/{tprof_name}: FETCH_SIZE / WRITE_SIZE of separate rocprofv3 --pmc passes "
+                                           "of this command, committed; not measured in this run") if tprof_name else None,
+                        "valu_issue": valu or None,
                         "alg_bytes_per_launch": ab, "avg_launch_ms": kernels[dom]["avg_ms"],
                         "launches_per_view": kernels[dom]["launches_per_step"],
                         "event_bracket_overhead_ms": round(float(lib.pgdvs_prof_overhead_ms()), 5),
@@ -610,9 +681,9 @@ def main():
                         "note": ("dominant kernel by time per view (HIP events on the launch stream, one view at a time, the "
                                  "empty-launch bracket cost subtracted; of the kernels within 20 % of the largest time per view "
                                  "-- co_dominant, ms per view -- the one with the most algorithmic bytes); "
-                                 + ("a VALU-bound search kernel, not an HBM stream" if dom in ("raster_tile", "grid_query", "grid_query_tpq", "agg_push0")
+                                 + ("a VALU-bound search kernel, not an HBM stream (valu_issue)" if dom in ("raster_tile", "grid_query", "grid_query_tpq", "agg_push0")
                                     else "a short kernel launched once per source frame, bound by its dependent global round trips "
-                                         "(tile counts -> ordered offsets -> append), not by bandwidth")
+                                         "(mask + map -> selected pixels -> depth -> stamps), not by bandwidth")
                                  + " (DESIGN.md section 4); the whole path's figure is roofline_path")}
 
     # ---------------- latency of ONE view (nothing else in flight): the throughput above comes from overlapping
@@ -819,12 +890,14 @@ def main():
                 "whole_view_alg_bytes": alg_total,
                 "whole_view_alg_GBps": round(alg_total * fps / 1e9 / max(world, 1), 2),
             },
+            "steady_state": steady,
             "roofline": roofline,
             # BASELINE.md section 3 defines the path's roofline figure over the whole view:
             # bytes(S,P) = (20 S + 120) H W algorithmic bytes per novel view x views per second per GPU
             "roofline_path": {"bound": "hbm", "achieved": round(alg_total * fps / 1e9 / max(world, 1), 2), "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": round(alg_total * fps / 1e9 / max(world, 1) / HBM_PEAK_GBS, 5),
                               "alg_bytes_per_view": alg_total, "traffic_bytes_per_view": measured_view_traffic(H, W, S),
+                              "traffic_source": "committed profile (see roofline.traffic_source)",
                               "note": "all kernels of a view; the path is bound by search / z-buffer / fp64 re-projection work, "
                                       "not by streaming its inputs (DESIGN.md section 4)"},
             "cpu_baseline": cpu_baseline, "gnt": gnt, "variants": variants, "kernels": kernels,

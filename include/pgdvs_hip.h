@@ -182,6 +182,18 @@ int pgdvs_dyn_splat_composite(int H, int W, const float *rgb1, const float *rgb2
                               float *combined_dyn, void *workspace, int64_t workspace_bytes,
                               pgdvs_stream_t stream);
 
+/* The same with the noise drawn inside the scatter kernel where it is consumed (upstream: torch.randn_like per forward,
+ * pgdvs_renderer_dyn.py:177-182): rng_state = DEVICE uint64[2] {seed, draw number}; the field is a pure function of
+ * (seed, draw number, pixel) -- Philox4x32-10 + Box-Muller -- and the call increments the draw number, so a replayed
+ * HIP graph draws a fresh field per replay.  pgdvs_splat_noise_field writes the field [3,H,W] the NEXT such call will
+ * use (tests: the injected-noise entry point fed with it gives the same images). */
+int pgdvs_dyn_splat_composite_rng(int H, int W, const float *rgb1, const float *rgb2, const float *flow12,
+                                  const float *flow_1_to_tgt, const float *valid_dyn_mask_1, uint64_t *rng_state,
+                                  float alpha, const float *static_rgb, float *render_dyn_rgb, float *render_dyn_mask,
+                                  float *combined, float *combined_static, float *combined_dyn, void *workspace,
+                                  int64_t workspace_bytes, pgdvs_stream_t stream);
+int pgdvs_splat_noise_field(int H, int W, const uint64_t *rng_state, float *noise_out, pgdvs_stream_t stream);
+
 /* ---- static branch --------------------------------------------------------- */
 /* A9: pytorch3d PointsRasterizer(bin_size=0) + PointsRenderer + NormWeightedCompositor
  * as used by StaticGeoPointRenderer.forward (pgdvs/renderers/st_geo_renderer.py:77-120)

@@ -882,7 +882,8 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
   const int cx = cell_coord(qx, g.mn[0], g.inv_h, g.G[0]);
   const int cy = cell_coord(qy, g.mn[1], g.inv_h, g.G[1]);
   const int cz = cell_coord(qz, g.mn[2], g.inv_h, g.G[2]);
-  // the nine (dy,dz) rows of the block as x-runs, nearest first (same order as the ring-1 pass above)
+  // the nine (dy,dz) rows of the block as x-runs
+  unsigned key[9];
   {
     const int x0 = cx - 1 < 0 ? 0 : cx - 1;
     const int x1 = cx + 1 >= g.G[0] ? g.G[0] - 1 : cx + 1;
@@ -902,8 +903,35 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
       }
       s_run[k][tid] = se;
       s_bd[k][tid] = bd;
+      // visiting key: the row's box distance with the row number in its low four bits (non-negative floats order like
+      // their bit patterns; rows without points last)
+      key[k] = se.y > se.x ? ((__float_as_uint(bd) & ~15u) | (unsigned)k) : (0xfffffff0u | (unsigned)k);
     }
   }
+  // Every lane visits ITS rows nearest first (sorting network on the nine keys, 25 min / max pairs): the fixed row
+  // order above is the nearest-first order of a query in the middle of its cell, but for a query near a cell corner
+  // it is close to farthest-first -- nearly every candidate then enters the list only to be evicted (~280 accepted
+  // candidates on the busiest lane of a wavefront against ~115 on average), and the insertion chains run for all 64
+  // lanes whenever ONE lane's queue is full.  The result does not depend on the order.
+  {
+#define PGDVS_CE(i, j)                        \
+  {                                           \
+    const unsigned lo = key[i] < key[j] ? key[i] : key[j]; \
+    key[j] = key[i] < key[j] ? key[j] : key[i];            \
+    key[i] = lo;                              \
+  }
+    PGDVS_CE(0, 3) PGDVS_CE(1, 7) PGDVS_CE(2, 5) PGDVS_CE(4, 8)
+    PGDVS_CE(0, 7) PGDVS_CE(2, 4) PGDVS_CE(3, 8) PGDVS_CE(5, 6)
+    PGDVS_CE(0, 2) PGDVS_CE(1, 3) PGDVS_CE(4, 5) PGDVS_CE(7, 8)
+    PGDVS_CE(1, 4) PGDVS_CE(3, 6) PGDVS_CE(5, 7)
+    PGDVS_CE(0, 1) PGDVS_CE(2, 4) PGDVS_CE(3, 5) PGDVS_CE(6, 8)
+    PGDVS_CE(2, 3) PGDVS_CE(4, 5) PGDVS_CE(6, 7)
+    PGDVS_CE(1, 2) PGDVS_CE(3, 4) PGDVS_CE(5, 6)
+#undef PGDVS_CE
+  }
+  unsigned long long order = 0;  // row numbers in visiting order, four bits each
+#pragma unroll
+  for (int k = 0; k < 9; ++k) order |= (unsigned long long)(key[k] & 15u) << (4 * k);
   float a[KK];
 #pragma unroll
   for (int i = 0; i < KK; ++i) a[i] = __builtin_inff();
@@ -928,9 +956,10 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
     if (j >= e && k < 9) {  // this lane's run is exhausted: next row (one per half-step)
       ++k;
       if (k < 9) {
-        const int2 se = s_run[k][tid];
+        const int row = (int)(order >> (4 * k)) & 15;
+        const int2 se = s_run[row][tid];
         j = (unsigned)se.x * 16u;
-        e = s_bd[k][tid] < mx ? (unsigned)se.y * 16u : j;  // no point of the run can enter the list: skip it
+        e = s_bd[row][tid] < mx ? (unsigned)se.y * 16u : j;  // no point of the run can enter the list: skip it
       }
     }
     v_issue = j < e;

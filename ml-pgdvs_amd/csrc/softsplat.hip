@@ -161,12 +161,51 @@ dyn_splat_flag_kernel(int H, int W, const float *__restrict__ flow_1_to_tgt,
 // memory directly.
 constexpr int kSplatTile = 16, kSplatWin = 40;
 
+// torch.randn_like(rgb_src_1) of the reference (pgdvs_renderer_dyn.py:177-182), drawn where it is consumed: the
+// noise only shows on static source pixels that splat next to dynamic content (a few per cent of the frame), so
+// a Philox4x32-10 block per such pixel (key = the caller's seed, counter = (draw number, pixel)) replaces a
+// 25 MB normal field written by one kernel and read back by this one.  Three of the block's four uniforms pairs:
+// Box-Muller, channels 0 / 1 from the first pair, channel 2 from the second.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+__device__ __forceinline__ void splat_noise3(const unsigned long long *__restrict__ rng, int p, float (&nz)[3]) {
+  const unsigned long long seed = rng[0], draw = rng[1];
+  const uint4 r = philox4x32_10(make_uint4((uint32_t)p, 0u, (uint32_t)draw, (uint32_t)(draw >> 32)),
+                                make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+  const float u0 = ((float)(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(r.y >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(r.z >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = ((float)(r.w >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+  nz[0] = ra * cosf(6.283185307179586f * u1);
+  nz[1] = ra * sinf(6.283185307179586f * u1);
+  nz[2] = rb * cosf(6.283185307179586f * u3);
+}
+// the field dyn_splat_scatter_kernel draws for the state `rng` (tests; [3,H,W], un-clamped like torch.randn)
+__global__ void __launch_bounds__(256) splat_noise_field_kernel(int P, const unsigned long long *__restrict__ rng,
+                                                                float *__restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float nz[3];
+  splat_noise3(rng, p, nz);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) out[(size_t)k * P + p] = nz[k];
+}
+
 __global__ void __launch_bounds__(256)
 dyn_splat_scatter_kernel(int H, int W, const float *__restrict__ rgb1,
                          const float *__restrict__ rgb2, const float *__restrict__ flow12,
                          const float *__restrict__ flow_1_to_tgt,
                          const float *__restrict__ valid_mask, const float *__restrict__ noise,
-                         float alpha, float *__restrict__ acc, const uint8_t *__restrict__ flags) {
+                         const unsigned long long *__restrict__ rng, float alpha, float *__restrict__ acc,
+                         const uint8_t *__restrict__ flags) {
   __shared__ float s_acc[5][kSplatWin * kSplatWin];
   __shared__ int s_org[2];
   const int P = H * W;
@@ -205,10 +244,11 @@ dyn_splat_scatter_kernel(int H, int W, const float *__restrict__ rgb1,
   const int ox = s_org[0], oy = s_org[1];
   if (part) {
     // rgb_src_1 = rgb*mask + clamp(randn,0,1)*(1-mask)   (pgdvs_renderer_dyn.py:177-182)
-    float c1[3];
+    float c1[3], drawn[3] = {0.0f, 0.0f, 0.0f};
+    if (noise == nullptr && rng != nullptr && m != 1.0f) splat_noise3(rng, p, drawn);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      float nz = noise ? clampf(noise[(size_t)k * P + p], 0.0f, 1.0f) : 0.0f;
+      float nz = clampf(noise ? noise[(size_t)k * P + p] : drawn[k], 0.0f, 1.0f);
       c1[k] = rgb1[(size_t)p * 3 + k] * m + nz * (1.0f - m);
     }
     // backwarp rgb2 by flow12, align_corners=True (pgdvs_renderer_base.py:91-138)
@@ -278,9 +318,10 @@ dyn_splat_finish_kernel(int P, const float *__restrict__ acc, const uint8_t *__r
                         const float *__restrict__ static_rgb,
                         float *__restrict__ dyn_rgb, float *__restrict__ dyn_mask,
                         float *__restrict__ comb, float *__restrict__ comb_st,
-                        float *__restrict__ comb_dy) {
+                        float *__restrict__ comb_dy, unsigned long long *__restrict__ rng) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
+  if (p == 0 && rng != nullptr) rng[1] = rng[1] + 1ull;  // the next call draws a fresh field (the scatter launch is done)
   // a pixel no dynamic source pixel reaches has splatted mask 0 -> below the 1e-3 threshold -> (.) * 0:
   // its accumulators (never initialised) are not read
   const bool live = flags[p] != 0;
@@ -413,6 +454,12 @@ PGDVS_API int64_t pgdvs_dyn_splat_workspace_bytes(int H, int W) {
   return align_up((int64_t)5 * H * W * (int64_t)sizeof(float) + (int64_t)H * W, 256);
 }
 
+static int dyn_splat_composite_impl(int H, int W, const float *rgb1, const float *rgb2, const float *flow12,
+                                    const float *flow_1_to_tgt, const float *valid_dyn_mask_1, const float *noise,
+                                    unsigned long long *rng, float alpha, const float *static_rgb, float *render_dyn_rgb,
+                                    float *render_dyn_mask, float *combined, float *combined_static, float *combined_dyn,
+                                    void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream);
+
 PGDVS_API int pgdvs_dyn_splat_composite(int H, int W, const float *rgb1, const float *rgb2,
                                         const float *flow12, const float *flow_1_to_tgt,
                                         const float *valid_dyn_mask_1, const float *noise,
@@ -421,6 +468,36 @@ PGDVS_API int pgdvs_dyn_splat_composite(int H, int W, const float *rgb1, const f
                                         float *combined_static, float *combined_dyn,
                                         void *workspace, int64_t workspace_bytes,
                                         pgdvs_stream_t stream) {
+  return dyn_splat_composite_impl(H, W, rgb1, rgb2, flow12, flow_1_to_tgt, valid_dyn_mask_1, noise, nullptr, alpha, static_rgb,
+                                  render_dyn_rgb, render_dyn_mask, combined, combined_static, combined_dyn, workspace,
+                                  workspace_bytes, stream);
+}
+
+PGDVS_API int pgdvs_dyn_splat_composite_rng(int H, int W, const float *rgb1, const float *rgb2, const float *flow12,
+                                            const float *flow_1_to_tgt, const float *valid_dyn_mask_1,
+                                            uint64_t *rng_state, float alpha, const float *static_rgb,
+                                            float *render_dyn_rgb, float *render_dyn_mask, float *combined,
+                                            float *combined_static, float *combined_dyn, void *workspace,
+                                            int64_t workspace_bytes, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(rng_state, "pgdvs_dyn_splat_composite_rng: null rng_state");
+  return dyn_splat_composite_impl(H, W, rgb1, rgb2, flow12, flow_1_to_tgt, valid_dyn_mask_1, nullptr,
+                                  reinterpret_cast<unsigned long long *>(rng_state), alpha, static_rgb, render_dyn_rgb,
+                                  render_dyn_mask, combined, combined_static, combined_dyn, workspace, workspace_bytes, stream);
+}
+
+PGDVS_API int pgdvs_splat_noise_field(int H, int W, const uint64_t *rng_state, float *noise_out, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(H > 0 && W > 0 && (int64_t)H * W < (1ll << 31) && rng_state && noise_out, "pgdvs_splat_noise_field: bad argument");
+  const int P = H * W;
+  PGDVS_LAUNCH("splat_noise_field", splat_noise_field_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, as_stream(stream), P,
+               reinterpret_cast<const unsigned long long *>(rng_state), noise_out);
+  return check_launch("splat_noise_field");
+}
+
+static int dyn_splat_composite_impl(int H, int W, const float *rgb1, const float *rgb2, const float *flow12,
+                                    const float *flow_1_to_tgt, const float *valid_dyn_mask_1, const float *noise,
+                                    unsigned long long *rng, float alpha, const float *static_rgb, float *render_dyn_rgb,
+                                    float *render_dyn_mask, float *combined, float *combined_static, float *combined_dyn,
+                                    void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream) {
   PGDVS_REQUIRE(H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), "pgdvs_dyn_splat_composite: bad H/W");
   PGDVS_REQUIRE(rgb1 && rgb2 && flow12 && flow_1_to_tgt && valid_dyn_mask_1 && render_dyn_rgb &&
                     render_dyn_mask,
@@ -444,9 +521,9 @@ PGDVS_API int pgdvs_dyn_splat_composite(int H, int W, const float *rgb1, const f
                flags, acc);
   const dim3 tgrid((unsigned)cdiv(W, kSplatTile), (unsigned)cdiv(H, kSplatTile));
   PGDVS_LAUNCH("dyn_splat_scatter", dyn_splat_scatter_kernel, tgrid, block, 0, st, H, W, rgb1, rgb2, flow12,
-                     flow_1_to_tgt, valid_dyn_mask_1, noise, alpha, acc, (const uint8_t *)flags);
+                     flow_1_to_tgt, valid_dyn_mask_1, noise, (const unsigned long long *)rng, alpha, acc, (const uint8_t *)flags);
   PGDVS_LAUNCH("dyn_splat_finish", dyn_splat_finish_kernel, grid, block, 0, st, P, acc, (const uint8_t *)flags, static_rgb,
-                     render_dyn_rgb, render_dyn_mask, combined, combined_static, combined_dyn);
+                     render_dyn_rgb, render_dyn_mask, combined, combined_static, combined_dyn, rng);
   return check_launch("dyn_splat_composite");
 }
 

@@ -274,10 +274,28 @@ def softsplat_bwd(ten_in, ten_flow, grad_out, need_in: bool = True, need_flow: b
     return gi, gf
 
 
-def dyn_splat_composite(rgb1, rgb2, flow12, flow_1_to_tgt, valid_mask, noise, alpha, static_rgb, out_combined=None):
+def splat_rng_state(device, seed: int | None = None) -> torch.Tensor:
+    """Device-resident state {seed, draw number} of the splat kernel's own noise (``dyn_splat_composite(rng_state=...)``);
+    the seed defaults to torch's (``torch.initial_seed()``)."""
+    s = torch.initial_seed() if seed is None else int(seed)
+    return torch.tensor([s & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+
+
+def splat_noise_field(rng_state, H: int, W: int) -> torch.Tensor:
+    """[3,H,W]: the un-clamped normal field the NEXT ``dyn_splat_composite(rng_state=rng_state)`` call draws."""
+    st = _req(rng_state, torch.int64, "rng_state")
+    out = torch.empty((3, H, W), dtype=torch.float32, device=st.device)
+    check(_lib.load().pgdvs_splat_noise_field(H, W, _ptr(st), _ptr(out), _stream()), "pgdvs_splat_noise_field")
+    return out
+
+
+def dyn_splat_composite(rgb1, rgb2, flow12, flow_1_to_tgt, valid_mask, noise, alpha, static_rgb, out_combined=None,
+                        rng_state=None):
     """Returns planar (render_dyn_rgb[3,H,W], render_dyn_mask[H,W], combined, combined_static, combined_dyn).
     ``out_combined``: optional caller-owned contiguous [3,H,W] fp32 buffer the kernel writes the composite into
-    (e.g. a slice of the caller's image stack: no copy afterwards)."""
+    (e.g. a slice of the caller's image stack: no copy afterwards).  ``noise`` [3,H,W]: the injected normal field
+    (parity tests); ``noise=None`` with ``rng_state`` (``splat_rng_state``): the kernel draws it itself and advances
+    the state; both None: zeros."""
     r1 = _req(rgb1, torch.float32, "rgb1")
     H, W = r1.shape[0], r1.shape[1]
     dev = r1.device
@@ -298,12 +316,15 @@ def dyn_splat_composite(rgb1, rgb2, flow12, flow_1_to_tgt, valid_mask, noise, al
     nz = _req(noise, torch.float32, "noise") if noise is not None else None
     lib = _lib.load()
     ws = _ws(lib.pgdvs_dyn_splat_workspace_bytes(H, W), dev)
-    check(lib.pgdvs_dyn_splat_composite(
+    draw = nz is None and rng_state is not None
+    fn = lib.pgdvs_dyn_splat_composite_rng if draw else lib.pgdvs_dyn_splat_composite
+    check(fn(
         H, W, _ptr(r1), _ptr(_req(rgb2, torch.float32, "rgb2")), _ptr(_req(flow12, torch.float32, "flow12")),
         _ptr(_req(flow_1_to_tgt, torch.float32, "flow_1_to_tgt")), _ptr(_req(valid_mask, torch.float32, "valid_mask")),
-        _ptr(nz), float(alpha), _ptr(st), _ptr(dyn_rgb), _ptr(dyn_mask),
+        _ptr(_req(rng_state, torch.int64, "rng_state") if draw else nz), float(alpha), _ptr(st), _ptr(dyn_rgb), _ptr(dyn_mask),
         _ptr(comb[0] if comb is not None else None), _ptr(comb[1] if comb is not None else None),
-        _ptr(comb[2] if comb is not None else None), _ptr(ws), ws.numel(), _stream()), "pgdvs_dyn_splat_composite")
+        _ptr(comb[2] if comb is not None else None), _ptr(ws), ws.numel(), _stream()),
+        "pgdvs_dyn_splat_composite_rng" if draw else "pgdvs_dyn_splat_composite")
     if comb is None:
         return dyn_rgb, dyn_mask, None, None, None
     return dyn_rgb, dyn_mask, comb[0], comb[1], comb[2]

@@ -162,12 +162,19 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
         same_res = (render_h == orig_h) and (render_w == orig_w)
         fuse_static = static_rgb is not None and same_res and dyn_type == "softsplat" and not self.use_tracker
 
-        noise = None
+        noise = rng_state = None
         if dyn_type == "softsplat":
-            # torch.randn_like(rgb_src_1) upstream (:181); injectable for parity tests
+            # torch.randn_like(rgb_src_1) upstream (:181): injectable for parity tests (``static_noise``); otherwise the
+            # splat kernel draws the field itself, per forward, where it consumes it (only static pixels that land next
+            # to dynamic content ever show it) -- seeded from torch's seed, one state per device, advanced by the kernel
             noise = data.get("static_noise", None)
             if noise is None:
-                noise = torch.randn((n_b, 3, orig_h, orig_w), dtype=torch.float32, device=dev)
+                # (one state per stream: views in flight on different streams neither share draws nor race on the counter)
+                states = self.__dict__.setdefault("_splat_rng", {})
+                key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+                rng_state = states.get(key)
+                if rng_state is None:
+                    rng_state = states[key] = ops.splat_rng_state(dev, torch.initial_seed() + 0x9E3779B97F4A7C15 * len(states))
 
         dyn_rgbs, dyn_masks, combs = [], [], []
         # optional caller-owned output [B,3,H,W] for combined_rgb (a slice of the caller's image stack): the
@@ -178,9 +185,9 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
             if dyn_type == "softsplat":
                 rgb, mask, c, cs, cd = ops.dyn_splat_composite(
                     data["rgb_src_temporal"][i_b, 0], data["rgb_src_temporal"][i_b, 1], data["flow_fwd"][i_b],
-                    flow_1_to_tgt, valid_mask, noise[i_b], self.softsplat_metric_abs_alpha,
+                    flow_1_to_tgt, valid_mask, noise[i_b] if noise is not None else None, self.softsplat_metric_abs_alpha,
                     static_rgb[i_b] if fuse_static else None,
-                    out_combined=out_comb[i_b] if (fuse_static and out_comb is not None) else None)
+                    out_combined=out_comb[i_b] if (fuse_static and out_comb is not None) else None, rng_state=rng_state)
                 if fuse_static:
                     combs.append((c, cs, cd))
             elif dyn_type == "mesh":

@@ -1,0 +1,146 @@
+"""GPU tests added in round 3 (MI355X): the randomised GPU-vs-oracle sweep over the kernels with data-dependent
+fast paths (formerly the uncollected tests/fuzz_parity.py), the splat kernel's own noise, the rasteriser's
+right-sized workspace with its overflow status, and the bounded receive ring of the image gather."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402  (checker only)
+from pgdvs_amd import ops, synth  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from pgdvs_amd import _lib
+
+    _lib.load()
+
+
+def _renderer(static="geo", **over):
+    from pgdvs_amd.instantiate import load_config
+    from pgdvs_amd.renderers.pgdvs_renderer import PGDVSRenderer
+
+    cfg = load_config(static_renderer=static)
+    rc = cfg.engine.engine_cfg.render_cfg
+    for k, v in over.items():
+        rc[k] = v
+    return PGDVSRenderer(cfg, render_cfg=rc, softsplat_metric_abs_alpha=100.0).to(DEV).eval(), rc
+
+
+# ---------------------------------------------------------------- randomised sweep (fixed budget: 8 seeds)
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_knn_raster_view_vs_oracle(seed):
+    """many seeds, ragged sizes: kNN (thread-per-query pass and ring search; surface + clusters + duplicates; K inside
+    and outside the thread-per-query set), rasteriser (layered depths with exact ties, random radius / K) and a whole
+    small view (splat with the flag pre-pass, outlier filter on) -- bit-exact / 1e-4 against the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(60, 6000))
+    K = int(rng.choice([4, 8, 16, 20, 50, 7, 30]))
+    u = rng.uniform(-1, 1, (n, 2))
+    pts = np.stack([u[:, 0], u[:, 1], 2 + 0.3 * np.sin(3 * u[:, 0]) + rng.normal(0, 0.003, n)], 1)
+    pts[: n // 20] += rng.normal(0, 0.7, (n // 20, 3))
+    pts[n // 2: n // 2 + n // 30] = pts[:n // 30]
+    pts = pts.astype(np.float32)
+    cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
+    a = N(ops.knn_mean_dist(T(pts), cnt, K, algo=2))[:n]
+    assert np.array_equal(a.view(np.uint32), orc.knn_mean_dist(pts, K).view(np.uint32)), f"knn n={n} K={K}"
+
+    H, W = int(rng.integers(20, 70)), int(rng.integers(20, 70))
+    m, Kp, radius = int(rng.integers(500, 20000)), int(rng.integers(1, 9)), float(rng.uniform(0.01, 0.09))
+    fc = synth.flat_cam(H, W, *synth.frame_camera(1, 4, H, W))
+    z = 1.0 + 0.2 * rng.integers(0, 5, m) + np.where(rng.random(m) < 0.4, 0.0, rng.uniform(0, 0.05, m))
+    xy = rng.uniform(-1.3, 1.3, (m, 2)) * z[:, None] * 0.6
+    p3 = np.concatenate([xy, z[:, None]], 1).astype(np.float32)
+    cloud = T(np.concatenate([p3, rng.random((m, 3), dtype=np.float32)], 1))
+    r = ops.points_raster(cloud, cloud[:, 3:], ops.cam_prep(T(fc)), radius, Kp, H, W, want_fragments=True)
+    idx, zbuf, d2 = orc.rasterize_points(p3, fc, H, W, radius, Kp)
+    assert np.array_equal(N(r["idx"]), idx), f"raster {H}x{W} n={m} K={Kp} r={radius:.3f}"
+    assert np.array_equal(N(r["zbuf"]).view(np.uint32), zbuf.view(np.uint32))
+    assert np.array_equal(N(r["dist2"]).view(np.uint32), d2.view(np.uint32))
+
+    Hh, Ww, S = int(rng.integers(40, 90)), int(rng.integers(48, 120)), 3
+    v = synth.make_video(S, Hh, Ww, seed=seed)
+    d = synth.make_view(v, int(rng.integers(0, 2)), seed=seed)
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=True, dyn_pcl_outlier_knn=20, st_render_pcl_pts_per_pixel=3)
+    cloud_s = orc.aggregate_static_pcl(v["rgbs"], v["depths"], v["dyn_masks"], v["K3s"], v["c2ws"])
+    data = synth.to_torch(d, DEV)
+    data["st_pcl_rgb"] = T(cloud_s.astype(np.float32))[None]
+    with torch.no_grad():
+        ret = model.forward(data, render_cfg=rc)
+    od = dict(d)
+    od["st_pcl_rgb"] = cloud_s[None]
+    o = orc.render_view(od, dict(rc), static_noise=d["static_noise"], alpha=100.0)
+    assert np.array_equal(N(ret["render_dyn_mask"]), o["render_dyn_mask"])
+    np.testing.assert_allclose(N(ret["combined_rgb"]), o["combined_rgb"], rtol=0, atol=1e-4)
+
+
+# ---------------------------------------------------------------- the splat kernel's own noise (A8, :177-182)
+def test_splat_noise_field_is_standard_normal_and_advances():
+    H, W = 270, 480
+    st = ops.splat_rng_state(DEV, seed=1234)
+    f0 = N(ops.splat_noise_field(st, H, W)).astype(np.float64)
+    assert f0.shape == (3, H, W) and np.isfinite(f0).all()
+    n = f0.size
+    assert abs(f0.mean()) < 4 / np.sqrt(n) and abs(f0.std() - 1) < 0.01
+    assert abs((f0 ** 3).mean()) < 0.02 and abs((f0 ** 4).mean() - 3) < 0.06
+    # channels and neighbouring pixels are uncorrelated
+    assert abs(np.corrcoef(f0[0].ravel(), f0[1].ravel())[0, 1]) < 0.01 and abs(np.corrcoef(f0[0].ravel(), f0[2].ravel())[0, 1]) < 0.01
+    assert abs(np.corrcoef(f0[0, :, 1:].ravel(), f0[0, :, :-1].ravel())[0, 1]) < 0.01
+    # E clamp(X, 0, 1) = phi(0) - phi(1) + 1 - Phi(1)
+    assert abs(np.clip(f0, 0, 1).mean() - 0.315626) < 2e-3
+    # same state -> same field; another seed or another draw number -> another field
+    assert np.array_equal(N(ops.splat_noise_field(ops.splat_rng_state(DEV, seed=1234), H, W)), f0.astype(np.float32))
+    assert not np.array_equal(N(ops.splat_noise_field(ops.splat_rng_state(DEV, seed=1235), H, W)), f0.astype(np.float32))
+    st[1] += 1
+    assert abs(np.corrcoef(N(ops.splat_noise_field(st, H, W)).ravel(), f0.ravel())[0, 1]) < 0.01
+
+
+def test_renderer_draws_its_noise_in_the_splat_kernel():
+    """no ``static_noise`` in the data dict: the reference draws torch.randn_like per forward (:181); here the scatter
+    kernel draws the field for the pixels that consume it.  The images equal those of the injected-noise path (and of
+    the oracle) fed with the field of that draw, and every forward uses a new draw."""
+    H, W, S = 96, 160, 3
+    v = synth.make_video(S, H, W, seed=11)
+    d = synth.make_view(v, 1, seed=3)
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=True, dyn_pcl_outlier_knn=16, st_render_pcl_pts_per_pixel=3)
+    cloud = orc.aggregate_static_pcl(v["rgbs"], v["depths"], v["dyn_masks"], v["K3s"], v["c2ws"])
+    data = synth.to_torch(d, DEV)
+    data["st_pcl_rgb"] = T(cloud)[None]
+    data.pop("static_noise")
+    with torch.no_grad():
+        r0 = model.forward(dict(data), render_cfg=rc)
+        r1 = model.forward(dict(data), render_cfg=rc)
+    (state,) = model.dyn_renderer._splat_rng.values()
+    assert int(state[1]) == 2  # two forwards, two draws
+    for draw, ret in ((0, r0), (1, r1)):
+        st = state.clone()
+        st[1] = draw
+        field = ops.splat_noise_field(st, H, W)
+        inj = dict(data)
+        inj["static_noise"] = field[None]
+        with torch.no_grad():
+            ri = model.forward(inj, render_cfg=rc)
+        assert torch.equal(ret["render_dyn_mask"], ri["render_dyn_mask"])
+        assert torch.allclose(ret["combined_rgb"], ri["combined_rgb"], rtol=0, atol=1e-6)  # (float atomics: to rounding)
+        od = dict(d)
+        od["st_pcl_rgb"] = cloud[None]
+        o = orc.render_view(od, dict(rc), static_noise=N(field)[None], alpha=100.0)
+        assert np.array_equal(N(ret["render_dyn_mask"]), o["render_dyn_mask"])
+        np.testing.assert_allclose(N(ret["combined_rgb"]), o["combined_rgb"], rtol=0, atol=1e-4)
+    # the noise shows (only) where static source pixels splat beside dynamic content
+    diff = (r0["render_dyn_rgb"] - r1["render_dyn_rgb"]).abs().amax(1)[0]
+    assert float(diff.max()) > 1e-3 and float((diff > 0).float().mean()) < 0.2

@@ -150,7 +150,8 @@ def dry_main(args, world, rank):
         print(f"rank {rank}: failing on request", file=sys.stderr)
         sys.exit(3)
     like = torch.empty(1, 3, 4, 6)
-    gather = pdist.AsyncImageGather(dst=0, n_steps=args.steps, like=like)
+    ring = min(args.steps, args.run_ahead + 3)
+    gather = pdist.AsyncImageGather(dst=0, n_steps=args.steps, like=like, ring=ring)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -167,11 +168,13 @@ def dry_main(args, world, rank):
         dist.all_gather(allt, t)
         per_rank = [float(x.item()) for x in allt]
     if rank == 0:
-        assert out.shape[0] == args.steps * world and [float(x) for x in out[:, 0, 0, 0]] == [float(v) for v in range(args.steps * world)]
+        # every view arrived exactly once: checksum of view v = 72 v (72 pixels of value v)
+        assert out["sums"].flatten().tolist() == [72.0 * v for v in range(args.steps * world)], out["sums"]
+        assert [float(x) for x in out["tail"][:, 0, 0, 0]] == [float(v) for v in range(out["tail_first_step"] * world, args.steps * world)]
         print(json.dumps({"metric": "novel-view frames/s at 1080p x 24 src frames; achieved HBM GB/s vs gfx950 peak",
                           "value": None, "unit": "frames/s", "dry_run": True, "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(max(per_rank) / max(args.steps, 1) * 1e3, 3),
-                          "scaling": "weak", "views_gathered": int(out.shape[0]),
+                          "scaling": "weak", "views_gathered": int(out["sums"].numel()), "receive_ring_slots": ring,
                           "per_rank_seconds": [round(x, 4) for x in per_rank],
                           "gather_bytes_to_rank0": int(like.numel() * 4 * args.steps * (world - 1))}), flush=True)
     if world > 1:
@@ -338,13 +341,22 @@ def main():
             data["_combined_rgb_out"] = out
         # dynamic-branch geometry on a side stream, overlapping the static aggregation + raster
         data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=side if use_side else None)
-        cloud, cnt, xyz = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=cap, return_xyz=True)
+        # (cloud buffers: capacity S*H*W rows for the first view, then the same bound as the rasteriser's workspace --
+        # the aggregation clamps at its capacity, so a count that REACHES the bound is treated as an overflow below)
+        cloud, cnt, xyz = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=row_bound[0] or cap, return_xyz=True)
         data["st_pcl_rgb"] = cloud[None]
         data["st_pcl_rgb_count"] = cnt
         data["st_pcl_xyz"] = xyz[None]  # the packed coordinates: the rasteriser's binning reads 12 bytes per point, not 24
+        if row_bound[0] is not None:
+            # the cloud buffer is capacity-sized (S*H*W rows, a device-side count): the rasteriser's tile lists are sized
+            # for the rows the first view had plus a margin, and a status word says if a later view outgrew that
+            data["st_pcl_rgb_row_bound"] = row_bound[0]
         with torch.no_grad():
             ret = model.forward(data, render_cfg=rc, disable_tqdm=True)
+        raster_status[0] = ret.get("geo_static_raster_status", None)
         return ret["combined_rgb"], cnt
+
+    row_bound, raster_status = [None], [None]
 
     def step_eager(j, lane=None, out=None, use_side=None):
         main, side = lanes[(j % n_lanes) if lane is None else lane]
@@ -373,8 +385,6 @@ def main():
             graphs, graph_note = None, f"eager launches (graph capture failed: {type(e).__name__}: {e})"
             torch.cuda.synchronize()
 
-    if args.launch == "graph":
-        build_graphs()
 
     def step_graph(j):
         g = graphs[j % len(graphs)]
@@ -398,14 +408,43 @@ def main():
         if world > 1:
             dist.barrier(device_ids=[local_rank])
 
+    # the first view sizes the rasteriser's workspace for the views that follow (one host read of the count, untimed;
+    # before any graph is captured: the bound is baked into the captured launches)
+    _, cnt0, _ = step_eager(0, 0)
+    join_lanes()
+    torch.cuda.synchronize()
+    row_bound[0] = min(cap, int(1.25 * ops.checked_count(cnt0, "pgdvs_static_aggregate")) + 65536)
+    if os.environ.get("PGDVS_BENCH_NO_ROW_BOUND"):  # diagnostic: capacity-sized buffers and workspaces as in round 2
+        row_bound[0] = None
+    if args.launch == "graph":
+        build_graphs()
+
     host_enqueue = [0.0]
     host_wait = [0.0]  # part of host_enqueue spent blocked on the run-ahead bound (the GPU is behind)
     mem_probe = {}
 
+    gather_box = [None]
+    ctl_stream = torch.cuda.Stream(device=dev)
+    # ring slots: the views in flight at the deepest lane count tried, the host's run-ahead and a spare
+    lanes_max_ring = [max(base_run_ahead, max(lane_candidates) + 1 if auto_lanes else n_lanes + 1) + (max(lane_candidates) if auto_lanes else n_lanes) + 2]
+
+    def trace(msg):
+        if os.environ.get("PGDVS_BENCH_TRACE"):
+            torch.cuda.synchronize()
+            print(f"[trace] {msg}", file=sys.stderr, flush=True)
+
     def timed(n_steps, profile):
+        trace(f"timed({n_steps}, profile={profile}) begins")
         lib.pgdvs_prof_enable(1 if profile else 0)
         # step j's image travels while step j+1 renders; rank 0 receives into one stack allocated here
-        gather = pdist.AsyncImageGather(dst=0, n_steps=n_steps, like=ref_img)
+        # (bounded memory: a ring of slots covering the views in flight; rank 0 checksums every view as its slot comes
+        # up for reuse -- 200 steps x 8 ranks x 25 MB would be 40 GB of receive stack beside the lane workspaces)
+        # One gather object for the whole process: its buffers are allocated before the first loop and reused by every
+        # later one (reset) -- with captured HIP graphs alive, a fresh allocation between two replay loops was followed
+        # by a GPU memory fault on replay (ROCm 7.2); the eager path does not care.
+        if gather_box[0] is None or n_steps > gather_box[0].capacity_steps or (lanes_max_ring[0] != gather_box[0].ring):
+            gather_box[0] = pdist.AsyncImageGather(dst=0, n_steps=max(n_steps, 256), like=ref_img, ring=lanes_max_ring[0])
+        gather = gather_box[0].reset(n_steps)
         barrier()
         torch.cuda.synchronize()
         mem_probe["before"] = torch.cuda.memory_stats(dev)
@@ -414,27 +453,37 @@ def main():
         t0 = time.perf_counter()
         done = []
         host_wait[0] = 0.0
-        for j in range(n_steps):
-            # bounded run-ahead: the host enqueues a view in ~0.7 ms and the GPU renders one in ~1.2, so an
-            # unbounded loop gets tens of views ahead, and every view enqueued but not yet executed pins the
-            # workspace blocks its two streams share (the caching allocator cannot hand a block that
-            # another stream used back before that stream's work has run): the pool then grows by
-            # hipMalloc calls in the middle of the timed region, each of which drains the pipeline
-            if len(done) >= args.run_ahead:
-                w0 = time.perf_counter()
-                done[j - args.run_ahead].synchronize()
-                host_wait[0] += time.perf_counter() - w0
-            # per-kernel HIP events need real launches; one view at a time, so that a kernel's
-            # duration is its own and not the queueing behind the other lanes' kernels
-            img, cnt, main = step(j, eager=profile, lane=0 if profile else None, out=gather.slot())
-            with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
-                gather.submit(img)
-                ev = torch.cuda.Event()
-                ev.record()
-            done.append(ev)
-        host_enqueue[0] = time.perf_counter() - t0  # host time to enqueue everything (incl. the waits of the run-ahead bound)
-        join_lanes()
-        gathered = gather.finish()
+        # (everything the loop itself enqueues -- slot retirement, joins, the final checksums -- runs on a control stream of
+        # its own, never on the null stream: with captured HIP graphs alive, a kernel on the null stream between two
+        # replays was followed by a GPU memory fault on this ROCm)
+        with torch.cuda.stream(ctl_stream):
+            for j in range(n_steps):
+                # bounded run-ahead: the host enqueues a view in ~0.7 ms and the GPU renders one in ~1.2, so an
+                # unbounded loop gets tens of views ahead, and every view enqueued but not yet executed pins the
+                # workspace blocks its two streams share (the caching allocator cannot hand a block that
+                # another stream used back before that stream's work has run): the pool then grows by
+                # hipMalloc calls in the middle of the timed region, each of which drains the pipeline
+                if len(done) >= args.run_ahead:
+                    w0 = time.perf_counter()
+                    done[j - args.run_ahead].synchronize()
+                    host_wait[0] += time.perf_counter() - w0
+                # per-kernel HIP events need real launches; one view at a time, so that a kernel's
+                # duration is its own and not the queueing behind the other lanes' kernels
+                # (graph replay renders into the graph's own buffer: no slot is handed out, and the ring retires its oldest
+                # step inside submit(), on the lane's stream)
+                img, cnt, main = step(j, eager=profile, lane=0 if profile else None,
+                                      out=gather.slot() if (graphs is None or profile) else None)
+                trace(f"step {j} enqueued")
+                with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
+                    gather.submit(img)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                done.append(ev)
+            host_enqueue[0] = time.perf_counter() - t0  # host time to enqueue everything (incl. the waits of the run-ahead bound)
+            join_lanes()
+            trace("loop done")
+            gathered = gather.finish()
+            trace("gather finished")
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
@@ -469,6 +518,7 @@ def main():
         print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=50),
               file=sys.stderr)
 
+    trace("graphs built" if graphs else "no graphs")
     ref_img = None
     for j in range(max(args.warmup, n_lanes)):
         img = step(j)[0]
@@ -603,7 +653,20 @@ def main():
         per_rank_s = [float(x.item()) for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    n_static = int(cnt.item())
+    # who took part (first contact with an 8-GPU node: a silent rank / device mismatch must show in the line)
+    peers = [(rank, local_rank, torch.cuda.get_device_name(dev))]
+    if world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, peers[0])
+        peers = sorted(got)
+        assert [p_[0] for p_ in peers] == list(range(world)), f"ranks seen: {peers}"
+    if rank == 0 and isinstance(gathered, dict):
+        sums = gathered["sums"]
+        assert tuple(sums.shape) == (args.steps, world) and bool(torch.isfinite(sums).all()) and bool((sums != 0).all()), \
+            "a gathered view is missing or empty"
+    n_static = ops.checked_count(cnt, "pgdvs_static_aggregate")
+    ops.check_raster_status(raster_status[0])  # (the last view's status word; every view renders the same cloud)
+    assert row_bound[0] is None or n_static < row_bound[0], f"the static cloud ({n_static} rows) filled its buffer of {row_bound[0]} rows: rows may have been dropped"
     # concurrency must not change results: the same view (fixed noise field) alone on one lane and on every lane at once
     if True:
         torch.cuda.synchronize()
@@ -883,10 +946,14 @@ def main():
                 "workload": f"{W}x{H} target view, {S} source frames resident in HBM: static aggregation (A12) + "
                             f"point z-buffer raster K={K} (A9) + flow-warped dynamic splat (A1-A8, outlier filter "
                             f"{'on' if not args.no_outlier else 'off'}) + composite (A11)",
-                "views_in_flight": (len(graphs) if graphs else n_lanes), "views_in_flight_choice": lanes_note, "host_run_ahead_views": args.run_ahead, "memory": mem_note, "launch": graph_note, "height": H, "width": W, "src_frames": S, "static_points": n_static, "dyn_pixels": n_dyn,
+                "views_in_flight": (len(graphs) if graphs else n_lanes), "views_in_flight_choice": lanes_note, "host_run_ahead_views": args.run_ahead, "memory": mem_note, "raster_row_bound": row_bound[0], "launch": graph_note, "height": H, "width": W, "src_frames": S, "static_points": n_static, "dyn_pixels": n_dyn,
                 "parallelism": f"frames sharded over {world} GPU(s), RCCL gather of the image stack" if world > 1 else "1 GPU",
                 "per_rank_frames_per_s": [round(args.steps / x, 2) for x in per_rank_s],
                 "gather_bytes_to_rank0": int(3 * H * W * 4 * args.steps * (world - 1)),
+                "gather_GBps_into_rank0": round(3 * H * W * 4 * args.steps * (world - 1) / elapsed / 1e9, 2),
+                "gather_receive_ring_slots": args.run_ahead + n_lanes + 2,
+                "collective_backend": (dist.get_backend() if world > 1 else None), "rccl_ranks_seen": [p_[0] for p_ in peers],
+                "rank_devices": [f"rank {p_[0]}: cuda:{p_[1]} {p_[2]}" for p_ in peers],
                 "whole_view_alg_bytes": alg_total,
                 "whole_view_alg_GBps": round(alg_total * fps / 1e9 / max(world, 1), 2),
             },

@@ -213,6 +213,17 @@ int pgdvs_points_raster(const float *pts, int64_t pts_stride, const float *feat,
                         float *zbuf, float *dist2, float *rgb, int rgb_planar, float *mask,
                         void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream);
 
+/* The same with a workspace sized for `row_bound` rows -- pgdvs_points_raster_workspace_bytes(row_bound, ...) -- instead
+ * of the arrays' capacity n_points (callers keep capacity-sized cloud buffers with a device-side count; a hint such as
+ * the previous view's count plus a margin saves gigabytes of tile lists per view in flight).  status_dev: DEVICE int32,
+ * written by the call: 0 = all rows drawn, 1 = the device count exceeds row_bound (the rows beyond it are not drawn: the
+ * images are not valid), 2 = the device count is negative (the producer's error status; nothing drawn). */
+int pgdvs_points_raster_bounded(const float *pts, int64_t pts_stride, const float *feat, int64_t feat_stride,
+                                int64_t n_points, const int64_t *n_points_dev, int64_t row_bound, int32_t *status_dev,
+                                const float *cam_tgt, float radius, int K, int H, int W, int64_t *idx, float *zbuf,
+                                float *dist2, float *rgb, int rgb_planar, float *mask, void *workspace,
+                                int64_t workspace_bytes, pgdvs_stream_t stream);
+
 /* A12: static point-cloud aggregation across the S frames of a video with the
  * projection-occupancy dedup (pgdvs/datasets/nvidia_eval_pure_geo.py:183-277,
  * pgdvs/datasets/nvidia_eval.py:840-847, pgdvs/datasets/base.py:507-546).

@@ -870,6 +870,8 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
                       int32_t *__restrict__ open_count, int32_t *__restrict__ open_list) {
   __shared__ int2 s_run[9][256];
   __shared__ float s_bd[9][256];
+  __shared__ float s_thr[256];  // the lane's starting threshold (see below)
+  __shared__ unsigned long long s_order[256];  // ... and its row numbers in visiting order, four bits each
   const GridParams g = *gp;
   const int n = g.n;
   const int tid = threadIdx.x;
@@ -929,13 +931,39 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
     PGDVS_CE(1, 2) PGDVS_CE(3, 4) PGDVS_CE(5, 6)
 #undef PGDVS_CE
   }
-  unsigned long long order = 0;  // row numbers in visiting order, four bits each
+  {
+    unsigned long long order = 0;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) order |= (unsigned long long)(key[k] & 15u) << (4 * k);
+    for (int k = 0; k < 9; ++k) order |= (unsigned long long)(key[k] & 15u) << (4 * k);
+    s_order[tid] = order;  // (read back per row switch: two registers fewer across the candidate loop)
+  }
+  // Acceptance threshold from the start.  The points sample a surface: the squared radius that holds K+1 of them is
+  // about (K+1) / (pi * density), and the block's own candidate count measures the density -- on the benchmark cloud
+  // r^2 / ((K+1) h^2 / candidates) is 3.3 in the median, 4.0 at the 99th percentile.  Starting from 4.5 x that instead
+  // of +inf, a lane accepts ~70 candidates instead of ~100 (every accepted candidate costs all 64 lanes a (K+1)-long
+  // insertion chain) and skips rows farther than the threshold.  The list simply starts out filled with the threshold
+  // (no register beside it -- the kernel sits at the 96-register edge of five waves per SIMD -- and a copy in LDS for
+  // the check at the end): accepted candidates are strictly smaller and push it out.  A lane whose last slot still holds it at the end (0.5 %: the estimate was too
+  // small for it) proves nothing and goes to the wavefront-per-query search like any other open query, so the results
+  // do not depend on the estimate.
+  auto threshold = [&]() {
+    int ncand = 0;  // points in the block (the runs are still in this lane's LDS column)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int2 se = s_run[k][tid];
+      ncand += se.y - se.x;
+    }
+    return (KK >= 17 && ncand >= KK) ? (KK >= 40 ? 4.5f : 6.0f) * (float)KK * g.h * g.h / (float)ncand : __builtin_inff();
+  };
   float a[KK];
+  __builtin_amdgcn_sched_barrier(0);  // (the 51 copies must not become live while the run set-up above still is)
+  {
+    const float t0 = threshold();
+    s_thr[tid] = t0;
 #pragma unroll
-  for (int i = 0; i < KK; ++i) a[i] = __builtin_inff();
-  float mx = __builtin_inff();
+    for (int i = 0; i < KK; ++i) a[i] = t0;
+  }
+  float mx = a[KK - 1];
   float qd[kTpqQueue];
 #pragma unroll
   for (int u = 0; u < kTpqQueue; ++u) qd[u] = __builtin_inff();
@@ -956,7 +984,7 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
     if (j >= e && k < 9) {  // this lane's run is exhausted: next row (one per half-step)
       ++k;
       if (k < 9) {
-        const int row = (int)(order >> (4 * k)) & 15;
+        const int row = (int)(s_order[tid] >> (4 * k)) & 15;
         const int2 se = s_run[row][tid];
         j = (unsigned)se.x * 16u;
         e = s_bd[row][tid] < mx ? (unsigned)se.y * 16u : j;  // no point of the run can enter the list: skip it
@@ -996,6 +1024,7 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
     __builtin_amdgcn_sched_barrier(0);
   }
   mx = a[KK - 1];
+  const bool cut = mx < __builtin_inff() && mx == s_thr[tid];  // the threshold left the list short
   if (!live) continue;
   // complete?  distance to the nearest face of the 3x3x3 block that still has cells behind it
   float db = __builtin_inff();
@@ -1018,13 +1047,14 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
     const float safe = db - 0.02f * g.h;
     done = safe > 0.0f && mx <= safe * safe;
   }
-  if (!done) {
+  if (!done || cut || n < KK || first_col > 1) {
     open_list[atomicAdd(open_count, 1)] = q;
     continue;
   }
   // mean over columns first_col..K in the 64-slot butterfly order of knn_finish (zeros skipped: x + 0 = x)
-#pragma unroll
-  for (int i = 0; i < KK; ++i) a[i] = (i >= first_col && i < n) ? a[i] : 0.0f;
+  // (clouds with fewer than K+1 points and first_col > 1 took the other search above: one wave-uniform condition here
+  // instead of one per column -- 51 hoisted mask pairs spilled scalar registers into vector lanes)
+  a[0] = first_col == 1 ? 0.0f : a[0];
   int len = KK;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {

@@ -116,11 +116,14 @@ __global__ void __launch_bounds__(kBinThreads)
 raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_host,
                             const int64_t *__restrict__ n_dev, const float *__restrict__ cam,
                             float radius, int H, int W, int ntx, int nty,
-                            int32_t *__restrict__ tile_count) {
+                            int32_t *__restrict__ tile_count, int32_t *__restrict__ status) {
   __shared__ int s_tab[kSlots];  // one counter per tile (unused when the image has more tiles)
   // a device-side count never exceeds the rows the caller sized the workspace for (and a
   // negative one -- the aggregation's error status -- renders nothing)
   int64_t n = n_dev ? *n_dev : n_host;
+  // the status word of pgdvs_points_raster_bounded: 1 = the device count exceeds the row bound the workspace was sized
+  // for (the rows beyond it are NOT drawn), 2 = the count is negative (the producer's own error status), 0 = fine
+  if (status != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *status = n > n_host ? 1 : (n < 0 ? 2 : 0);
   n = n > n_host ? n_host : (n < 0 ? 0 : n);
   RasterCam rc = make_raster_cam(cam, H, W);
   const int ntiles = ntx * nty;
@@ -771,6 +774,10 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
   if (mask_out) mask_out[pix] = ones > 0.0f ? 1.0f : 0.0f;
 }
 
+__global__ void raster_status_kernel(const int64_t *__restrict__ n_dev, int32_t *__restrict__ status) {
+  if (threadIdx.x == 0) *status = (n_dev && *n_dev > 0) ? 1 : ((n_dev && *n_dev < 0) ? 2 : 0);
+}
+
 static int64_t max_tiles_per_point(float radius, int H, int W) {
   float range_x = W > H ? 2.0f * (float)W / (float)H : 2.0f;
   float range_y = H > W ? 2.0f * (float)H / (float)W : 2.0f;
@@ -831,12 +838,46 @@ static void launch_tile(dim3 grid, hipStream_t st, const RasterWs &ws, const flo
                ws.list_capacity, feat, feat_stride, radius, H, W, ntx, nty, tiles_per_xcd, idx, zbuf, dist2, rgb, rgb_planar, mask);
 }
 
+static int points_raster_impl(const float *pts, int64_t pts_stride, const float *feat, int64_t feat_stride, int64_t n_points,
+                              const int64_t *n_points_dev, int32_t *status_dev, const float *cam_tgt, float radius, int K,
+                              int H, int W, int64_t *idx, float *zbuf, float *dist2, float *rgb, int rgb_planar, float *mask,
+                              void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream);
+
 PGDVS_API int pgdvs_points_raster(const float *pts, int64_t pts_stride, const float *feat,
                                   int64_t feat_stride, int64_t n_points,
                                   const int64_t *n_points_dev, const float *cam_tgt, float radius,
                                   int K, int H, int W, int64_t *idx, float *zbuf, float *dist2,
                                   float *rgb, int rgb_planar, float *mask, void *workspace,
                                   int64_t workspace_bytes, pgdvs_stream_t stream) {
+  return points_raster_impl(pts, pts_stride, feat, feat_stride, n_points, n_points_dev, nullptr, cam_tgt, radius, K, H, W, idx,
+                            zbuf, dist2, rgb, rgb_planar, mask, workspace, workspace_bytes, stream);
+}
+
+// The same with the workspace sized for `row_bound` rows instead of the arrays' capacity (a cloud buffer is
+// capacity-sized -- S*H*W rows -- while a few per cent of the rows exist: 3.2 GB of tile lists per view in flight at
+// 1080p x 24 frames against 0.25 GB for the rows actually there).  The device count is clamped to the bound and
+// status_dev reports whether that cut rows off.
+PGDVS_API int pgdvs_points_raster_bounded(const float *pts, int64_t pts_stride, const float *feat, int64_t feat_stride,
+                                          int64_t n_points, const int64_t *n_points_dev, int64_t row_bound,
+                                          int32_t *status_dev, const float *cam_tgt, float radius, int K, int H, int W,
+                                          int64_t *idx, float *zbuf, float *dist2, float *rgb, int rgb_planar, float *mask,
+                                          void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(row_bound >= 0 && status_dev, "pgdvs_points_raster_bounded: bad row_bound / null status_dev");
+  PGDVS_REQUIRE(n_points >= 0, "pgdvs_points_raster_bounded: bad n_points");
+  if (n_points_dev == nullptr && n_points > row_bound) {
+    set_error("pgdvs_points_raster_bounded: %lld rows given (host count) but the row bound is %lld", (long long)n_points,
+              (long long)row_bound);
+    return PGDVS_ERR_INVALID;
+  }
+  return points_raster_impl(pts, pts_stride, feat, feat_stride, n_points < row_bound ? n_points : row_bound, n_points_dev,
+                            status_dev, cam_tgt, radius, K, H, W, idx, zbuf, dist2, rgb, rgb_planar, mask, workspace,
+                            workspace_bytes, stream);
+}
+
+static int points_raster_impl(const float *pts, int64_t pts_stride, const float *feat, int64_t feat_stride, int64_t n_points,
+                              const int64_t *n_points_dev, int32_t *status_dev, const float *cam_tgt, float radius, int K,
+                              int H, int W, int64_t *idx, float *zbuf, float *dist2, float *rgb, int rgb_planar, float *mask,
+                              void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream) {
   PGDVS_REQUIRE(H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), "pgdvs_points_raster: bad H/W");
   PGDVS_REQUIRE(n_points >= 0 && n_points < (1ll << 31), "pgdvs_points_raster: bad n_points");
   PGDVS_REQUIRE(cam_tgt && (n_points == 0 || pts) && pts_stride >= 3, "pgdvs_points_raster: bad points");
@@ -865,14 +906,17 @@ PGDVS_API int pgdvs_points_raster(const float *pts, int64_t pts_stride, const fl
     return PGDVS_ERR_LAUNCH;
   }
   const bool small_table = ntiles <= kBinSlots / 2;  // the binning kernels' table of tile counters: 32 KB or 64 KB
+  if (n_points == 0 && status_dev != nullptr) {  // (row bound 0: nothing runs that could look at the device count)
+    PGDVS_LAUNCH("raster_status", raster_status_kernel, dim3(1), dim3(64), 0, st, n_points_dev, status_dev);
+  }
   if (n_points > 0) {
     unsigned g = (unsigned)(cdiv(n_points, kBinThreads) < 512 ? cdiv(n_points, kBinThreads) : 512);
     if (small_table) {
       PGDVS_LAUNCH("raster_project_count", raster_project_count_kernel<kBinSlots / 2>, dim3(g), dim3(kBinThreads), 0, st, pts,
-                   pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count);
+                   pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count, status_dev);
     } else {
       PGDVS_LAUNCH("raster_project_count", raster_project_count_kernel<kBinSlots>, dim3(g), dim3(kBinThreads), 0, st, pts,
-                   pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count);
+                   pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count, status_dev);
     }
   }
   PGDVS_LAUNCH("raster_scan", raster_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_count, ntiles, ws.offsets);

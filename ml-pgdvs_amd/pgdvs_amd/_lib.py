@@ -47,6 +47,8 @@ SIGNATURES = {
     "pgdvs_splat_noise_field": (_i, [_i, _i, _vp, _vp, _vp]),
     "pgdvs_points_raster_workspace_bytes": (_i64, [_i64, _i, _i, _f]),
     "pgdvs_points_raster": (_i, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp]),
+    "pgdvs_points_raster_bounded": (_i, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp,
+                                         _vp, _i64, _vp]),
     "pgdvs_static_aggregate_workspace_bytes": (_i64, [_i, _i, _i, _i64]),
     "pgdvs_static_aggregate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _vp, _i64, _vp]),
     "pgdvs_static_aggregate_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),

@@ -61,26 +61,105 @@ class AsyncImageGather:
     image shares with the renderer's other outputs -- is free again right after the step), and
     ``dst`` receives every step directly into the slices of one receive stack.  Nothing is
     allocated or concatenated while steps are in flight (at 1080p and 8 ranks a step brings
-    200 MB to ``dst``; a caching-allocator miss there is a hipMalloc in the middle of the pipeline)."""
+    200 MB to ``dst``; a caching-allocator miss there is a hipMalloc in the middle of the pipeline).
 
-    def __init__(self, dst: int = 0, n_steps: int | None = None, like: torch.Tensor | None = None):
+    ``ring=R`` bounds that memory: R local slots per rank and R x world receive slots on ``dst`` instead of
+    ``n_steps`` of each (200 steps x 8 ranks x 25 MB = 40 GB on rank 0 otherwise, beside the renderer's
+    workspaces).  Step j uses slot j % R; before the slot is handed out again (``slot(j)``, i.e. before step
+    j renders into it) step j - R is *retired*: its transfer is waited for and ``consumer(step, images)`` runs
+    on the receiving rank -- default: one float64 checksum per image, kept in ``sums[n_steps, world]`` (a real
+    caller writes the images out here, as the reference's evaluator does per rank,
+    pgdvs/engines/evaluator_pgdvs.py:432-440).  ``finish()`` then returns ``{"sums": ..., "tail": ...}``: the
+    checksums of all views and the images of the last min(R, n_steps) steps in view order (``None`` off ``dst``).
+    R must cover the steps in flight: lanes + the host's run-ahead (+ a spare)."""
+
+    def __init__(self, dst: int = 0, n_steps: int | None = None, like: torch.Tensor | None = None, ring: int | None = None,
+                 consumer=None):
         self.dst = dst
         self.works, self.bufs, self.keep = [], [], []
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.on else 1
+        self.is_dst = (not self.on) or dist.get_rank() == dst
         self.local = self.stack = None
-        if n_steps and like is not None:
+        self.ring = int(ring) if ring else None
+        self.n_steps = n_steps
+        self.consumer = consumer
+        self.events, self.retired, self.sums = [], 0, None
+        self.capacity_steps = n_steps
+        if self.ring:
+            assert n_steps and like is not None, "ring mode needs n_steps and like"
+            self.ring = max(1, min(self.ring, n_steps))
+            self.local = torch.empty((self.ring,) + tuple(like.shape), dtype=like.dtype, device=like.device)
+            if self.is_dst:
+                self.stack = (torch.empty((self.ring, self.world) + tuple(like.shape), dtype=like.dtype, device=like.device)
+                              if self.on else None)
+                self.sums = torch.empty((n_steps, self.world), dtype=torch.float64, device=like.device)  # every used row is written
+        elif n_steps and like is not None:
             self.local = torch.empty((n_steps,) + tuple(like.shape), dtype=like.dtype, device=like.device)
             if self.on and dist.get_rank() == dst:
                 self.stack = torch.empty((n_steps, dist.get_world_size()) + tuple(like.shape), dtype=like.dtype, device=like.device)
 
+    # -- ring mode -------------------------------------------------------------
+    def reset(self, n_steps: int) -> "AsyncImageGather":
+        """Start another run of ``n_steps`` steps on the SAME buffers (ring mode; ``n_steps`` at most what the gather
+        was created for): nothing is allocated or freed between runs.  (bench.py: with captured HIP graphs alive, a
+        fresh allocation between two replay loops was followed by a GPU memory fault on this ROCm.)"""
+        assert self.ring and self.retired == len(self.keep), "reset() needs a finished ring-mode gather"
+        assert n_steps <= self.capacity_steps, (n_steps, self.capacity_steps)
+        self.n_steps = n_steps
+        self.works, self.bufs, self.keep, self.events, self.retired = [], [], [], [], 0
+        return self
+
+    def _received(self, i: int) -> torch.Tensor:
+        """[world, ...] images of step i as they sit in the ring (on ``dst``)"""
+        return self.stack[i % self.ring] if self.on else self.local[i % self.ring][None]
+
+    def _retire(self, i: int) -> None:
+        """step i's slot is about to be reused: wait for its transfer (and, single rank, for its render) on the
+        current stream and consume the images there"""
+        if self.on:
+            self.works[i].wait()
+        elif self.events[i] is not None:
+            torch.cuda.current_stream().wait_event(self.events[i])
+        if self.is_dst:
+            imgs = self._received(i)
+            if self.consumer is not None:
+                self.consumer(i, imgs)
+            else:
+                self.sums[i] = imgs.reshape(self.world, -1).sum(dim=1, dtype=torch.float64)
+        self.retired = i + 1
+
     def slot(self, j: int | None = None):
         """The preallocated local buffer of step ``j`` (default: the next one), or None.  A renderer that
-        writes its image straight into it (``data["_combined_rgb_out"]``) makes ``submit`` copy-free."""
+        writes its image straight into it (``data["_combined_rgb_out"]``) makes ``submit`` copy-free.
+        (Ring mode: retires the step that held the slot; call it on the stream the step's own stream will wait for.)"""
         j = len(self.keep) if j is None else j
+        if self.ring:
+            while self.retired <= j - self.ring:
+                self._retire(self.retired)
+            return self.local[j % self.ring]
         return self.local[j] if (self.local is not None and j < self.local.shape[0]) else None
 
     def submit(self, img: torch.Tensor) -> None:
         j = len(self.keep)
+        if self.ring:
+            assert j < self.n_steps, "more steps than announced"
+            while self.retired <= j - self.ring:  # (slot() not used by the caller)
+                self._retire(self.retired)
+            mine = self.local[j % self.ring]
+            if img.data_ptr() != mine.data_ptr():
+                mine.copy_(img)
+            self.keep.append(None)
+            if self.on:
+                bufs = list(self.stack[j % self.ring].unbind(0)) if self.is_dst else None
+                self.works.append(dist.gather(mine, bufs, dst=self.dst, async_op=True))
+            else:
+                ev = None
+                if mine.is_cuda:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                self.events.append(ev)
+            return
         if self.local is not None and j < self.local.shape[0] and tuple(img.shape) == tuple(self.local.shape[1:]):
             if img.data_ptr() != self.local[j].data_ptr():  # not rendered in place
                 self.local[j].copy_(img)  # on the caller's current stream, like the gather below
@@ -101,6 +180,21 @@ class AsyncImageGather:
 
     def finish(self):
         n = len(self.keep)
+        if self.ring:
+            first_tail = max(0, n - self.ring)
+            tail = None
+            if self.is_dst and n:
+                # the last steps are still in the ring: hand their images back in view order, then retire them
+                for i in range(first_tail, n):
+                    if self.on:
+                        self.works[i].wait()
+                    elif self.events[i] is not None:
+                        torch.cuda.current_stream().wait_event(self.events[i])
+                tail = torch.cat([self._received(i).flatten(0, 1) for i in range(first_tail, n)], 0).clone()
+            while self.retired < n:
+                self._retire(self.retired)
+            # (a copy: reset() reuses the buffer)
+            return {"sums": self.sums[:n].clone(), "tail": tail, "tail_first_step": first_tail} if self.is_dst else None
         if not self.on:
             if not self.keep:
                 return None

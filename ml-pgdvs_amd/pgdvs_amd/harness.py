@@ -54,6 +54,15 @@ def eval_step(model, data: dict, render_cfg, *, device=None, disable_tqdm=True, 
     model.eval()
     n_batch = data["rgb_src_temporal"].shape[0]
     ret = model.forward(data_gpu, render_cfg=render_cfg, disable_tqdm=disable_tqdm, for_debug=False)
+    # device-side status words of the geometry path (the step synchronises for its metrics anyway): a static cloud whose
+    # aggregation reported an error (count -1) or that outgrew the rasteriser's row bound would otherwise show up as a
+    # silently blank or truncated static image
+    from . import ops
+
+    if isinstance(data_gpu.get("st_pcl_rgb_count", None), torch.Tensor):
+        for c in data_gpu["st_pcl_rgb_count"].reshape(-1):
+            ops.checked_count(c, "st_pcl_rgb_count")
+    ops.check_raster_status(ret.get("geo_static_raster_status", None))
     pred = OrderedDict({"combined": ret["combined_rgb"].clamp(0.0, 1.0)})
     for k in pred:
         if torch.any(torch.isnan(pred[k])):

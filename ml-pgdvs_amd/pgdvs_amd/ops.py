@@ -331,9 +331,11 @@ def dyn_splat_composite(rgb1, rgb2, flow12, flow_1_to_tgt, valid_mask, noise, al
 
 
 def points_raster(pts, feat, cam_tgt, radius: float, K: int, H: int, W: int, *, n_points_dev=None,
-                  want_fragments: bool = False, rgb_planar: bool = False, want_rgb: bool = True):
+                  want_fragments: bool = False, rgb_planar: bool = False, want_rgb: bool = True, row_bound: int | None = None):
     """pts[N,>=3] (xyz in the first 3 columns of each row), feat[N,>=3] rows.
-    Returns dict(rgb, mask[, idx, zbuf, dist2])."""
+    Returns dict(rgb, mask[, idx, zbuf, dist2]).  ``row_bound``: size the workspace for that many rows instead of N
+    (capacity-sized cloud buffers with a device count: ``n_points_dev``); the dict then carries ``status`` (device
+    int32[1]: 0 fine, 1 = the count exceeded the bound and rows were cut off, 2 = negative count; ``check_raster_status``)."""
     p = _rows(pts, "pts")
     n = p.shape[0]
     dev = p.device
@@ -347,13 +349,35 @@ def points_raster(pts, feat, cam_tgt, radius: float, K: int, H: int, W: int, *, 
         rgb = torch.empty((3, H, W) if rgb_planar else (H, W, 3), dtype=torch.float32, device=dev)
     mask = torch.empty((H, W), dtype=torch.float32, device=dev)
     lib = _lib.load()
-    ws = _ws(lib.pgdvs_points_raster_workspace_bytes(n, H, W, float(radius)), dev)
-    check(lib.pgdvs_points_raster(
+    if row_bound is None:
+        ws = _ws(lib.pgdvs_points_raster_workspace_bytes(n, H, W, float(radius)), dev)
+        check(lib.pgdvs_points_raster(
+            _ptr(p), p.stride(0) if n else 3, _ptr(ft), ft.stride(0) if (ft is not None and n) else 3, n,
+            _ptr(n_points_dev), _ptr(cam),
+            float(radius), int(K), H, W, _ptr(idx), _ptr(zbuf), _ptr(d2), _ptr(rgb), int(bool(rgb_planar)), _ptr(mask),
+            _ptr(ws), ws.numel(), _stream()), "pgdvs_points_raster")
+        return {"rgb": rgb, "mask": mask, "idx": idx, "zbuf": zbuf, "dist2": d2}
+    bound = max(0, min(int(row_bound), n))
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = _ws(lib.pgdvs_points_raster_workspace_bytes(bound, H, W, float(radius)), dev)
+    check(lib.pgdvs_points_raster_bounded(
         _ptr(p), p.stride(0) if n else 3, _ptr(ft), ft.stride(0) if (ft is not None and n) else 3, n,
-        _ptr(n_points_dev), _ptr(cam),
+        _ptr(n_points_dev), bound, _ptr(status), _ptr(cam),
         float(radius), int(K), H, W, _ptr(idx), _ptr(zbuf), _ptr(d2), _ptr(rgb), int(bool(rgb_planar)), _ptr(mask),
-        _ptr(ws), ws.numel(), _stream()), "pgdvs_points_raster")
-    return {"rgb": rgb, "mask": mask, "idx": idx, "zbuf": zbuf, "dist2": d2}
+        _ptr(ws), ws.numel(), _stream()), "pgdvs_points_raster_bounded")
+    return {"rgb": rgb, "mask": mask, "idx": idx, "zbuf": zbuf, "dist2": d2, "status": status}
+
+
+def check_raster_status(status, what: str = "pgdvs_points_raster_bounded") -> None:
+    """Host read of the bounded rasteriser's status word (synchronises): raises when rows were cut off."""
+    if status is None:
+        return
+    for v in status.reshape(-1).tolist():
+        if v == 1:
+            raise PgdvsHipError(f"{what}: the device-side point count exceeds the row bound the workspace was sized for; "
+                                "rows were cut off and the static image is not valid -- pass a larger bound")
+        if v != 0:
+            raise PgdvsHipError(f"{what}: the device-side point count is negative (the producer's error status); nothing was drawn")
 
 
 def mesh_render(cam_tgt, keep, pcl, rgb, H: int, W: int, want_faces: bool = False):

@@ -110,18 +110,24 @@ class PGDVSRenderer(PGDVSBaseRenderer):
         static_rgb, static_mask = [], []
         counts = data.get("st_pcl_rgb_count", None)  # optional device counts [B] (int64)
         xyz = data.get("st_pcl_xyz", None)  # optional packed coordinates [B,#pt,3] (ops.static_aggregate(return_xyz=True))
+        # optional row bound (int) for the rasteriser's workspace when the cloud buffer is capacity-sized with a device
+        # count: the status words come back as ret["geo_static_raster_status"] (harness.eval_step checks them)
+        bound = data.get("st_pcl_rgb_row_bound", None)
+        status = []
         for i_b in range(data["flat_cam_tgt"].shape[0]):
             tmp_rgb, tmp_mask = self.static_renderer(
                 tgt_h=ray_batch["render_h"], tgt_w=ray_batch["render_w"], flat_tgt_cam=data["flat_cam_tgt"][i_b],
                 st_pcl_rgb=data["st_pcl_rgb"][i_b], render_cfg=render_cfg,
                 n_points_dev=None if counts is None else counts[i_b:i_b + 1], planar=True,
-                st_pcl_xyz=None if xyz is None else xyz[i_b])
+                st_pcl_xyz=None if xyz is None else xyz[i_b], row_bound=bound, status_out=status)
             static_rgb.append(tmp_rgb)
             static_mask.append(tmp_mask)
         if len(static_rgb) == 1:  # a view, not a 25 MB copy
             ret_dict = {"geo_static_rgb": static_rgb[0][None], "geo_static_mask": static_mask[0][None]}
         else:
             ret_dict = {"geo_static_rgb": torch.stack(static_rgb, 0), "geo_static_mask": torch.stack(static_mask, 0)}
+        if status:
+            ret_dict["geo_static_raster_status"] = status[0] if len(status) == 1 else torch.cat(status)
         return ret_dict["geo_static_rgb"], ret_dict
 
     def forward_st_gnt(self, *, data, ray_batch, render_cfg, disable_tqdm=True):

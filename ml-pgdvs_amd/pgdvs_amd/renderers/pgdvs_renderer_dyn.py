@@ -244,14 +244,15 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
         return render_dyn_rgb_final, render_dyn_mask_final, info_dict
 
     def _zeros_like(self, t):
-        """read-only zero images of the no-tracker outputs, kept per shape instead of being
-        re-filled (33 MB at 1080p) for every view"""
+        """zero images of the no-tracker outputs without filling 33 MB per view at 1080p: ONE zero element expanded to
+        the shape (stride 0).  Reads behave like a zeros tensor; an in-place write raises (torch refuses to write
+        through overlapping memory), so a caller cannot corrupt what later views return -- ``.clone()`` it to edit."""
         cache = self.__dict__.setdefault("_zero_cache", {})
-        key = (tuple(t.shape), t.dtype, t.device)
+        key = (t.dtype, t.device)
         z = cache.get(key)
         if z is None:
-            z = cache[key] = torch.zeros_like(t)
-        return z
+            z = cache[key] = torch.zeros(1, dtype=t.dtype, device=t.device)
+        return z.expand(t.shape)
 
     def resize_rgb_mask(self, rgb, mask, render_h, render_w):
         # :259-270 -- only taken when render_stride != 1; torch resampling (plumbing, GPU)

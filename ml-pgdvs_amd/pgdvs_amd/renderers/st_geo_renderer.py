@@ -13,12 +13,14 @@ class StaticGeoPointRenderer(torch.nn.Module):
         self.projector = Projector()
 
     def forward(self, *, tgt_h, tgt_w, flat_tgt_cam, st_pcl_rgb, render_cfg, n_points_dev=None, planar=False,
-                st_pcl_xyz=None):
+                st_pcl_xyz=None, row_bound=None, status_out=None):
         """st_pcl_rgb[#pt,6] (xyz,rgb).  Returns (mesh_img[H,W,3], mesh_mask[H,W,1]) like the
         reference, or planar ([3,H,W], [1,H,W]) with ``planar=True``.
         ``n_points_dev``: optional device int64 count (rows beyond it are ignored).
         ``st_pcl_xyz``: optional packed copy [#pt,3] of the coordinates (``ops.static_aggregate(...,
-        return_xyz=True)``): the binning passes then read 12 instead of 24 bytes per point."""
+        return_xyz=True)``): the binning passes then read 12 instead of 24 bytes per point.
+        ``row_bound``: with a device count, size the rasteriser's workspace for that many rows instead of the buffer's
+        capacity; ``status_out`` (a list) then receives the device status word (``ops.check_raster_status``)."""
         assert st_pcl_rgb.ndim == 2, f"{st_pcl_rgb.shape}"
         cam = ops.cam_prep(flat_tgt_cam)
         pts = st_pcl_rgb
@@ -26,7 +28,10 @@ class StaticGeoPointRenderer(torch.nn.Module):
             assert st_pcl_xyz.shape == (st_pcl_rgb.shape[0], 3), f"{st_pcl_xyz.shape}"
             r = ops.points_raster(
                 st_pcl_xyz, st_pcl_rgb[:, 3:], cam, render_cfg.st_render_pcl_pt_radius,
-                render_cfg.st_render_pcl_pts_per_pixel, tgt_h, tgt_w, n_points_dev=n_points_dev, rgb_planar=planar)
+                render_cfg.st_render_pcl_pts_per_pixel, tgt_h, tgt_w, n_points_dev=n_points_dev, rgb_planar=planar,
+                row_bound=row_bound if n_points_dev is not None else None)
+            if status_out is not None and "status" in r:
+                status_out.append(r["status"])
             if planar:
                 return r["rgb"], r["mask"][None]
             return r["rgb"], r["mask"][..., None]
@@ -46,7 +51,10 @@ class StaticGeoPointRenderer(torch.nn.Module):
             n_points_dev = cnt2.to(torch.int64)
         r = ops.points_raster(
             pts, pts[:, 3:], cam, render_cfg.st_render_pcl_pt_radius, render_cfg.st_render_pcl_pts_per_pixel,
-            tgt_h, tgt_w, n_points_dev=n_points_dev, rgb_planar=planar)
+            tgt_h, tgt_w, n_points_dev=n_points_dev, rgb_planar=planar,
+            row_bound=row_bound if (n_points_dev is not None and not render_cfg.st_pcl_remove_outlier) else None)
+        if status_out is not None and "status" in r:
+            status_out.append(r["status"])
         if planar:
             return r["rgb"], r["mask"][None]
         return r["rgb"], r["mask"][..., None]

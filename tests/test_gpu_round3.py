@@ -144,3 +144,100 @@ def test_renderer_draws_its_noise_in_the_splat_kernel():
     # the noise shows (only) where static source pixels splat beside dynamic content
     diff = (r0["render_dyn_rgb"] - r1["render_dyn_rgb"]).abs().amax(1)[0]
     assert float(diff.max()) > 1e-3 and float((diff > 0).float().mean()) < 0.2
+
+
+# ---------------------------------------------------------------- rasteriser workspace sized by a row bound
+def _cloud_case(n=4000, cap=20000, H=72, W=96, seed=0):
+    rng = np.random.default_rng(seed)
+    pts = np.zeros((cap, 6), np.float32)
+    pts[:n] = np.concatenate([rng.uniform(-0.6, 0.6, (n, 2)), rng.uniform(1.0, 2.0, (n, 1)), rng.random((n, 3))], 1)
+    pts[n:] = np.nan  # rows beyond the count must never be read into the image
+    cam = ops.cam_prep(T(synth.flat_cam(H, W, np.array([[70.0, 0, W / 2], [0, 70.0, H / 2], [0, 0, 1]]), np.eye(4)).astype(np.float32)))
+    return T(pts), cam, H, W
+
+
+def test_points_raster_row_bound_matches_capacity_sized_call():
+    from pgdvs_amd import _lib
+
+    pts, cam, H, W = _cloud_case()
+    cnt = torch.tensor([4000], dtype=torch.int64, device=DEV)
+    full = ops.points_raster(pts, pts[:, 3:], cam, 0.03, 3, H, W, n_points_dev=cnt, want_fragments=True)
+    bnd = ops.points_raster(pts, pts[:, 3:], cam, 0.03, 3, H, W, n_points_dev=cnt, want_fragments=True, row_bound=4500)
+    for k in ("idx", "zbuf", "dist2", "rgb", "mask"):
+        assert torch.equal(full[k], bnd[k]), k
+    assert int(bnd["status"]) == 0
+    ops.check_raster_status(bnd["status"])
+    lib = _lib.load()
+    assert lib.pgdvs_points_raster_workspace_bytes(4500, H, W, 0.03) < lib.pgdvs_points_raster_workspace_bytes(20000, H, W, 0.03) / 3
+    # exactly at the bound: fine
+    assert int(ops.points_raster(pts, pts[:, 3:], cam, 0.03, 3, H, W, n_points_dev=cnt, row_bound=4000)["status"]) == 0
+
+
+def test_points_raster_row_bound_overflow_and_negative_count_are_reported():
+    from pgdvs_amd._lib import PgdvsHipError
+
+    pts, cam, H, W = _cloud_case()
+    cnt = torch.tensor([4000], dtype=torch.int64, device=DEV)
+    cut = ops.points_raster(pts, pts[:, 3:], cam, 0.03, 3, H, W, n_points_dev=cnt, want_fragments=True, row_bound=3000)
+    assert int(cut["status"]) == 1
+    with pytest.raises(PgdvsHipError, match="row bound"):
+        ops.check_raster_status(cut["status"])
+    # what was drawn is the first 3000 rows, nothing from beyond
+    ref = ops.points_raster(pts[:3000], pts[:3000, 3:], cam, 0.03, 3, H, W, want_fragments=True)
+    assert torch.equal(cut["idx"], ref["idx"]) and torch.equal(cut["rgb"], ref["rgb"])
+    neg = ops.points_raster(pts, pts[:, 3:], cam, 0.03, 3, H, W, n_points_dev=torch.tensor([-1], dtype=torch.int64, device=DEV),
+                            want_fragments=True, row_bound=3000)
+    assert int(neg["status"]) == 2 and int((neg["idx"] >= 0).sum()) == 0
+    with pytest.raises(PgdvsHipError, match="negative"):
+        ops.check_raster_status(neg["status"])
+    zero = ops.points_raster(pts, pts[:, 3:], cam, 0.03, 3, H, W, n_points_dev=cnt, row_bound=0)
+    assert int(zero["status"]) == 1 and float(zero["mask"].sum()) == 0.0
+
+
+def test_eval_step_raises_on_a_cut_or_failed_static_cloud():
+    """harness.eval_step (which synchronises for its metrics anyway) reads the geometry path's status words: a cloud
+    that outgrew the rasteriser's row bound, or an aggregation that reported an error (count -1), must not pass as a
+    truncated / blank static image"""
+    from pgdvs_amd import harness
+    from pgdvs_amd._lib import PgdvsHipError
+
+    H, W, S = 64, 96, 3
+    v = synth.make_video(S, H, W, seed=2)
+    d = synth.make_view(v, 0, seed=1)
+    model, rc = _renderer("geo", st_render_pcl_pts_per_pixel=3)
+    cloud, cnt = ops.static_aggregate(T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]), v["K3s"], v["c2ws"], capacity=S * H * W)
+    n = ops.checked_count(cnt, "agg")
+    hd = {k: torch.from_numpy(np.ascontiguousarray(x)) for k, x in d.items()}
+    hd["st_pcl_rgb"], hd["st_pcl_rgb_count"] = cloud[None], cnt
+    hd["rgb_tgt"] = torch.rand(1, H, W, 3)
+    hd["eval_mask"] = torch.zeros(1, H, W, 3)
+    hd["st_pcl_rgb_row_bound"] = n + 100
+    m_ok, ex = harness.eval_step(model, hd, rc, device=DEV, return_images=True)
+    assert int(ex["ret"]["geo_static_raster_status"]) == 0
+    ref = harness.eval_step(model, {k: x for k, x in hd.items() if k != "st_pcl_rgb_row_bound"}, rc, device=DEV)
+    assert float(m_ok["eval/psnr_full_combined"]) == float(ref["eval/psnr_full_combined"])
+    hd["st_pcl_rgb_row_bound"] = n - 1
+    with pytest.raises(PgdvsHipError, match="row bound"):
+        harness.eval_step(model, hd, rc, device=DEV)
+    hd["st_pcl_rgb_row_bound"] = n + 100
+    hd["st_pcl_rgb_count"] = torch.tensor([-1], dtype=torch.int64, device=DEV)
+    with pytest.raises(PgdvsHipError, match="error flag"):
+        harness.eval_step(model, hd, rc, device=DEV)
+
+
+def test_no_tracker_zero_outputs_cannot_be_written_through():
+    H, W, S = 48, 64, 3
+    v = synth.make_video(S, H, W, seed=2)
+    model, rc = _renderer("geo")
+    cloud = orc.aggregate_static_pcl(v["rgbs"], v["depths"], v["dyn_masks"], v["K3s"], v["c2ws"])
+    data = synth.to_torch(synth.make_view(v, 0, seed=1), DEV)
+    data["st_pcl_rgb"] = T(cloud)[None]
+    with torch.no_grad():
+        ret = model.forward(data, render_cfg=rc)
+    z = ret["render_dyn_temporal_track_rgb"]
+    assert z.shape == ret["render_dyn_rgb"].shape and float(z.abs().sum()) == 0.0
+    with pytest.raises(RuntimeError):
+        z.add_(1.0)
+    with torch.no_grad():
+        again = model.forward(data, render_cfg=rc)
+    assert float(again["render_dyn_temporal_track_mask"].abs().sum()) == 0.0

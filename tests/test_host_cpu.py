@@ -110,6 +110,42 @@ for kw in ({}, dict(n_steps=3, like=torch.empty(1, 3, 2, 2)), dict(n_steps=2, li
         assert (ag.stack is not None) == bool(kw)
     else:
         assert stack is None
+# bounded receive memory: a ring of 3 slots serves 8 steps; every view is consumed (checksummed) before its slot is
+# reused, rank 0 holds 3 x world images instead of 8 x world, and the last ring-full comes back in view order
+ag = AsyncImageGather(n_steps=8, like=torch.empty(1, 3, 2, 2), ring=3)
+assert ag.local.shape[0] == 3 and (ag.stack is None or ag.stack.shape[:2] == (3, world))
+seen = []
+for step in range(8):
+    s = ag.slot()
+    s.fill_(float(step * world + rank))
+    ag.submit(s)
+res = ag.finish()
+if rank == 0:
+    assert res["sums"].shape == (8, world)
+    assert res["sums"].flatten().tolist() == [12.0 * v for v in range(8 * world)], res["sums"]
+    assert res["tail_first_step"] == 5 and [int(x) for x in res["tail"][:, 0, 0, 0]] == list(range(5 * world, 8 * world))
+else:
+    assert res is None
+# the same buffers serve a second, shorter run (reset): nothing is allocated between runs
+ptr = ag.local.data_ptr()
+ag.reset(4)
+for step in range(4):
+    ag.submit(torch.full((1, 3, 2, 2), float(100 + step * world + rank)))
+res2 = ag.finish()
+assert ag.local.data_ptr() == ptr
+if rank == 0:
+    assert res2["sums"].flatten().tolist() == [12.0 * (100 + v) for v in range(4 * world)], res2["sums"]
+    assert res["sums"].flatten().tolist() == [12.0 * v for v in range(8 * world)]  # the first run's result is its own copy
+# a caller-supplied consumer sees every step exactly once, in order, with all ranks' images
+got = []
+ag = AsyncImageGather(n_steps=5, like=torch.empty(1, 3, 2, 2), ring=2, consumer=lambda i, imgs: got.append((i, imgs[:, 0, 0, 0, 0].tolist())))
+for step in range(5):
+    ag.submit(torch.full((1, 3, 2, 2), float(step * world + rank)))
+ag.finish()
+if rank == 0:
+    assert got == [(i, [float(i * world + r) for r in range(world)]) for i in range(5)], got
+else:
+    assert got == []
 # evaluator-shaped step on every rank: the metric sums arrive on rank 0 through ONE packed reduce
 from pgdvs_amd.harness import eval_step
 class Fake(torch.nn.Module):

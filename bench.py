@@ -620,6 +620,8 @@ def main():
     elapsed, gathered, cnt = timed(args.steps, profile=False)
     gc.enable()
     ms0, ms1, seg0 = mem_probe["before"], mem_probe["after"], mem_probe["segments"]
+    host_ms = host_enqueue[0] / args.steps * 1e3  # (of the headline loop: the steady-state loop below overwrites the counters)
+    host_wait_ms = host_wait[0] / args.steps * 1e3
     # a short timed region (the driver's --steps 20) spends a visible share filling and draining the lanes: the
     # steady-state rate of the same loop is reported beside it (never `value`)
     steady = None
@@ -643,8 +645,6 @@ def main():
             if (x["address"], x["total_size"]) not in seg0:
                 print(f"  new segment {x['total_size'] / 1e6:9.1f} MB on {names.get(x['stream'], x['stream'])}: blocks "
                       + ", ".join(f"{b['size'] / 1e6:.1f}{'*' if b['state'] == 'active_allocated' else ''}" for b in x["blocks"][:8]), file=sys.stderr)
-    host_ms = host_enqueue[0] / args.steps * 1e3
-    host_wait_ms = host_wait[0] / args.steps * 1e3
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     per_rank_s = [elapsed]
     if world > 1:
@@ -897,34 +897,62 @@ def main():
             out = net(gg["rgb_feat"], gg["ray_diff"], gg["mask"], gg["pts"], rd, ret_view_entropy=True, ret_view_std=True)
             return gg, out
 
+        def telemetry():
+            """engine clock (MHz, the level sysfs marks current) and board power (W) from sysfs, or None"""
+            import glob
+            out = {}
+            try:
+                for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+                    for ln in open(f).read().splitlines():
+                        if ln.rstrip().endswith("*"):
+                            out["sclk_MHz"] = int(ln.split(":")[1].strip().split("Mhz")[0].split("MHz")[0])
+                    break
+                for f in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") + glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
+                    out["power_W"] = round(int(open(f).read()) / 1e6, 1)
+                    break
+            except Exception:  # noqa: BLE001 -- telemetry is optional
+                pass
+            return out or None
+
         with torch.no_grad():
             gg, _ = gnt_chunk()
             torch.cuda.synchronize()
             valid_frac = float(gg["mask"].mean())
             e0, e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t_gather = t_net = 0.0
-            g0 = time.perf_counter()
-            for _ in range(3):
+            # ten repetitions, each timed on its own (wall clock around gather + transformer, HIP events for the split), with
+            # the clock / power the driver reports right after each: the figure quoted is the MEDIAN, the spread is beside it
+            reps, tele = [], []
+            for _ in range(10):
+                g0 = time.perf_counter()
                 e0.record()
                 gg = ops.gnt_gather(ro, rd, drange, Sg, True, cam_t, cams_s, rgbs, featmaps, inv_masks)
                 e1.record()
                 net(gg["rgb_feat"], gg["ray_diff"], gg["mask"], gg["pts"], rd, ret_view_entropy=True, ret_view_std=True)
                 e2.record()
+                tele.append(telemetry())  # (read while the chunk is still running: after the synchronise the card idles)
                 torch.cuda.synchronize()
-                t_gather += e0.elapsed_time(e1) / 3
-                t_net += e1.elapsed_time(e2) / 3
-        gdt = (time.perf_counter() - g0) / 3
+                reps.append((time.perf_counter() - g0, e0.elapsed_time(e1), e1.elapsed_time(e2)))
+        reps.sort()
+        gdt, t_gather, t_net = reps[len(reps) // 2]
         gflop = 2.0 * Rg * Sg * (1048064 + 84416 * Vg)
         gather_bytes = Rg * Sg * Vg * (4 * 35 * 4 + (44 + 4 * 32))  # 4 bilinear corners x 35 channels read, one row written
+        tf = lambda sec: round(gflop / sec / 1e12, 2)  # noqa: E731
+        clk = [t_["sclk_MHz"] for t_ in tele if t_ and "sclk_MHz" in t_]
+        pw = [t_["power_W"] for t_ in tele if t_ and "power_W" in t_]
         gnt = {"rays": Rg, "samples_per_ray": Sg, "views": Vg, "layers": 8, "ms_per_chunk": round(gdt * 1e3, 2),
                "ms_gather_A13": round(t_gather, 3), "ms_transformer_A14": round(t_net, 3),
-               "tflops": round(gflop / gdt / 1e12, 2), "tflops_A14_alone": round(gflop / (t_net * 1e-3) / 1e12, 2),
+               "tflops": tf(gdt), "tflops_A14_alone": round(gflop / (t_net * 1e-3) / 1e12, 2),
+               "repetitions": {"n": len(reps), "statistic": "median", "tflops_min": tf(reps[-1][0]), "tflops_max": tf(reps[0][0]),
+                               "ms_per_chunk_all": [round(r_[0] * 1e3, 2) for r_ in reps],
+                               "sclk_MHz_range": [min(clk), max(clk)] if clk else None,
+                               "power_W_range": [min(pw), max(pw)] if pw else None},
                "peak_tflops_fp32_mfma": 157.3, "frac_of_peak": round(gflop / gdt / 157.3e12, 4),
                "gather_alg_GBps": round(gather_bytes / (t_gather * 1e-3) / 1e9, 1), "valid_projection_fraction": round(valid_frac, 3),
                "dtype": "f32 (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)",
                "est_seconds_per_1080p_frame": round(gdt * (H * W / Rg), 1),
                "note": "pgdvs_gnt_gather (real projections of target-ray samples into the resident source frames, dynamic masks "
-                       "applied) + GNT.forward incl. view entropy/std side outputs; FLOPs counted for A14 only, time for both"}
+                       "applied) + GNT.forward incl. view entropy/std side outputs; FLOPs counted for A14 only, time for both; "
+                       "median of ten repetitions (sclk / power as sysfs reports them while each runs)"}
         # The whole renderer with the GNT static renderer at the reference's own benchmark setting
         # (NVIDIA Dynamic Scenes: 288 x 550 targets, 10 spatial + 2 temporal source views, 256 samples
         # per ray, chunks of 1024 rays; BASELINE.md section 1).  Informational, never `value`.

@@ -212,11 +212,15 @@ struct RunInfo {
   bool is_leader;
 };
 
+// PRECONDITION: all 64 lanes of the wavefront call it together (callers pad their loops to whole wavefronts and pass
+// t < 0 for lanes without work).  An inactive left neighbour leaves the DPP read at the lane's own value; the ballot of
+// active lanes below makes such a lane a leader anyway, so a partial wavefront still gets correct (shorter) runs.
 __device__ __forceinline__ RunInfo wave_runs(int t) {
   const int lane = threadIdx.x & 63;
   // wave_shr:1 -- lane i reads lane i-1 through the DPP path (no LDS round trip); lane 0 is a leader anyway
   int prev = __builtin_amdgcn_update_dpp(t, t, 0x138, 0xf, 0xf, false);
-  bool lead = lane == 0 || prev != t;
+  const unsigned long long act = __ballot(1);
+  bool lead = lane == 0 || prev != t || !((act >> (lane ? lane - 1 : 0)) & 1ull);
   unsigned long long L = __ballot(lead);
   RunInfo r;
   r.is_leader = lead;

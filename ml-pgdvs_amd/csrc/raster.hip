@@ -388,7 +388,7 @@ struct TopK {
   }
 };
 
-constexpr int kSortCap = 2048;       // list entries the sorted path holds in LDS (52 KB with the rest: 3 workgroups per CU)
+constexpr int kSortCap = 2048;       // list entries the sorted path holds in LDS (<= 40 KB with the rest: 4 workgroups per CU, see the static_assert)
 constexpr int kSortPerThread = kSortCap / 256;
 constexpr int kSortBuckets = 1024;   // monotone z-buckets of the distribution pass
 constexpr int kSortMaxBucket = 64;   // more entries than this in one bucket (equal depths): general path
@@ -520,7 +520,7 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
       }
     }
     __syncthreads();
-    // ---- 3. exclusive scan of the 2048 counters (8 per thread)
+    // ---- 3. exclusive scan of the kSortBuckets (1024) counters, four per thread
     {
       unsigned c[kSortBuckets / 256], tot = 0u, mx = 0u;
 #pragma unroll

@@ -126,8 +126,18 @@ class AsyncImageGather:
             if self.consumer is not None:
                 self.consumer(i, imgs)
             else:
-                self.sums[i] = imgs.reshape(self.world, -1).sum(dim=1, dtype=torch.float64)
+                self.sums[i] = self.checksum(imgs)
         self.retired = i + 1
+
+    def checksum(self, imgs: torch.Tensor) -> torch.Tensor:
+        """[world] float64: the default consumer's proof of arrival -- head, tail and a strided sample of every image
+        (one small kernel; summing all of it would cost rank 0 a 25 MB read per view and rank, 1.6 TB/s at 8 ranks x 1000
+        views/s, for a benchmark-side stub: real consumers write the image out)"""
+        flat = imgs.reshape(self.world, -1)
+        n = flat.shape[1]
+        if n <= 3 * 4096:
+            return flat.sum(dim=1, dtype=torch.float64)
+        return torch.cat([flat[:, :4096], flat[:, -4096:], flat[:, 4096:-4096:4099]], dim=1).sum(dim=1, dtype=torch.float64)
 
     def slot(self, j: int | None = None):
         """The preallocated local buffer of step ``j`` (default: the next one), or None.  A renderer that

@@ -71,3 +71,43 @@ json.dump({"command": cmd, "note": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE
            "views_profiled": views, "total_hbm_bytes_per_view": total,
            "kernels": traffic}, open(out / f"{tag}_hbm_traffic.json", "w"), indent=1)
 print("wrote", out / f"{tag}_kernel_stats.csv", out / f"{tag}_hbm_traffic.json")
+
+# ---- instruction-mix counters of the co-dominant kernels (gpurun_out/<tag>_pmc1, _pmc2: separate --pmc passes of
+# `bench.py --steps 4 --warmup 1 --inflight 1 --launch eager ...` restricted to those kernels) ->
+#   profiles/<tag>_pmc_instructions.json  (read by bench.py for the VALU-issue figure)
+#   profiles/<tag>_pmc_<kernel>.txt       (one text block per kernel, every counter, mean per launch)
+pmc = collections.defaultdict(dict)
+for d in (f"{tag}_pmc1", f"{tag}_pmc2"):
+    for f in glob.glob(str(root / "gpurun_out" / d / "**" / "*counter_collection.csv"), recursive=True):
+        agg, disp = collections.defaultdict(lambda: collections.defaultdict(float)), collections.defaultdict(set)
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            disp[k].add(r["Dispatch_Id"])
+        for k, v in agg.items():
+            for c, val in v.items():
+                pmc[k][c] = val / len(disp[k])
+            pmc[k]["launches_profiled"] = max(pmc[k].get("launches_profiled", 0), len(disp[k]))
+if pmc:
+    import re
+    keyed = {re.sub(r"<.*>", "", k).replace("_kernel", ""): {c: round(v, 1) for c, v in sorted(cs.items())} for k, cs in pmc.items()}
+    # (agg_push_kernel<1024> is frame 0's launch: bench.py names it agg_push0)
+    if "agg_push" in keyed:
+        keyed["agg_push0"] = keyed.pop("agg_push")
+    json.dump({"command": "rocprofv3 --pmc <8 SQ counters> --kernel-include-regex <co-dominant kernels> -- python3 bench.py --steps 4 "
+                          "--warmup 1 --inflight 1 --launch eager --no-cpu-baseline --no-kernel-timing --gnt-rays 0 (two passes)",
+               "note": "mean per launch; SQ_INSTS_* are wave-instructions; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles "
+                       "summed over waves (MI355X_MICROARCH.md); issue cost per wave-instruction and SIMD: profiles/r03_valu_rate.txt",
+               "kernels": keyed}, open(out / f"{tag}_pmc_instructions.json", "w"), indent=1)
+    names = {"raster_tile": "raster_tile", "grid_query_tpq": "knn_tpq", "agg_push0": "agg_push0", "agg_step": "agg_step",
+             "agg_rows": "agg_rows", "dyn_splat_scatter": "dyn_splat_scatter"}
+    for k, cs in keyed.items():
+        with open(out / f"{tag}_pmc_{names.get(k, k)}.txt", "w") as fh:
+            fh.write(f"# {k}: rocprofv3 --pmc counters, mean per launch ({int(cs.get('launches_profiled', 0))} launches x XCDs profiled)\n")
+            for c, v in cs.items():
+                if c != "launches_profiled":
+                    fh.write(f"{c:28s} {v:16.1f}\n")
+            if cs.get("SQ_INSTS_VALU") and cs.get("SQ_WAVES"):
+                fh.write(f"{'VALU insts per wave':28s} {cs['SQ_INSTS_VALU'] / cs['SQ_WAVES']:16.1f}\n")
+                fh.write(f"{'SALU insts per wave':28s} {cs.get('SQ_INSTS_SALU', 0) / cs['SQ_WAVES']:16.1f}\n")
+    print("wrote", out / f"{tag}_pmc_instructions.json")

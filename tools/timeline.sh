@@ -3,9 +3,9 @@
 # region, GPU busy time (union of kernel intervals), per-kernel wall share when running concurrently
 # and idle gaps.  Run on the GPU box through gpurun: tools/timeline.sh <tag> [bench flags]
 tag=${1:-tl}; shift
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/${tag}_trace
+rm -rf "$R/gpurun_out/${tag}_trace"
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_trace -o k -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-kernel-timing --gnt-rays 0 "$@" > $R/gpurun_out/${tag}_trace.log 2>&1
 tail -1 $R/gpurun_out/${tag}_trace.log | cut -c1-160
 f=$(find $R/gpurun_out/${tag}_trace -name "*kernel_trace.csv" | head -1)
@@ -13,9 +13,12 @@ python3 - "$f" <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("pgdvs::", "")[:40], r.get("Stream_Id", r.get("Queue_Id", "?"))) for r in rows)
-# the timed region: the last 30 views = last 30 agg_finalize kernels (one per view) and everything between them
+# the timed region: the last views of the run = the last agg_finalize kernels (one per view) and everything between
+# them -- 24 of them when the trace holds that many (the command above times 30 steps), otherwise all but the first
 fin = [i for i, e in enumerate(ev) if e[2].startswith("agg_finalize")]
-n_views = 24
+if len(fin) < 3:
+    sys.exit(f"only {len(fin)} agg_finalize kernels in the trace: nothing to reduce (pass more --steps)")
+n_views = min(24, len(fin) - 1)
 lo = ev[fin[-n_views - 1]][1]
 hi = ev[fin[-1]][1]
 sel = [e for e in ev if e[0] >= lo and e[1] <= hi]

@@ -1087,8 +1087,11 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
     // 32 chunks of 128 pixels per workgroup, dealt round-robin; a multiple of 8 workgroups per row (see the kernel)
     const unsigned gx = (unsigned)align_up(cdiv(ws.Wd * 32 / kStepChunkPx, kStepChunks), 8);
     static const int sfpg_env = getenv("PGDVS_AGG_STEP_FPG") ? atoi(getenv("PGDVS_AGG_STEP_FPG")) : 0;
-    // frames per workgroup row: 2: 9.9, 3: 8.4, 4: 7.9, 6: 7.6, 8: 7.6 us per link at 1080p x 24 frames
-    const int sfpg = sfpg_env > 0 ? (sfpg_env < kPushMaxFpg ? sfpg_env : kPushMaxFpg) : 6;
+    // frames per workgroup row.  Alone on the chip a link takes 9.9 / 8.4 / 7.9 / 7.6 / 7.6 / 8.2 us with 2 / 3 / 4 / 6 / 8 / 16 frames per
+    // row (more rows = more parallel frames), but every row re-reads the chunk and re-gathers the depths, and with seven views
+    // in flight the throughput is the other way round: 1037 frames/s with 6, 1048 with 8, 1055 with 16, 1058 with 24-32 -- one
+    // row whenever the later frames fit a queue entry's mask
+    const int sfpg = sfpg_env > 0 ? (sfpg_env < kPushMaxFpg ? sfpg_env : kPushMaxFpg) : kPushMaxFpg;
     for (int i = 1; i < S; ++i) {
       SelArgs a;
       a.dyn_mask = dyn_masks + (size_t)i * P;

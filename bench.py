@@ -482,7 +482,7 @@ def main():
             host_enqueue[0] = time.perf_counter() - t0  # host time to enqueue everything (incl. the waits of the run-ahead bound)
             join_lanes()
             trace("loop done")
-            gathered = gather.finish()
+            gathered = gather.finish(tail=False)
             trace("gather finished")
         torch.cuda.synchronize()
         barrier()

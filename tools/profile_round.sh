@@ -18,5 +18,18 @@ rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_A
   --kernel-include-regex "$KERNELS" --output-format csv -d $R/gpurun_out/${tag}_pmc2 -o k -- $PMCCMD > $R/gpurun_out/${tag}_pmc2.log 2>&1
 tail -1 $R/gpurun_out/${tag}_stats.log | cut -c1-200
 ls $R/gpurun_out/${tag}_stats $R/gpurun_out/${tag}_fetch $R/gpurun_out/${tag}_write $R/gpurun_out/${tag}_pmc1 $R/gpurun_out/${tag}_pmc2
+# which runtime copies / fills the loop issues (grid size, stream, calls): they are not launches of this library
+python3 - $R/gpurun_out/${tag}_stats/k_kernel_trace.csv > $R/gpurun_out/${tag}_stats/runtime_copies.txt 2>&1 <<'PY'
+import collections, csv, sys
+c = collections.Counter()
+n = 0
+for r in csv.DictReader(open(sys.argv[1])):
+    n += 1
+    if "rocclr" in r["Kernel_Name"]:
+        c[(r["Kernel_Name"][:40], r["Grid_Size_X"], r["Stream_Id"])] += 1
+print(n, "dispatches")
+for k, v in c.most_common(30):
+    print(v, k)
+PY
 # drop the bulky per-dispatch traces before the merge back (only the summaries are needed)
 find $R/gpurun_out/${tag}_stats -name "*kernel_trace.csv" -delete

@@ -19,6 +19,37 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// fp32 adds onto LDS accumulators.  The LDS's own float atomic (ds_add_f32) takes ~80 ns per wavefront instruction and CU
+// on gfx950 -- forty times an integer LDS atomic (tools/lds_atomic_rate.hip, profiles/r03_lds_atomic_rate.txt) -- so the
+// add is a compare-and-swap on the bit pattern: the kN accumulators of one lane are distinct, so they are read together,
+// swapped together, and only a lane that lost a race (another lane of the tile hit the same accumulator in between) goes
+// round again.  ~6 ns per accumulator and wavefront.
+template <int kN>
+__device__ __forceinline__ void lds_add_f32(uint32_t *const (&cell)[kN], const float (&add)[kN], const bool (&on)[kN]) {
+  uint32_t seen[kN], want[kN];
+#pragma unroll
+  for (int i = 0; i < kN; ++i)
+    if (on[i]) seen[i] = __hip_atomic_load(cell[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  bool again = false;
+#pragma unroll
+  for (int i = 0; i < kN; ++i)
+    if (on[i]) {
+      want[i] = seen[i];
+      seen[i] = atomicCAS(cell[i], want[i], __float_as_uint(__uint_as_float(want[i]) + add[i]));
+    }
+#pragma unroll
+  for (int i = 0; i < kN; ++i) again = again || (on[i] && seen[i] != want[i]);
+  if (again) {
+#pragma unroll
+    for (int i = 0; i < kN; ++i)
+      if (on[i])
+        while (seen[i] != want[i]) {
+          want[i] = seen[i];
+          seen[i] = atomicCAS(cell[i], want[i], __float_as_uint(__uint_as_float(want[i]) + add[i]));
+        }
+  }
+}
+
 struct SplatCorners {
   int idx[4];   // flat destination index (y*W+x) or -1; order nw, ne, sw, se
   float w[4];
@@ -234,9 +265,18 @@ dyn_splat_scatter_kernel(int H, int W, const float *__restrict__ rgb1,
     }
   }
   if (!__syncthreads_or(part ? 1 : 0)) return;  // nothing of this tile can matter
-  if (part) {  // window origin: the smallest in-image target coordinates of the tile
-    atomicMin(&s_org[0], c.x0 < 0 ? 0 : c.x0);
-    atomicMin(&s_org[1], c.y0 < 0 ? 0 : c.y0);
+  {  // window origin: the smallest in-image target coordinates of the tile (one LDS atomic per wavefront, not per lane:
+     // 64 lanes on one LDS word are served one after the other)
+    int mx = part ? (c.x0 < 0 ? 0 : c.x0) : 0x7fffffff, my = part ? (c.y0 < 0 ? 0 : c.y0) : 0x7fffffff;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      mx = min(mx, __shfl_xor(mx, d));
+      my = min(my, __shfl_xor(my, d));
+    }
+    if ((threadIdx.x & 63) == 0 && mx != 0x7fffffff) {
+      atomicMin(&s_org[0], mx);
+      atomicMin(&s_org[1], my);
+    }
   }
   for (int i = threadIdx.x; i < 5 * kSplatWin * kSplatWin / 4; i += 256)
     reinterpret_cast<float4 *>(&s_acc[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -287,16 +327,20 @@ dyn_splat_scatter_kernel(int H, int W, const float *__restrict__ rgb1,
       if (c.idx[k] < 0) continue;
       const int wx = c.x0 + (k & 1) - ox, wy = c.y0 + (k >> 1) - oy;
       const bool in_win = wx >= 0 && wx < kSplatWin && wy >= 0 && wy < kSplatWin;
+      uint32_t *cell[5];
+      float add[5];
+      bool on[5];
 #pragma unroll
       for (int pl = 0; pl < 5; ++pl) {
         const float v = val[pl];
-        if (pl == 4 && me == 0.0f) continue;
-        if (c.w[k] == 0.0f && isfinite(v)) continue;  // adding +-0 changes nothing (splat_value's rule)
-        if (in_win)
-          __hip_atomic_fetch_add(&s_acc[pl][wy * kSplatWin + wx], v * c.w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else
-          atomic_add_f32(acc + (size_t)pl * P + c.idx[k], v * c.w[k]);
+        // (the mask plane of a static pixel; adding +-0 changes nothing -- splat_value's rule)
+        const bool skip = (pl == 4 && me == 0.0f) || (c.w[k] == 0.0f && isfinite(v));
+        add[pl] = v * c.w[k];
+        on[pl] = in_win && !skip;
+        cell[pl] = reinterpret_cast<uint32_t *>(&s_acc[pl][in_win ? wy * kSplatWin + wx : 0]);
+        if (!in_win && !skip) atomic_add_f32(acc + (size_t)pl * P + c.idx[k], add[pl]);
       }
+      lds_add_f32(cell, add, on);
     }
   }
   __syncthreads();

@@ -1,10 +1,12 @@
 #!/bin/bash
+# (the command pins eager launches and seven lanes: under the profiler the host is slow enough for `--launch auto` to switch to
+# graph replay, whose input copies and output clones are not what an unprofiled run executes)
 # rocprofv3 passes behind profiles/<tag>_*: kernel-trace stats, then FETCH_SIZE and WRITE_SIZE in their own --pmc
 # passes, then two instruction-mix passes restricted to the co-dominant kernels (never combined with traces).
 # Run on the GPU box through gpurun; tools/make_profile_summary.py condenses the output into profiles/.
 tag=${1:-r03}
 R=$GRAFT_REPO_ROOT
-CMD="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-timing --gnt-rays 0"
+CMD="python3 $R/bench.py --steps 10 --warmup 2 --launch eager --inflight 7 --no-cpu-baseline --no-kernel-timing --gnt-rays 0"
 PMCCMD="python3 $R/bench.py --steps 4 --warmup 1 --inflight 1 --launch eager --no-cpu-baseline --no-kernel-timing --gnt-rays 0"
 KERNELS="raster_tile|grid_query_tpq|agg_push|agg_step|agg_rows|dyn_splat_scatter"
 cd /tmp && export TMPDIR=/tmp

@@ -186,7 +186,7 @@ dyn_splat_flag_kernel(int H, int W, const float *__restrict__ flow_1_to_tgt,
 // One workgroup per 16x16 tile of source pixels.  The scatter is bound by the L2 atomic rate,
 // and neighbouring source pixels land on the same target pixels (every target pixel of a smooth
 // flow field collects ~4 bilinear contributions per plane): the tile's contributions are first
-// summed in an LDS window anchored at the tile's smallest target coordinates (LDS float atomics),
+// summed in an LDS window anchored at the tile's smallest target coordinates (lds_add_f32 above),
 // then each touched target pixel receives ONE global atomic per plane.  Corners that fall outside
 // the window (flows that diverge by more than kSplatWin - 17 pixels inside a tile) go to global
 // memory directly.

@@ -241,3 +241,56 @@ def test_no_tracker_zero_outputs_cannot_be_written_through():
     with torch.no_grad():
         again = model.forward(data, render_cfg=rc)
     assert float(again["render_dyn_temporal_track_mask"].abs().sum()) == 0.0
+
+
+def test_splat_composite_converging_and_diverging_flows():
+    """pgdvs_dyn_splat_composite directly against the oracle's softsplat_img (pgdvs_renderer_base.py:59-89,
+    pgdvs_renderer_dyn.py:177-202) on flows that stress the scatter's LDS accumulation: a 32 x 32 block whose pixels all
+    land on the SAME four target pixels (every lane of a tile races for the same accumulators: the compare-and-swap add
+    must lose nothing), a block that spreads to three times its size (corners outside a tile's 40 x 40 window: global
+    atomics), static pixels with noise next to both.  fp32 sums in another order: 1e-4."""
+    H, W = 64, 96
+    rng = np.random.default_rng(7)
+    rgb1 = rng.random((H, W, 3), dtype=np.float32)
+    rgb2 = rng.random((H, W, 3), dtype=np.float32)
+    flow12 = (rng.standard_normal((H, W, 2)) * 0.7).astype(np.float32)
+    noise = rng.standard_normal((3, H, W)).astype(np.float32)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    f1t = np.zeros((2, H, W), np.float32)
+    f1t[0] = 0.25 * np.sin(ys / 5.0)  # the static pixels drift a little
+    f1t[1] = 0.25 * np.cos(xs / 7.0)
+    mask = np.zeros((H, W), np.float32)
+    a = (slice(0, 32), slice(0, 32))  # converging block -> target (40.3, 20.6)
+    f1t[0][a] = 40.3 - xs[a]
+    f1t[1][a] = 20.6 - ys[a]
+    mask[a] = 1.0
+    b = (slice(32, 48), slice(48, 64))  # diverging block: x3 about its corner
+    f1t[0][b] = 2.0 * (xs[b] - 48.0) + 0.4
+    f1t[1][b] = 2.0 * (ys[b] - 32.0) * 0.5 + 0.2
+    mask[b] = 1.0
+    static_rgb = rng.random((3, H, W), dtype=np.float32)
+    alpha = 100.0
+
+    m4 = mask[None, None]
+    c1 = np.transpose(rgb1, (2, 0, 1))[None] * m4 + np.clip(noise, 0.0, 1.0)[None] * (1.0 - m4)
+    c2 = np.transpose(rgb2, (2, 0, 1))[None]
+    f12 = np.transpose(flow12, (2, 0, 1))[None]
+    splat_full, metric = orc.softsplat_img(c1.astype(np.float32), f1t[None], c2, f12, alpha)
+    splat_mask, _ = orc.softsplat_img(m4.astype(np.float32), f1t[None], c2, f12, alpha, metric=metric)
+    want_mask = (splat_mask > 1e-3).astype(np.float32)[0, 0]
+    want_rgb = (splat_full * want_mask[None, None])[0]
+    # pixels whose splatted mask sits on the 1e-3 threshold may flip with the summation order
+    sure = np.abs(splat_mask[0, 0] - 1e-3) > 1e-5
+
+    got_rgb, got_mask, comb, comb_st, comb_dy = ops.dyn_splat_composite(
+        T(rgb1), T(rgb2), T(flow12), T(f1t), T(mask), T(noise), alpha, T(static_rgb))
+    torch.cuda.synchronize()
+    got_rgb, got_mask = N(got_rgb), N(got_mask)
+    assert want_mask.sum() > 200 and (want_mask[18:24, 38:44] > 0).any()
+    np.testing.assert_array_equal(got_mask[sure], want_mask[sure])
+    np.testing.assert_allclose(got_rgb[:, sure], want_rgb[:, sure], rtol=1e-4, atol=1e-4)
+    want_comb = (1.0 - want_mask)[None] * static_rgb + want_mask[None] * want_rgb
+    np.testing.assert_allclose(N(comb)[:, sure], want_comb[:, sure], rtol=1e-4, atol=1e-4)
+    # the same call again: the LDS adds lose nothing under contention, so the two results agree to rounding
+    again = N(ops.dyn_splat_composite(T(rgb1), T(rgb2), T(flow12), T(f1t), T(mask), T(noise), alpha, T(static_rgb))[0])
+    np.testing.assert_allclose(again[:, sure], got_rgb[:, sure], rtol=1e-5, atol=1e-5)

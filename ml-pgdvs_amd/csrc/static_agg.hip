@@ -101,15 +101,30 @@ struct ProjChunk {
 static_assert(sizeof(ProjChunk) + 32 <= 4096, "agg_params_kernel's arguments");
 
 struct PushConsts;
-__global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, float *__restrict__ pc32, int first, int n) {
+__global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, float *__restrict__ pc32, int first, int n, float q_hi) {
   const int words = (int)(sizeof(ProjF64) / 4);
   for (int k = threadIdx.x; k < n * words; k += blockDim.x)
     reinterpret_cast<uint32_t *>(dst + first)[k] = reinterpret_cast<const uint32_t *>(&c.p[0])[k];
-  // the fp32 screening record (PushConsts: M32[12], e32[3], pad), 16 floats per frame
+  // the fp32 screening record (PushConsts: M32[12], e[3], pad), 16 floats per frame.  e[0], e[1]: the error bound of BOTH
+  // image coordinates as one affine function of |r| amax for every quotient of magnitude <= q_hi = max(W, H) + 1 (see
+  // screen_frames), rounded up; e[2]: e32[2] (unused by the kernels)
   for (int k = threadIdx.x; k < n * 16; k += blockDim.x) {
     const ProjF64 &pj = c.p[k >> 4];
     const int j = k & 15;
-    pc32[(size_t)(first + (k >> 4)) * 16 + j] = j < 12 ? pj.M32[j] : (j < 15 ? (pj.screen32 ? pj.e32[j - 12] : INFINITY) : 0.0f);
+    float v = 0.0f;
+    if (j < 12) {
+      v = pj.M32[j];
+    } else if (!pj.screen32) {
+      v = j < 15 ? INFINITY : 0.0f;
+    } else if (j == 12) {
+      const double e01 = pj.e32[0] > pj.e32[1] ? (double)pj.e32[0] : (double)pj.e32[1];
+      v = (float)((e01 + ((double)q_hi + 1.0) * (double)pj.e32[2]) * 1.000001);
+    } else if (j == 13) {
+      v = (float)((double)q_hi * 2.5e-7 * 1.000001);
+    } else if (j == 14) {
+      v = pj.e32[2];
+    }
+    pc32[(size_t)(first + (k >> 4)) * 16 + j] = v;
   }
 }
 
@@ -194,7 +209,7 @@ __device__ __attribute__((noinline)) void mark_fp64(const ProjF64 *__restrict__ 
 typedef float f2v __attribute__((ext_vector_type(2)));
 struct PushConsts {
   float M[12];  // in ProjF64::M32's order: (row 0, row 1) column pairs, then row 2
-  float e[3];   // +inf when the frame has no fp32 screening form: every projection is then undecided
+  float e[3];   // e[0] |r| amax + e[1] bounds the error of both quotients (agg_params_kernel); +inf without an fp32 form
   float pad;
 };
 static_assert(sizeof(PushConsts) == 64, "PushConsts");
@@ -270,8 +285,8 @@ constexpr int kPushMaxFpg = 32;    // frames per workgroup row (one bit each in 
 // One point against the frames [fa, fb): fp32 screening of each projection, stamp where it decides; returns the
 // bitmask (bit f - fa) of the frames it could not decide (lanes that are not `live`: all bits).  Per-frame constants
 // are wave-uniform scalar loads.
-//   q~ = (M32 X)_k / (M32 X)_2 differs from the reference's fp64 value by at most t_k (see ProjF64).  With
-//   ts = 1/4 - (tx + ty), A = min(dx - tx, dy - ty) (dx, dy: distance of q~ to the nearest integer) and
+//   q~ = (M32 X)_k / (M32 X)_2 differs from the reference's fp64 value by at most T (see ProjF64 and below).  With
+//   ts = 1/4 - 2 T, A = min(dx, dy) - T (dx, dy: distance of q~ to the nearest integer) and
 //   mi = min(qx, W-1 - qx, qy, H-1 - qy):   stamp  <=>  ts > 0 and A > 0 and mi >= 0        (in range, both sure)
 //                                          decided <=>  ts > 0 and (A > 0 or mi < -1/2)    (else: fp64)
 //   ts > 0 implies that every quantity is finite (NaN / inf coordinates, a zero denominator: ts is NaN or -inf and
@@ -298,14 +313,18 @@ __device__ __forceinline__ unsigned screen_frames(const PushConsts *__restrict__
     const float s2 = __builtin_fmaf(M[8], x, __builtin_fmaf(M[9], y, __builtin_fmaf(M[10], z, M[11])));
     const float r = __builtin_amdgcn_rcpf(s2);  // v_rcp_f32: 1 ulp
     const float qx = s0 * r, qy = s1 * r;
-    // |q~ - q_ref| <= (E_row + (|q~| + 1) E_2) |r| + 2^-22 |q~|, E_k = e32[k] amax (see ProjF64)
+    // |q~ - q_ref| <= (E_row + (|q~| + 1) E_2) |r| + 2^-22 |q~|, E_k = e32[k] amax (see ProjF64): for |q~| <= Q = max(W, H) + 1
+    // at most T = e[0] |r| amax + e[1] with e[0] = max(e32[0], e32[1]) + (Q + 1) e32[2], e[1] = 2.5e-7 Q -- one bound for
+    // both coordinates, one multiply-add per frame.  A quotient beyond Q can be off by more than T, but it never stamps
+    // (mi < 0) and "decided" is right for it: ts > 0 means e[0] |r| amax < 1/8, hence its true error is below
+    // 1/8 + (|q~| + 1) / (8 (Q + 1)) + 2.5e-7 |q~| and the true quotient still lies more than 1/2 outside [0, max(W, H) - 1].
     const float ar = fabsf(r) * amax * 1.001f;
-    const float tx = (c.e[0] + (fabsf(qx) + 1.0f) * c.e[2]) * ar + fabsf(qx) * 2.5e-7f;
-    const float ty = (c.e[1] + (fabsf(qy) + 1.0f) * c.e[2]) * ar + fabsf(qy) * 2.5e-7f;
+    const float T = __builtin_fmaf(c.e[0], ar, c.e[1]);
     const float fx = floorf(qx), fy = floorf(qy);
     const float dx = fminf(qx - fx, (fx + 1.0f) - qx), dy = fminf(qy - fy, (fy + 1.0f) - qy);
-    const float ts = 0.25f - (tx + ty);
-    const float A = fminf(dx - tx, dy - ty);
+    // (0 * (qx + qy): NaN for an infinite or NaN quotient, so that ts > 0 still implies finite coordinates)
+    const float ts = __builtin_fmaf(qx + qy, 0.0f, __builtin_fmaf(-2.0f, T, 0.25f));
+    const float A = fminf(dx, dy) - T;
     const float mi = fminf(fminf(qx, wm1 - qx), fminf(qy, hm1 - qy));
     const float B = fmaxf(A, -0.5f - mi);
     const bool sure = ts > 0.0f;
@@ -997,7 +1016,7 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       if (i % kProjChunk == kProjChunk - 1 || i == S - 1) {
         const int first = i - i % kProjChunk, cnt = i % kProjChunk + 1;
         PGDVS_LAUNCH("agg_params", agg_params_kernel, dim3(1), dim3(256), 0, st, chunk, ws.proj, reinterpret_cast<float *>(ws.pc32), first,
-                     cnt);
+                     cnt, (float)((W > H ? W : H) + 1));
       }
     }
   }

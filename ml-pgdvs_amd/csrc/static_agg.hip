@@ -320,8 +320,9 @@ __device__ __forceinline__ unsigned screen_frames(const PushConsts *__restrict__
     // 1/8 + (|q~| + 1) / (8 (Q + 1)) + 2.5e-7 |q~| and the true quotient still lies more than 1/2 outside [0, max(W, H) - 1].
     const float ar = fabsf(r) * amax * 1.001f;
     const float T = __builtin_fmaf(c.e[0], ar, c.e[1]);
-    const float fx = floorf(qx), fy = floorf(qy);
-    const float dx = fminf(qx - fx, (fx + 1.0f) - qx), dy = fminf(qy - fy, (fy + 1.0f) - qy);
+    // distance to the nearest integer: qx - floor(qx) is exact, and 1 - that is the same real number as (floor + 1) - qx
+    const float gx = qx - floorf(qx), gy = qy - floorf(qy);
+    const float dx = fminf(gx, 1.0f - gx), dy = fminf(gy, 1.0f - gy);
     // (0 * (qx + qy): NaN for an infinite or NaN quotient, so that ts > 0 still implies finite coordinates)
     const float ts = __builtin_fmaf(qx + qy, 0.0f, __builtin_fmaf(-2.0f, T, 0.25f));
     const float A = fminf(dx, dy) - T;

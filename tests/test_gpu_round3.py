@@ -294,3 +294,24 @@ def test_splat_composite_converging_and_diverging_flows():
     # the same call again: the LDS adds lose nothing under contention, so the two results agree to rounding
     again = N(ops.dyn_splat_composite(T(rgb1), T(rgb2), T(flow12), T(f1t), T(mask), T(noise), alpha, T(static_rgb))[0])
     np.testing.assert_allclose(again[:, sure], got_rgb[:, sure], rtol=1e-5, atol=1e-5)
+
+
+def test_static_aggregate_adversarial_cameras():
+    """A12 on scenes built to strain the fp32 screening's error bound (tools/agg_stress.py: large rotations, depths over
+    four decades, projections far outside / behind / next to the image plane, integer-valued projections of planes):
+    the cloud equals the oracle's fp64 evaluation (nvidia_eval_pure_geo.py:257-277, 407-451) bit for bit."""
+    import importlib.util
+    import pathlib
+
+    spec = importlib.util.spec_from_file_location(
+        "agg_stress", pathlib.Path(__file__).resolve().parents[1] / "tools" / "agg_stress.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for seed in range(40):
+        rgbs, depths, masks, K3s, c2ws = mod.scene(seed)
+        want = orc.aggregate_static_pcl(rgbs, depths, masks, K3s, c2ws).astype(np.float32)
+        cloud, cnt = ops.static_aggregate(T(rgbs), T(depths), T(masks), K3s, c2ws)
+        k = ops.checked_count(cnt, "pgdvs_static_aggregate")
+        got = N(cloud[:k])
+        assert got.shape == want.shape, f"seed {seed}: {k} points, the oracle has {want.shape[0]}"
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"seed {seed}"

@@ -107,7 +107,7 @@ __global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, float 
     reinterpret_cast<uint32_t *>(dst + first)[k] = reinterpret_cast<const uint32_t *>(&c.p[0])[k];
   // the fp32 screening record (PushConsts: M32[12], e[3], pad), 16 floats per frame.  e[0], e[1]: the error bound of BOTH
   // image coordinates as one affine function of |r| amax for every quotient of magnitude <= q_hi = max(W, H) + 1 (see
-  // screen_frames), rounded up; e[2]: e32[2] (unused by the kernels)
+  // screen_frames), rounded up; e[2] = 1/8 - e[1], rounded down
   for (int k = threadIdx.x; k < n * 16; k += blockDim.x) {
     const ProjF64 &pj = c.p[k >> 4];
     const int j = k & 15;
@@ -118,11 +118,12 @@ __global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, float 
       v = j < 15 ? INFINITY : 0.0f;
     } else if (j == 12) {
       const double e01 = pj.e32[0] > pj.e32[1] ? (double)pj.e32[0] : (double)pj.e32[1];
-      v = (float)((e01 + ((double)q_hi + 1.0) * (double)pj.e32[2]) * 1.000001);
+      // (x 1.001: the fp32 roundings of |r| amax and of the product with it)
+      v = (float)((e01 + ((double)q_hi + 1.0) * (double)pj.e32[2]) * 1.001 * 1.000001);
     } else if (j == 13) {
-      v = (float)((double)q_hi * 2.5e-7 * 1.000001);
+      v = (float)(((double)q_hi * 2.6e-7 + 1e-7) * 1.000001);
     } else if (j == 14) {
-      v = pj.e32[2];
+      v = (float)((0.125 - ((double)q_hi * 2.6e-7 + 1e-7) * 1.000001) * 0.999999);
     }
     pc32[(size_t)(first + (k >> 4)) * 16 + j] = v;
   }
@@ -286,11 +287,11 @@ constexpr int kPushMaxFpg = 32;    // frames per workgroup row (one bit each in 
 // bitmask (bit f - fa) of the frames it could not decide (lanes that are not `live`: all bits).  Per-frame constants
 // are wave-uniform scalar loads.
 //   q~ = (M32 X)_k / (M32 X)_2 differs from the reference's fp64 value by at most T (see ProjF64 and below).  With
-//   ts = 1/4 - 2 T, A = min(dx, dy) - T (dx, dy: distance of q~ to the nearest integer) and
-//   mi = min(qx, W-1 - qx, qy, H-1 - qy):   stamp  <=>  ts > 0 and A > 0 and mi >= 0        (in range, both sure)
-//                                          decided <=>  ts > 0 and (A > 0 or mi < -1/2)    (else: fp64)
-//   ts > 0 implies that every quantity is finite (NaN / inf coordinates, a zero denominator: ts is NaN or -inf and
-//   every comparison false), and the subtractions keep the sign of the comparisons they replace exactly.
+//   sure = T < 1/8, clear = min(dx, dy) > T (dx, dy: distance of q~ to the nearest integer) and
+//   mi = min(qx, W-1 - qx, qy, H-1 - qy):   stamp  <=>  sure and clear and mi >= 0        (in range, both coordinates)
+//                                          decided <=>  sure and (clear or mi < -1/2)    (else: fp64)
+//   "sure" implies that every quantity is finite (NaN / inf coordinates, a zero denominator: its left-hand side is NaN
+//   or inf and the comparison false).
 //   The decisions are arithmetic (min / max on the vector unit) with four comparisons at the end: written as twelve
 //   comparisons combined in scalar registers the loop spent 42 scalar against 50 vector instructions per frame, and
 //   the scalar unit -- one per CU for four SIMDs -- set the pace of frame 0's launch (38 M scalar wave-instructions
@@ -314,23 +315,22 @@ __device__ __forceinline__ unsigned screen_frames(const PushConsts *__restrict__
     const float r = __builtin_amdgcn_rcpf(s2);  // v_rcp_f32: 1 ulp
     const float qx = s0 * r, qy = s1 * r;
     // |q~ - q_ref| <= (E_row + (|q~| + 1) E_2) |r| + 2^-22 |q~|, E_k = e32[k] amax (see ProjF64): for |q~| <= Q = max(W, H) + 1
-    // at most T = e[0] |r| amax + e[1] with e[0] = max(e32[0], e32[1]) + (Q + 1) e32[2], e[1] = 2.5e-7 Q -- one bound for
-    // both coordinates, one multiply-add per frame.  A quotient beyond Q can be off by more than T, but it never stamps
-    // (mi < 0) and "decided" is right for it: ts > 0 means e[0] |r| amax < 1/8, hence its true error is below
+    // at most T = e0 |r| amax + e[1] with e0 = max(e32[0], e32[1]) + (Q + 1) e32[2], e[1] = 2.6e-7 Q + 1e-7 (the rounding of
+    // dx, dy and of the subtraction below included) -- one bound for both coordinates.  A quotient beyond Q can be off by
+    // more than T, but it never stamps (mi < 0) and "decided" is right for it: sure means e0 |r| amax < 1/8, hence its true error is below
     // 1/8 + (|q~| + 1) / (8 (Q + 1)) + 2.5e-7 |q~| and the true quotient still lies more than 1/2 outside [0, max(W, H) - 1].
-    const float ar = fabsf(r) * amax * 1.001f;
-    const float T = __builtin_fmaf(c.e[0], ar, c.e[1]);
+    // The two constants stay in scalar registers: u = e[0] |r| amax (e[0] carries the rounding allowance of this product),
+    // "sure" <=> u < e[2] = 1/8 - e[1], "clear of every integer" <=> min(dx, dy) - u > e[1].
+    const float u = c.e[0] * (fabsf(r) * amax);
     // distance to the nearest integer: qx - floor(qx) is exact, and 1 - that is the same real number as (floor + 1) - qx
     const float gx = qx - floorf(qx), gy = qy - floorf(qy);
     const float dx = fminf(gx, 1.0f - gx), dy = fminf(gy, 1.0f - gy);
-    // (0 * (qx + qy): NaN for an infinite or NaN quotient, so that ts > 0 still implies finite coordinates)
-    const float ts = __builtin_fmaf(qx + qy, 0.0f, __builtin_fmaf(-2.0f, T, 0.25f));
-    const float A = fminf(dx, dy) - T;
+    // (0 * (qx + qy): NaN for an infinite or NaN quotient, so that "sure" still implies finite coordinates)
+    const bool sure = __builtin_fmaf(qx + qy, 0.0f, u) < c.e[2];
+    const bool clear = fminf(dx, dy) - u > c.e[1];
     const float mi = fminf(fminf(qx, wm1 - qx), fminf(qy, hm1 - qy));
-    const float B = fmaxf(A, -0.5f - mi);
-    const bool sure = ts > 0.0f;
-    if (sure & (A > 0.0f) & (mi >= 0.0f)) stamp(f, (int)qy * W + (int)qx);
-    dmask |= ((sure & (B > 0.0f)) ? 0u : 1u) << (f - fa);
+    if (sure & clear & (mi >= 0.0f)) stamp(f, (int)qy * W + (int)qx);
+    dmask |= ((sure & (clear | (mi < -0.5f))) ? 0u : 1u) << (f - fa);
   };
   // Two frames per trip with two sets of constants: each set is requested (scalar loads, wave-uniform) while the
   // other frame is evaluated and lands in its own registers -- a single set renamed per frame cost ~14 scalar

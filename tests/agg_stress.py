@@ -1,11 +1,11 @@
-"""Adversarial sweep for the static aggregation's fp32 screening (run on the GPU box: ``python tools/agg_stress.py [n]``).
+"""Adversarial sweep for the static aggregation's fp32 screening (run on the GPU box: ``python tests/agg_stress.py [n]``).
 
 Small random scenes whose cameras differ by large rotations and translations, with depths over four decades, so that
 many projections fall far outside the later frames, behind their cameras or next to their image planes -- the cases the
 error bound of ``screen_frames`` (csrc/static_agg.hip) has to get right without the smooth orbits of the benchmark
 video.  Every cloud must equal the oracle's (``_compute_pcl_proj_mask`` in fp64, nvidia_eval_pure_geo.py:257-277) bit
 for bit (run it once more with PGDVS_AGG_ORDERED=1 for the ordered chain; the library reads the switch once per process).
-The oracle is the checker here, as in tests/."""
+Test infrastructure (the oracle is the checker): tests/test_gpu_round3.py runs a 40-scene slice."""
 import os
 import sys
 

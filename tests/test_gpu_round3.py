@@ -297,14 +297,14 @@ def test_splat_composite_converging_and_diverging_flows():
 
 
 def test_static_aggregate_adversarial_cameras():
-    """A12 on scenes built to strain the fp32 screening's error bound (tools/agg_stress.py: large rotations, depths over
+    """A12 on scenes built to strain the fp32 screening's error bound (tests/agg_stress.py: large rotations, depths over
     four decades, projections far outside / behind / next to the image plane, integer-valued projections of planes):
     the cloud equals the oracle's fp64 evaluation (nvidia_eval_pure_geo.py:257-277, 407-451) bit for bit."""
     import importlib.util
     import pathlib
 
     spec = importlib.util.spec_from_file_location(
-        "agg_stress", pathlib.Path(__file__).resolve().parents[1] / "tools" / "agg_stress.py")
+        "agg_stress", pathlib.Path(__file__).resolve().parent / "agg_stress.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     for seed in range(40):

@@ -98,10 +98,13 @@ constexpr int kProjChunk = 10;  // (kernel arguments are limited to 4 KB)
 struct ProjChunk {
   ProjF64 p[kProjChunk];
 };
-static_assert(sizeof(ProjChunk) + 32 <= 4096, "agg_params_kernel's arguments");
+static_assert(sizeof(ProjChunk) + 64 <= 4096, "agg_params_kernel's arguments");
 
 struct PushConsts;
-__global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, float *__restrict__ pc32, int first, int n, float q_hi) {
+__global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, float *__restrict__ pc32, int first, int n, float q_hi,
+                                  uint32_t *__restrict__ zero, int n_zero) {
+  // (the call's first launch also clears the state block: counts, tickets, error flag, look-back descriptors)
+  for (int k = threadIdx.x; k < n_zero; k += blockDim.x) zero[k] = 0u;
   const int words = (int)(sizeof(ProjF64) / 4);
   for (int k = threadIdx.x; k < n * words; k += blockDim.x)
     reinterpret_cast<uint32_t *>(dst + first)[k] = reinterpret_cast<const uint32_t *>(&c.p[0])[k];
@@ -732,8 +735,11 @@ __global__ void __launch_bounds__(kBitTileWords) agg_count_kernel(const uint32_t
 
 // ... their running sum in (frame, tile) order: tile_off[u] = selected pixels of the later frames before entry u
 // (u = f * tiles + t, from u = tiles on); tile_off[S * tiles] = all of them.  One workgroup.
+// ... and the count the caller sees (what agg_finalize_kernel computes for the ordered chain).
 __global__ void __launch_bounds__(1024) agg_scan_kernel(const int32_t *__restrict__ tile_cnt, int64_t *__restrict__ tile_off,
-                                                        int64_t lo, int64_t hi) {
+                                                        int64_t lo, int64_t hi, const int64_t *__restrict__ cnts,
+                                                        const int32_t *__restrict__ error, int64_t capacity,
+                                                        int64_t *__restrict__ count_out) {
   __shared__ long long s_w[16];
   __shared__ long long s_carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -764,7 +770,11 @@ __global__ void __launch_bounds__(1024) agg_scan_kernel(const int32_t *__restric
     if (tid == 1023) s_carry = run;
     __syncthreads();
   }
-  if (tid == 0) tile_off[hi] = s_carry;
+  if (tid == 0) {
+    tile_off[hi] = s_carry;
+    const long long n = cnts[1] + s_carry;
+    *count_out = *error ? -1 : (n > capacity ? capacity : n);
+  }
 }
 
 // ... and their rows, in the reference's order (frame, then row-major pixel: tmp_pcl[tmp_st_mask] :247-251): tile (t, f)
@@ -942,8 +952,9 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
   if (xyz_out) ws.xyz = xyz_out;
   hipStream_t st = as_stream(stream);
   const int64_t P = (int64_t)H * W;
-  hipError_t e = hipMemsetAsync(ws.state, 0, (size_t)ws.state_bytes, st);
-  if (e == hipSuccess && S > 1) e = fill_async(ws.occ + P, 0, (size_t)(S - 1) * (size_t)P, st);  // (frame 0 has no map)
+  // (the state block is cleared by the first agg_params launch below)
+  hipError_t e = hipSuccess;
+  if (S > 1) e = fill_async(ws.occ + P, 0, (size_t)(S - 1) * (size_t)P, st);  // (frame 0 has no map)
   if (e != hipSuccess) {
     set_error("static_aggregate memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
@@ -1017,7 +1028,8 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       if (i % kProjChunk == kProjChunk - 1 || i == S - 1) {
         const int first = i - i % kProjChunk, cnt = i % kProjChunk + 1;
         PGDVS_LAUNCH("agg_params", agg_params_kernel, dim3(1), dim3(256), 0, st, chunk, ws.proj, reinterpret_cast<float *>(ws.pc32), first,
-                     cnt, (float)((W > H ? W : H) + 1));
+                     cnt, (float)((W > H ? W : H) + 1), first == 0 ? reinterpret_cast<uint32_t *>(ws.state) : nullptr,
+                     first == 0 ? (int)(ws.state_bytes / 4) : 0);
       }
     }
   }
@@ -1128,7 +1140,7 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
   PGDVS_LAUNCH("agg_count", agg_count_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,
                (const uint32_t *)ws.sel, ws.Wd, tiles, ws.tile_cnt);
   PGDVS_LAUNCH("agg_count", agg_scan_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)ws.tile_cnt, ws.tile_off, (int64_t)tiles,
-               (int64_t)S * tiles);
+               (int64_t)S * tiles, (const int64_t *)ws.cnts, (const int32_t *)ws.error, capacity, count_out);
   {
     RowsArgs ra;
     ra.depths = depths;
@@ -1142,7 +1154,5 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
                  (const uint32_t *)ws.sel, ws.Wd, tiles, (const int64_t *)ws.tile_off, (const int64_t *)ws.cnts,
                  (const CamBlock *)ws.cams, ra);
   }
-  PGDVS_LAUNCH("agg_finalize", agg_finalize_kernel, dim3(1), dim3(64), 0, st, (const int64_t *)ws.cnts,
-               (const int32_t *)ws.error, (const int64_t *)(ws.tile_off + (int64_t)S * tiles), S, capacity, count_out);
   return check_launch("static_aggregate");
 }

@@ -77,7 +77,10 @@ class PGDVSRenderer(PGDVSBaseRenderer):
                 ret_dict["combined_rgb"] = static_rgb
                 return ret_dict
         elif isinstance(self.static_renderer, StaticGeoPointRenderer):
-            static_rgb, st_ret_dict = self.forward_st_geo(data=data, ray_batch=ray_batch, render_cfg=render_cfg)
+            # (the dynamic branch's preparation already holds the target cameras' blocks: same stream -> no second launch)
+            cams_tgt = prepared["cams_tgt"] if (prepared is not None and prepared.get("stream", None) is None) else None
+            static_rgb, st_ret_dict = self.forward_st_geo(data=data, ray_batch=ray_batch, render_cfg=render_cfg,
+                                                          cams_tgt=cams_tgt)
             ret_dict.update(st_ret_dict)
         else:
             raise TypeError(type(self.static_renderer))
@@ -105,7 +108,7 @@ class PGDVSRenderer(PGDVSBaseRenderer):
         ret_dict["combined_rgb_dyn"] = combined_rgb_dyn
         return ret_dict
 
-    def forward_st_geo(self, *, data, ray_batch, render_cfg):
+    def forward_st_geo(self, *, data, ray_batch, render_cfg, cams_tgt=None):
         """:182-201"""
         static_rgb, static_mask = [], []
         counts = data.get("st_pcl_rgb_count", None)  # optional device counts [B] (int64)
@@ -119,7 +122,8 @@ class PGDVSRenderer(PGDVSBaseRenderer):
                 tgt_h=ray_batch["render_h"], tgt_w=ray_batch["render_w"], flat_tgt_cam=data["flat_cam_tgt"][i_b],
                 st_pcl_rgb=data["st_pcl_rgb"][i_b], render_cfg=render_cfg,
                 n_points_dev=None if counts is None else counts[i_b:i_b + 1], planar=True,
-                st_pcl_xyz=None if xyz is None else xyz[i_b], row_bound=bound, status_out=status)
+                st_pcl_xyz=None if xyz is None else xyz[i_b], row_bound=bound, status_out=status,
+                cam_block=None if cams_tgt is None else cams_tgt[i_b])
             static_rgb.append(tmp_rgb)
             static_mask.append(tmp_mask)
         if len(static_rgb) == 1:  # a view, not a 25 MB copy

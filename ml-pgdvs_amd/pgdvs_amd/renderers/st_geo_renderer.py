@@ -13,16 +13,17 @@ class StaticGeoPointRenderer(torch.nn.Module):
         self.projector = Projector()
 
     def forward(self, *, tgt_h, tgt_w, flat_tgt_cam, st_pcl_rgb, render_cfg, n_points_dev=None, planar=False,
-                st_pcl_xyz=None, row_bound=None, status_out=None):
+                st_pcl_xyz=None, row_bound=None, status_out=None, cam_block=None):
         """st_pcl_rgb[#pt,6] (xyz,rgb).  Returns (mesh_img[H,W,3], mesh_mask[H,W,1]) like the
         reference, or planar ([3,H,W], [1,H,W]) with ``planar=True``.
         ``n_points_dev``: optional device int64 count (rows beyond it are ignored).
         ``st_pcl_xyz``: optional packed copy [#pt,3] of the coordinates (``ops.static_aggregate(...,
         return_xyz=True)``): the binning passes then read 12 instead of 24 bytes per point.
         ``row_bound``: with a device count, size the rasteriser's workspace for that many rows instead of the buffer's
-        capacity; ``status_out`` (a list) then receives the device status word (``ops.check_raster_status``)."""
+        capacity; ``status_out`` (a list) then receives the device status word (``ops.check_raster_status``).
+        ``cam_block``: the target camera's block if the caller already has it (``ops.cam_prep(flat_tgt_cam)``)."""
         assert st_pcl_rgb.ndim == 2, f"{st_pcl_rgb.shape}"
-        cam = ops.cam_prep(flat_tgt_cam)
+        cam = cam_block if cam_block is not None else ops.cam_prep(flat_tgt_cam)
         pts = st_pcl_rgb
         if st_pcl_xyz is not None and not render_cfg.st_pcl_remove_outlier:
             assert st_pcl_xyz.shape == (st_pcl_rgb.shape[0], 3), f"{st_pcl_xyz.shape}"

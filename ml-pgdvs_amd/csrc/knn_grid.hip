@@ -379,109 +379,73 @@ grid_occ_count_kernel(const GridParams *__restrict__ gp, int32_t *__restrict__ c
 }
 
 // exclusive scan of in[0 .. n) -> out[0 .. n]; n = *n_ptr is a device value (the cells of a dense grid, or the
-// occupied cells of the sparse one), blocks beyond it exit at once
+// occupied cells of the sparse one).  (Rounds 1-2: three launches -- block sums, their scan, apply.)
 constexpr int kScanItems = 16;
 constexpr int kScanTile = 1024 * kScanItems;
+// ONE workgroup walks the tiles with a carry: one launch instead of three.  The inputs here are the
+// occupied cells of the sparse grid (~points / 24) and the cells of the coarse grid (<= 256 K): a handful of tiles; an
+// input of millions of entries (every point alone in its cell) still scans correctly, at ~2 us per 16 K entries.
 __global__ void __launch_bounds__(1024)
-grid_scan_blocks_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ n_ptr,
-                        int32_t *__restrict__ block_sums) {
+grid_scan_one_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ n_ptr, int32_t *__restrict__ out) {
   __shared__ int ws[16];
+  __shared__ int s_carry;
   const int n = *n_ptr;
-  int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-  int s = 0;
-  if (blockIdx.x * kScanTile < n) {
+  const int tid = threadIdx.x;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int tile = 0; tile * kScanTile <= n; ++tile) {  // (<= n: the tile that holds out[n])
+    const int base = tile * kScanTile + tid * kScanItems;
+    int v[kScanItems];
+    int s = 0;
+    if (base + kScanItems <= n) {
 #pragma unroll
-    for (int k = 0; k < kScanItems; k += 4) {
-      if (base + k + 3 < n) {
-        int4 v = *reinterpret_cast<const int4 *>(in + base + k);
-        s += v.x + v.y + v.z + v.w;
-      } else {
-        for (int kk = 0; kk < 4; ++kk)
-          if (base + k + kk < n) s += in[base + k + kk];
+      for (int k = 0; k < kScanItems; k += 4) {
+        const int4 q = *reinterpret_cast<const int4 *>(in + base + k);
+        v[k] = q.x;
+        v[k + 1] = q.y;
+        v[k + 2] = q.z;
+        v[k + 3] = q.w;
+        s += q.x + q.y + q.z + q.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kScanItems; ++k) {
+        v[k] = base + k < n ? in[base + k] : 0;
+        s += v[k];
       }
     }
-  }
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int t = 0;
-    for (int i = 0; i < 16; ++i) t += ws[i];
-    block_sums[blockIdx.x] = t;
-  }
-}
-
-__global__ void __launch_bounds__(1024)
-grid_scan_sums_kernel(int32_t *__restrict__ block_sums, int nb) {
-  // nb <= 1024: one pass
-  __shared__ int ws[16];
-  int v = threadIdx.x < nb ? block_sums[threadIdx.x] : 0;
-  int x = v;
-  for (int off = 1; off < 64; off <<= 1) {
-    int y = __shfl_up(x, off, 64);
-    if ((threadIdx.x & 63) >= off) x += y;
-  }
-  if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = x;
-  __syncthreads();
-  int wo = 0;
-  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wo += ws[w];
-  if (threadIdx.x < nb) block_sums[threadIdx.x] = wo + x - v;
-}
-
-__global__ void __launch_bounds__(1024)
-grid_scan_apply_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ n_ptr,
-                       const int32_t *__restrict__ block_sums, int32_t *__restrict__ out) {
-  __shared__ int ws[16];
-  const int n = *n_ptr;
-  if (blockIdx.x * kScanTile > n) return;
-  int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-  int v[kScanItems];
-  int s = 0;
-  if (base + kScanItems <= n) {  // 16 contiguous ints per thread: four 16-byte loads
-#pragma unroll
-    for (int k = 0; k < kScanItems; k += 4) {
-      int4 q = *reinterpret_cast<const int4 *>(in + base + k);
-      v[k] = q.x;
-      v[k + 1] = q.y;
-      v[k + 2] = q.z;
-      v[k + 3] = q.w;
-      s += q.x + q.y + q.z + q.w;
+    int x = s;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off, 64);
+      if ((tid & 63) >= off) x += y;
     }
-  } else {
+    if ((tid & 63) == 63) ws[tid >> 6] = x;
+    __syncthreads();
+    int wo = 0;
+    for (int w = 0; w < (tid >> 6); ++w) wo += ws[w];
+    int run = s_carry + wo + x - s;
+    if (base + kScanItems <= n) {
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-      v[k] = base + k < n ? in[base + k] : 0;
-      s += v[k];
-    }
-  }
-  int x = s;
-  for (int off = 1; off < 64; off <<= 1) {
-    int y = __shfl_up(x, off, 64);
-    if ((threadIdx.x & 63) >= off) x += y;
-  }
-  if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = x;
-  __syncthreads();
-  int wo = 0;
-  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wo += ws[w];
-  int run = block_sums[blockIdx.x] + wo + x - s;
-  if (base + kScanItems <= n) {
+      for (int k = 0; k < kScanItems; k += 4) {
+        int4 q;
+        q.x = run;
+        q.y = q.x + v[k];
+        q.z = q.y + v[k + 1];
+        q.w = q.z + v[k + 2];
+        run = q.w + v[k + 3];
+        *reinterpret_cast<int4 *>(out + base + k) = q;
+      }
+      if (base + kScanItems == n) out[n] = run;  // total
+    } else {
 #pragma unroll
-    for (int k = 0; k < kScanItems; k += 4) {
-      int4 q;
-      q.x = run;
-      q.y = q.x + v[k];
-      q.z = q.y + v[k + 1];
-      q.w = q.z + v[k + 2];
-      run = q.w + v[k + 3];
-      *reinterpret_cast<int4 *>(out + base + k) = q;
+      for (int k = 0; k < kScanItems; ++k) {
+        if (base + k <= n) out[base + k] = run;  // includes out[n] = total
+        run += v[k];
+      }
     }
-    if (base + kScanItems == n) out[n] = run;  // total
-  } else {
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-      if (base + k <= n) out[base + k] = run;  // includes out[n] = total
-      run += v[k];
-    }
+    __syncthreads();  // everyone has read s_carry and ws
+    if (tid == 1023) s_carry = run;
+    __syncthreads();
   }
 }
 
@@ -1321,11 +1285,9 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
                (const uint4 *)ws.tab, ws.occ_count);
   const int64_t occ_cap = capacity < kGridMaxCells ? capacity : (int64_t)kGridMaxCells;
   const int nb = (int)cdiv(occ_cap + 1, kScanTile);  // (<= kGridMaxCells / kScanTile = 1024: one pass over the block sums)
-  PGDVS_LAUNCH("grid_scan_blocks", grid_scan_blocks_kernel, dim3(nb), dim3(1024), 0, st, ws.occ_count,
-               (const int32_t *)ws.nocc, ws.block_sums);
-  PGDVS_LAUNCH("grid_scan_sums", grid_scan_sums_kernel, dim3(1), dim3(1024), 0, st, ws.block_sums, nb);
-  PGDVS_LAUNCH("grid_scan_apply", grid_scan_apply_kernel, dim3(nb), dim3(1024), 0, st, ws.occ_count,
-               (const int32_t *)ws.nocc, ws.block_sums, ws.occ_start);
+  (void)nb;
+  PGDVS_LAUNCH("grid_scan", grid_scan_one_kernel, dim3(1), dim3(1024), 0, st, ws.occ_count, (const int32_t *)ws.nocc,
+               ws.occ_start);
   PGDVS_LAUNCH("grid_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
                ws.occ_start, ws.occ_count, ws.sorted, (const int32_t *)nullptr);
   CellIndex ci;
@@ -1374,11 +1336,9 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   PGDVS_LAUNCH("grid2_zero", grid_zero_kernel, dim3(256), dim3(256), 0, st, ws.gp2, ws.cell_count2, (int32_t *)nullptr);
   PGDVS_LAUNCH("grid2_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp2, ws.cell_of,
                ws.cell_count2, (const int32_t *)ws.fb_count);
-  PGDVS_LAUNCH("grid2_scan", grid_scan_blocks_kernel, dim3(nb2), dim3(1024), 0, st, ws.cell_count2, (const int32_t *)&ws.gp2->ncells,
-               ws.block_sums2);
-  PGDVS_LAUNCH("grid2_scan", grid_scan_sums_kernel, dim3(1), dim3(1024), 0, st, ws.block_sums2, nb2);
-  PGDVS_LAUNCH("grid2_scan", grid_scan_apply_kernel, dim3(nb2), dim3(1024), 0, st, ws.cell_count2, (const int32_t *)&ws.gp2->ncells,
-               ws.block_sums2, ws.cell_start2);
+  (void)nb2;
+  PGDVS_LAUNCH("grid2_scan", grid_scan_one_kernel, dim3(1), dim3(1024), 0, st, ws.cell_count2, (const int32_t *)&ws.gp2->ncells,
+               ws.cell_start2);
   PGDVS_LAUNCH("grid2_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp2, ws.cell_of,
                ws.cell_start2, ws.cell_count2, ws.sorted2, (const int32_t *)ws.fb_count);
   CellIndex ci2;  // the coarse grid stays dense (<= 256 K cells)

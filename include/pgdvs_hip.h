@@ -377,6 +377,91 @@ int pgdvs_combine(const float *static_rgb, const float *dyn_rgb, const float *dy
                   int64_t n, float *combined, float *combined_static, float *combined_dyn,
                   pgdvs_stream_t stream);
 
+/* ---- 8f-1, the caller's metric: PGDVSEvaluator.eval_step's image statistics for one view in one pass
+ * (pgdvs/engines/evaluator_pgdvs.py:52-77: clamp -> NaN to 0 -> (x*255).byte().float()/255 of prediction and ground
+ * truth; :190-283 with pgdvs/utils/training.py:281-313: sum((gt - pred)^2 * mask) and sum(mask) in float64 for the
+ * masks ones / eval_mask / 1 - eval_mask).
+ *   pred_planar[3,H,W] raw render (combined_rgb); gt_hwc[H,W,3] raw ground truth; mask_hwc[H,W,3] eval_mask
+ *   pred_q / gt_q [3,H,W] (nullable): the quantised images
+ *   sums: DEVICE double[6] = sum d2, sum d2*m, sum d2*(1-m), 3*H*W, sum m, sum (1-m)
+ *   PSNR_k = 10 log10(1 / (sums[k] / (sums[3+k] + 1e-8))), 0 when the sum of squares is 0 (upstream's quirk). */
+int64_t pgdvs_eval_psnr_workspace_bytes(void);
+int pgdvs_eval_psnr_sums(const float *pred_planar, const float *gt_hwc, const float *mask_hwc, int H, int W,
+                         float *pred_q, float *gt_q, double *sums, void *workspace, int64_t workspace_bytes,
+                         pgdvs_stream_t stream);
+
+/* ---- one native call per target view -------------------------------------------------
+ * PGDVSRenderer.forward with static_renderer = StaticGeoPointRenderer, dyn_render_type = "softsplat",
+ * batch item of size 1, render_stride 1, no tracker (pgdvs/renderers/pgdvs_renderer.py:84-178 ->
+ * st_geo_renderer.py:77-120 + pgdvs_renderer_dyn.py:63-257,275-540), as the evaluator drives it once per
+ * target view (pgdvs/engines/evaluator_pgdvs.py:36-54) -- and, when agg_S > 0, the static cloud aggregated
+ * first from the resident video (A12, nvidia_eval_pure_geo.py:183-277).  Enqueues the whole chain (A12, A9,
+ * A2-A5 with the kNN outlier filter, A6-A8, A11) from C++: one ctypes call instead of ~85, same kernels, same
+ * results as the per-op entry points above.
+ * Every pointer is a DEVICE pointer except agg_K3s_host / agg_c2ws_host. */
+typedef struct pgdvs_view_geo_desc {
+  int32_t H, W;                 /* source and target resolution (render_stride 1)                      */
+  /* cameras and times: rows of the data dict (A0)                                                    */
+  const float *flat_cam_tgt;    /* [34]                                                                */
+  const float *flat_cam_src;    /* [2,34]  the two temporally closest source frames                    */
+  const float *time_src;        /* [2]     time_src_temporal                                           */
+  const float *time_tgt;        /* [1]                                                                 */
+  /* dynamic branch inputs                                                                            */
+  const float *rgb1, *rgb2;     /* [H,W,3] each (rgb_src_temporal[0], [1])                             */
+  const float *depth1, *depth2; /* [H,W]                                                               */
+  const float *dyn_mask1;       /* [H,W]   0/1 floats (dyn_mask_src_temporal[0])                       */
+  const float *flow12;          /* [H,W,2] flow_fwd                                                    */
+  const float *flow_occ;        /* [H,W]   flow_fwd_occ_mask (needed when use_flow_consistency)        */
+  int32_t use_flow_consistency; /* render_cfg.dyn_render_use_flow_consistency                          */
+  int32_t remove_outlier;       /* render_cfg.dyn_pcl_remove_outlier                                   */
+  int32_t outlier_knn;          /* render_cfg.dyn_pcl_outlier_knn                                      */
+  float outlier_std_thres;      /* render_cfg.dyn_pcl_outlier_std_thres                                */
+  float alpha;                  /* softsplat_metric_abs_alpha                                          */
+  const float *noise;           /* [3,H,W] injected normal field, or NULL                              */
+  uint64_t *rng_state;          /* {seed, draw number} (pgdvs_dyn_splat_composite_rng), or NULL; both NULL: zeros */
+  /* static cloud, given ...                                                                          */
+  const float *st_pcl_rgb;      /* [st_rows,6] (xyz,rgb); ignored when agg_S > 0                       */
+  const float *st_pcl_xyz;      /* [st_rows,3] packed coordinates or NULL                              */
+  int64_t st_rows;              /* rows of the two buffers                                             */
+  const int64_t *st_count_dev;  /* device count (rows actually present) or NULL = st_rows              */
+  /* ... or aggregated inside the call (A12; arguments of pgdvs_static_aggregate_packed)              */
+  int32_t agg_S;                /* 0: use st_pcl_rgb                                                   */
+  const float *agg_rgbs;        /* [S,H,W,3]                                                           */
+  const float *agg_depths;      /* [S,H,W]                                                             */
+  const uint8_t *agg_masks;     /* [S,H,W]                                                             */
+  const double *agg_K3s_host;   /* HOST [S,9]                                                          */
+  const double *agg_c2ws_host;  /* HOST [S,16]                                                         */
+  float *agg_cloud_out;         /* [agg_capacity,6]                                                    */
+  float *agg_xyz_out;           /* [agg_capacity,3]                                                    */
+  int64_t agg_capacity;
+  int64_t *agg_count_out;       /* device int64 (or -1, see pgdvs_static_aggregate)                    */
+  /* rasteriser                                                                                       */
+  int64_t row_bound;            /* rows the tile lists are sized for (<= the buffers' rows); <= 0: all rows */
+  float radius;                 /* render_cfg.st_render_pcl_pt_radius                                  */
+  int32_t K;                    /* render_cfg.st_render_pcl_pts_per_pixel                              */
+  /* outputs, planar                                                                                  */
+  float *static_rgb;            /* [3,H,W] geo_static_rgb                                              */
+  float *static_mask;           /* [H,W]   geo_static_mask                                             */
+  int32_t *raster_status;       /* device int32 (pgdvs_points_raster_bounded)                          */
+  float *render_dyn_rgb;        /* [3,H,W]                                                             */
+  float *render_dyn_mask;       /* [H,W]                                                               */
+  float *combined;              /* [3,H,W] combined_rgb                                                */
+  float *combined_static;       /* [3,H,W]                                                             */
+  float *combined_dyn;          /* [3,H,W]                                                             */
+  /* optional: the dynamic branch's geometry (A2-A5) on a second stream, joined before the splat       */
+  pgdvs_stream_t side_stream;   /* NULL: everything on `stream`                                        */
+} pgdvs_view_geo_desc;
+
+/* sizeof(pgdvs_view_geo_desc) as this library was compiled: a binding checks its own struct against it */
+int64_t pgdvs_view_geo_desc_size(void);
+/* bytes of workspace pgdvs_view_geo_forward needs for this description (negative status on a bad one) */
+int64_t pgdvs_view_geo_workspace_bytes(const pgdvs_view_geo_desc *desc);
+int pgdvs_view_geo_forward(const pgdvs_view_geo_desc *desc, void *workspace, int64_t workspace_bytes,
+                           pgdvs_stream_t stream);
+/* host enqueue statistics of pgdvs_view_geo_forward since the last call of this function: calls made and the
+ * wall-clock seconds spent inside them (bench.py's host_enqueue figure); resets both. */
+void pgdvs_view_geo_host_stats(int64_t *calls, double *seconds);
+
 #ifdef __cplusplus
 }
 #endif

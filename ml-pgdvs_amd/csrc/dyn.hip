@@ -57,13 +57,8 @@ __device__ __forceinline__ bool inv_f64_wave(double (&m)[N], int lane) {
 }
 
 // one wavefront per camera: flat_cam[34] -> camera block (same values as cam_block_from_flat)
-__global__ void __launch_bounds__(64) cam_prep_kernel(const float *__restrict__ flat_cams, int n,
-                                                      float *__restrict__ blocks) {
-  const int i = blockIdx.x, lane = threadIdx.x;
-  if (i >= n) return;
-  const float *fc = flat_cams + (size_t)i * 34;
+__device__ __forceinline__ void cam_prep_one(const float *__restrict__ fc, float *__restrict__ blk, const int lane) {
   const float *K = fc + 2, *c2w = fc + 18;
-  float *blk = blocks + (size_t)i * PGDVS_CAM_BLOCK;
   __shared__ float s_kinv[9], s_w2c[16];
   // K[:3,:3]^-1: lanes 0..5 hold the columns of [K3 | I]
   double a3[3];
@@ -105,6 +100,24 @@ __global__ void __launch_bounds__(64) cam_prep_kernel(const float *__restrict__ 
     blk[PGDVS_CAM_K + lane] = K[lane];
   }
   if (lane < 2) blk[PGDVS_CAM_HW + lane] = fc[lane];
+}
+
+__global__ void __launch_bounds__(64) cam_prep_kernel(const float *__restrict__ flat_cams, int n,
+                                                      float *__restrict__ blocks) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  cam_prep_one(flat_cams + (size_t)i * 34, blocks + (size_t)i * PGDVS_CAM_BLOCK, threadIdx.x);
+}
+
+// The per-view native call (view_geo.cpp): the camera blocks of the target and of the two temporal source frames
+// (blocks[0] = target, blocks[1..2] = sources) and the packed time stamps (t1, t2, t_tgt) in ONE launch instead of two
+// cam_prep launches and a torch.cat.
+__global__ void __launch_bounds__(64) view_prep_kernel(const float *__restrict__ flat_tgt, const float *__restrict__ flat_src,
+                                                       const float *__restrict__ time_src, const float *__restrict__ time_tgt,
+                                                       float *__restrict__ blocks, float *__restrict__ times) {
+  const int i = blockIdx.x;
+  if (i == 0 && threadIdx.x < 3) times[threadIdx.x] = threadIdx.x < 2 ? time_src[threadIdx.x] : time_tgt[0];
+  cam_prep_one(i == 0 ? flat_tgt : flat_src + (size_t)(i - 1) * 34, blocks + (size_t)i * PGDVS_CAM_BLOCK, threadIdx.x);
 }
 
 // A1 -- pgdvs_renderer_base.py:17-57
@@ -356,6 +369,14 @@ PGDVS_API int pgdvs_cam_prep(const float *flat_cams, int n, float *cam_blocks,
                      flat_cams, n, cam_blocks);
   return check_launch("cam_prep");
 }
+
+namespace pgdvs {
+int view_prep(const float *flat_tgt, const float *flat_src, const float *time_src, const float *time_tgt, float *blocks,
+              float *times, hipStream_t st) {
+  PGDVS_LAUNCH("view_prep", view_prep_kernel, dim3(3), dim3(64), 0, st, flat_tgt, flat_src, time_src, time_tgt, blocks, times);
+  return check_launch("view_prep");
+}
+}  // namespace pgdvs
 
 PGDVS_API int pgdvs_get_rays(const float *cam_block, int H, int W, int stride, float *rays_o,
                              float *rays_d, float *uvs, pgdvs_stream_t stream) {

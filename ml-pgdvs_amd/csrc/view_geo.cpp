@@ -1,0 +1,296 @@
+// One native call per target view: the whole geometric path of PGDVSRenderer.forward
+// (pgdvs/renderers/pgdvs_renderer.py:84-178 with StaticGeoPointRenderer + the softsplat dynamic branch) enqueued
+// from C++, as the reference's evaluator drives it once per view (pgdvs/engines/evaluator_pgdvs.py:36-54).
+//
+// Nothing new is computed here: the function carves one caller-given workspace into the scratch of the per-op
+// entry points (include/pgdvs_hip.h) and calls them in the order the Python classes do.  What it removes is the host
+// cost of ~85 ctypes calls, ~40 allocator round trips and the Python between them (0.53-0.74 ms per view in round 3
+// against 0.86 ms of GPU time).
+#include <chrono>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "scan.h"
+
+namespace pgdvs {
+
+int view_prep(const float *flat_tgt, const float *flat_src, const float *time_src, const float *time_tgt, float *blocks,
+              float *times, hipStream_t st);  // dyn.hip
+
+namespace {
+
+struct ViewWs {
+  float *cams;   // [3][80]: target, source 1, source 2
+  float *times;  // [3]
+  void *agg;
+  int64_t agg_bytes;
+  void *raster;
+  int64_t raster_bytes;
+  uint8_t *mask_eff, *valid, *keep, *flag;
+  float *pcl, *rgbf, *pts, *avg, *thres;
+  int32_t *idx, *cnt;
+  void *compact;
+  int64_t compact_bytes;
+  void *knn;
+  int64_t knn_bytes;
+  void *outlier;
+  int64_t outlier_bytes;
+  float *flow_1_to_tgt, *valid_mask;
+  void *splat;
+  int64_t splat_bytes;
+  int64_t raster_rows;  // rows the tile lists are sized for
+  int64_t total_bytes;
+};
+
+struct Carver {
+  char *base;
+  int64_t off = 0;
+  template <class T>
+  T *take(int64_t bytes) {
+    T *p = reinterpret_cast<T *>(base + off);
+    off += align_up(bytes > 0 ? bytes : 1, 256);
+    return p;
+  }
+};
+
+int view_layout(const pgdvs_view_geo_desc &d, void *base, ViewWs &w) {
+  if (d.H <= 0 || d.W <= 0 || (int64_t)d.H * d.W >= (1ll << 31)) {
+    set_error("pgdvs_view_geo: bad H/W");
+    return PGDVS_ERR_INVALID;
+  }
+  const int64_t P = (int64_t)d.H * d.W;
+  const int64_t rows = d.agg_S > 0 ? d.agg_capacity : d.st_rows;
+  if (rows < 0 || rows >= (1ll << 31)) {
+    set_error("pgdvs_view_geo: bad row count %lld", (long long)rows);
+    return PGDVS_ERR_INVALID;
+  }
+  w.raster_rows = (d.row_bound > 0 && d.row_bound < rows) ? d.row_bound : rows;
+  Carver c{reinterpret_cast<char *>(base)};
+  w.cams = c.take<float>(3 * PGDVS_CAM_BLOCK * 4);
+  w.times = c.take<float>(16);
+  w.agg_bytes = 0;
+  w.agg = nullptr;
+  if (d.agg_S > 0) {
+    w.agg_bytes = pgdvs_static_aggregate_workspace_bytes(d.agg_S, d.H, d.W, d.agg_capacity);
+    if (w.agg_bytes < 0) {
+      set_error("pgdvs_view_geo: bad aggregation shape");
+      return PGDVS_ERR_INVALID;
+    }
+    w.agg = c.take<char>(w.agg_bytes);
+  }
+  w.raster_bytes = pgdvs_points_raster_workspace_bytes(w.raster_rows, d.H, d.W, d.radius);
+  if (w.raster_bytes < 0) return (int)w.raster_bytes;  // (message set by the query)
+  w.raster = c.take<char>(w.raster_bytes);
+  w.mask_eff = c.take<uint8_t>(P);
+  w.valid = c.take<uint8_t>(P);
+  w.keep = c.take<uint8_t>(P);
+  w.flag = c.take<uint8_t>(P);
+  w.pcl = c.take<float>(P * 12);
+  w.rgbf = c.take<float>(P * 12);
+  w.flow_1_to_tgt = c.take<float>(P * 8);
+  w.valid_mask = c.take<float>(P * 4);
+  w.splat_bytes = pgdvs_dyn_splat_workspace_bytes(d.H, d.W);
+  w.splat = c.take<char>(w.splat_bytes);
+  w.idx = nullptr;
+  w.cnt = nullptr;
+  w.pts = w.avg = w.thres = nullptr;
+  w.compact = w.knn = w.outlier = nullptr;
+  w.compact_bytes = w.knn_bytes = w.outlier_bytes = 0;
+  if (d.remove_outlier) {
+    w.idx = c.take<int32_t>(P * 4);
+    w.cnt = c.take<int32_t>(16);
+    w.thres = c.take<float>(16);
+    w.pts = c.take<float>(P * 12);
+    w.avg = c.take<float>(P * 4);
+    w.compact_bytes = compact_workspace_bytes(P);
+    w.compact = c.take<char>(w.compact_bytes);
+    w.knn_bytes = pgdvs_knn_workspace_bytes(P);
+    w.knn = c.take<char>(w.knn_bytes);
+    w.outlier_bytes = pgdvs_outlier_workspace_bytes(P);
+    w.outlier = c.take<char>(w.outlier_bytes);
+  }
+  w.total_bytes = c.off;
+  return PGDVS_OK;
+}
+
+// fork / join events of the optional side stream (timing disabled); a process-wide pool behind a mutex
+std::mutex g_ev_mu;
+std::vector<hipEvent_t> g_ev_pool;
+hipEvent_t ev_get() {
+  {
+    std::lock_guard<std::mutex> lk(g_ev_mu);
+    if (!g_ev_pool.empty()) {
+      hipEvent_t e = g_ev_pool.back();
+      g_ev_pool.pop_back();
+      return e;
+    }
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  return e;
+}
+void ev_put(hipEvent_t e) {
+  std::lock_guard<std::mutex> lk(g_ev_mu);
+  g_ev_pool.push_back(e);
+}
+
+std::mutex g_stat_mu;
+int64_t g_stat_calls = 0;
+double g_stat_seconds = 0.0;
+
+#define VG_TRY(expr)            \
+  do {                          \
+    const int _rc = (expr);     \
+    if (_rc != PGDVS_OK) return _rc; \
+  } while (0)
+
+// A2-A5: the dynamic branch's geometry on stream `s` (cams / times already there)
+int dyn_geometry(const pgdvs_view_geo_desc &d, const ViewWs &w, pgdvs_stream_t s) {
+  const int H = d.H, W = d.W;
+  const int64_t P = (int64_t)H * W;
+  const float *cam_t = w.cams, *cam1 = w.cams + PGDVS_CAM_BLOCK, *cam2 = w.cams + 2 * PGDVS_CAM_BLOCK;
+  VG_TRY(pgdvs_dyn_warp(H, W, d.dyn_mask1, d.flow_occ, d.use_flow_consistency, d.flow12, d.depth1, d.depth2, d.rgb1, d.rgb2,
+                        cam1, cam2, w.times, w.mask_eff, w.valid, w.pcl, w.rgbf, s));
+  const uint8_t *keep = w.valid;
+  if (d.remove_outlier) {
+    // pytorch3d's kNN + the statistical filter (pgdvs_renderer_dyn.py:401-457)
+    VG_TRY(pgdvs_compact_u8(w.valid, P, w.idx, w.cnt, w.compact, w.compact_bytes, s));
+    VG_TRY(pgdvs_gather_rows(w.pcl, w.idx, w.cnt, P, 3, w.pts, s));
+    VG_TRY(pgdvs_knn_mean_dist(w.pts, w.cnt, P, d.outlier_knn, w.avg, 0, w.knn, w.knn_bytes, s));
+    VG_TRY(pgdvs_outlier_flags(w.avg, w.cnt, P, d.outlier_std_thres, 1, w.thres, w.flag, w.outlier, w.outlier_bytes, s));
+    VG_TRY(pgdvs_scatter_keep(w.idx, w.flag, w.cnt, P, w.keep, P, s));
+    keep = w.keep;
+  }
+  VG_TRY(pgdvs_project_flow_dense(H, W, cam_t, w.pcl, keep, w.flow_1_to_tgt, w.valid_mask, s));
+  return PGDVS_OK;
+}
+
+int view_forward(const pgdvs_view_geo_desc &d, void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(d.flat_cam_tgt && d.flat_cam_src && d.time_src && d.time_tgt && d.rgb1 && d.rgb2 && d.depth1 && d.depth2 &&
+                    d.dyn_mask1 && d.flow12,
+                "pgdvs_view_geo_forward: null input pointer");
+  PGDVS_REQUIRE(d.static_rgb && d.static_mask && d.render_dyn_rgb && d.render_dyn_mask && d.combined && d.combined_static &&
+                    d.combined_dyn && d.raster_status,
+                "pgdvs_view_geo_forward: null output pointer");
+  PGDVS_REQUIRE(!d.use_flow_consistency || d.flow_occ, "pgdvs_view_geo_forward: flow_occ required");
+  PGDVS_REQUIRE(d.agg_S > 0 || d.st_rows == 0 || d.st_pcl_rgb, "pgdvs_view_geo_forward: no static cloud");
+  PGDVS_REQUIRE(d.agg_S <= 0 || (d.agg_rgbs && d.agg_depths && d.agg_masks && d.agg_K3s_host && d.agg_c2ws_host &&
+                                  d.agg_cloud_out && d.agg_xyz_out && d.agg_count_out && d.agg_capacity > 0),
+                "pgdvs_view_geo_forward: incomplete aggregation arguments");
+  PGDVS_REQUIRE(!d.remove_outlier || (d.outlier_knn >= 1 && d.outlier_knn + 1 <= 64),
+                "pgdvs_view_geo_forward: dyn_pcl_outlier_knn must be in [1, 63]");
+  ViewWs w;
+  VG_TRY(view_layout(d, workspace, w));
+  if (!workspace || workspace_bytes < w.total_bytes) {
+    set_error("pgdvs_view_geo_forward: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)w.total_bytes);
+    return PGDVS_ERR_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  const int H = d.H, W = d.W;
+  VG_TRY(view_prep(d.flat_cam_tgt, d.flat_cam_src, d.time_src, d.time_tgt, w.cams, w.times, st));
+  // ---- dynamic branch geometry: on the side stream when one is given (it depends on nothing the static branch makes)
+  hipStream_t side = as_stream(d.side_stream);
+  hipEvent_t ev_join = nullptr;
+  if (side != nullptr && side != st) {
+    hipEvent_t ev_fork = ev_get();
+    ev_join = ev_get();
+    hipError_t e = hipEventRecord(ev_fork, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
+    ev_put(ev_fork);
+    if (e != hipSuccess) {
+      ev_put(ev_join);
+      set_error("pgdvs_view_geo_forward: fork onto the side stream: %s", hipGetErrorString(e));
+      return PGDVS_ERR_LAUNCH;
+    }
+    const int rc = dyn_geometry(d, w, d.side_stream);
+    e = hipEventRecord(ev_join, side);
+    if (rc != PGDVS_OK || e != hipSuccess) {
+      // (the join below must still happen so that the side stream's work is ordered before the caller's next use of `st`)
+      (void)hipStreamWaitEvent(st, ev_join, 0);
+      ev_put(ev_join);
+      if (rc == PGDVS_OK) set_error("pgdvs_view_geo_forward: join event: %s", hipGetErrorString(e));
+      return rc != PGDVS_OK ? rc : PGDVS_ERR_LAUNCH;
+    }
+  } else {
+    VG_TRY(dyn_geometry(d, w, stream));
+  }
+  // ---- static branch: A12 (optional) + A9
+  const float *cloud = d.st_pcl_rgb, *xyz = d.st_pcl_xyz;
+  const int64_t *count_dev = d.st_count_dev;
+  int64_t rows = d.st_rows;
+  int rc = PGDVS_OK;
+  if (d.agg_S > 0) {
+    rc = pgdvs_static_aggregate_packed(d.agg_rgbs, d.agg_depths, d.agg_masks, d.agg_K3s_host, d.agg_c2ws_host, d.agg_S, H, W,
+                                       d.agg_cloud_out, d.agg_xyz_out, d.agg_capacity, d.agg_count_out, w.agg, w.agg_bytes,
+                                       stream);
+    cloud = d.agg_cloud_out;
+    xyz = d.agg_xyz_out;
+    count_dev = d.agg_count_out;
+    rows = d.agg_capacity;
+  }
+  if (rc == PGDVS_OK) {
+    const float *pts = xyz ? xyz : cloud;
+    const int64_t pts_stride = xyz ? 3 : 6;
+    const float *feat = cloud ? cloud + 3 : nullptr;
+    rc = pgdvs_points_raster_bounded(pts, pts_stride, feat, 6, rows, count_dev, w.raster_rows, d.raster_status, w.cams, d.radius,
+                                     d.K, H, W, nullptr, nullptr, nullptr, d.static_rgb, 1, d.static_mask, w.raster,
+                                     w.raster_bytes, stream);
+  }
+  if (ev_join != nullptr) {
+    const hipError_t e = hipStreamWaitEvent(st, ev_join, 0);
+    ev_put(ev_join);
+    if (e != hipSuccess && rc == PGDVS_OK) {
+      set_error("pgdvs_view_geo_forward: join: %s", hipGetErrorString(e));
+      rc = PGDVS_ERR_LAUNCH;
+    }
+  }
+  VG_TRY(rc);
+  // ---- A6-A8 + A11: metric, splat, threshold, composite
+  if (d.noise == nullptr && d.rng_state != nullptr)
+    return pgdvs_dyn_splat_composite_rng(H, W, d.rgb1, d.rgb2, d.flow12, w.flow_1_to_tgt, w.valid_mask, d.rng_state, d.alpha,
+                                         d.static_rgb, d.render_dyn_rgb, d.render_dyn_mask, d.combined, d.combined_static,
+                                         d.combined_dyn, w.splat, w.splat_bytes, stream);
+  return pgdvs_dyn_splat_composite(H, W, d.rgb1, d.rgb2, d.flow12, w.flow_1_to_tgt, w.valid_mask, d.noise, d.alpha, d.static_rgb,
+                                   d.render_dyn_rgb, d.render_dyn_mask, d.combined, d.combined_static, d.combined_dyn, w.splat,
+                                   w.splat_bytes, stream);
+}
+
+}  // namespace
+}  // namespace pgdvs
+
+using namespace pgdvs;
+
+PGDVS_API int64_t pgdvs_view_geo_desc_size(void) { return (int64_t)sizeof(pgdvs_view_geo_desc); }
+
+PGDVS_API int64_t pgdvs_view_geo_workspace_bytes(const pgdvs_view_geo_desc *desc) {
+  if (!desc) {
+    set_error("pgdvs_view_geo_workspace_bytes: null description");
+    return PGDVS_ERR_INVALID;
+  }
+  ViewWs w;
+  const int rc = view_layout(*desc, nullptr, w);
+  return rc != PGDVS_OK ? (int64_t)rc : w.total_bytes;
+}
+
+PGDVS_API int pgdvs_view_geo_forward(const pgdvs_view_geo_desc *desc, void *workspace, int64_t workspace_bytes,
+                                     pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(desc, "pgdvs_view_geo_forward: null description");
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = view_forward(*desc, workspace, workspace_bytes, stream);
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  {
+    std::lock_guard<std::mutex> lk(g_stat_mu);
+    g_stat_calls += 1;
+    g_stat_seconds += dt;
+  }
+  return rc;
+}
+
+PGDVS_API void pgdvs_view_geo_host_stats(int64_t *calls, double *seconds) {
+  std::lock_guard<std::mutex> lk(g_stat_mu);
+  if (calls) *calls = g_stat_calls;
+  if (seconds) *seconds = g_stat_seconds;
+  g_stat_calls = 0;
+  g_stat_seconds = 0.0;
+}

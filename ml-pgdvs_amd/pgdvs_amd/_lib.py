@@ -71,6 +71,36 @@ SIGNATURES = {
     "pgdvs_combine": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
 }
 
+
+
+class ViewGeoDesc(C.Structure):
+    """``pgdvs_view_geo_desc`` (include/pgdvs_hip.h), field for field."""
+    _fields_ = [
+        ("H", C.c_int32), ("W", C.c_int32),
+        ("flat_cam_tgt", _vp), ("flat_cam_src", _vp), ("time_src", _vp), ("time_tgt", _vp),
+        ("rgb1", _vp), ("rgb2", _vp), ("depth1", _vp), ("depth2", _vp), ("dyn_mask1", _vp), ("flow12", _vp), ("flow_occ", _vp),
+        ("use_flow_consistency", C.c_int32), ("remove_outlier", C.c_int32), ("outlier_knn", C.c_int32),
+        ("outlier_std_thres", _f), ("alpha", _f),
+        ("noise", _vp), ("rng_state", _vp),
+        ("st_pcl_rgb", _vp), ("st_pcl_xyz", _vp), ("st_rows", _i64), ("st_count_dev", _vp),
+        ("agg_S", C.c_int32), ("agg_rgbs", _vp), ("agg_depths", _vp), ("agg_masks", _vp), ("agg_K3s_host", _vp),
+        ("agg_c2ws_host", _vp), ("agg_cloud_out", _vp), ("agg_xyz_out", _vp), ("agg_capacity", _i64), ("agg_count_out", _vp),
+        ("row_bound", _i64), ("radius", _f), ("K", C.c_int32),
+        ("static_rgb", _vp), ("static_mask", _vp), ("raster_status", _vp), ("render_dyn_rgb", _vp), ("render_dyn_mask", _vp),
+        ("combined", _vp), ("combined_static", _vp), ("combined_dyn", _vp),
+        ("side_stream", _vp),
+    ]
+
+
+SIGNATURES.update({
+    "pgdvs_eval_psnr_workspace_bytes": (_i64, []),
+    "pgdvs_eval_psnr_sums": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "pgdvs_view_geo_desc_size": (_i64, []),
+    "pgdvs_view_geo_workspace_bytes": (_i64, [C.POINTER(ViewGeoDesc)]),
+    "pgdvs_view_geo_forward": (_i, [C.POINTER(ViewGeoDesc), _vp, _i64, _vp]),
+    "pgdvs_view_geo_host_stats": (None, [C.POINTER(_i64), C.POINTER(C.c_double)]),
+})
+
 _lib = None
 
 
@@ -100,6 +130,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.pgdvs_view_geo_desc_size() != C.sizeof(ViewGeoDesc):
+        raise PgdvsHipError(f"pgdvs_view_geo_desc: the library's struct has {lib.pgdvs_view_geo_desc_size()} bytes, this binding's "
+                            f"{C.sizeof(ViewGeoDesc)} -- rebuild the extension (stale {LIB_PATH.name})")
     _lib = lib
     return lib
 

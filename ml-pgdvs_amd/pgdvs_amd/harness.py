@@ -54,15 +54,49 @@ def eval_step(model, data: dict, render_cfg, *, device=None, disable_tqdm=True, 
     model.eval()
     n_batch = data["rgb_src_temporal"].shape[0]
     ret = model.forward(data_gpu, render_cfg=render_cfg, disable_tqdm=disable_tqdm, for_debug=False)
-    # device-side status words of the geometry path (the step synchronises for its metrics anyway): a static cloud whose
-    # aggregation reported an error (count -1) or that outgrew the rasteriser's row bound would otherwise show up as a
-    # silently blank or truncated static image
     from . import ops
 
-    if isinstance(data_gpu.get("st_pcl_rgb_count", None), torch.Tensor):
-        for c in data_gpu["st_pcl_rgb_count"].reshape(-1):
-            ops.checked_count(c, "st_pcl_rgb_count")
-    ops.check_raster_status(ret.get("geo_static_raster_status", None))
+    def check_status():
+        # device-side status words of the geometry path (the step synchronises for its metrics anyway): a static cloud whose
+        # aggregation reported an error (count -1), filled its buffer (rows may have been dropped: the aggregation clamps
+        # at its capacity) or outgrew the rasteriser's row bound would otherwise show up as a silently blank or truncated
+        # static image
+        cnts = ret.get("st_pcl_rgb_count", data_gpu.get("st_pcl_rgb_count", None))
+        if isinstance(cnts, torch.Tensor):
+            cloud = ret.get("st_pcl_rgb", None)
+            for c in cnts.reshape(-1):
+                n = ops.checked_count(c, "st_pcl_rgb_count")
+                limited = cloud is not None and "_st_pcl_video" in data_gpu and cloud.shape[1] < data_gpu["_st_pcl_video"]["depths"].numel()
+                if limited and n >= cloud.shape[1]:
+                    raise ops.PgdvsHipError(f"the aggregated static cloud filled its buffer of {cloud.shape[1]} rows (capacity-limited): "
+                                            "rows may have been dropped -- pass a larger capacity")
+        ops.check_raster_status(ret.get("geo_static_raster_status", None))
+
+    comb = ret["combined_rgb"]
+    if (comb.is_cuda and comb.dtype == torch.float32 and tuple(comb.shape[2:]) == tuple(data_gpu["rgb_tgt"].shape[1:3])
+            and data_gpu["rgb_tgt"].dtype == torch.float32 and data_gpu["eval_mask"].dtype == torch.float32):
+        # GPU, render size == ground-truth size (render_stride 1): quantisation and the three masked sums of a view in ONE
+        # pass (csrc/eval.hip), one host read for the whole batch
+        res = [ops.eval_psnr_sums(comb[i_b], data_gpu["rgb_tgt"][i_b], data_gpu["eval_mask"][i_b], want_images=return_images)
+               for i_b in range(n_batch)]
+        sums = torch.stack([r_[0] for r_ in res]).cpu().tolist()  # (the step's synchronisation)
+        check_status()
+        per_view = {k: [] for k in METRIC_KEYS}
+        for s_ in sums:
+            for j, k in enumerate(METRIC_KEYS):
+                mse = s_[j] / (s_[3 + j] + 1e-8)
+                per_view[k].append(0 if mse == 0 else 10 * math.log10(1.0 / mse))
+        packed = torch.tensor([float(n_batch)] + [float(torch.tensor(per_view[k], dtype=torch.float32).sum()) for k in METRIC_KEYS],
+                              dtype=torch.float64, device=comb.device)
+        packed = pdist.reduce_metrics(packed, dst=0)
+        metric = {"eval/count": packed[:1].round().to(torch.int64)}
+        for j, k in enumerate(METRIC_KEYS):
+            metric[f"eval/{k}"] = packed[1 + j].to(torch.float32)
+        if return_images:
+            return metric, {"pred": torch.stack([r_[1] for r_ in res]), "gt": torch.stack([r_[2] for r_ in res]),
+                            "eval_mask": data_gpu["eval_mask"].permute(0, 3, 1, 2), "per_view": per_view, "ret": ret}
+        return metric
+    check_status()
     pred = OrderedDict({"combined": ret["combined_rgb"].clamp(0.0, 1.0)})
     for k in pred:
         if torch.any(torch.isnan(pred[k])):

@@ -424,6 +424,151 @@ def static_aggregate(rgbs, depths, dyn_masks, K3s, c2ws, capacity: int | None = 
     return out, cnt
 
 
+class ViewGeoState:
+    """What ``view_geo_forward`` keeps between calls for ONE HIP stream: the workspace of the native call (reused, so a
+    view costs no allocator round trips beyond its outputs) and the description struct.  Views in flight on different
+    streams need different states (``PGDVSRenderer`` keeps one per stream it is called on)."""
+
+    def __init__(self):
+        self.desc = _lib.ViewGeoDesc()
+        self.workspace = None
+        self.ws_key = None
+        self.ws_bytes = 0
+
+
+def view_geo_forward(state: ViewGeoState, *, H: int, W: int, flat_cam_tgt, flat_cam_src, time_src, time_tgt, rgb1, rgb2, depth1,
+                     depth2, dyn_mask1, flow12, flow_occ, use_flow_consistency: bool, remove_outlier: bool, outlier_knn: int,
+                     outlier_std_thres: float, alpha: float, noise=None, rng_state=None, st_pcl_rgb=None, st_pcl_xyz=None,
+                     st_count=None, video=None, row_bound=None, radius: float, K: int, out_combined=None, side_stream=None):
+    """ONE native call for the whole geometric per-view path (``pgdvs_view_geo_forward``): A12 (when ``video`` is given)
+    + A9 + A2-A5 + A6-A8 + A11.  All tensors fp32 contiguous on the GPU (checked; no conversions are made here -- the
+    caller falls back to the per-op path for anything else).
+    ``video``: dict(rgbs[S,H,W,3], depths[S,H,W], dyn_masks[S,H,W] u8, K3s, c2ws (float64 numpy), capacity) -- the cloud
+    is aggregated inside the call and returned (``st_pcl_rgb``, ``st_pcl_xyz``, ``st_pcl_rgb_count``).
+    Returns a dict of planar images (see the keys below)."""
+    lib = _lib.load()
+    d = state.desc
+    dev = rgb1.device
+    P = H * W
+
+    def ptr(t, name, dtype=torch.float32, numel=None):
+        if t is None:
+            return None
+        if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+            raise PgdvsHipError(f"view_geo_forward: {name} must be a contiguous {dtype} GPU tensor (got {t.dtype}, {t.device}, "
+                                f"contiguous={t.is_contiguous()})")
+        if numel is not None and t.numel() != numel:
+            raise PgdvsHipError(f"view_geo_forward: {name} has {t.numel()} elements, expected {numel}")
+        return t.data_ptr()
+
+    d.H, d.W = H, W
+    d.flat_cam_tgt = ptr(flat_cam_tgt, "flat_cam_tgt", numel=34)
+    d.flat_cam_src = ptr(flat_cam_src, "flat_cam_src", numel=68)
+    d.time_src = ptr(time_src, "time_src")
+    d.time_tgt = ptr(time_tgt, "time_tgt")
+    if time_src.numel() < 2 or time_tgt.numel() < 1:
+        raise PgdvsHipError("view_geo_forward: time_src needs 2 entries, time_tgt 1")
+    d.rgb1, d.rgb2 = ptr(rgb1, "rgb1", numel=3 * P), ptr(rgb2, "rgb2", numel=3 * P)
+    d.depth1, d.depth2 = ptr(depth1, "depth1", numel=P), ptr(depth2, "depth2", numel=P)
+    d.dyn_mask1 = ptr(dyn_mask1, "dyn_mask1", numel=P)
+    d.flow12 = ptr(flow12, "flow12", numel=2 * P)
+    d.flow_occ = ptr(flow_occ, "flow_occ", numel=P)
+    d.use_flow_consistency, d.remove_outlier, d.outlier_knn = int(bool(use_flow_consistency)), int(bool(remove_outlier)), int(outlier_knn)
+    d.outlier_std_thres, d.alpha = float(outlier_std_thres), float(alpha)
+    d.noise = ptr(noise, "noise", numel=3 * P)
+    d.rng_state = ptr(rng_state, "rng_state", torch.int64, 2) if noise is None else None
+    out = {}
+    keep_alive = None
+    if video is not None:
+        r, dp, m = video["rgbs"], video["depths"], video["dyn_masks"]
+        S = dp.shape[0]
+        cap = int(video.get("capacity") or S * P)
+        K3 = np.ascontiguousarray(video["K3s"], dtype=np.float64).reshape(S, 9)
+        c2w = np.ascontiguousarray(video["c2ws"], dtype=np.float64).reshape(S, 16)
+        keep_alive = (K3, c2w)
+        block = torch.empty(cap * 9, dtype=torch.float32, device=dev)  # cloud rows and packed coordinates in one block
+        cloud, xyz = block[: cap * 6].view(cap, 6), block[cap * 6:].view(cap, 3)
+        cnt = torch.empty(1, dtype=torch.int64, device=dev)
+        d.agg_S = S
+        d.agg_rgbs, d.agg_depths = ptr(r, "video.rgbs", numel=S * P * 3), ptr(dp, "video.depths", numel=S * P)
+        d.agg_masks = ptr(m, "video.dyn_masks", torch.uint8, S * P)
+        d.agg_K3s_host, d.agg_c2ws_host = K3.ctypes.data, c2w.ctypes.data
+        d.agg_cloud_out, d.agg_xyz_out, d.agg_capacity, d.agg_count_out = cloud.data_ptr(), xyz.data_ptr(), cap, cnt.data_ptr()
+        d.st_pcl_rgb = d.st_pcl_xyz = d.st_count_dev = None
+        d.st_rows = 0
+        rows = cap
+        out.update(st_pcl_rgb=cloud, st_pcl_xyz=xyz, st_pcl_rgb_count=cnt)
+    else:
+        d.agg_S = 0
+        rows = st_pcl_rgb.shape[0]
+        d.st_pcl_rgb = ptr(st_pcl_rgb, "st_pcl_rgb", numel=rows * 6) if rows else None
+        d.st_pcl_xyz = ptr(st_pcl_xyz, "st_pcl_xyz", numel=rows * 3) if (st_pcl_xyz is not None and rows) else None
+        d.st_rows = rows
+        d.st_count_dev = ptr(st_count, "st_pcl_rgb_count", torch.int64, 1)
+    d.row_bound = int(row_bound) if (row_bound is not None and (video is not None or st_count is not None)) else 0
+    d.radius, d.K = float(radius), int(K)
+    # outputs: one block for the images, one for the masks
+    n_img = 4 if out_combined is not None else 5
+    imgs = torch.empty((n_img, 3, H, W), dtype=torch.float32, device=dev)
+    masks = torch.empty((2, H, W), dtype=torch.float32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    if out_combined is not None:
+        if not (out_combined.is_cuda and out_combined.dtype == torch.float32 and out_combined.is_contiguous()
+                and out_combined.numel() == 3 * P):
+            raise PgdvsHipError(f"out_combined: expected a contiguous fp32 GPU tensor [3,{H},{W}], got {tuple(out_combined.shape)}")
+        comb = out_combined.view(3, H, W)
+    else:
+        comb = imgs[4]
+    d.static_rgb, d.render_dyn_rgb, d.combined_static, d.combined_dyn = (imgs[i].data_ptr() for i in range(4))
+    d.combined = comb.data_ptr()
+    d.static_mask, d.render_dyn_mask = masks[0].data_ptr(), masks[1].data_ptr()
+    d.raster_status = status.data_ptr()
+    d.side_stream = side_stream.cuda_stream if side_stream is not None else None
+    # workspace: reused while the shape of the problem stays the same
+    key = (H, W, d.agg_S, int(d.agg_capacity) if d.agg_S else rows, int(d.row_bound), d.radius, d.remove_outlier, dev)
+    if state.ws_key != key:
+        need = lib.pgdvs_view_geo_workspace_bytes(C.byref(d))
+        if need < 0:
+            check(int(need), "pgdvs_view_geo_workspace_bytes")
+        if state.workspace is None or state.ws_bytes < need or state.workspace.device != dev:
+            state.workspace = None  # (release first: two of these do not have to coexist)
+            state.workspace = torch.empty(int(need), dtype=torch.uint8, device=dev)
+            state.ws_bytes = int(need)
+        state.ws_key = key
+    check(lib.pgdvs_view_geo_forward(C.byref(d), state.workspace.data_ptr(), state.ws_bytes, _stream()), "pgdvs_view_geo_forward")
+    del keep_alive
+    out.update(geo_static_rgb=imgs[0], geo_static_mask=masks[0], render_dyn_rgb=imgs[1], render_dyn_mask=masks[1],
+               combined_rgb=comb, combined_rgb_static=imgs[2], combined_rgb_dyn=imgs[3], raster_status=status)
+    return out
+
+
+def view_geo_host_stats():
+    """(calls, seconds) spent inside ``pgdvs_view_geo_forward`` since the last call of this function (resets)."""
+    calls, secs = C.c_int64(0), C.c_double(0.0)
+    _lib.load().pgdvs_view_geo_host_stats(C.byref(calls), C.byref(secs))
+    return int(calls.value), float(secs.value)
+
+
+def eval_psnr_sums(pred_planar, gt_hwc, mask_hwc, want_images: bool = False):
+    """The evaluator's per-view statistics in one pass (``pgdvs_eval_psnr_sums``): pred[3,H,W] raw render, gt[H,W,3] raw,
+    mask[H,W,3] -> device float64[6] (sum d2, sum d2 m, sum d2 (1-m), count, sum m, sum (1-m)) and, with ``want_images``,
+    the quantised prediction / ground truth [3,H,W]."""
+    p = _req(pred_planar, torch.float32, "pred")
+    g = _req(gt_hwc, torch.float32, "gt")
+    m = _req(mask_hwc, torch.float32, "eval_mask")
+    _, H, W = p.shape
+    assert tuple(g.shape) == (H, W, 3) and tuple(m.shape) == (H, W, 3), (p.shape, g.shape, m.shape)
+    lib = _lib.load()
+    nws = int(lib.pgdvs_eval_psnr_workspace_bytes())
+    buf = torch.empty(nws + 64, dtype=torch.uint8, device=p.device)  # partials, then the six sums
+    sums = buf[nws:nws + 48].view(torch.float64)
+    pq = torch.empty_like(p) if want_images else None
+    gq = torch.empty_like(p) if want_images else None
+    check(lib.pgdvs_eval_psnr_sums(_ptr(p), _ptr(g), _ptr(m), H, W, _ptr(pq), _ptr(gq), _ptr(sums), _ptr(buf), nws, _stream()),
+          "pgdvs_eval_psnr_sums")
+    return sums, pq, gq
+
+
 def checked_count(cnt, what: str) -> int:
     """Host read of a device-side count that doubles as a status word: negative = the kernel chain
     reported an internal error (e.g. ``agg_select``'s ordered-offset look-back gave up) and its

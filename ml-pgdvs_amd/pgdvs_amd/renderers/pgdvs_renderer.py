@@ -50,7 +50,94 @@ class PGDVSRenderer(PGDVSBaseRenderer):
             proj_func=self.static_renderer.projector.compute_projections, local_rank=local_rank,
             use_tracker=render_cfg.dyn_render_track_temporal == "no_tgt")
 
+    # -- one native call per view (include/pgdvs_hip.h: pgdvs_view_geo_forward) -----------------------------------
+    def _native_view_ok(self, data, render_cfg):
+        """The geometric path with softsplat, one batch item, full resolution, everything fp32 on the GPU: what the
+        reference's benchmark configurations run (scripts/benchmark.sh).  Anything else takes the per-op path below."""
+        import os
+
+        if os.environ.get("PGDVS_NATIVE_VIEW", "1") in ("0", ""):
+            return False
+        if not isinstance(self.static_renderer, StaticGeoPointRenderer) or self.dyn_renderer.use_tracker:
+            return False
+        if render_cfg.dyn_render_type != "softsplat" or render_cfg.render_stride != 1 or render_cfg.st_pcl_remove_outlier:
+            return False
+        if data.get("_dyn_prepared", None) is not None:
+            return False
+        t = data["rgb_src_temporal"]
+        if not t.is_cuda or t.shape[0] != 1 or t.shape[1] < 2:
+            return False
+        if not 1 <= int(render_cfg.st_render_pcl_pts_per_pixel) <= 8:
+            return False
+        if render_cfg.dyn_pcl_remove_outlier and not 1 <= int(render_cfg.dyn_pcl_outlier_knn) <= 63:
+            return False
+        if "_st_pcl_video" not in data and ("st_pcl_rgb" not in data or data["st_pcl_rgb"].shape[1] >= (1 << 31)):
+            return False
+        keys = ["rgb_src_temporal", "depth_src_temporal", "dyn_mask_src_temporal", "flow_fwd", "flat_cam_tgt",
+                "flat_cam_src_temporal", "time_src_temporal", "time_tgt"]
+        if render_cfg.dyn_render_use_flow_consistency:
+            keys.append("flow_fwd_occ_mask")
+        for k in keys:
+            v = data.get(k, None)
+            if not (isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.float32 and v.is_contiguous()):
+                return False
+        for k in ("st_pcl_rgb", "st_pcl_xyz", "static_noise"):
+            v = data.get(k, None)
+            if v is not None and not (v.is_cuda and v.dtype == torch.float32 and v.is_contiguous()):
+                return False
+        return data["flat_cam_src_temporal"].shape[1] == 2 or data["flat_cam_src_temporal"][0, :2].is_contiguous()
+
+    def _forward_native(self, data, render_cfg):
+        """PGDVSRenderer.forward (:84-178) as ONE C-ABI call; same output keys and values as the per-op path."""
+        _, _, H, W, _ = data["rgb_src_temporal"].shape
+        dev = data["rgb_src_temporal"].device
+        states = self.__dict__.setdefault("_view_states", {})
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        st = states.get(key)
+        if st is None:
+            st = states[key] = ops.ViewGeoState()
+        noise = data.get("static_noise", None)
+        rng_state = None if noise is not None else self.dyn_renderer.splat_rng_state(dev)
+        occ = data.get("flow_fwd_occ_mask", None)
+        video = data.get("_st_pcl_video", None)
+        counts = data.get("st_pcl_rgb_count", None)
+        xyz = data.get("st_pcl_xyz", None)
+        out_comb = data.get("_combined_rgb_out", None)
+        r = ops.view_geo_forward(
+            st, H=H, W=W, flat_cam_tgt=data["flat_cam_tgt"][0], flat_cam_src=data["flat_cam_src_temporal"][0, :2],
+            time_src=data["time_src_temporal"][0], time_tgt=data["time_tgt"][0],
+            rgb1=data["rgb_src_temporal"][0, 0], rgb2=data["rgb_src_temporal"][0, 1],
+            depth1=data["depth_src_temporal"][0, 0], depth2=data["depth_src_temporal"][0, 1],
+            dyn_mask1=data["dyn_mask_src_temporal"][0, 0], flow12=data["flow_fwd"][0],
+            flow_occ=occ[0] if (occ is not None and occ.is_cuda and occ.dtype == torch.float32) else None,
+            use_flow_consistency=render_cfg.dyn_render_use_flow_consistency,
+            remove_outlier=render_cfg.dyn_pcl_remove_outlier, outlier_knn=render_cfg.dyn_pcl_outlier_knn,
+            outlier_std_thres=render_cfg.dyn_pcl_outlier_std_thres, alpha=self.softsplat_metric_abs_alpha,
+            noise=noise[0] if noise is not None else None, rng_state=rng_state,
+            st_pcl_rgb=None if video is not None else data["st_pcl_rgb"][0],
+            st_pcl_xyz=None if (video is not None or xyz is None) else xyz[0],
+            st_count=None if (video is not None or counts is None) else counts.reshape(-1)[0:1],
+            video=video, row_bound=data.get("st_pcl_rgb_row_bound", None),
+            radius=render_cfg.st_render_pcl_pt_radius, K=render_cfg.st_render_pcl_pts_per_pixel,
+            out_combined=out_comb[0] if out_comb is not None else None, side_stream=data.get("_side_stream", None))
+        dyn_rgb, dyn_mask = r["render_dyn_rgb"][None], r["render_dyn_mask"][None, None]
+        ret = {
+            "geo_static_rgb": r["geo_static_rgb"][None], "geo_static_mask": r["geo_static_mask"][None, None],
+            "geo_static_raster_status": r["raster_status"],
+            "render_dyn_rgb": dyn_rgb, "render_dyn_mask": dyn_mask,
+            "render_dyn_temporal_closest_rgb": dyn_rgb, "render_dyn_temporal_closest_mask": dyn_mask,
+            "render_dyn_temporal_track_rgb": self.dyn_renderer._zeros_like(dyn_rgb),
+            "render_dyn_temporal_track_mask": self.dyn_renderer._zeros_like(dyn_mask),
+            "combined_rgb": out_comb if out_comb is not None else r["combined_rgb"][None],
+            "combined_rgb_static": r["combined_rgb_static"][None], "combined_rgb_dyn": r["combined_rgb_dyn"][None],
+        }
+        if video is not None:  # the cloud the call aggregated, in the data dict's shapes
+            ret["st_pcl_rgb"], ret["st_pcl_xyz"], ret["st_pcl_rgb_count"] = r["st_pcl_rgb"][None], r["st_pcl_xyz"][None], r["st_pcl_rgb_count"]
+        return ret
+
     def forward(self, data, render_cfg={}, disable_tqdm=False, for_debug=False):
+        if not for_debug and self._native_view_ok(data, render_cfg):
+            return self._forward_native(data, render_cfg)
         n_b, _, orig_h, orig_w, _ = data["rgb_src_temporal"].shape
         ray_batch = self.prepare_ray_batch(data=data, B=n_b, H=orig_h, W=orig_w,
                                            render_stride=render_cfg.render_stride, render_cfg=render_cfg)

@@ -169,12 +169,7 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
             # to dynamic content ever show it) -- seeded from torch's seed, one state per device, advanced by the kernel
             noise = data.get("static_noise", None)
             if noise is None:
-                # (one state per stream: views in flight on different streams neither share draws nor race on the counter)
-                states = self.__dict__.setdefault("_splat_rng", {})
-                key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-                rng_state = states.get(key)
-                if rng_state is None:
-                    rng_state = states[key] = ops.splat_rng_state(dev, torch.initial_seed() + 0x9E3779B97F4A7C15 * len(states))
+                rng_state = self.splat_rng_state(dev)
 
         dyn_rgbs, dyn_masks, combs = [], [], []
         # optional caller-owned output [B,3,H,W] for combined_rgb (a slice of the caller's image stack): the
@@ -242,6 +237,29 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
             info_dict["combined_rgb_static"] = st(1)
             info_dict["combined_rgb_dyn"] = st(2)
         return render_dyn_rgb_final, render_dyn_mask_final, info_dict
+
+    _RNG_SLOTS = 64
+
+    def splat_rng_state(self, dev):
+        """Device-resident {seed, draw number} of the splat kernel's own noise for the CURRENT stream of ``dev``: one
+        state per stream, so that views in flight on different streams neither share draws nor race on the counter.
+        All states of a device live in one block of ``_RNG_SLOTS`` rows made at the first call for that device (a single
+        host-to-device copy; nothing is allocated later, e.g. under a graph capture on a stream first seen there);
+        a process that uses more streams than rows wraps around (two streams then share a counter: their draws stay
+        valid normal fields, only no longer distinct per stream)."""
+        pools = self.__dict__.setdefault("_splat_rng", {})
+        pool = pools.get(dev)
+        if pool is None:
+            seeds = [((torch.initial_seed() + 0x9E3779B97F4A7C15 * i) & 0x7FFFFFFFFFFFFFFF, 0) for i in range(self._RNG_SLOTS)]
+            pool = pools[dev] = {"block": torch.tensor(seeds, dtype=torch.int64, device=dev), "slots": {}}
+        key = torch.cuda.current_stream(dev).cuda_stream
+        slot = pool["slots"].get(key)
+        if slot is None:
+            if len(pool["slots"]) >= 4 * self._RNG_SLOTS:  # (stream handles come and go: forget the oldest mapping)
+                pool["slots"].pop(next(iter(pool["slots"])))
+            slot = pool["slots"][key] = pool.setdefault("next", 0) % self._RNG_SLOTS
+            pool["next"] = pool["next"] + 1
+        return pool["block"][slot]
 
     def _zeros_like(self, t):
         """zero images of the no-tracker outputs without filling 33 MB per view at 1080p: ONE zero element expanded to

@@ -70,3 +70,92 @@ class GraphedRender:
             _copy_into(self.static_in, inputs, self._seen)
             self.graph.replay()
         return self.static_out
+
+
+class ResidentVideoRenderer:
+    """Novel views of ONE video whose S source frames stay resident in HBM, rendered through ``PGDVSRenderer.forward``
+    with the static cloud aggregated per view (A12) inside the same native call (``data["_st_pcl_video"]``): what
+    ``bench.py`` times, what ``harness.eval_step`` can be pointed at, and what the C3 parity test renders -- one
+    arrangement for all three.
+
+    ``lanes`` independent views may be in flight, each on its own HIP stream (``side_streams``: plus a second stream per
+    lane for the dynamic branch's geometry, forked and joined inside the native call).  Cloud buffers and the
+    rasteriser's tile lists are capacity-sized (S*H*W rows) until ``calibrate`` has read one view's count back; after
+    that they are bounded by 1.25 x that count + 65536 rows, and a view that outgrows the bound says so in its status
+    word (``ops.check_raster_status``) and in a count equal to the bound (``ops.checked_count`` + the caller's check).
+    """
+
+    def __init__(self, model, render_cfg, rgbs, depths, dyn_masks, K3s, c2ws, *, lanes: int = 3, side_streams: bool = False,
+                 native: bool = True):
+        import numpy as np
+
+        self.model, self.rc = model, render_cfg
+        self.dev = rgbs.device
+        S, H, W = depths.shape
+        self.S, self.H, self.W = S, H, W
+        self.capacity = S * H * W
+        self.row_bound = None
+        self.native = native
+        self.video = {"rgbs": rgbs.contiguous(), "depths": depths.contiguous(),
+                      "dyn_masks": (dyn_masks.view(torch.uint8) if dyn_masks.dtype == torch.bool else dyn_masks).contiguous(),
+                      "K3s": np.ascontiguousarray(K3s, dtype=np.float64), "c2ws": np.ascontiguousarray(c2ws, dtype=np.float64)}
+        self.side_streams = side_streams
+        self.set_lanes(lanes)
+
+    def set_lanes(self, n: int) -> None:
+        have = getattr(self, "lanes", [])
+        while len(have) < n:
+            have.append((torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev) if self.side_streams else None))
+        self.lanes = have
+        self.n_lanes = n
+
+    def calibrate(self, data) -> int:
+        """render one view with capacity-sized buffers, read its count back (one host synchronisation) and bound the
+        buffers of the views that follow; returns the count"""
+        from . import ops
+
+        self.row_bound = None
+        ret, main = self.render(data, 0)
+        torch.cuda.current_stream(self.dev).wait_stream(main)
+        n = ops.checked_count(ret["st_pcl_rgb_count"], "pgdvs_static_aggregate")
+        self.row_bound = min(self.capacity, int(1.25 * n) + 65536)
+        return n
+
+    def render(self, data, lane: int, out=None):
+        """enqueue one view on lane ``lane``; ``out`` [1,3,H,W]: the caller's slot for ``combined_rgb`` (written by the
+        splat epilogue itself).  Returns (ret dict incl. ``st_pcl_rgb`` / ``st_pcl_rgb_count``, the lane's stream)."""
+        from . import ops
+
+        main, side = self.lanes[lane % self.n_lanes]
+        main.wait_stream(torch.cuda.current_stream(self.dev))
+        d = dict(data)
+        if out is not None:
+            d["_combined_rgb_out"] = out
+        cap = self.row_bound or self.capacity
+        with torch.cuda.stream(main), torch.no_grad():
+            if self.native:
+                v = dict(self.video)
+                v["capacity"] = cap
+                d["_st_pcl_video"] = v
+                if self.row_bound is not None:
+                    d["st_pcl_rgb_row_bound"] = self.row_bound
+                if side is not None:
+                    d["_side_stream"] = side
+                ret = self.model.forward(d, render_cfg=self.rc, disable_tqdm=True)
+            else:
+                # the per-op arrangement of rounds 1-3: ~85 C-ABI calls enqueued from Python
+                d["_dyn_prepared"] = self.model.dyn_renderer.prepare(d, self.rc, stream=side)
+                v = self.video
+                cloud, cnt, xyz = ops.static_aggregate(v["rgbs"], v["depths"], v["dyn_masks"], v["K3s"], v["c2ws"], capacity=cap,
+                                                       return_xyz=True)
+                d["st_pcl_rgb"], d["st_pcl_rgb_count"], d["st_pcl_xyz"] = cloud[None], cnt, xyz[None]
+                if self.row_bound is not None:
+                    d["st_pcl_rgb_row_bound"] = self.row_bound
+                ret = self.model.forward(d, render_cfg=self.rc, disable_tqdm=True)
+                ret["st_pcl_rgb"], ret["st_pcl_rgb_count"], ret["st_pcl_xyz"] = cloud[None], cnt, xyz[None]
+        return ret, main
+
+    def join(self) -> None:
+        cur = torch.cuda.current_stream(self.dev)
+        for main, side in self.lanes:
+            cur.wait_stream(main)

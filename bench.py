@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def _traffic_profile():
     """the committed rocprofv3 FETCH_SIZE / WRITE_SIZE summary of this same command (made by
     tools/make_profile_summary.py from separate --pmc passes): newest round first"""
-    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
         f = ROOT / "profiles" / name
         if f.exists():
             return name, json.loads(f.read_text())
@@ -68,45 +68,70 @@ def measured_view_traffic(H, W, S):
 def pmc_instruction_profile():
     """per-kernel instruction counters per launch (SQ_INSTS_VALU / SALU / LDS wave-instructions, busy and wait
     cycles) from the committed rocprofv3 --pmc summary of this command, or {}"""
-    f = ROOT / "profiles" / "r03_pmc_instructions.json"
-    return json.loads(f.read_text()) if f.exists() else {}
+    for name in ("r04_pmc_instructions.json", "r03_pmc_instructions.json"):
+        f = ROOT / "profiles" / name
+        if f.exists():
+            return name, json.loads(f.read_text())
+    return None, {}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200,
-                    help="timed views per rank (filling and draining eleven lanes costs a few views: 60 steps measure 1028 frames/s where 200 measure 1076 and 1500 measure 1081)")
-    ap.add_argument("--graph-lanes", type=int, default=7,
-                    help="views in flight when replaying HIP graphs (2: 853, 4: 885, 7: 1000, 11: 1017 frames/s; eager: 1055-1075)")
+    ap.add_argument("--steps", type=int, default=200, help="timed views per rank")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--views", type=int, default=4, help="distinct target views kept resident and cycled")
+    ap.add_argument("--scene", choices=list(SCENES), default="nominal",
+                    help="statistics of the synthetic video (pgdvs_amd.synth.make_video); the headline is 'nominal'")
+    ap.add_argument("--no-scene-sweep", action="store_true", help="skip the `variants.scenes` objects (the other scenes at this size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel pass")
     ap.add_argument("--pts-per-pixel", type=int, default=3)
     ap.add_argument("--no-outlier", action="store_true", help="dyn_pcl_remove_outlier=false (YAML default)")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="independent target views rendered concurrently, each on its own HIP stream; 0 (default): "
-                         "measured during warm-up among 3, 7 and 11 (the best count is not monotone: 4 and 8 lose 10-15 %%)")
+                    help="independent target views rendered concurrently, each on its own HIP stream; 0 (default): one GPU "
+                         "measures a few counts during warm-up, several ranks take the fixed default (no probe collectives)")
     ap.add_argument("--side-stream", action="store_true",
-                    help="throughput runs: give every lane a second stream for the dynamic-branch geometry (round 1's "
-                         "arrangement, best with --inflight 3); default: one stream per lane")
-    ap.add_argument("--stream-pool", type=int, default=0, help="experiment: lanes draw their (main, side) streams from a pool of this many")
-    ap.add_argument("--lane-priorities", default="", help="experiment: stream priorities, main/side per lane, e.g. -1,-1,0,0,0,0")
+                    help="give every lane a second stream for the dynamic branch's geometry (forked / joined inside the native call)")
+    ap.add_argument("--per-op", action="store_true",
+                    help="rounds 1-3 arrangement: ~85 C-ABI calls per view enqueued from Python instead of ONE native call (A/B)")
     ap.add_argument("--run-ahead", type=int, default=6, help="views the host may have enqueued beyond the last finished one")
-    ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
-                    help="eager: enqueue every kernel of every view from Python; graph: replay one captured HIP graph "
-                         "per lane (--graph-lanes of them, no lane probe); auto: eager unless the host turns out to be "
-                         "the bottleneck during warm-up (then a replay probe decides)")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0,
+                    help="seconds after which a rank that has not finished exits non-zero (a lost peer must not hang the job)")
     ap.add_argument("--gnt-rays", type=int, default=1024, help="rays of the GNT sub-benchmark chunk (0 = skip)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: exercise the launcher, the view sharding, the per-step gather and the timing "
                          "protocol on CPU tensors over gloo (tests); prints a line with dry_run=true and value=null")
     ap.add_argument("--dry-fail-rank", type=int, default=-1, help="(dry run) this rank exits non-zero: launcher error path")
+    ap.add_argument("--dry-hang-rank", type=int, default=-1, help="(dry run) this rank never reaches the timed loop: watchdog path")
     return ap.parse_args()
+
+
+DEFAULT_LANES_MULTI_RANK = 3  # views in flight per rank when several ranks run (no probe: see main)
+SCENES = ("nominal", "wide_baseline", "noisy_depth")
+
+
+def start_watchdog(seconds, rank):
+    """A rank that is still alive after `seconds` exits with status 124 from a daemon thread -- a peer that died or
+    never arrived leaves the others inside a collective that no Python exception can leave (reference:
+    trainer_pgdvs.py relies on the launcher for this).  Fresh-process semantics: the process ENDS (os._exit), nothing is
+    re-executed; torch.distributed.run then tears the other ranks down and the launcher returns non-zero."""
+    import threading
+
+    if seconds <= 0:
+        return None
+
+    def fire():
+        print(f"bench.py: rank {rank} did not finish within {seconds:.0f} s (--rank-timeout): giving up", file=sys.stderr, flush=True)
+        os._exit(124)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def _free_port():
@@ -149,7 +174,10 @@ def dry_main(args, world, rank):
     if rank == args.dry_fail_rank:
         print(f"rank {rank}: failing on request", file=sys.stderr)
         sys.exit(3)
+    if rank == args.dry_hang_rank:  # a rank that never joins its peers again: only the watchdogs end the job
+        time.sleep(10 ** 6)
     like = torch.empty(1, 3, 4, 6)
+    start_watchdog(args.rank_timeout, rank)
     ring = min(args.steps, args.run_ahead + 3)
     gather = pdist.AsyncImageGather(dst=0, n_steps=args.steps, like=like, ring=ring)
     if world > 1:
@@ -261,8 +289,9 @@ def main():
     if args.dry_run:
         return dry_main(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    start_watchdog(args.rank_timeout, rank)
     # test hook (tests/test_gpu_round2.py): every rank on GPU 0 with gloo moving the device tensors, so that the
-    # N-rank code of this file (lane agreement, per-step gather, max-over-ranks timing) runs on a 1-GPU box
+    # N-rank code of this file (per-step gather, max-over-ranks timing) runs on a 1-GPU box
     shared_gpu_test = os.environ.get("PGDVS_BENCH_SHARED_GPU_TEST") == "1"
     if shared_gpu_test:
         local_rank = 0
@@ -276,27 +305,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == args.gpus, f"world size {dist.get_world_size()} != --gpus {args.gpus}"
 
-    from pgdvs_amd import _lib, dist as pdist, ops, synth
+    from pgdvs_amd import _lib, dist as pdist, harness, ops, synth
     from pgdvs_amd.instantiate import load_config
     from pgdvs_amd.renderers.pgdvs_renderer import PGDVSRenderer
+    from pgdvs_amd.runtime import ResidentVideoRenderer
 
     lib = _lib.load()
     H, W, S, K = args.height, args.width, args.frames, args.pts_per_pixel
-    # ---------------- synthetic, seeded inputs (no datasets offline) -> resident in HBM
-    video = synth.make_video(S, H, W, seed=1234)
-    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    rgbs, depths, masks = T(video["rgbs"]), T(video["depths"]), T(video["dyn_masks"]).view(torch.uint8)
-    K3s, c2ws = video["K3s"], video["c2ws"]
-    n_views = max(1, min(args.views, S - 1))
-    view_ids = [int(round(j * (S - 2) / max(n_views - 1, 1))) for j in range(n_views)]
-    # each rank starts at a different view so that ranks do different work (frame sharding)
-    views = [synth.to_torch(synth.make_view(video, i, frac=0.4, seed=5), dev) for i in view_ids]
-    # The timed views carry NO injected noise: like the reference (torch.randn_like per forward,
-    # pgdvs_renderer_dyn.py:177-182) every step draws its own -- in the splat kernel, where it is consumed.  One
-    # view keeps the synthetic generator's field for the checks that need two renders to agree.
-    check_view = dict(views[0])
-    for d_ in views:
-        d_.pop("static_noise", None)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
 
     cfg = load_config(static_renderer="geo", overrides={
         "engine.engine_cfg.render_cfg.dyn_pcl_remove_outlier": not args.no_outlier,
@@ -304,226 +320,133 @@ def main():
     })
     rc = cfg.engine.engine_cfg.render_cfg
     model = PGDVSRenderer(cfg, render_cfg=rc, softsplat_metric_abs_alpha=100.0).to(dev).eval()
+    n_views = max(1, min(args.views, S - 1))
+    view_ids = [int(round(j * (S - 2) / max(n_views - 1, 1))) for j in range(n_views)]
+
+    def load_scene(scene):
+        """synthetic, seeded inputs (no datasets offline) -> resident in HBM; the renderer around them"""
+        video = synth.make_video(S, H, W, seed=1234, scene=scene)
+        rgbs, depths, masks = T(video["rgbs"]), T(video["depths"]), T(video["dyn_masks"]).view(torch.uint8)
+        views = [synth.to_torch(synth.make_view(video, i, frac=0.4, seed=5), dev) for i in view_ids]
+        # The timed views carry NO injected noise: like the reference (torch.randn_like per forward,
+        # pgdvs_renderer_dyn.py:177-182) every step draws its own -- in the splat kernel, where it is consumed.  One
+        # view keeps the synthetic generator's field for the checks that need two renders to agree.
+        check_view = dict(views[0])
+        for d_ in views:
+            d_.pop("static_noise", None)
+        rvr = ResidentVideoRenderer(model, rc, rgbs, depths, masks, video["K3s"], video["c2ws"], lanes=1,
+                                    side_streams=args.side_stream, native=not args.per_op)
+        return video, views, check_view, rvr
+
+    video, views, check_view, rvr = load_scene(args.scene)
+    K3s, c2ws = video["K3s"], video["c2ws"]
     cap = S * H * W
 
-    # Views are independent (the reference shards them over ranks): `inflight` of them are kept
-    # in flight per GPU, each on its own (main, side) stream pair, so one view's launch-bound
-    # chains fill the gaps of another's.  Every view still runs the complete path.
-    lane_candidates = (3, 7, 11)
-    auto_lanes = args.inflight <= 0
-    if auto_lanes and args.launch == "graph":  # replay: one graph per lane, no lane probe through the graphs
-        auto_lanes, args.inflight = False, max(1, args.graph_lanes)
+    # Views are independent (the reference shards them over ranks): `inflight` of them are kept in flight per GPU, each
+    # on its own stream, so one view's launch-bound chains fill the gaps of another's.  Every view still runs the
+    # complete path.  One GPU: the count is measured during warm-up; several ranks: a fixed default, because a probe
+    # needs collectives to agree on its outcome and the N > 1 path must not depend on anything that has never run with
+    # peers (first contact with an 8-GPU node happens in the driver's run).
+    lane_candidates = (2, 3, 5)
+    auto_lanes = args.inflight <= 0 and world == 1
+    if args.inflight <= 0 and world > 1:
+        args.inflight = DEFAULT_LANES_MULTI_RANK
     n_lanes = max(lane_candidates) if auto_lanes else max(1, args.inflight)
+    rvr.set_lanes(n_lanes)
     base_run_ahead = args.run_ahead
     args.run_ahead = max(base_run_ahead, n_lanes + 1)  # the bound must leave every lane a view to work on
-    if args.stream_pool > 0 and n_lanes > 1:
-        pool = [torch.cuda.Stream(device=dev) for _ in range(args.stream_pool)]
-        lanes = [(pool[(2 * i) % len(pool)], pool[(2 * i + 1) % len(pool)]) for i in range(n_lanes)]
-    elif args.lane_priorities and n_lanes > 1:
-        pr = [int(x) for x in args.lane_priorities.split(",")]
-        lanes = [(torch.cuda.Stream(device=dev, priority=pr[(2 * i) % len(pr)]), torch.cuda.Stream(device=dev, priority=pr[(2 * i + 1) % len(pr)]))
-                 for i in range(n_lanes)]
-    elif args.side_stream or os.environ.get("PGDVS_BENCH_PAIRED_STREAMS"):
-        lanes = [(torch.cuda.Stream(device=dev) if n_lanes > 1 else None, torch.cuda.Stream(device=dev)) for _ in range(n_lanes)]
-    else:
-        # one stream per lane; a single side stream (lane 0's, for the latency measurement) is created last
-        mains = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
-        side0 = torch.cuda.Stream(device=dev)
-        lanes = [(mains[i], side0 if i == 0 else None) for i in range(n_lanes)]
-
-    def render_view(data, side, out=None, use_side=None):
-        """the whole per-view path: A12 + A9 on the current stream, A1-A5 on `side` (or on the current stream
-        as well), A6-A8 + A11; `out` [1,3,H,W]: the caller's slot for the final image (written by the splat
-        epilogue itself)"""
-        data = dict(data)
-        use_side = args.side_stream if use_side is None else use_side
-        if out is not None:
-            data["_combined_rgb_out"] = out
-        # dynamic-branch geometry on a side stream, overlapping the static aggregation + raster
-        data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=side if use_side else None)
-        # (cloud buffers: capacity S*H*W rows for the first view, then the same bound as the rasteriser's workspace --
-        # the aggregation clamps at its capacity, so a count that REACHES the bound is treated as an overflow below)
-        cloud, cnt, xyz = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=row_bound[0] or cap, return_xyz=True)
-        data["st_pcl_rgb"] = cloud[None]
-        data["st_pcl_rgb_count"] = cnt
-        data["st_pcl_xyz"] = xyz[None]  # the packed coordinates: the rasteriser's binning reads 12 bytes per point, not 24
-        if row_bound[0] is not None:
-            # the cloud buffer is capacity-sized (S*H*W rows, a device-side count): the rasteriser's tile lists are sized
-            # for the rows the first view had plus a margin, and a status word says if a later view outgrew that
-            data["st_pcl_rgb_row_bound"] = row_bound[0]
-        with torch.no_grad():
-            ret = model.forward(data, render_cfg=rc, disable_tqdm=True)
-        raster_status[0] = ret.get("geo_static_raster_status", None)
-        return ret["combined_rgb"], cnt
-
-    row_bound, raster_status = [None], [None]
-
-    def step_eager(j, lane=None, out=None, use_side=None):
-        main, side = lanes[(j % n_lanes) if lane is None else lane]
-        if main is not None:
-            main.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
-            img, cnt = render_view(views[(j + rank) % n_views], side, out, use_side)
-        return img, cnt, main
-
-    # One captured HIP graph per lane (pgdvs_amd.runtime.GraphedRender): per view the host copies
-    # the view's inputs into the graph's static buffers and launches the graph instead of
-    # enqueuing ~170 kernels; any capture problem falls back to the eager path.
-    graphs, graph_note = None, "eager launches"
-
-    def build_graphs():
-        nonlocal graphs, graph_note
-        try:
-            from pgdvs_amd.runtime import GraphedRender
-
-            # (one graph per lane; with single-stream lanes replay gains from more of them like eager launches do)
-            graphs = [GraphedRender(lambda d, side=side: render_view(d, side), views[0],
-                                    stream=main if main is not None else torch.cuda.Stream(device=dev))
-                      for main, side in lanes[:max(1, min(n_lanes, args.graph_lanes))]]
-            graph_note = f"one HIP graph per lane ({len(graphs)} lanes), replayed per view"
-        except Exception as e:  # noqa: BLE001 -- report and measure eagerly
-            graphs, graph_note = None, f"eager launches (graph capture failed: {type(e).__name__}: {e})"
-            torch.cuda.synchronize()
-
-
-    def step_graph(j):
-        g = graphs[j % len(graphs)]
-        g.stream.wait_stream(torch.cuda.current_stream())
-        img, cnt = g(views[(j + rank) % n_views])
-        with torch.cuda.stream(g.stream):
-            img = img.clone()  # the graph's output buffer is overwritten by its next replay
-        return img, cnt, g.stream
-
-    def step(j, eager=False, lane=None, out=None):
-        return step_eager(j, lane, out) if (graphs is None or eager) else step_graph(j)
-
-    def join_lanes():
-        for main, _ in lanes:
-            if main is not None:
-                torch.cuda.current_stream().wait_stream(main)
-        for g in graphs or []:
-            torch.cuda.current_stream().wait_stream(g.stream)
 
     def barrier():
         if world > 1:
             dist.barrier(device_ids=[local_rank])
 
-    # the first view sizes the rasteriser's workspace for the views that follow (one host read of the count, untimed;
-    # before any graph is captured: the bound is baked into the captured launches)
-    _, cnt0, _ = step_eager(0, 0)
-    join_lanes()
-    torch.cuda.synchronize()
-    row_bound[0] = min(cap, int(1.25 * ops.checked_count(cnt0, "pgdvs_static_aggregate")) + 65536)
+    # the first view sizes the cloud buffers and the rasteriser's workspace for the views that follow (one host read of
+    # the count, untimed)
+    n_first = rvr.calibrate(views[rank % n_views])
     if os.environ.get("PGDVS_BENCH_NO_ROW_BOUND"):  # diagnostic: capacity-sized buffers and workspaces as in round 2
-        row_bound[0] = None
-    if args.launch == "graph":
-        build_graphs()
+        rvr.row_bound = None
+    torch.cuda.synchronize()
 
     host_enqueue = [0.0]
     host_wait = [0.0]  # part of host_enqueue spent blocked on the run-ahead bound (the GPU is behind)
+    host_native = [0.0]  # seconds inside pgdvs_view_geo_forward (the C ABI's own clock)
     mem_probe = {}
-
     gather_box = [None]
     ctl_stream = torch.cuda.Stream(device=dev)
     # ring slots: the views in flight at the deepest lane count tried, the host's run-ahead and a spare
-    lanes_max_ring = [max(base_run_ahead, max(lane_candidates) + 1 if auto_lanes else n_lanes + 1) + (max(lane_candidates) if auto_lanes else n_lanes) + 2]
+    ring_slots = max(base_run_ahead, n_lanes + 1) + n_lanes + 2
+    last = {}
 
-    def trace(msg):
-        if os.environ.get("PGDVS_BENCH_TRACE"):
-            torch.cuda.synchronize()
-            print(f"[trace] {msg}", file=sys.stderr, flush=True)
-
-    def timed(n_steps, profile):
-        trace(f"timed({n_steps}, profile={profile}) begins")
+    def timed(n_steps, profile=False, rv=None, vs=None):
+        """the benchmark loop: n_steps views through `rv` (default: the headline scene's renderer), image of step j
+        gathered to rank 0 while step j+1 renders, bounded host run-ahead; returns wall seconds"""
+        rv = rv or rvr
+        vs = vs or views
         lib.pgdvs_prof_enable(1 if profile else 0)
-        # step j's image travels while step j+1 renders; rank 0 receives into one stack allocated here
-        # (bounded memory: a ring of slots covering the views in flight; rank 0 checksums every view as its slot comes
-        # up for reuse -- 200 steps x 8 ranks x 25 MB would be 40 GB of receive stack beside the lane workspaces)
-        # One gather object for the whole process: its buffers are allocated before the first loop and reused by every
-        # later one (reset) -- with captured HIP graphs alive, a fresh allocation between two replay loops was followed
-        # by a GPU memory fault on replay (ROCm 7.2); the eager path does not care.
-        if gather_box[0] is None or n_steps > gather_box[0].capacity_steps or (lanes_max_ring[0] != gather_box[0].ring):
-            gather_box[0] = pdist.AsyncImageGather(dst=0, n_steps=max(n_steps, 256), like=ref_img, ring=lanes_max_ring[0])
+        # step j's image travels while step j+1 renders; rank 0 receives into one ring allocated before the first loop
+        # and reused by every later one (bounded memory; rank 0 checksums every view as its slot comes up for reuse)
+        if gather_box[0] is None or n_steps > gather_box[0].capacity_steps:
+            gather_box[0] = pdist.AsyncImageGather(dst=0, n_steps=max(n_steps, 256), like=ref_img, ring=ring_slots)
         gather = gather_box[0].reset(n_steps)
         barrier()
         torch.cuda.synchronize()
         mem_probe["before"] = torch.cuda.memory_stats(dev)
-        mem_probe["segments"] = ({(x["address"], x["total_size"]) for x in torch.cuda.memory_snapshot()}
-                                 if os.environ.get("PGDVS_BENCH_MEM") else None)
+        ops.view_geo_host_stats()
         t0 = time.perf_counter()
         done = []
         host_wait[0] = 0.0
-        # (everything the loop itself enqueues -- slot retirement, joins, the final checksums -- runs on a control stream of
-        # its own, never on the null stream: with captured HIP graphs alive, a kernel on the null stream between two
-        # replays was followed by a GPU memory fault on this ROCm)
+        # (everything the loop itself enqueues -- slot retirement, joins, the final checksums -- runs on a control stream
+        # of its own, never on the null stream)
         with torch.cuda.stream(ctl_stream):
             for j in range(n_steps):
-                # bounded run-ahead: the host enqueues a view in ~0.7 ms and the GPU renders one in ~1.2, so an
-                # unbounded loop gets tens of views ahead, and every view enqueued but not yet executed pins the
-                # workspace blocks its two streams share (the caching allocator cannot hand a block that
-                # another stream used back before that stream's work has run): the pool then grows by
-                # hipMalloc calls in the middle of the timed region, each of which drains the pipeline
+                # bounded run-ahead: an unbounded loop gets tens of views ahead, and every view enqueued but not yet
+                # executed pins its output blocks: the allocator's pools then grow by hipMalloc calls in the middle of the
+                # timed region, each of which drains the pipeline
                 if len(done) >= args.run_ahead:
                     w0 = time.perf_counter()
                     done[j - args.run_ahead].synchronize()
                     host_wait[0] += time.perf_counter() - w0
-                # per-kernel HIP events need real launches; one view at a time, so that a kernel's
-                # duration is its own and not the queueing behind the other lanes' kernels
-                # (graph replay renders into the graph's own buffer: no slot is handed out, and the ring retires its oldest
-                # step inside submit(), on the lane's stream)
-                img, cnt, main = step(j, eager=profile, lane=0 if profile else None,
-                                      out=gather.slot() if (graphs is None or profile) else None)
-                trace(f"step {j} enqueued")
-                with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
-                    gather.submit(img)
+                # per-kernel HIP events need one view at a time, so that a kernel's duration is its own and not the
+                # queueing behind the other lanes' kernels
+                ret, main = rv.render(vs[(j + rank) % n_views], 0 if profile else j, out=gather.slot())
+                with torch.cuda.stream(main):
+                    gather.submit(ret["combined_rgb"])
                     ev = torch.cuda.Event()
                     ev.record()
                 done.append(ev)
             host_enqueue[0] = time.perf_counter() - t0  # host time to enqueue everything (incl. the waits of the run-ahead bound)
-            join_lanes()
-            trace("loop done")
+            rv.join()
             gathered = gather.finish(tail=False)
-            trace("gather finished")
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
+        host_native[0] = ops.view_geo_host_stats()[1]
         mem_probe["after"] = torch.cuda.memory_stats(dev)
         lib.pgdvs_prof_enable(0)
-        return t1 - t0, gathered, cnt
+        last["ret"], last["gathered"] = ret, gathered
+        return t1 - t0
 
-    if os.environ.get("PGDVS_BENCH_HOST_PROFILE"):  # diagnostic: where the host time of an eager view goes
+    if os.environ.get("PGDVS_BENCH_HOST_PROFILE"):  # diagnostic: where the host time of a view goes
         import cProfile
         import pstats
 
         for j in range(6):
-            step_eager(j, 0)
+            rvr.render(views[j % n_views], 0)
         torch.cuda.synchronize()
         pr = cProfile.Profile()
         pr.enable()
         for j in range(60):
-            step_eager(j, 0)
+            rvr.render(views[j % n_views], 0)
             if j % 6 == 5:
                 torch.cuda.synchronize()
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
 
-    if os.environ.get("PGDVS_BENCH_OP_TABLE"):  # diagnostic: which torch ops / copies one eager view issues
-        from torch.profiler import ProfilerActivity, profile
-
-        step_eager(0, 0)
-        torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
-            step_eager(1, 0)
-            torch.cuda.synchronize()
-        print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=50),
-              file=sys.stderr)
-
-    trace("graphs built" if graphs else "no graphs")
     ref_img = None
     for j in range(max(args.warmup, n_lanes)):
-        img = step(j)[0]
-        ref_img = img if j == 0 else ref_img
-    join_lanes()
+        ret, _ = rvr.render(views[(j + rank) % n_views], j)
+        ref_img = ret["combined_rgb"] if j == 0 else ref_img
+    rvr.join()
     torch.cuda.synchronize()
     if world > 1:
         # RCCL sets its point-to-point connections up at the first send / receive between two ranks:
@@ -535,116 +458,48 @@ def main():
         del g
         torch.cuda.synchronize()
         barrier()
-    lanes_note = f"{n_lanes} (--inflight)"
+    lanes_note = f"{n_lanes} (" + ("--inflight" if world == 1 or args.inflight != DEFAULT_LANES_MULTI_RANK else "fixed default for several ranks: no probe collectives") + ")"
     if auto_lanes:
-        # How many views in flight?  Measured, not guessed: throughput is not monotone in the lane count on this
-        # runtime (3: 907, 4: 799, 5: 858, 6: 914, 7: 955, 8: 873, 11: 968 frames/s on one box; later in round 2
-        # 4: 885, 5: 928, 7: 1009, 8: 934, 9: 994, 10: 1021, 11: 1028, 13: 995), so a few counts are
-        # timed through the same loop as the headline (a rehearsal first: every lane's allocator pool must exist)
+        # How many views in flight?  Measured, not guessed: a few counts are timed through the same loop as the headline,
+        # each on as many views as the timed region will render (filling and draining k lanes is part of a short run)
         trial = {}
         for k in lane_candidates:
-            n_lanes = k
+            rvr.set_lanes(k)
             args.run_ahead = max(base_run_ahead, k + 1)
-            timed(2 * k, profile=False)
-            # as many views as the timed region will render (filling and draining k lanes is part of a short run:
-            # a count chosen on 6 k views overrated the deep pipelines for the driver's --steps 20), at most 6 k
-            n_probe = max(k, min(6 * k, args.steps))
-            trial[k] = timed(n_probe, profile=False)[0] / n_probe
-        tt = torch.tensor([trial[k] for k in lane_candidates], dtype=torch.float64, device=dev)
-        if world > 1:  # every rank must take the same count
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        n_lanes = lane_candidates[int(torch.argmin(tt).item())]
+            timed(2 * k)  # (rehearsal: every lane's workspace and allocator pool must exist)
+            n_probe = max(2 * k, min(8 * k, args.steps))
+            trial[k] = timed(n_probe) / n_probe
+        n_lanes = min(lane_candidates, key=lambda k: trial[k])
+        rvr.set_lanes(n_lanes)
         args.run_ahead = max(base_run_ahead, n_lanes + 1)
-        lanes_note = ("auto (probed on min(6 k, --steps) views each): " + ", ".join(f"{k} lanes {float(tt[i]) * 1e3:.3f} ms/view" for i, k in enumerate(lane_candidates))
+        lanes_note = ("auto (probed on min(8 k, --steps) views each): " + ", ".join(f"{k} lanes {trial[k] * 1e3:.3f} ms/view" for k in lane_candidates)
                       + f" -> {n_lanes}")
-    if args.launch == "auto":
-        # Eager launches or graph replay?  Measured, not guessed: a few views each way during warm-up.
-        # Eager costs the host ~0.7 ms per view when it is idle -- below the ~1.3 ms the GPU needs -- but
-        # several times that on a busy shared box; replay costs the host ~0.4 ms and the GPU the copies
-        # of a view's inputs into the graph's static buffers.
-        n_try = 3 * n_lanes
-
-        def probe(fn):
-            t0 = time.perf_counter()
-            for j in range(n_try):
-                fn(j)
-            t_host = time.perf_counter() - t0
-            join_lanes()
-            torch.cuda.synchronize()
-            return t_host, time.perf_counter() - t0
-
-        th_e, t_eager = probe(step_eager)
-        # replay can only win when the host is the limit: its enqueue time then fills (nearly) the whole
-        # wall time of the probe.  Otherwise no graph is built at all -- building them leaves the process
-        # in a state in which eager launches measure ~2 % slower (825-831 against 840-849 frames/s).
-        # (PGDVS_BENCH_HOST_BOUND_RATIO: 0 forces the replay probe, 2 switches it off.  A lane probe run THROUGH
-        # graphs built before it faulted on replay: graphs are only built here, after the lane count is settled, and
-        # --launch graph skips the lane probe; tools/graph_check.py replays every op of the path on its own.)
-        ratio = os.environ.get("PGDVS_BENCH_HOST_BOUND_RATIO", "0.85")
-        host_bound = th_e > float(ratio) * t_eager
-        if world > 1:
-            hb = torch.tensor([1.0 if host_bound else 0.0], dtype=torch.float64, device=dev)
-            dist.all_reduce(hb, op=dist.ReduceOp.MAX)
-            host_bound = bool(hb.item() > 0)
-        if host_bound:
-            build_graphs()
-        t_graph = float("inf")
-        if graphs is not None:
-            for j in range(n_lanes):
-                step_graph(j)
-            join_lanes()
-            torch.cuda.synchronize()
-            _, t_graph = probe(step_graph)
-        if world > 1:  # every rank must take the same path (collectives inside the timed loop)
-            tt = torch.tensor([t_eager, min(t_graph, 1e9)], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-            t_eager, t_graph = float(tt[0].item()) / world, float(tt[1].item()) / world
-        probe_note = (f"auto: eager {t_eager / n_try * 1e3:.2f} ms/view with {th_e / n_try * 1e3:.2f} ms of host enqueue, "
-                      + (f"graph replay {t_graph / n_try * 1e3:.2f} ms/view" if host_bound else
-                         "host not the limit: no graphs built"))
-        if graphs is not None and t_graph < 0.97 * t_eager:
-            graph_note += f" ({probe_note})"
-        else:
-            # (the graphs stay alive until the process ends: releasing their memory pools here would
-            # put allocator traffic -- frees, re-allocations, implicit synchronisations -- into the timed loop)
-            unused_graphs, graphs = graphs, None  # noqa: F841
-            graph_note = f"eager launches ({probe_note})"
 
     import gc
 
     # untimed rehearsal through the same loop: the allocator's pools reach the state the bounded
     # run-ahead needs, so that the timed region allocates from them only (`device_mallocs_in_timed_region`)
-    timed(2 * args.run_ahead + n_lanes, profile=False)
+    timed(2 * args.run_ahead + n_lanes)
     gc.collect()
     gc.disable()  # no collector pauses inside the timed loop
-    elapsed, gathered, cnt = timed(args.steps, profile=False)
+    elapsed = timed(args.steps)
     gc.enable()
-    ms0, ms1, seg0 = mem_probe["before"], mem_probe["after"], mem_probe["segments"]
+    gathered, cnt = last["gathered"], last["ret"]["st_pcl_rgb_count"]
+    raster_status = last["ret"].get("geo_static_raster_status", None)
+    ms0, ms1 = mem_probe["before"], mem_probe["after"]
     host_ms = host_enqueue[0] / args.steps * 1e3  # (of the headline loop: the steady-state loop below overwrites the counters)
     host_wait_ms = host_wait[0] / args.steps * 1e3
+    host_native_ms = host_native[0] / args.steps * 1e3
     # a short timed region (the driver's --steps 20) spends a visible share filling and draining the lanes: the
     # steady-state rate of the same loop is reported beside it (never `value`)
     steady = None
     if args.steps < 100 and world == 1:
-        e2 = timed(200, profile=False)[0]
+        e2 = timed(200)
         steady = {"frames_per_s": round(200 / e2, 2), "steps": 200,
                   "note": "same loop and lane count over 200 views, measured right after the timed region; not the headline value"}
     mem_note = {"device_mallocs_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
                 "reserved_GB_peak": round(ms1.get("reserved_bytes.all.peak", 0) / 1e9, 2),
                 "allocated_GB_peak": round(ms1.get("allocated_bytes.all.peak", 0) / 1e9, 2)}
-    if os.environ.get("PGDVS_BENCH_MEM"):  # diagnostic: which segments the timed region had to get from the device
-        print("mem:", mem_note, file=sys.stderr)
-        known = {id(m): f"lane{i}.main" for i, (m, _) in enumerate(lanes) if m is not None}
-        names = {}
-        for i, (m, sd) in enumerate(lanes):
-            if m is not None:
-                names[m.cuda_stream] = f"lane{i}.main"
-            if sd is not None:
-                names[sd.cuda_stream] = f"lane{i}.side"
-        for x in torch.cuda.memory_snapshot():
-            if (x["address"], x["total_size"]) not in seg0:
-                print(f"  new segment {x['total_size'] / 1e6:9.1f} MB on {names.get(x['stream'], x['stream'])}: blocks "
-                      + ", ".join(f"{b['size'] / 1e6:.1f}{'*' if b['state'] == 'active_allocated' else ''}" for b in x["blocks"][:8]), file=sys.stderr)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     per_rank_s = [elapsed]
     if world > 1:
@@ -665,28 +520,20 @@ def main():
         assert tuple(sums.shape) == (args.steps, world) and bool(torch.isfinite(sums).all()) and bool((sums != 0).all()), \
             "a gathered view is missing or empty"
     n_static = ops.checked_count(cnt, "pgdvs_static_aggregate")
-    ops.check_raster_status(raster_status[0])  # (the last view's status word; every view renders the same cloud)
-    assert row_bound[0] is None or n_static < row_bound[0], f"the static cloud ({n_static} rows) filled its buffer of {row_bound[0]} rows: rows may have been dropped"
+    ops.check_raster_status(raster_status)  # (the last view's status word; every view renders the same cloud)
+    assert rvr.row_bound is None or n_static < rvr.row_bound, \
+        f"the static cloud ({n_static} rows) filled its buffer of {rvr.row_bound} rows: rows may have been dropped"
     # concurrency must not change results: the same view (fixed noise field) alone on one lane and on every lane at once
-    if True:
-        torch.cuda.synchronize()
-        main0, side0_ = lanes[0]
-        with torch.cuda.stream(main0) if main0 is not None else contextlib.nullcontext():
-            alone = render_view(check_view, side0_)[0].clone()
-        join_lanes()
-        torch.cuda.synchronize()
-        together = []
-        for li in range(n_lanes):
-            main, side = lanes[li]
-            if main is not None:
-                main.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
-                together.append(render_view(check_view, side)[0])
-        join_lanes()
-        torch.cuda.synchronize()
-        # (the splat accumulates with float atomics, so the comparison is to rounding, not bit-exact)
-        assert all(torch.allclose(t_, alone, rtol=0, atol=1e-5) for t_ in together), "in-flight views disagree with the sequential result"
-        del together
+    torch.cuda.synchronize()
+    alone = rvr.render(check_view, 0)[0]["combined_rgb"].clone()
+    rvr.join()
+    torch.cuda.synchronize()
+    together = [rvr.render(check_view, li)[0]["combined_rgb"] for li in range(n_lanes)]
+    rvr.join()
+    torch.cuda.synchronize()
+    # (the splat accumulates with float atomics, so the comparison is to rounding, not bit-exact)
+    assert all(torch.allclose(t_, alone, rtol=0, atol=1e-5) for t_ in together), "in-flight views disagree with the sequential result"
+    del together
     n_dyn = int(views[0]["dyn_mask_src_temporal"][0, 0].sum().item())
 
     # ---------------- per-kernel durations with HIP events on the launch stream
@@ -709,9 +556,9 @@ def main():
                     "ms_per_step": round(total_ms / n_prof, 4),
                     "alg_GBps": round(ab / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 and ab > 0 else None}
             # dominant kernel = most time per view; among kernels within 20 % of the maximum (the tile raster, the kNN
-            # thread-per-query pass and the 23 small pushes together take 0.22-0.27 ms each: their order changes from
-            # box to box) the one that moves the most algorithmic bytes, for which an HBM roofline says something --
-            # the kNN pass reads 6 MB and is a pure VALU search, a small push is a latency chain
+            # thread-per-query pass and the chain of aggregation links: their order changes from box to box) the one that
+            # moves the most algorithmic bytes, for which an HBM roofline says something -- the kNN pass reads 6 MB and
+            # is a pure VALU search, a chain link is a latency chain
             top = max(v["ms_per_step"] for v in kernels.values())
             near = [k for k, v in kernels.items() if v["ms_per_step"] >= 0.8 * top]
             dom = max(near, key=lambda k: algorithmic_bytes(k, H, W, S, n_static, n_dyn, K))
@@ -720,7 +567,8 @@ def main():
             # the binding limit of the co-dominant kernels is vector-instruction issue, not HBM: SQ_INSTS_VALU per
             # launch from the committed --pmc summary x 2 cycles per wave64 instruction on a SIMD-32
             # (MI355X_MICROARCH.md) / (1024 SIMDs x 2.4 GHz x this run's launch duration)
-            pmc = pmc_instruction_profile().get("kernels", {}) if (H, W, S) == (1080, 1920, 24) else {}
+            pmc_name, pmc_all = pmc_instruction_profile()
+            pmc = pmc_all.get("kernels", {}) if (H, W, S) == (1080, 1920, 24) else {}
             valu = {}
             for k in near:
                 c = pmc.get(k)
@@ -729,8 +577,7 @@ def main():
                     valu[k] = {"bound": "valu", "valu_wave_insts_per_launch": c["SQ_INSTS_VALU"],
                                "salu_wave_insts_per_launch": c.get("SQ_INSTS_SALU"),
                                "valu_issue_frac": round(t_issue / (kernels[k]["avg_ms"] * 1e-3), 4),
-                               "source": "profiles/r03_pmc_instructions.json (committed rocprofv3 --pmc pass of this command), "
-                                         "duration from this run"}
+                               "source": f"profiles/{pmc_name} (committed rocprofv3 --pmc pass of this command), duration from this run"}
             tprof_name, _ = _traffic_profile()
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dom, H, W, S),
@@ -751,55 +598,131 @@ def main():
 
     # ---------------- latency of ONE view (nothing else in flight): the throughput above comes from overlapping
     # `inflight` independent views; this is the time a single view takes from first launch to last kernel
-    latency_ms = None
-    if True:  # (every rank, so that all ranks reach the end of the run together; rank 0 reports its own)
+    torch.cuda.synchronize()
+    lat = []
+    for j in range(12):  # (every rank, so that all ranks reach the end of the run together; rank 0 reports its own)
+        l0 = time.perf_counter()
+        rvr.render(views[j % n_views], 0)
+        rvr.join()
         torch.cuda.synchronize()
-        lat = []
-        for j in range(12):
-            l0 = time.perf_counter()
-            step_eager(j, 0, use_side=True)  # (lowest latency: the two branches of the view side by side)
-            join_lanes()
-            torch.cuda.synchronize()
-            lat.append((time.perf_counter() - l0) * 1e3)
-        lat = sorted(lat[2:])
-        latency_ms = {"median": round(lat[len(lat) // 2], 3), "min": round(lat[0], 3), "views": len(lat),
-                      "note": "one view in flight on one (main, side) stream pair, eager launches, wall clock around launch + synchronize"}
+        lat.append((time.perf_counter() - l0) * 1e3)
+    lat = sorted(lat[2:])
+    latency_ms = {"median": round(lat[len(lat) // 2], 3), "min": round(lat[0], 3), "views": len(lat),
+                  "note": "one view in flight on one lane, wall clock around enqueue + synchronize"}
 
-    # ---------------- informational variants (never `value`): what the reference's own flow would
-    # time per view -- it aggregates the static cloud ONCE per scene at dataset construction
-    # (nvidia_eval_pure_geo.py:166-178) and only renders per target view
+    # ---------------- what a drop-in caller of pgdvs.engines gets: the reference's evaluator renders ONE view, then
+    # synchronises for its metrics (evaluator_pgdvs.py:36-188) -- the same workload through harness.eval_step, one view
+    # at a time, ground truth = a source frame (the values do not matter for the timing)
+    eval_loop = None
+    if rank == 0 and world == 1:
+        ev_views = []
+        for d_ in views:
+            e_ = dict(d_)
+            e_["_st_pcl_video"] = dict(rvr.video, capacity=rvr.row_bound or cap)
+            if rvr.row_bound is not None:
+                e_["st_pcl_rgb_row_bound"] = rvr.row_bound
+            e_["rgb_tgt"] = d_["rgb_src_temporal"][:, 0]
+            e_["eval_mask"] = d_["dyn_mask_src_temporal"][:, 0].expand(-1, -1, -1, 3).contiguous()
+            ev_views.append(e_)
+        for j in range(3):
+            harness.eval_step(model, ev_views[j % n_views], rc, device=dev)
+        torch.cuda.synchronize()
+        n_ev = max(8, min(args.steps, 40))
+        e0 = time.perf_counter()
+        for j in range(n_ev):
+            md = harness.eval_step(model, ev_views[j % n_views], rc, device=dev)
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - e0
+        eval_loop = {"frames_per_s": round(n_ev / e1, 2), "ms_per_view": round(e1 / n_ev * 1e3, 3), "views": n_ev,
+                     "psnr_full_last": round(float(md["eval/psnr_full_combined"]), 3),
+                     "note": "pgdvs_amd.harness.eval_step per view (to-device, forward = one native call incl. A12, quantisation + "
+                             "the three masked PSNRs in one pass, ONE host synchronisation, status words checked): the "
+                             "reference evaluator's loop shape, one view in flight; `value` presumes a pipelined caller"}
+
+    # ---------------- informational variants (never `value`)
     variants = None
     if rank == 0 and world == 1 and not args.no_kernel_timing:
-        cloud_c, cnt_c, xyz_c = ops.static_aggregate(rgbs, depths, masks, K3s, c2ws, capacity=cap, return_xyz=True)
+        variants = {}
+        # what the reference's own flow would time per view -- it aggregates the static cloud ONCE per scene at dataset
+        # construction (nvidia_eval_pure_geo.py:166-178) and only renders per target view
+        cloud_c, cnt_c, xyz_c = ops.static_aggregate(rvr.video["rgbs"], rvr.video["depths"], rvr.video["dyn_masks"], K3s, c2ws,
+                                                     capacity=rvr.row_bound or cap, return_xyz=True)
 
         def step_cached(j):
-            main, side = lanes[j % n_lanes]
-            if main is not None:
-                main.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(main) if main is not None else contextlib.nullcontext():
+            main, _ = rvr.lanes[j % n_lanes]
+            main.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(main), torch.no_grad():
                 data = dict(views[j % n_views])
-                data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=side if args.side_stream else None)
                 data["st_pcl_rgb"], data["st_pcl_rgb_count"], data["st_pcl_xyz"] = cloud_c[None], cnt_c, xyz_c[None]
-                with torch.no_grad():
-                    return model.forward(data, render_cfg=rc, disable_tqdm=True)["combined_rgb"]
+                if rvr.row_bound is not None:
+                    data["st_pcl_rgb_row_bound"] = rvr.row_bound
+                return model.forward(data, render_cfg=rc, disable_tqdm=True)["combined_rgb"]
 
-        # same arrangement as the headline (views round-robin over the lanes), bounded run-ahead by lane reuse
-        for j in range(n_lanes):
+        for j in range(2 * n_lanes):
             step_cached(j)
-        join_lanes()
+        rvr.join()
         torch.cuda.synchronize()
         v0 = time.perf_counter()
         nv = max(min(args.steps, 40), n_lanes)
         for j in range(nv):
             step_cached(j)
             if j % (2 * n_lanes) == 2 * n_lanes - 1:
-                join_lanes()
+                rvr.join()
                 torch.cuda.synchronize()
-        join_lanes()
+        rvr.join()
         torch.cuda.synchronize()
-        variants = {"static_cloud_aggregated_once_per_scene": {
+        variants["static_cloud_aggregated_once_per_scene"] = {
             "frames_per_s": round(nv / (time.perf_counter() - v0), 2), "steps": nv,
-            "note": "A12 outside the per-view loop, as the reference's dataset does; not the headline value"}}
+            "note": "A12 outside the per-view loop, as the reference's dataset does; not the headline value"}
+        del cloud_c, xyz_c
+
+    # ---------------- scene statistics (never `value`): the same loop on videos whose statistics differ from the smooth
+    # nominal scene -- a 12-camera rig cycled per frame (the NVIDIA monocular protocol: consecutive frames come from
+    # different cameras, far more newly visible pixels per frame), noisy depth with flying pixels at object borders --
+    # with the counters of every fast path's exit
+    scene_stats = None
+    if rank == 0 and world == 1 and not args.no_scene_sweep:
+        scene_stats = {}
+
+        def stats_of(rv, vs, label):
+            rv.set_lanes(n_lanes)
+            n0 = rv.calibrate(vs[0]) if rv is not rvr else n_static
+            torch.cuda.synchronize()
+            timed(2 * args.run_ahead + n_lanes, rv=rv, vs=vs)
+            n_sc = max(min(args.steps, 40), 2 * n_lanes)
+            dt = timed(n_sc, rv=rv, vs=vs)
+            ret_ = last["ret"]
+            ops.check_raster_status(ret_.get("geo_static_raster_status", None))
+            n_now = ops.checked_count(ret_["st_pcl_rgb_count"], "pgdvs_static_aggregate")
+            assert rv.row_bound is None or n_now < rv.row_bound, f"{label}: the cloud filled its buffer"
+            torch.cuda.synchronize()
+            ret1, _ = rv.render(vs[0], 0)
+            rv.join()
+            counters = model.view_counters() if hasattr(model, "view_counters") else None
+            o = {"frames_per_s": round(n_sc / dt, 2), "ms_per_view": round(dt / n_sc * 1e3, 3), "steps": n_sc,
+                 "static_points": n_now, "static_points_per_pixel": round(n_now / (H * W), 3),
+                 "us_per_million_points": round(dt / n_sc * 1e6 / (n_now / 1e6), 1), "counters": counters}
+            return o
+
+        scene_stats[args.scene] = stats_of(rvr, views, args.scene)
+        for sc in SCENES:
+            if sc == args.scene:
+                continue
+            try:
+                _, vs_, _, rv_ = load_scene(sc)
+                scene_stats[sc] = stats_of(rv_, vs_, sc)
+                del vs_, rv_
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001 -- the headline does not depend on it; the line says what failed
+                scene_stats[sc] = {"error": f"{type(e).__name__}: {e}"}
+        nom = scene_stats[args.scene]["us_per_million_points"]
+        for sc, o in scene_stats.items():
+            if "us_per_million_points" in o:
+                o["per_point_cost_vs_headline_scene"] = round(o["us_per_million_points"] / nom, 3)
+        if variants is None:
+            variants = {}
+        variants["scenes"] = scene_stats
+        rvr.set_lanes(n_lanes)
 
     # ---------------- CPU baseline: the oracle (port of the reference algorithm) on host cores, on the SAME
     # workload (this video, view 0).  Aggregation and the dynamic branch (brute-force kNN as pytorch3d's) run in
@@ -810,7 +733,6 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
-        from pgdvs_amd import harness
 
         cores = orc.num_threads()
         c0 = time.perf_counter()
@@ -843,7 +765,7 @@ def main():
         o1 = orc.render_view(od, dict(rc), static_noise=sd["static_noise"], alpha=100.0)
         t_c1 = time.perf_counter() - c0
         hd = {k: torch.from_numpy(np.ascontiguousarray(x)) for k, x in sd.items()}
-        hd["st_pcl_rgb"] = ops.static_aggregate(T(sv["rgbs"]), T(sv["depths"]), T(sv["dyn_masks"]).view(torch.uint8), sv["K3s"], sv["c2ws"])[0][None, :sc.shape[0]]
+        hd["st_pcl_rgb"] = ops.static_aggregate(T(sv["rgbs"]), T(sv["depths"]), T(sv["dyn_masks"]).view(torch.uint8), sv["K3s"], sv["c2ws"])[0][None, :sc.shape[0]].contiguous()
         hd["rgb_tgt"] = torch.from_numpy(np.ascontiguousarray(o1["combined_rgb"].transpose(0, 2, 3, 1)))
         hd["eval_mask"] = torch.from_numpy(np.repeat(o1["render_dyn_mask"].transpose(0, 2, 3, 1), 3, axis=-1).astype(np.float32))
         md, ex = harness.eval_step(model, hd, rc, device=dev, return_images=True)
@@ -898,21 +820,15 @@ def main():
             return gg, out
 
         def telemetry():
-            """engine clock (MHz, the level sysfs marks current) and board power (W) from sysfs, or None"""
+            """board power (W) from sysfs while a chunk runs, or None (the clock level sysfs marks as current does not
+            move on this driver and is no longer recorded)"""
             import glob
-            out = {}
             try:
-                for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
-                    for ln in open(f).read().splitlines():
-                        if ln.rstrip().endswith("*"):
-                            out["sclk_MHz"] = int(ln.split(":")[1].strip().split("Mhz")[0].split("MHz")[0])
-                    break
                 for f in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") + glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
-                    out["power_W"] = round(int(open(f).read()) / 1e6, 1)
-                    break
+                    return {"power_W": round(int(open(f).read()) / 1e6, 1)}
             except Exception:  # noqa: BLE001 -- telemetry is optional
                 pass
-            return out or None
+            return None
 
         with torch.no_grad():
             gg, _ = gnt_chunk()
@@ -937,14 +853,12 @@ def main():
         gflop = 2.0 * Rg * Sg * (1048064 + 84416 * Vg)
         gather_bytes = Rg * Sg * Vg * (4 * 35 * 4 + (44 + 4 * 32))  # 4 bilinear corners x 35 channels read, one row written
         tf = lambda sec: round(gflop / sec / 1e12, 2)  # noqa: E731
-        clk = [t_["sclk_MHz"] for t_ in tele if t_ and "sclk_MHz" in t_]
         pw = [t_["power_W"] for t_ in tele if t_ and "power_W" in t_]
         gnt = {"rays": Rg, "samples_per_ray": Sg, "views": Vg, "layers": 8, "ms_per_chunk": round(gdt * 1e3, 2),
                "ms_gather_A13": round(t_gather, 3), "ms_transformer_A14": round(t_net, 3),
                "tflops": tf(gdt), "tflops_A14_alone": round(gflop / (t_net * 1e-3) / 1e12, 2),
                "repetitions": {"n": len(reps), "statistic": "median", "tflops_min": tf(reps[-1][0]), "tflops_max": tf(reps[0][0]),
                                "ms_per_chunk_all": [round(r_[0] * 1e3, 2) for r_ in reps],
-                               "sclk_MHz_range": [min(clk), max(clk)] if clk else None,
                                "power_W_range": [min(pw), max(pw)] if pw else None},
                "peak_tflops_fp32_mfma": 157.3, "frac_of_peak": round(gflop / gdt / 157.3e12, 4),
                "gather_alg_GBps": round(gather_bytes / (t_gather * 1e-3) / 1e9, 1), "valid_projection_fraction": round(valid_frac, 3),
@@ -952,7 +866,7 @@ def main():
                "est_seconds_per_1080p_frame": round(gdt * (H * W / Rg), 1),
                "note": "pgdvs_gnt_gather (real projections of target-ray samples into the resident source frames, dynamic masks "
                        "applied) + GNT.forward incl. view entropy/std side outputs; FLOPs counted for A14 only, time for both; "
-                       "median of ten repetitions (sclk / power as sysfs reports them while each runs)"}
+                       "median of ten repetitions (board power as sysfs reports it while each runs)"}
         # The whole renderer with the GNT static renderer at the reference's own benchmark setting
         # (NVIDIA Dynamic Scenes: 288 x 550 targets, 10 spatial + 2 temporal source views, 256 samples
         # per ray, chunks of 1024 rays).  Informational, never `value`.
@@ -968,18 +882,23 @@ def main():
         out = {
             "metric": "novel-view frames/s at 1080p x 24 src frames; achieved HBM GB/s vs gfx950 peak",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "latency_ms": latency_ms, "host_enqueue_ms_per_step": round(host_ms, 3), "host_blocked_on_gpu_ms_per_step": round(host_wait_ms, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "latency_ms": latency_ms, "eval_step_frames_per_s": (eval_loop or {}).get("frames_per_s"), "eval_step": eval_loop,
+            "host_enqueue_ms_per_step": round(host_ms, 3), "host_blocked_on_gpu_ms_per_step": round(host_wait_ms, 3),
+            "host_native_call_ms_per_step": round(host_native_ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{W}x{H} target view, {S} source frames resident in HBM: static aggregation (A12) + "
                             f"point z-buffer raster K={K} (A9) + flow-warped dynamic splat (A1-A8, outlier filter "
                             f"{'on' if not args.no_outlier else 'off'}) + composite (A11)",
-                "views_in_flight": (len(graphs) if graphs else n_lanes), "views_in_flight_choice": lanes_note, "host_run_ahead_views": args.run_ahead, "memory": mem_note, "raster_row_bound": row_bound[0], "launch": graph_note, "height": H, "width": W, "src_frames": S, "static_points": n_static, "dyn_pixels": n_dyn,
+                "scene": args.scene, "views_in_flight": n_lanes, "views_in_flight_choice": lanes_note, "host_run_ahead_views": args.run_ahead, "memory": mem_note, "raster_row_bound": rvr.row_bound,
+                "launch": ("per-op: ~85 C-ABI calls per view enqueued from Python (--per-op)" if args.per_op else
+                           "one native call per view (pgdvs_view_geo_forward: A12 + A9 + A2-A8 + A11 enqueued from C++)")
+                          + (", dynamic-branch geometry on a second stream per lane" if args.side_stream else ""), "height": H, "width": W, "src_frames": S, "static_points": n_static, "dyn_pixels": n_dyn,
                 "parallelism": f"frames sharded over {world} GPU(s), RCCL gather of the image stack" if world > 1 else "1 GPU",
                 "per_rank_frames_per_s": [round(args.steps / x, 2) for x in per_rank_s],
                 "gather_bytes_to_rank0": int(3 * H * W * 4 * args.steps * (world - 1)),
                 "gather_GBps_into_rank0": round(3 * H * W * 4 * args.steps * (world - 1) / elapsed / 1e9, 2),
-                "gather_receive_ring_slots": args.run_ahead + n_lanes + 2,
+                "gather_receive_ring_slots": ring_slots,
                 "collective_backend": (dist.get_backend() if world > 1 else None), "rccl_ranks_seen": [p_[0] for p_ in peers],
                 "rank_devices": [f"rank {p_[0]}: cuda:{p_[1]} {p_[2]}" for p_ in peers],
                 "whole_view_alg_bytes": alg_total,

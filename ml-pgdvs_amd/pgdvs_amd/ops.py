@@ -666,6 +666,8 @@ def gnt_fallback(kernel: str, why: str) -> None:
     import os
     import warnings
 
+    if not _GNT_VIEW_ENABLED:  # the fused kernels are switched off on purpose (tests: the torch statement as the reference half)
+        return
     msg = f"pgdvs_amd: {kernel} does not cover {why}; this stage runs on torch/rocBLAS (results identical, slower)"
     if os.environ.get("PGDVS_GNT_STRICT", "0") not in ("", "0"):
         raise PgdvsHipError(msg)

@@ -49,19 +49,33 @@ def _background(H, W, K3, c2w):
     return t, _texture(X, Y)
 
 
-def frame_camera(i, S, H, W):
-    """Source camera i of S: small yaw sweep + translation along x."""
+RIG_CAMERAS = 12  # the NVIDIA Dynamic Scenes rig (12 cameras; the monocular protocol takes camera i % 12 at time i)
+
+
+def frame_camera(i, S, H, W, scene="nominal"):
+    """Source camera i of S: small yaw sweep + translation along x.  ``scene="wide_baseline"``: the camera
+    of frame i is camera i % 12 of a fixed 12-camera rig spanning the same baseline (pgdvs/datasets/nvidia_eval.py's
+    monocular protocol): consecutive frames are a rig spacing apart and frame 12 jumps back across the whole rig."""
     f = 0.9 * W
     K3 = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1.0]])
+    if scene == "wide_baseline":
+        c = i % RIG_CAMERAS
+        fr = c / (RIG_CAMERAS - 1.0)
+        return K3, _pose(2.0 * (fr - 0.5), 0.6 * (fr - 0.5), [0.46 * fr, 0.069 * fr, 0.0])
     frac = i / max(S - 1, 1)
     c2w = _pose(2.0 * (frac - 0.5), 0.6 * (frac - 0.5), [0.02 * i, 0.003 * i, 0.0])
     return K3, c2w
 
 
-def make_video(S, H, W, seed=1234, dyn_frac=0.15):
+def make_video(S, H, W, seed=1234, dyn_frac=0.15, scene="nominal"):
     """S source frames: dict(rgbs[S,H,W,3] f32, depths[S,H,W] f32, dyn_masks[S,H,W] bool,
-    K3s[S,3,3] f64, c2ws[S,4,4] f64, centers[S,2,2])."""
+    K3s[S,3,3] f64, c2ws[S,4,4] f64, centers[S,2,2]).
+    ``scene``: "nominal" (smooth camera path, exact depth), "wide_baseline" (12-camera rig cycled per frame, see
+    ``frame_camera``), "noisy_depth" (estimated-depth statistics: 1.5 % multiplicative noise on every depth and flying
+    pixels -- depths between foreground and background -- in a 2-pixel band along the objects' borders)."""
+    assert scene in ("nominal", "wide_baseline", "noisy_depth"), scene
     rng = np.random.default_rng(seed)
+    rng_depth = np.random.default_rng(seed + 99991)  # (its own stream: the nominal scene's draws are unchanged)
     rgbs = np.empty((S, H, W, 3), np.float32)
     depths = np.empty((S, H, W), np.float32)
     masks = np.empty((S, H, W), bool)
@@ -75,9 +89,11 @@ def make_video(S, H, W, seed=1234, dyn_frac=0.15):
     centers = np.empty((S, 2, 2))
 
     def frame(i):
-        K3, c2w = frame_camera(i, S, H, W)
+        K3, c2w = frame_camera(i, S, H, W, scene)
         z, tex = _background(H, W, K3, c2w)
+        z_bg = z
         m = np.zeros((H, W), bool)
+        border = np.zeros((H, W), bool)
         cs = np.empty((2, 2))
         for j in range(2):
             c = c0[j] + vel * i
@@ -85,10 +101,11 @@ def make_video(S, H, W, seed=1234, dyn_frac=0.15):
             du, dv = (u - c[0]) / rad, (v - c[1]) / rad
             disc = du * du + dv * dv < 1.0
             m |= disc
+            border |= np.abs(np.sqrt(du * du + dv * dv) - 1.0) * rad < 2.0
             z = np.where(disc, 1.0 + 0.08 * du + 0.05 * dv + 0.2 * j, z)
             obj = np.stack([0.6 + 0.3 * np.sin(4 * du + j), 0.4 + 0.3 * np.cos(3 * dv), 0.5 + 0.3 * np.sin(5 * du * dv + 1)], -1)
             tex = np.where(disc[..., None], obj, tex)
-        return K3, c2w, z.astype(np.float32), tex, m, cs
+        return K3, c2w, z.astype(np.float32), tex, m, cs, border, z_bg.astype(np.float32)
 
     # frames are independent except for the noise stream, which is drawn in frame order: the geometry
     # (numpy ufuncs release the GIL) runs on a thread pool, a few frames ahead of the sequential part
@@ -103,8 +120,13 @@ def make_video(S, H, W, seed=1234, dyn_frac=0.15):
             while nxt < S and nxt < i + 2 * workers:
                 pending[nxt] = ex.submit(frame, nxt)
                 nxt += 1
-            K3s[i], c2ws[i], depths[i], tex, masks[i], centers[i] = pending.pop(i).result()
+            K3s[i], c2ws[i], depths[i], tex, masks[i], centers[i], border, z_bg = pending.pop(i).result()
             rgbs[i] = np.clip(tex + rng.normal(0, 0.01, tex.shape), 0, 1).astype(np.float32)
+            if scene == "noisy_depth":
+                # flying pixels: a depth somewhere between the object (~1.1) and the background behind it
+                mix = rng_depth.random((H, W)).astype(np.float32)
+                depths[i] = np.where(border, np.float32(1.1) + mix * (z_bg - np.float32(1.1)), depths[i])
+                depths[i] *= (1.0 + 0.015 * rng_depth.standard_normal((H, W))).astype(np.float32)
     return dict(rgbs=rgbs, depths=depths, dyn_masks=masks, K3s=K3s, c2ws=c2ws, centers=centers, vel=vel, rad=rad)
 
 

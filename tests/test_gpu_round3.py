@@ -124,7 +124,7 @@ def test_renderer_draws_its_noise_in_the_splat_kernel():
     with torch.no_grad():
         r0 = model.forward(dict(data), render_cfg=rc)
         r1 = model.forward(dict(data), render_cfg=rc)
-    (state,) = model.dyn_renderer._splat_rng.values()
+    state = model.dyn_renderer.splat_rng_state(data["rgb_src_temporal"].device)  # (the current stream's state)
     assert int(state[1]) == 2  # two forwards, two draws
     for draw, ret in ((0, r0), (1, r1)):
         st = state.clone()

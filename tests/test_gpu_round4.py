@@ -1,0 +1,332 @@
+"""GPU tests added in round 4 (MI355X): the one-native-call-per-view entry point against the per-op path and the oracle,
+the benchmark's own arrangement (resident video, cloud aggregated inside the call, bounded buffers, views in flight,
+noise drawn in the kernel) at BASELINE.json's configs[2] against the oracle, the evaluator's metric kernel against the
+torch statement pinned by the reference's fixture, scenes with other statistics than the nominal one, and the
+counters of the fast paths' exits."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402  (checker only)
+from pgdvs_amd import ops, synth  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from pgdvs_amd import _lib
+
+    _lib.load()
+
+
+def _renderer(static="geo", **over):
+    from pgdvs_amd.instantiate import load_config
+    from pgdvs_amd.renderers.pgdvs_renderer import PGDVSRenderer
+
+    cfg = load_config(static_renderer=static)
+    rc = cfg.engine.engine_cfg.render_cfg
+    for k, v in over.items():
+        rc[k] = v
+    return PGDVSRenderer(cfg, render_cfg=rc, softsplat_metric_abs_alpha=100.0).to(DEV).eval(), rc
+
+
+def _video_dict(v, capacity=None):
+    d = {"rgbs": T(v["rgbs"]), "depths": T(v["depths"]), "dyn_masks": T(v["dyn_masks"]).view(torch.uint8), "K3s": v["K3s"],
+         "c2ws": v["c2ws"]}
+    if capacity is not None:
+        d["capacity"] = capacity
+    return d
+
+
+IMAGE_KEYS = ["geo_static_rgb", "render_dyn_rgb", "combined_rgb", "combined_rgb_static", "combined_rgb_dyn"]
+
+
+# ---------------------------------------------------------------- one native call per view
+@pytest.mark.parametrize("outlier,use_xyz,use_count,side", [(True, False, False, False), (True, True, True, False),
+                                                            (False, True, True, True), (True, False, True, True)])
+def test_native_view_call_equals_per_op_path(outlier, use_xyz, use_count, side, monkeypatch):
+    """PGDVSRenderer.forward through pgdvs_view_geo_forward (ONE C-ABI call) and through the ~85 per-op calls: the same
+    kernels on the same inputs -- static image, masks and status identical, splat images to float-atomic rounding; and
+    both against the oracle"""
+    H, W, S = 120, 200, 5
+    v = synth.make_video(S, H, W, seed=31)
+    d = synth.make_view(v, 2, frac=0.3, seed=4)
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=outlier, dyn_pcl_outlier_knn=20, st_render_pcl_pts_per_pixel=3,
+                          st_render_pcl_pt_radius=0.015)
+    cap = S * H * W
+    cloud, cnt, xyz = ops.static_aggregate(T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]), v["K3s"], v["c2ws"], capacity=cap,
+                                           return_xyz=True)
+    n = ops.checked_count(cnt, "agg")
+    data = synth.to_torch(d, DEV)
+    if use_count:
+        data["st_pcl_rgb"], data["st_pcl_rgb_count"] = cloud[None], cnt
+        data["st_pcl_rgb_row_bound"] = n + 1000
+        if use_xyz:
+            data["st_pcl_xyz"] = xyz[None]
+    else:
+        data["st_pcl_rgb"] = cloud[None, :n].contiguous()
+    if side:
+        data["_side_stream"] = torch.cuda.Stream(device=DEV)
+    assert model._native_view_ok(data, rc)
+    with torch.no_grad():
+        rn = model.forward(dict(data), render_cfg=rc)
+        monkeypatch.setenv("PGDVS_NATIVE_VIEW", "0")
+        assert not model._native_view_ok(data, rc)
+        rp = model.forward(dict(data), render_cfg=rc)
+    torch.cuda.synchronize()
+    assert set(rp) <= set(rn), set(rp) - set(rn)
+    assert torch.equal(rn["geo_static_rgb"], rp["geo_static_rgb"]) and torch.equal(rn["geo_static_mask"], rp["geo_static_mask"])
+    assert torch.equal(rn["render_dyn_mask"], rp["render_dyn_mask"])
+    for k in IMAGE_KEYS:
+        assert rn[k].shape == rp[k].shape, k
+        assert torch.allclose(rn[k], rp[k], rtol=0, atol=1e-6), k
+    for k in ("render_dyn_temporal_closest_mask", "render_dyn_temporal_track_rgb", "render_dyn_temporal_track_mask"):
+        assert rn[k].shape == rp[k].shape and torch.equal(rn[k], rp[k]), k
+    if use_count:
+        assert int(rn["geo_static_raster_status"]) == 0 and int(rp["geo_static_raster_status"]) == 0
+    o_cloud = orc.aggregate_static_pcl(v["rgbs"], v["depths"], v["dyn_masks"], v["K3s"], v["c2ws"])
+    od = dict(d)
+    od["st_pcl_rgb"] = o_cloud[None]
+    o = orc.render_view(od, dict(rc), static_noise=d["static_noise"], alpha=100.0)
+    assert np.array_equal(N(rn["geo_static_mask"]), o["geo_static_mask"]) and np.array_equal(N(rn["render_dyn_mask"]), o["render_dyn_mask"])
+    for k in IMAGE_KEYS:
+        np.testing.assert_allclose(N(rn[k]), o[k], rtol=0, atol=1e-4, err_msg=k)
+
+
+def test_native_view_call_aggregates_the_cloud_itself():
+    """``data["_st_pcl_video"]``: A12 inside the same native call -- the cloud it returns is the oracle's, bit for bit
+    and in order, and the images are those of a forward fed with that cloud"""
+    H, W, S = 96, 160, 6
+    v = synth.make_video(S, H, W, seed=13)
+    d = synth.make_view(v, 3, frac=0.5, seed=8)
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=True, dyn_pcl_outlier_knn=16, st_render_pcl_pts_per_pixel=3)
+    data = synth.to_torch(d, DEV)
+    data["_st_pcl_video"] = _video_dict(v)
+    out = torch.full((1, 3, H, W), float("nan"), device=DEV)
+    data["_combined_rgb_out"] = out
+    with torch.no_grad():
+        r = model.forward(data, render_cfg=rc)
+    o_cloud = orc.aggregate_static_pcl(v["rgbs"], v["depths"], v["dyn_masks"], v["K3s"], v["c2ws"])
+    n = ops.checked_count(r["st_pcl_rgb_count"], "agg")
+    assert n == o_cloud.shape[0] and r["st_pcl_rgb"].shape == (1, S * H * W, 6)
+    assert np.array_equal(N(r["st_pcl_rgb"][0, :n]).view(np.uint32), o_cloud.view(np.uint32))
+    assert np.array_equal(N(r["st_pcl_xyz"][0, :n]).view(np.uint32), o_cloud[:, :3].view(np.uint32))
+    assert r["combined_rgb"].data_ptr() == out.data_ptr()  # rendered into the caller's slot
+    od = dict(d)
+    od["st_pcl_rgb"] = o_cloud[None]
+    o = orc.render_view(od, dict(rc), static_noise=d["static_noise"], alpha=100.0)
+    assert np.array_equal(N(r["render_dyn_mask"]), o["render_dyn_mask"])
+    np.testing.assert_allclose(N(out), o["combined_rgb"], rtol=0, atol=1e-4)
+    # a capacity the cloud does not fit: count == capacity, and the evaluator-shaped caller refuses the view
+    from pgdvs_amd import harness
+
+    small = dict(data)
+    small["_st_pcl_video"] = _video_dict(v, capacity=n - 5)
+    small["st_pcl_rgb_row_bound"] = n - 5
+    small.pop("_combined_rgb_out")
+    small["rgb_tgt"] = data["rgb_src_temporal"][:, 0]
+    small["eval_mask"] = torch.zeros(1, H, W, 3, device=DEV)
+    with pytest.raises(ops.PgdvsHipError, match="filled its buffer"):
+        harness.eval_step(model, small, rc, device=DEV)
+
+
+def test_native_view_call_rejects_bad_descriptions():
+    from pgdvs_amd import _lib
+    import ctypes as C
+
+    lib = _lib.load()
+    d = _lib.ViewGeoDesc()
+    d.H, d.W = 8, 8
+    assert lib.pgdvs_view_geo_forward(C.byref(d), None, 0, None) == -1
+    assert b"null input pointer" in lib.pgdvs_last_error()
+    H, W, S = 48, 64, 3
+    v = synth.make_video(S, H, W, seed=2)
+    data = synth.to_torch(synth.make_view(v, 1, seed=1), DEV)
+    st = ops.ViewGeoState()
+    kw = dict(H=H, W=W, flat_cam_tgt=data["flat_cam_tgt"][0], flat_cam_src=data["flat_cam_src_temporal"][0],
+              time_src=data["time_src_temporal"][0], time_tgt=data["time_tgt"][0], rgb1=data["rgb_src_temporal"][0, 0],
+              rgb2=data["rgb_src_temporal"][0, 1], depth1=data["depth_src_temporal"][0, 0], depth2=data["depth_src_temporal"][0, 1],
+              dyn_mask1=data["dyn_mask_src_temporal"][0, 0], flow12=data["flow_fwd"][0], flow_occ=None, use_flow_consistency=False,
+              remove_outlier=True, outlier_knn=16, outlier_std_thres=0.1, alpha=100.0, radius=0.01, K=3,
+              st_pcl_rgb=torch.rand(100, 6, device=DEV))
+    r = ops.view_geo_forward(st, **kw)
+    assert tuple(r["combined_rgb"].shape) == (3, H, W)
+    with pytest.raises(ops.PgdvsHipError, match="contiguous"):
+        ops.view_geo_forward(st, **dict(kw, rgb1=data["rgb_src_temporal"][0, 0].double()))
+    with pytest.raises(ops.PgdvsHipError, match="flow_occ required"):
+        ops.view_geo_forward(st, **dict(kw, use_flow_consistency=True))
+    with pytest.raises(ops.PgdvsHipError, match="points_per_pixel"):
+        ops.view_geo_forward(st, **dict(kw, K=9))
+    with pytest.raises(ops.PgdvsHipError):  # CPU tensors: no fallback
+        ops.view_geo_forward(st, **dict(kw, rgb1=data["rgb_src_temporal"][0, 0].cpu()))
+
+
+# ---------------------------------------------------------------- the timed arrangement == the tested arrangement
+def test_config_c3_in_the_benchmarks_arrangement_vs_oracle():
+    """BASELINE.json configs[2] rendered EXACTLY as bench.py's timed loop renders it -- `ResidentVideoRenderer`: 24 source
+    frames resident, the cloud aggregated inside the per-view native call into buffers bounded by the first view's
+    count, packed coordinates, the composite written into the caller's slot, the noise field drawn inside the splat
+    kernel, three views in flight on three streams -- against the oracle: cloud bit-exact, masks exact, images within
+    1e-4 (the field of each draw recovered through ops.splat_noise_field)"""
+    from pgdvs_amd.runtime import ResidentVideoRenderer
+
+    H, W, S = 1080, 1920, 24
+    v = synth.make_video(S, H, W, seed=1234)
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=True, st_render_pcl_pts_per_pixel=3)
+    rvr = ResidentVideoRenderer(model, rc, T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]), v["K3s"], v["c2ws"], lanes=3)
+    view_ids = [0, 7, 15]
+    ds = [synth.make_view(v, i, frac=0.4, seed=5) for i in view_ids]
+    datas = []
+    for d in ds:
+        t = synth.to_torch(d, DEV)
+        t.pop("static_noise")
+        datas.append(t)
+    n0 = rvr.calibrate(datas[0])
+    assert rvr.row_bound == min(S * H * W, int(1.25 * n0) + 65536)
+    torch.cuda.synchronize()
+    slots = torch.full((3, 1, 3, H, W), float("nan"), device=DEV)
+    # the state each lane's stream will draw from, and the draw number it is at
+    states = []
+    for li in range(3):
+        with torch.cuda.stream(rvr.lanes[li][0]):
+            st = model.dyn_renderer.splat_rng_state(torch.device(DEV))
+        states.append(st)
+    torch.cuda.synchronize()
+    before = [s.clone() for s in states]
+    rets = [rvr.render(datas[li], li, out=slots[li])[0] for li in range(3)]  # three views in flight
+    rvr.join()
+    torch.cuda.synchronize()
+    o_cloud = orc.aggregate_static_pcl(v["rgbs"], v["depths"], v["dyn_masks"], v["K3s"], v["c2ws"])
+    ndc_cache = {}
+    for li, (d, ret) in enumerate(zip(ds, rets)):
+        n = ops.checked_count(ret["st_pcl_rgb_count"], "agg")
+        assert n == o_cloud.shape[0] == n0 and ret["st_pcl_rgb"].shape[1] == rvr.row_bound
+        assert int(ret["geo_static_raster_status"]) == 0
+        assert np.array_equal(N(ret["st_pcl_rgb"][0, :n]).view(np.uint32), o_cloud.view(np.uint32)), f"lane {li}: cloud"
+        assert int(states[li][1]) == int(before[li][1]) + 1
+        field = ops.splat_noise_field(before[li], H, W)
+        # static image: the oracle's point-major sweep over all pixels (same lists as the naive loop)
+        ndc = orc.points_to_ndc(o_cloud[:, :3], d["flat_cam_tgt"][0], H, W)
+        idx, zbuf, d2 = orc.rasterize_points_pointmajor(ndc, H, W, float(rc.st_render_pcl_pt_radius), 3)
+        img = orc.composite(idx, d2, float(rc.st_render_pcl_pt_radius), o_cloud[:, 3:])
+        ones = orc.composite(idx, d2, float(rc.st_render_pcl_pt_radius), None)
+        np.testing.assert_allclose(N(ret["geo_static_rgb"])[0], img.transpose(2, 0, 1), rtol=0, atol=1e-6)
+        assert np.array_equal(N(ret["geo_static_mask"])[0, 0], (ones[..., 0] > 0).astype(np.float32))
+        od = dict(d)
+        od["rgb_gnt"] = img[None]
+        o = orc.render_view(od, dict(rc), static_noise=N(field)[None], alpha=100.0)
+        assert np.array_equal(N(ret["render_dyn_mask"]), o["render_dyn_mask"]), f"lane {li}"
+        np.testing.assert_allclose(N(ret["render_dyn_rgb"]), o["render_dyn_rgb"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(N(slots[li]), o["combined_rgb"], rtol=0, atol=1e-4)
+        assert ret["combined_rgb"].data_ptr() == slots[li].data_ptr()
+    del ndc_cache
+
+
+# ---------------------------------------------------------------- the evaluator's metric in one pass
+@pytest.mark.parametrize("H,W", [(37, 53), (270, 480)])
+def test_eval_psnr_sums_vs_torch_statement(H, W):
+    """csrc/eval.hip against harness.quantize_like_evaluator / masked_psnr (pinned by the reference's own fixture in
+    tests/test_host_cpu.py): quantised images bit-exact, PSNRs to 1e-9 dB; NaNs in the prediction, values outside [0, 1]"""
+    from pgdvs_amd.harness import masked_psnr, quantize_like_evaluator
+
+    g = torch.Generator(device="cpu").manual_seed(H)
+    pred = torch.rand(3, H, W, generator=g) * 1.4 - 0.2
+    pred[0, 3, 5] = float("nan")
+    gt = torch.rand(H, W, 3, generator=g) * 1.2 - 0.1
+    mask = (torch.rand(H, W, 1, generator=g) < 0.3).float().expand(H, W, 3).contiguous()
+    sums, pq, gq = ops.eval_psnr_sums(pred.to(DEV), gt.to(DEV), mask.to(DEV), want_images=True)
+    s = sums.cpu().tolist()
+    pq_t = quantize_like_evaluator(pred)
+    gq_t = quantize_like_evaluator(gt.permute(2, 0, 1))
+    # (8-bit codes: the final division by 255 is correctly rounded on both sides, compare the floats as well)
+    assert torch.equal(pq.cpu(), pq_t) and torch.equal(gq.cpu(), gq_t)
+    m = mask.permute(2, 0, 1)
+    for j, mk in enumerate((torch.ones_like(m), m, 1.0 - m)):
+        want = masked_psnr(gq_t, pq_t, mk)
+        mse = s[j] / (s[3 + j] + 1e-8)
+        got = 0 if mse == 0 else 10 * np.log10(1.0 / mse)
+        assert abs(got - want) < 1e-9, (j, got, want)
+    assert s[3] == 3 * H * W and abs(s[4] + s[5] - s[3]) < 1e-6
+    # identical images: the reference's quirk of PSNR 0
+    s2 = ops.eval_psnr_sums(gq, gq_t.permute(1, 2, 0).contiguous().to(DEV), mask.to(DEV))[0].cpu().tolist()
+    assert s2[0] == 0 and s2[1] == 0 and s2[2] == 0
+
+
+def test_eval_step_fused_metric_equals_the_torch_path(monkeypatch):
+    """harness.eval_step around the HIP renderer: the one-pass metric and the torch statement of the reference's
+    evaluator give the same metric dict"""
+    from pgdvs_amd import harness
+
+    H, W, S = 72, 128, 4
+    v = synth.make_video(S, H, W, seed=21)
+    d = synth.make_view(v, 1, seed=3)
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=True, dyn_pcl_outlier_knn=20, st_render_pcl_pts_per_pixel=3)
+    data = synth.to_torch(d, DEV)
+    data["_st_pcl_video"] = _video_dict(v)
+    data["rgb_tgt"] = (data["rgb_src_temporal"][:, 1] * 0.9 + 0.03).contiguous()
+    data["eval_mask"] = data["dyn_mask_src_temporal"][:, 0].expand(-1, -1, -1, 3).contiguous()
+    md, ex = harness.eval_step(model, data, rc, device=DEV, return_images=True)
+    # the torch statement on the same prediction
+    pq = harness.quantize_like_evaluator(ex["ret"]["combined_rgb"][0])
+    gq = harness.quantize_like_evaluator(data["rgb_tgt"][0].permute(2, 0, 1))
+    assert torch.equal(ex["pred"][0], pq) and torch.equal(ex["gt"][0], gq)
+    m = data["eval_mask"][0].permute(2, 0, 1)
+    for key, mk in (("psnr_full_combined", torch.ones_like(m)), ("psnr_dyn_combined", m), ("psnr_static_combined", 1 - m)):
+        want = harness.masked_psnr(gq, pq, mk)
+        assert abs(float(md[f"eval/{key}"]) - want) < 1e-4 * max(1.0, abs(want)), key
+    assert int(md["eval/count"]) == 1
+
+
+# ---------------------------------------------------------------- scenes with other statistics
+@pytest.mark.parametrize("scene", ["wide_baseline", "noisy_depth"])
+def test_scene_statistics_540p_vs_oracle(scene):
+    """540p x 12 frames of the benchmark's off-nominal scenes (12-camera rig cycled per frame; noisy depth with flying
+    pixels): cloud bit-exact and in order, z-buffer fragments bit-exact on every pixel, dynamic branch + composite
+    within 1e-4 -- the statistics that lengthen tile lists and the aggregation's links change no result"""
+    H, W, S = 540, 960, 12
+    v = synth.make_video(S, H, W, seed=1234, scene=scene)
+    d = synth.make_view(v, 5, frac=0.4, seed=5)
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=True, st_render_pcl_pts_per_pixel=3)
+    data = synth.to_torch(d, DEV)
+    data["_st_pcl_video"] = _video_dict(v)
+    with torch.no_grad():
+        ret = model.forward(data, render_cfg=rc)
+    o_cloud = orc.aggregate_static_pcl(v["rgbs"], v["depths"], v["dyn_masks"], v["K3s"], v["c2ws"])
+    n = ops.checked_count(ret["st_pcl_rgb_count"], "agg")
+    assert n == o_cloud.shape[0]
+    assert np.array_equal(N(ret["st_pcl_rgb"][0, :n]).view(np.uint32), o_cloud.view(np.uint32))
+    # more newly visible pixels per frame than the nominal scene's ~3.6 % of P
+    nominal = synth.make_video(S, H, W, seed=1234)
+    n_nom = orc.aggregate_static_pcl(nominal["rgbs"], nominal["depths"], nominal["dyn_masks"], nominal["K3s"], nominal["c2ws"]).shape[0]
+    assert n > n_nom, (n, n_nom)
+    radius = float(rc.st_render_pcl_pt_radius)
+    cam = ops.cam_prep(data["flat_cam_tgt"][0])
+    frag = ops.points_raster(ret["st_pcl_rgb"][0, :n], ret["st_pcl_rgb"][0, :n, 3:], cam, radius, 3, H, W, want_fragments=True,
+                             rgb_planar=True)
+    assert torch.equal(frag["rgb"], ret["geo_static_rgb"][0])
+    ndc = orc.points_to_ndc(o_cloud[:, :3], d["flat_cam_tgt"][0], H, W)
+    idx, zbuf, d2 = orc.rasterize_points_pointmajor(ndc, H, W, radius, 3)
+    assert np.array_equal(N(frag["idx"]), idx)
+    assert np.array_equal(N(frag["zbuf"]).view(np.uint32), zbuf.view(np.uint32))
+    assert np.array_equal(N(frag["dist2"]).view(np.uint32), d2.view(np.uint32))
+    img = orc.composite(idx, d2, radius, o_cloud[:, 3:])
+    np.testing.assert_allclose(N(ret["geo_static_rgb"])[0], img.transpose(2, 0, 1), rtol=0, atol=1e-6)
+    od = dict(d)
+    od["rgb_gnt"] = img[None]
+    o = orc.render_view(od, dict(rc), static_noise=d["static_noise"], alpha=100.0)
+    assert np.array_equal(N(ret["render_dyn_mask"]), o["render_dyn_mask"])
+    for k in ["render_dyn_rgb", "combined_rgb"]:
+        np.testing.assert_allclose(N(ret[k]), o[k], rtol=0, atol=1e-4, err_msg=k)

@@ -38,6 +38,38 @@ def test_library_exports_every_declared_symbol():
     assert lib.pgdvs_points_raster_workspace_bytes(-1, 270, 480, 0.01) == -1
 
 
+def test_view_geo_description_struct_and_workspace_query():
+    """the one-call-per-view entry point: this binding's struct is the library's, field for field (size check at load),
+    and the pure host-side workspace query works without a GPU"""
+    import ctypes as C
+
+    from pgdvs_amd import _lib
+
+    lib = _lib.load()
+    assert lib.pgdvs_view_geo_desc_size() == C.sizeof(_lib.ViewGeoDesc)
+    # the C declaration and the ctypes fields, name for name and in order
+    text = (ROOT / "include" / "pgdvs_hip.h").read_text()
+    body = text[text.index("typedef struct pgdvs_view_geo_desc {"):text.index("} pgdvs_view_geo_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if decl:
+            names += [re.sub(r"[^a-zA-Z0-9_]", "", part.split()[-1]) for part in decl.split(",")]
+    assert names == [f[0] for f in _lib.ViewGeoDesc._fields_]
+    d = _lib.ViewGeoDesc()
+    d.H, d.W, d.agg_S, d.agg_capacity, d.row_bound, d.radius, d.K = 1080, 1920, 24, 4400000, 4400000, 0.01, 3
+    d.remove_outlier, d.outlier_knn = 1, 50
+    need = lib.pgdvs_view_geo_workspace_bytes(C.byref(d))
+    assert 300e6 < need < 2e9
+    d.remove_outlier = 0
+    assert 0 < lib.pgdvs_view_geo_workspace_bytes(C.byref(d)) < need
+    d.H = 0
+    assert lib.pgdvs_view_geo_workspace_bytes(C.byref(d)) == -1 and b"bad H/W" in lib.pgdvs_last_error()
+    assert lib.pgdvs_view_geo_forward(None, None, 0, None) == -1
+    assert lib.pgdvs_eval_psnr_workspace_bytes() > 0
+
+
 def test_no_cpu_fallback():
     from pgdvs_amd import ops
     from pgdvs_amd.utils.softsplat import softsplat
@@ -207,6 +239,20 @@ def test_bench_gpus_2_starts_two_ranks_dry():
 def test_bench_launcher_reports_a_failed_rank():
     r = _bench("--gpus", "2", "--steps", "2", "--dry-run", "--dry-fail-rank", "1")
     assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_watchdog_ends_a_job_with_a_lost_rank():
+    """a rank that never reaches its peers again: the other rank's wall-clock timeout ends ITS process with a non-zero
+    status (fresh-process semantics: it exits, nothing is re-executed), the launcher tears the job down and returns
+    non-zero -- instead of hanging inside a collective"""
+    import time
+
+    t0 = time.time()
+    r = _bench("--gpus", "2", "--steps", "2", "--dry-run", "--dry-hang-rank", "1", "--rank-timeout", "6")
+    assert r.returncode != 0
+    assert time.time() - t0 < 120
+    assert "did not finish within 6 s" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 

@@ -94,8 +94,9 @@ def parse():
     ap.add_argument("--inflight", type=int, default=0,
                     help="independent target views rendered concurrently, each on its own HIP stream; 0 (default): one GPU "
                          "measures a few counts during warm-up, several ranks take the fixed default (no probe collectives)")
-    ap.add_argument("--side-stream", action="store_true",
-                    help="give every lane a second stream for the dynamic branch's geometry (forked / joined inside the native call)")
+    ap.add_argument("--side-stream", action=argparse.BooleanOptionalAction, default=True,
+                    help="give every lane a second stream for the dynamic branch's geometry (forked / joined inside the native "
+                         "call); --no-side-stream: one stream per lane")
     ap.add_argument("--per-op", action="store_true",
                     help="rounds 1-3 arrangement: ~85 C-ABI calls per view enqueued from Python instead of ONE native call (A/B)")
     ap.add_argument("--run-ahead", type=int, default=6, help="views the host may have enqueued beyond the last finished one")
@@ -525,9 +526,10 @@ def main():
         f"the static cloud ({n_static} rows) filled its buffer of {rvr.row_bound} rows: rows may have been dropped"
     # concurrency must not change results: the same view (fixed noise field) alone on one lane and on every lane at once
     torch.cuda.synchronize()
-    alone = rvr.render(check_view, 0)[0]["combined_rgb"].clone()
+    alone = rvr.render(check_view, 0)[0]["combined_rgb"]
     rvr.join()
     torch.cuda.synchronize()
+    alone = alone.clone()  # (after the join: this stream has not seen the lane's work before)
     together = [rvr.render(check_view, li)[0]["combined_rgb"] for li in range(n_lanes)]
     rvr.join()
     torch.cuda.synchronize()
@@ -696,9 +698,9 @@ def main():
             n_now = ops.checked_count(ret_["st_pcl_rgb_count"], "pgdvs_static_aggregate")
             assert rv.row_bound is None or n_now < rv.row_bound, f"{label}: the cloud filled its buffer"
             torch.cuda.synchronize()
-            ret1, _ = rv.render(vs[0], 0)
+            _, main1 = rv.render(vs[0], 0)
             rv.join()
-            counters = model.view_counters() if hasattr(model, "view_counters") else None
+            counters = model.view_counters(main1) if rv.native else None
             o = {"frames_per_s": round(n_sc / dt, 2), "ms_per_view": round(dt / n_sc * 1e3, 3), "steps": n_sc,
                  "static_points": n_now, "static_points_per_pixel": round(n_now / (H * W), 3),
                  "us_per_million_points": round(dt / n_sc * 1e6 / (n_now / 1e6), 1), "counters": counters}

@@ -458,6 +458,23 @@ int64_t pgdvs_view_geo_desc_size(void);
 int64_t pgdvs_view_geo_workspace_bytes(const pgdvs_view_geo_desc *desc);
 int pgdvs_view_geo_forward(const pgdvs_view_geo_desc *desc, void *workspace, int64_t workspace_bytes,
                            pgdvs_stream_t stream);
+/* What the fast paths of the LAST pgdvs_view_geo_forward on this (description, workspace) left to their slower exits, read
+ * from device words the kernels write anyway: counters_dev = DEVICE int64[PGDVS_VIEW_COUNTERS], written on `stream` (enqueue
+ * it behind the forward call, before the workspace is used again). */
+#define PGDVS_VIEW_CNT_STATIC_ROWS 0         /* rows of the static cloud (device count)                                   */
+#define PGDVS_VIEW_CNT_RASTER_ENTRIES 1      /* tile-list entries of the rasteriser                                       */
+#define PGDVS_VIEW_CNT_RASTER_LONGEST 2      /* longest tile list                                                         */
+#define PGDVS_VIEW_CNT_RASTER_TILES_LONG 3   /* tiles whose list exceeds the LDS-sorted path's 2048 entries (general path) */
+#define PGDVS_VIEW_CNT_RASTER_TILES_TIES 4   /* tiles the sorted path handed to the general path for > 64 equal depths     */
+#define PGDVS_VIEW_CNT_KNN_QUERIES 5         /* points of the dynamic cloud the outlier filter searched                   */
+#define PGDVS_VIEW_CNT_KNN_TO_RING 6         /* queries the thread-per-query pass left to the ring search                 */
+#define PGDVS_VIEW_CNT_KNN_TO_COARSE 7       /* queries the ring search left to the coarse grid                           */
+#define PGDVS_VIEW_CNT_KNN_TO_EXHAUSTIVE 8   /* queries scanned exhaustively                                              */
+#define PGDVS_VIEW_CNT_AGG_FP64_POINTS 9     /* aggregation: points with projections the fp32 screening left to the fp64 queue */
+#define PGDVS_VIEW_CNT_AGG_REFERENCE_ORDER 10 /* aggregation: projections evaluated in the reference's operation order      */
+#define PGDVS_VIEW_COUNTERS 12
+int pgdvs_view_geo_counters(const pgdvs_view_geo_desc *desc, const void *workspace, int64_t workspace_bytes,
+                            int64_t *counters_dev, pgdvs_stream_t stream);
 /* host enqueue statistics of pgdvs_view_geo_forward since the last call of this function: calls made and the
  * wall-clock seconds spent inside them (bench.py's host_enqueue figure); resets both. */
 void pgdvs_view_geo_host_stats(int64_t *calls, double *seconds);

@@ -30,7 +30,12 @@ constexpr int kRingCap = 24;
 // After the thread-per-query pass the ring search only sees the sparse remainder, whose long
 // searches are no longer hidden behind the bulk: hand them to the coarse grid after a few rings.
 constexpr int kRingCapAfterTpq = 3;
-constexpr float kTargetPerCellDefault = 24.0f;
+// points per occupied cell the grid aims at for K + 1 = 51 (scaled with K + 1).  Round 4 (tools/r04_knn_h.sh, the
+// benchmark's 311 k-point cloud): the thread-per-query pass costs 223 us at h = 4.6e-3 (24 per cell), 195 us at 4.1e-3,
+// 185 us at 4.0e-3 (18 per cell: a quarter fewer candidates in the 3 x 3 x 3 block, the 51-ball still inside it for
+// 99.8 % of the queries: 613 instead of 43 of 311 k go to the ring search, whose launch stays at 21 us) and 180 us at
+// ~3.5e-3, where the ring search grows to 28 us.
+constexpr float kTargetPerCellDefault = 18.0f;
 constexpr float kTrialCoarser = 4.0f;
 
 struct GridParams {
@@ -1225,6 +1230,16 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   off += align_up((qcap > 0 ? qcap : 1) * 4, 256);
   w.total_bytes = off;
   return w;
+}
+
+// the device-side exit counters the last search on this workspace left behind: queries the thread-per-query pass handed to
+// the ring search, queries the ring search handed to the coarse grid, queries scanned exhaustively
+void knn_grid_counter_words(const void *workspace, int64_t capacity, int64_t qcapacity, const int32_t **to_ring,
+                            const int32_t **to_coarse, const int32_t **to_exhaustive) {
+  const GridWs w = grid_ws_layout(const_cast<void *>(workspace), capacity, qcapacity);
+  *to_ring = w.open_count;
+  *to_coarse = w.fb_count;
+  *to_exhaustive = w.fb2_count;
 }
 
 int64_t knn_grid_workspace_bytes(int64_t capacity, int64_t qcapacity) {

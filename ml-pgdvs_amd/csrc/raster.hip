@@ -415,7 +415,7 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
                    const float *__restrict__ feat, int64_t feat_stride, float radius, int H, int W,
                    int ntx, int nty, int tiles_per_xcd, int64_t *__restrict__ idx_out,
                    float *__restrict__ zbuf_out, float *__restrict__ dist_out,
-                   float *__restrict__ rgb_out, int rgb_planar, float *__restrict__ mask_out) {
+                   float *__restrict__ rgb_out, int rgb_planar, float *__restrict__ mask_out, int32_t *__restrict__ stats) {
   __shared__ float2 s_xy[kSortCap];         // rank order: NDC x, y (general path: staging of 256 entries)
   __shared__ uint2 s_kz[kSortCap];          // bucket order: (z bits, id); after ranking, rank order: (id, z bits)
   __shared__ float4 s_wave[4][68];          // per-wave strip of culled points (+ padding)
@@ -553,6 +553,7 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
     }
     __syncthreads();
     sorted_path = s_flag == 0;
+    if (!sorted_path && tid == 0) atomicAdd(&stats[0], 1);  // (> kSortMaxBucket equal depths in one bucket: rare)
     if (sorted_path) {
       // ---- 4. keys into bucket order
 #pragma unroll
@@ -810,6 +811,7 @@ static int64_t max_tiles_per_point(float radius, int H, int W) {
 
 struct RasterWs {
   int32_t *tile_count, *cursor, *offsets;
+  int32_t *stats;  // [64] zeroed per call with the counters: [0] tiles the sorted path handed to the general path for equal depths
   float4 *lists;  // 16-byte entries (x_ndc, y_ndc, id, z)
   int64_t list_capacity;
   int64_t total_bytes;
@@ -824,6 +826,8 @@ static RasterWs raster_ws_layout(void *base, int64_t n, int H, int W, float radi
   off += align_up(ntiles * 4, 256);
   w.cursor = reinterpret_cast<int32_t *>(p + off);
   off += align_up(ntiles * 4, 256);
+  w.stats = reinterpret_cast<int32_t *>(p + off);
+  off += 256;
   w.offsets = reinterpret_cast<int32_t *>(p + off);
   off += align_up((ntiles + 1) * 4, 256);
   w.list_capacity = (n > 0 ? n : 1) * max_tiles_per_point(radius, H, W);
@@ -831,6 +835,47 @@ static RasterWs raster_ws_layout(void *base, int64_t n, int H, int W, float radi
   off += align_up(w.list_capacity * 16, 256);
   w.total_bytes = off;
   return w;
+}
+
+// what the last rasterisation on this workspace did: out[0] list entries, out[1] longest tile list, out[2] tiles whose list was
+// too long for the sorted path (general path), out[3] tiles the sorted path gave up on for equal depths.  One workgroup.
+__global__ void __launch_bounds__(1024) raster_counters_kernel(const int32_t *__restrict__ offsets, int ntiles,
+                                                                const int32_t *__restrict__ stats, int64_t *__restrict__ out) {
+  __shared__ int s_max[16], s_long[16];
+  int mx = 0, nlong = 0;
+  for (int t = threadIdx.x; t < ntiles; t += 1024) {
+    const int n = offsets[t + 1] - offsets[t];
+    mx = n > mx ? n : mx;
+    nlong += n > kSortCap ? 1 : 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const int a = __shfl_xor(mx, off, 64);
+    mx = a > mx ? a : mx;
+    nlong += __shfl_xor(nlong, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_max[threadIdx.x >> 6] = mx;
+    s_long[threadIdx.x >> 6] = nlong;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int m = 0, l = 0;
+    for (int w = 0; w < 16; ++w) {
+      m = s_max[w] > m ? s_max[w] : m;
+      l += s_long[w];
+    }
+    out[0] = offsets[ntiles];
+    out[1] = m;
+    out[2] = l;
+    out[3] = stats[0];
+  }
+}
+
+void raster_counters(const void *workspace, int64_t n_rows, int H, int W, float radius, int64_t *out_dev, hipStream_t st) {
+  const RasterWs ws = raster_ws_layout(const_cast<void *>(workspace), n_rows, H, W, radius);
+  const int ntiles = (int)(cdiv(W, kTile) * cdiv(H, kTile));
+  PGDVS_LAUNCH("raster_counters", raster_counters_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)ws.offsets, ntiles,
+               (const int32_t *)ws.stats, out_dev);
 }
 
 }  // namespace pgdvs
@@ -853,7 +898,8 @@ static void launch_tile(dim3 grid, hipStream_t st, const RasterWs &ws, const flo
                         int tiles_per_xcd, int64_t *idx, float *zbuf, float *dist2, float *rgb,
                         int rgb_planar, float *mask) {
   PGDVS_LAUNCH("raster_tile", raster_tile_kernel<K>, grid, dim3(256), 0, st, (const float4 *)ws.lists, (const int32_t *)ws.offsets,
-               ws.list_capacity, feat, feat_stride, radius, H, W, ntx, nty, tiles_per_xcd, idx, zbuf, dist2, rgb, rgb_planar, mask);
+               ws.list_capacity, feat, feat_stride, radius, H, W, ntx, nty, tiles_per_xcd, idx, zbuf, dist2, rgb, rgb_planar, mask,
+               ws.stats);
 }
 
 static int points_raster_impl(const float *pts, int64_t pts_stride, const float *feat, int64_t feat_stride, int64_t n_points,

@@ -138,6 +138,9 @@ __global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, float 
 struct ByteStamp {  // one occupancy byte per (frame, pixel): frame 0's chip-filling push (coalesced byte stores)
   uint8_t *occ_all;
   int64_t P;
+  // two counters of the call (pgdvs_view_geo_counters): [0] points whose projections the fp32 form left to the fp64 queue,
+  // [1] projections that went all the way to the reference operation order
+  unsigned *stat;
   __device__ __forceinline__ void operator()(int f, int q) const { occ_all[(int64_t)f * P + q] = 1; }
 };
 template <class Stamp>
@@ -206,6 +209,7 @@ __device__ __attribute__((noinline)) void mark_fp64(const ProjF64 *__restrict__ 
       return;
     }
   }
+  atomicAdd(stamp.stat + 1, 1u);  // (one projection in ~1e9)
   mark_reference_order(pj, x, y, z, H, W, f, stamp);
 }
 
@@ -329,7 +333,9 @@ __device__ __forceinline__ unsigned screen_frames(const PushConsts *__restrict__
     const float gx = qx - floorf(qx), gy = qy - floorf(qy);
     const float dx = fminf(gx, 1.0f - gx), dy = fminf(gy, 1.0f - gy);
     // (0 * (qx + qy): NaN for an infinite or NaN quotient, so that "sure" still implies finite coordinates)
-    const bool sure = __builtin_fmaf(qx + qy, 0.0f, u) < c.e[2];
+    // (|s2| < 2^100: beyond that v_rcp_f32's result is denormal -- flushed or short of 24 significant bits -- and the
+    // 1-ulp assumption behind the bound does not hold; such projections, coordinates around 1e30, take the fp64 queue)
+    const bool sure = (__builtin_fmaf(qx + qy, 0.0f, u) < c.e[2]) & (fabsf(s2) < 0x1p100f);
     const bool clear = fminf(dx, dy) - u > c.e[1];
     const float mi = fminf(fminf(qx, wm1 - qx), fminf(qy, hm1 - qy));
     if (sure & clear & (mi >= 0.0f)) stamp(f, (int)qy * W + (int)qx);
@@ -364,6 +370,7 @@ __device__ __forceinline__ void queue_doubtful(uint4 *s_q, int *s_qn, const unsi
     if (slot < kQueue) {
       s_q[slot] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), dmask);
     } else {  // queue full (degenerate views): decide in place
+      atomicAdd(stamp.stat, 1u);
       for (unsigned m = dmask; m; m &= m - 1) {
         const int f = fa + __builtin_ctz(m);
         mark_fp64(proj + f, x, y, z, H, W, f, stamp);
@@ -376,6 +383,7 @@ __device__ __forceinline__ void queue_doubtful(uint4 *s_q, int *s_qn, const unsi
   // drain -- and with it the barriers inside -- is the same on all of them
   __syncthreads();
   if (last || qn + kThreads > kQueue) {
+    if (threadIdx.x == 0 && qn > 0) atomicAdd(stamp.stat, (unsigned)qn);  // (one atomic per drain, nothing returned)
     for (int e = threadIdx.x; e < qn; e += kThreads) {
       const uint4 q = s_q[e];
       const float px = __uint_as_float(q.x), py = __uint_as_float(q.y), pz = __uint_as_float(q.z);
@@ -399,12 +407,13 @@ template <int kQueue>
 __global__ void __launch_bounds__(kPushThreads)
 agg_push_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ cnts, int src,
                 const ProjF64 *__restrict__ proj, const PushConsts *__restrict__ pc, int f_lo, int f_hi, int fpg, int H, int W,
-                uint8_t *__restrict__ occ_all, const int32_t *__restrict__ sel_pix, AppendSrc app, CamBlock cam) {
+                uint8_t *__restrict__ occ_all, const int32_t *__restrict__ sel_pix, AppendSrc app, CamBlock cam,
+                unsigned *__restrict__ stat) {
   __shared__ uint4 s_q[kQueue];
   __shared__ int s_qn;
   const int64_t begin = cnts[src], end = cnts[src + 1];
   if (begin >= end) return;
-  const ByteStamp stamp{occ_all, (int64_t)H * W};
+  const ByteStamp stamp{occ_all, (int64_t)H * W, stat};
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
   if (threadIdx.x == 0) s_qn = 0;
   __syncthreads();
@@ -684,7 +693,7 @@ template <int kQueue>
 __global__ void __launch_bounds__(kStepThreads)
 agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__ sel16, int64_t Wd, int src,
                 const ProjF64 *__restrict__ proj, const PushConsts *__restrict__ pc, int f_hi, int fpg, int H, int W,
-                AppendSrc app, CamBlock cam) {
+                AppendSrc app, CamBlock cam, unsigned *__restrict__ stat) {
   __shared__ uint16_t s_list[kStepThreads * kStepPx];  // (thread << 4 | pixel) of every selected pixel, 8 KB
   __shared__ uint4 s_q[kQueue];
   __shared__ int s_qn;
@@ -705,7 +714,7 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
   for (uint32_t m = bits; m; m &= m - 1) s_list[slot++] = (uint16_t)((tid << 4) | __builtin_ctz(m));
   if (tid == 0) s_qn = 0;
   __syncthreads();
-  const ByteStamp stamp{occ_all, (int64_t)H * W};
+  const ByteStamp stamp{occ_all, (int64_t)H * W, stat};
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
   for (int e0 = 0; e0 < n; e0 += kStepThreads) {
     const int e = e0 + tid;
@@ -900,6 +909,12 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   return w;
 }
 
+// the two statistics words the last aggregation on this workspace left behind (see ByteStamp::stat)
+const unsigned *agg_stat_words(const void *workspace, int S, int H, int W, int64_t capacity) {
+  const AggWs w = agg_ws_layout(const_cast<void *>(workspace), S, H, W, capacity);
+  return reinterpret_cast<const unsigned *>(w.error) + 1;
+}
+
 }  // namespace pgdvs
 
 using namespace pgdvs;
@@ -1083,12 +1098,12 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       PGDVS_LAUNCH("agg_push0", agg_push_kernel<kPushQueue>, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
                    (const float *)ws.xyz, (const int64_t *)ws.cnts, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, i + 1, S, fpg_i, H, W,
                    ws.occ,
-                   (const int32_t *)nullptr, frame_src(i), cams[(size_t)i]);
+                   (const int32_t *)nullptr, frame_src(i), cams[(size_t)i], reinterpret_cast<unsigned *>(ws.error) + 1);
     } else {
       PGDVS_LAUNCH("agg_push", agg_push_kernel<kPushQueueSmall>, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
                    (const float *)ws.xyz, (const int64_t *)ws.cnts, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, i + 1, S, fpg_i, H, W,
                    ws.occ,
-                   (const int32_t *)ws.sel_pix, frame_src(i), cams[(size_t)i]);
+                   (const int32_t *)ws.sel_pix, frame_src(i), cams[(size_t)i], reinterpret_cast<unsigned *>(ws.error) + 1);
     }
   };
   if (!bit_chain) {
@@ -1134,7 +1149,7 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       const unsigned gy = i + 1 < S ? (unsigned)cdiv(S - 1 - i, sfpg) : 1u;
       PGDVS_LAUNCH("agg_step", agg_step_kernel<kPushQueueSmall>, dim3(gx, gy), dim3(kStepThreads), 0, st, a, ws.occ,
                    reinterpret_cast<uint16_t *>(ws.sel), ws.Wd, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, sfpg, H, W,
-                   frame_src(i), cams[(size_t)i]);
+                   frame_src(i), cams[(size_t)i], reinterpret_cast<unsigned *>(ws.error) + 1);
     }
   }
   PGDVS_LAUNCH("agg_count", agg_count_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,

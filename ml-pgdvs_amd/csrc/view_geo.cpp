@@ -18,6 +18,27 @@ namespace pgdvs {
 int view_prep(const float *flat_tgt, const float *flat_src, const float *time_src, const float *time_tgt, float *blocks,
               float *times, hipStream_t st);  // dyn.hip
 
+// counters of the sub-workspaces (raster.hip, knn_grid.hip, static_agg.hip)
+void raster_counters(const void *workspace, int64_t n_rows, int H, int W, float radius, int64_t *out_dev, hipStream_t st);
+void knn_grid_counter_words(const void *workspace, int64_t capacity, int64_t qcapacity, const int32_t **to_ring,
+                            const int32_t **to_coarse, const int32_t **to_exhaustive);
+const unsigned *agg_stat_words(const void *workspace, int S, int H, int W, int64_t capacity);
+
+__global__ void view_counters_kernel(const int64_t *__restrict__ static_rows, int64_t static_rows_host,
+                                     const int32_t *__restrict__ knn_queries, const int32_t *__restrict__ to_ring,
+                                     const int32_t *__restrict__ to_coarse, const int32_t *__restrict__ to_exhaustive,
+                                     const unsigned *__restrict__ agg_stat, int64_t *__restrict__ out) {
+  if (threadIdx.x != 0) return;
+  out[PGDVS_VIEW_CNT_STATIC_ROWS] = static_rows ? *static_rows : static_rows_host;
+  out[PGDVS_VIEW_CNT_KNN_QUERIES] = knn_queries ? *knn_queries : 0;
+  out[PGDVS_VIEW_CNT_KNN_TO_RING] = to_ring ? *to_ring : 0;
+  out[PGDVS_VIEW_CNT_KNN_TO_COARSE] = to_coarse ? *to_coarse : 0;
+  out[PGDVS_VIEW_CNT_KNN_TO_EXHAUSTIVE] = to_exhaustive ? *to_exhaustive : 0;
+  out[PGDVS_VIEW_CNT_AGG_FP64_POINTS] = agg_stat ? agg_stat[0] : 0;
+  out[PGDVS_VIEW_CNT_AGG_REFERENCE_ORDER] = agg_stat ? agg_stat[1] : 0;
+  for (int k = PGDVS_VIEW_CNT_AGG_REFERENCE_ORDER + 1; k < PGDVS_VIEW_COUNTERS; ++k) out[k] = 0;
+}
+
 namespace {
 
 struct ViewWs {
@@ -189,28 +210,20 @@ int view_forward(const pgdvs_view_geo_desc &d, void *workspace, int64_t workspac
   hipStream_t st = as_stream(stream);
   const int H = d.H, W = d.W;
   VG_TRY(view_prep(d.flat_cam_tgt, d.flat_cam_src, d.time_src, d.time_tgt, w.cams, w.times, st));
-  // ---- dynamic branch geometry: on the side stream when one is given (it depends on nothing the static branch makes)
+  // ---- dynamic branch geometry (it depends on nothing the static branch makes): on the caller's stream ahead of the
+  // static branch, or -- with a side stream -- forked off here and enqueued BEHIND the static branch's launches (the
+  // longer of the two chains: its first kernels should not wait for the host to have enqueued the other ~45)
   hipStream_t side = as_stream(d.side_stream);
+  const bool forked = side != nullptr && side != st;
   hipEvent_t ev_join = nullptr;
-  if (side != nullptr && side != st) {
+  if (forked) {
     hipEvent_t ev_fork = ev_get();
-    ev_join = ev_get();
     hipError_t e = hipEventRecord(ev_fork, st);
     if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
     ev_put(ev_fork);
     if (e != hipSuccess) {
-      ev_put(ev_join);
       set_error("pgdvs_view_geo_forward: fork onto the side stream: %s", hipGetErrorString(e));
       return PGDVS_ERR_LAUNCH;
-    }
-    const int rc = dyn_geometry(d, w, d.side_stream);
-    e = hipEventRecord(ev_join, side);
-    if (rc != PGDVS_OK || e != hipSuccess) {
-      // (the join below must still happen so that the side stream's work is ordered before the caller's next use of `st`)
-      (void)hipStreamWaitEvent(st, ev_join, 0);
-      ev_put(ev_join);
-      if (rc == PGDVS_OK) set_error("pgdvs_view_geo_forward: join event: %s", hipGetErrorString(e));
-      return rc != PGDVS_OK ? rc : PGDVS_ERR_LAUNCH;
     }
   } else {
     VG_TRY(dyn_geometry(d, w, stream));
@@ -237,9 +250,14 @@ int view_forward(const pgdvs_view_geo_desc &d, void *workspace, int64_t workspac
                                      d.K, H, W, nullptr, nullptr, nullptr, d.static_rgb, 1, d.static_mask, w.raster,
                                      w.raster_bytes, stream);
   }
-  if (ev_join != nullptr) {
-    const hipError_t e = hipStreamWaitEvent(st, ev_join, 0);
+  if (forked) {
+    // (whatever happened above, the side stream is joined: its work must be ordered before the caller's next use of `st`)
+    const int rc_dyn = dyn_geometry(d, w, d.side_stream);
+    ev_join = ev_get();
+    hipError_t e = hipEventRecord(ev_join, side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, ev_join, 0);
     ev_put(ev_join);
+    if (rc == PGDVS_OK) rc = rc_dyn;
     if (e != hipSuccess && rc == PGDVS_OK) {
       set_error("pgdvs_view_geo_forward: join: %s", hipGetErrorString(e));
       rc = PGDVS_ERR_LAUNCH;
@@ -285,6 +303,27 @@ PGDVS_API int pgdvs_view_geo_forward(const pgdvs_view_geo_desc *desc, void *work
     g_stat_seconds += dt;
   }
   return rc;
+}
+
+PGDVS_API int pgdvs_view_geo_counters(const pgdvs_view_geo_desc *desc, const void *workspace, int64_t workspace_bytes,
+                                      int64_t *counters_dev, pgdvs_stream_t stream) {
+  PGDVS_REQUIRE(desc && counters_dev, "pgdvs_view_geo_counters: null argument");
+  ViewWs w;
+  VG_TRY(view_layout(*desc, const_cast<void *>(workspace), w));
+  if (!workspace || workspace_bytes < w.total_bytes) {
+    set_error("pgdvs_view_geo_counters: not the workspace of this description");
+    return PGDVS_ERR_WORKSPACE;
+  }
+  const pgdvs_view_geo_desc &d = *desc;
+  hipStream_t st = as_stream(stream);
+  raster_counters(w.raster, w.raster_rows, d.H, d.W, d.radius, counters_dev + PGDVS_VIEW_CNT_RASTER_ENTRIES, st);
+  const int32_t *to_ring = nullptr, *to_coarse = nullptr, *to_exh = nullptr;
+  if (d.remove_outlier) knn_grid_counter_words(w.knn, (int64_t)d.H * d.W, 0, &to_ring, &to_coarse, &to_exh);
+  const unsigned *agg_stat = d.agg_S > 0 ? agg_stat_words(w.agg, d.agg_S, d.H, d.W, d.agg_capacity) : nullptr;
+  PGDVS_LAUNCH("view_counters", view_counters_kernel, dim3(1), dim3(64), 0, st,
+               d.agg_S > 0 ? (const int64_t *)d.agg_count_out : d.st_count_dev, d.st_rows, (const int32_t *)w.cnt, to_ring,
+               to_coarse, to_exh, agg_stat, counters_dev);
+  return check_launch("view_geo_counters");
 }
 
 PGDVS_API void pgdvs_view_geo_host_stats(int64_t *calls, double *seconds) {

@@ -98,6 +98,7 @@ SIGNATURES.update({
     "pgdvs_view_geo_desc_size": (_i64, []),
     "pgdvs_view_geo_workspace_bytes": (_i64, [C.POINTER(ViewGeoDesc)]),
     "pgdvs_view_geo_forward": (_i, [C.POINTER(ViewGeoDesc), _vp, _i64, _vp]),
+    "pgdvs_view_geo_counters": (_i, [C.POINTER(ViewGeoDesc), _vp, _i64, _vp, _vp]),
     "pgdvs_view_geo_host_stats": (None, [C.POINTER(_i64), C.POINTER(C.c_double)]),
 })
 

@@ -542,6 +542,24 @@ def view_geo_forward(state: ViewGeoState, *, H: int, W: int, flat_cam_tgt, flat_
     return out
 
 
+VIEW_COUNTER_NAMES = ("static_rows", "raster_list_entries", "raster_longest_tile_list", "raster_tiles_general_path_long_list",
+                      "raster_tiles_general_path_equal_depths", "knn_queries", "knn_queries_to_ring_search",
+                      "knn_queries_to_coarse_grid", "knn_queries_scanned_exhaustively", "agg_points_in_fp64_queue",
+                      "agg_projections_in_reference_order")
+
+
+def view_geo_counters(state: ViewGeoState) -> dict:
+    """What the fast paths of the last ``view_geo_forward`` on ``state`` left to their slower exits
+    (``pgdvs_view_geo_counters``; enqueued on the current stream, which must be the one the view ran on; synchronises)."""
+    if state.workspace is None:
+        raise PgdvsHipError("view_geo_counters: no view has been rendered with this state")
+    out = torch.empty(12, dtype=torch.int64, device=state.workspace.device)
+    check(_lib.load().pgdvs_view_geo_counters(C.byref(state.desc), state.workspace.data_ptr(), state.ws_bytes, out.data_ptr(), _stream()),
+          "pgdvs_view_geo_counters")
+    vals = out.tolist()
+    return {k: int(vals[i]) for i, k in enumerate(VIEW_COUNTER_NAMES)}
+
+
 def view_geo_host_stats():
     """(calls, seconds) spent inside ``pgdvs_view_geo_forward`` since the last call of this function (resets)."""
     calls, secs = C.c_int64(0), C.c_double(0.0)

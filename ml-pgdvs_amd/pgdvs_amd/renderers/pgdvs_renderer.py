@@ -135,6 +135,17 @@ class PGDVSRenderer(PGDVSBaseRenderer):
             ret["st_pcl_rgb"], ret["st_pcl_xyz"], ret["st_pcl_rgb_count"] = r["st_pcl_rgb"][None], r["st_pcl_xyz"][None], r["st_pcl_rgb_count"]
         return ret
 
+    def view_counters(self, stream=None):
+        """device counters of the last native view rendered on ``stream`` (default: the current one): list lengths and
+        the number of tiles / queries / points that left a fast path (``ops.view_geo_counters``); synchronises"""
+        dev = torch.cuda.current_device()
+        s = stream if stream is not None else torch.cuda.current_stream()
+        st = self.__dict__.get("_view_states", {}).get((s.device.index if hasattr(s, "device") else dev, s.cuda_stream))
+        if st is None:
+            raise ops.PgdvsHipError("view_counters: no native view has been rendered on this stream")
+        with torch.cuda.stream(s):
+            return ops.view_geo_counters(st)
+
     def forward(self, data, render_cfg={}, disable_tqdm=False, for_debug=False):
         if not for_debug and self._native_view_ok(data, render_cfg):
             return self._forward_native(data, render_cfg)

@@ -409,7 +409,7 @@ def main():
                     host_wait[0] += time.perf_counter() - w0
                 # per-kernel HIP events need one view at a time, so that a kernel's duration is its own and not the
                 # queueing behind the other lanes' kernels
-                ret, main = rv.render(vs[(j + rank) % n_views], 0 if profile else j, out=gather.slot())
+                ret, main = rv.render(vs[(j + rank) % n_views], 0 if profile else j, out=gather.slot(), use_side=not profile)
                 with torch.cuda.stream(main):
                     gather.submit(ret["combined_rgb"])
                     ev = torch.cuda.Event()

@@ -98,6 +98,95 @@ __device__ __forceinline__ bool tile_box_within_2x2(const RasterCam &rc, float r
   return 2.0f * rpx + 2.0f < (float)kTile && 2.0f * rpy + 2.0f < (float)kTile;
 }
 
+// ---- a conservative depth bound per tile, BEFORE the binning (round 4) ---------------------------------------------
+// Behind K points whose discs certainly cover every pixel of a tile nothing can enter any of the tile's per-pixel lists:
+// the binning passes drop such (point, tile) pairs, and the tile pass neither loads nor sorts them.
+//   pass 0a: zmin[pixel] = smallest view depth among the points whose CENTRE is nearest to that pixel (atomic minimum on the
+//            depth's bit pattern: depths are >= 0, so the patterns order like the values);
+//   pass 0b: per b x b block of pixels (b = 4, or 2 for small radii) the K-th smallest of its per-pixel minima -- K
+//            different points, each within (b - 1/2) sqrt(2) pixels of every pixel centre of the block, which is inside
+//            every disc when the radius exceeds that by the margin the host checks -- and per tile the maximum over its
+//            blocks (+inf when a block holds fewer than K such points).
+// A pair is dropped only for z > bound (strictly): the K covering points then precede it in the (z, id) order at every
+// pixel of the tile, whatever the ids.  On a smooth surface seen obliquely this removes a quarter of the entries (the far
+// side of every tile's list: tools/raster_prune_sim.py, 0.76 kept on the benchmark's cloud); on clouds from noisy depth,
+// where the depth order inside a disc is random, five sixths (0.17 kept) -- the statistics under which lists otherwise
+// grow with every source frame.
+// The bound pays for itself only where lists are long: it costs a pass over the cloud with one atomic per point (25-40 us
+// at 3.5 M points), and on the benchmark's nominal cloud (1.7 points per pixel, depth order set by the surface's slope) the
+// quarter of the entries it removes is worth 12 us of the tile pass.  `gate_rows` (a density: rows >= gate x pixels, the count
+// is device-side) switches the three passes and the tests in the binning on together; below it the passes leave at once.
+__device__ __forceinline__ int64_t raster_rows(int64_t n_host, const int64_t *__restrict__ n_dev) {
+  int64_t n = n_dev ? *n_dev : n_host;
+  return n > n_host ? n_host : (n < 0 ? 0 : n);
+}
+
+__global__ void __launch_bounds__(256)
+raster_zmin_init_kernel(int64_t n_host, const int64_t *__restrict__ n_dev, int64_t gate_rows, uint4 *__restrict__ zmin16, int64_t n16) {
+  if (raster_rows(n_host, n_dev) < gate_rows) return;
+  const uint4 v = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) zmin16[i] = v;
+}
+
+__global__ void __launch_bounds__(256)
+raster_zmin_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_host, const int64_t *__restrict__ n_dev,
+                   int64_t gate_rows, const float *__restrict__ cam, int H, int W, unsigned *__restrict__ zmin) {
+  const int64_t n = raster_rows(n_host, n_dev);
+  if (n < gate_rows) return;
+  const RasterCam rc = make_raster_cam(cam, H, W);
+  const float offx = rc.range_x / 2.0f, offy = rc.range_y / 2.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float *X = pts + i * pts_stride;
+    const float3 p = point_to_ndc(rc, X[0], X[1], X[2]);
+    if (!(p.z >= 0.0f) || !isfinite(p.x) || !isfinite(p.y)) continue;
+    // the centre in pixel-index units, exactly as tile_box inverts PixToNonSquareNdc
+    const float xc = (float)(W - 1) - ((p.x + offx) * (float)W - offx) / rc.range_x;
+    const float yc = (float)(H - 1) - ((p.y + offy) * (float)H - offy) / rc.range_y;
+    const float xr = rintf(xc), yr = rintf(yc);
+    if (!(xr >= 0.0f && xr <= (float)(W - 1) && yr >= 0.0f && yr <= (float)(H - 1))) continue;
+    atomicMin(&zmin[(size_t)(int)yr * W + (int)xr], __float_as_uint(p.z + 0.0f));
+  }
+}
+
+// one workgroup per tile, one thread per pixel; kB x kB pixels per block = kB * kB adjacent lanes
+template <int kB>
+__global__ void __launch_bounds__(256)
+raster_bound_kernel(const unsigned *__restrict__ zmin, int64_t n_host, const int64_t *__restrict__ n_dev, int64_t gate_rows, int H,
+                    int W, int ntx, int K, float *__restrict__ tile_bound) {
+  if (raster_rows(n_host, n_dev) < gate_rows) return;  // (the binning passes apply the same gate: the bounds are not read)
+  constexpr int kG = kB * kB;            // lanes per block
+  constexpr int kPerRow = kTile / kB;    // blocks per tile row
+  __shared__ unsigned s_max;
+  const int tile = blockIdx.x, ty = tile / ntx, tx = tile - ty * ntx;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int blk = tid / kG, j = tid % kG;
+  const int x = tx * kTile + (blk % kPerRow) * kB + (j % kB), y = ty * kTile + (blk / kPerRow) * kB + (j / kB);
+  const bool inside = x < W && y < H;
+  const unsigned v = inside ? zmin[(size_t)y * W + x] : 0xffffffffu;
+  if (tid == 0) s_max = 0u;
+  __syncthreads();
+  // rank of this lane's minimum among its block's (ties by lane), and whether the block holds a pixel of the image
+  const int base = lane & ~(kG - 1);
+  int rank = 0;
+  bool any_inside = inside;
+#pragma unroll
+  for (int o = 1; o < kG; ++o) {
+    const int other = base | ((lane + o) & (kG - 1));
+    const unsigned w = (unsigned)__shfl((int)v, other, 64);
+    any_inside |= (bool)__shfl((int)inside, other, 64);
+    rank += (w < v) | ((w == v) & (other < lane)) ? 1 : 0;
+  }
+  if (any_inside) {
+    if (K > kG) {
+      if (j == 0) atomicMax(&s_max, 0x7f800000u);
+    } else if (rank == K - 1) {
+      atomicMax(&s_max, v < 0x7f800000u ? v : 0x7f800000u);  // (no point: +inf -- nothing may be dropped from this tile)
+    }
+  }
+  __syncthreads();
+  if (tid == 0) tile_bound[tile] = __uint_as_float(s_max);
+}
+
 // Binning, pass 1: entries per tile.  A workgroup takes one contiguous chunk of the cloud (a few rows of
 // one source frame: a few hundred tiles) and counts into an LDS table first, so that a tile costs the
 // chunk one global atomic instead of one per run of lanes.  Images with more tiles than the table holds
@@ -116,7 +205,8 @@ __global__ void __launch_bounds__(kBinThreads)
 raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_host,
                             const int64_t *__restrict__ n_dev, const float *__restrict__ cam,
                             float radius, int H, int W, int ntx, int nty,
-                            int32_t *__restrict__ tile_count, int32_t *__restrict__ status) {
+                            int32_t *__restrict__ tile_count, int32_t *__restrict__ status,
+                            const float *__restrict__ tile_bound, int64_t gate_rows) {
   __shared__ int s_tab[kSlots];  // one counter per tile (unused when the image has more tiles)
   // a device-side count never exceeds the rows the caller sized the workspace for (and a
   // negative one -- the aggregation's error status -- renders nothing)
@@ -125,6 +215,7 @@ raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, i
   // for (the rows beyond it are NOT drawn), 2 = the count is negative (the producer's own error status), 0 = fine
   if (status != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *status = n > n_host ? 1 : (n < 0 ? 2 : 0);
   n = n > n_host ? n_host : (n < 0 ? 0 : n);
+  if (n < gate_rows) tile_bound = nullptr;
   RasterCam rc = make_raster_cam(cam, H, W);
   const int ntiles = ntx * nty;
   const bool local = ntiles <= kSlots;
@@ -150,9 +241,11 @@ raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, i
     }
     TileBox b;
     b.tx0 = 1; b.tx1 = 0; b.ty0 = 1; b.ty1 = 0;
+    float pz = 0.0f;
     if (i < n) {
       float3 p = point_to_ndc(rc, cur[0], cur[1], cur[2]);
       b = tile_box(rc, p, radius, H, W, ntx, nty);
+      pz = p.z + 0.0f;
     }
     // (a disc narrower than a tile side touches at most 2 x 2 tiles: four fixed rounds instead of two wave-wide
     // maxima -- 2 x 26 instructions, as many as the projection -- to find the round count)
@@ -165,6 +258,7 @@ raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, i
       for (int jx = 0; jx < nx; ++jx) {
         int tx = b.tx0 + jx, ty = b.ty0 + jy;
         int t = (tx <= b.tx1 && ty <= b.ty1) ? ty * ntx + tx : -1;
+        if (tile_bound != nullptr && t >= 0 && pz > tile_bound[t]) t = -1;  // behind K covering points: see raster_bound_kernel
         if (local)
           wave_tile_count_lds(s_tab, t);
         else
@@ -244,12 +338,13 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
                    const float *__restrict__ cam, float radius, int H, int W, int ntx, int nty,
                    const int32_t *__restrict__ offsets,
                    int32_t *__restrict__ cursor, float4 *__restrict__ lists,
-                   int64_t list_capacity) {
+                   int64_t list_capacity, const float *__restrict__ tile_bound, int64_t gate_rows) {
   __shared__ int s_tab[kSlots];  // one counter per tile (unused on the slow path)
   // a device-side count never exceeds the rows the caller sized the workspace for (and a
   // negative one -- the aggregation's error status -- renders nothing)
   int64_t n = n_dev ? *n_dev : n_host;
   n = n > n_host ? n_host : (n < 0 ? 0 : n);
+  if (n < gate_rows) tile_bound = nullptr;
   RasterCam rc = make_raster_cam(cam, H, W);
   const int ntiles = ntx * nty;
   // tile boxes of at most 2 x 2 tiles (disc diameter + margins within one tile side) and a table that holds
@@ -288,6 +383,17 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
       }
       t0[u] = b.ty0 * ntx + b.tx0;
       span[u] = (b.tx1 - b.tx0 + 1) | ((b.ty1 - b.ty0 + 1) << 16);  // (0, 0) for a point that touches no tile
+      // tiles of the 2 x 2 box (bits 8-11: jy * 2 + jx) whose depth bound this point lies behind -- the same test on the
+      // same values as in the counting pass
+      if (tile_bound != nullptr && local) {
+        unsigned behind = 0;
+#pragma unroll
+        for (int jy = 0; jy < kFillMaxSpan; ++jy)
+#pragma unroll
+          for (int jx = 0; jx < kFillMaxSpan; ++jx)
+            if (jx < (span[u] & 0xff) && jy < (span[u] >> 16) && ez[u] > tile_bound[t0[u] + jy * ntx + jx]) behind |= 1u << (8 + jy * 2 + jx);
+        span[u] |= (int)behind;
+      }
     }
     if (local) {
       unsigned rank[kFillPer][kFillMaxSpan];  // two 16-bit ranks per word: [u][jy] holds jx = 0, 1
@@ -298,7 +404,8 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
           rank[u][jy] = 0;
 #pragma unroll
           for (int jx = 0; jx < kFillMaxSpan; ++jx) {
-            const int t = (jx < (span[u] & 0xffff) && jy < (span[u] >> 16)) ? t0[u] + jy * ntx + jx : -1;
+            const int t = (jx < (span[u] & 0xff) && jy < (span[u] >> 16) && !((span[u] >> (8 + jy * 2 + jx)) & 1))
+                              ? t0[u] + jy * ntx + jx : -1;
             rank[u][jy] |= ((unsigned)wave_tile_reserve_lds(s_tab, t) & 0xffffu) << (16 * jx);  // < kChunk <= 65536
           }
         }
@@ -331,7 +438,7 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
         for (int jy = 0; jy < kFillMaxSpan; ++jy)
 #pragma unroll
           for (int jx = 0; jx < kFillMaxSpan; ++jx)
-            if (jx < (span[u] & 0xffff) && jy < (span[u] >> 16)) {
+            if (jx < (span[u] & 0xff) && jy < (span[u] >> 16) && !((span[u] >> (8 + jy * 2 + jx)) & 1)) {
               const int t = t0[u] + jy * ntx + jx;
               const int64_t pos = (int64_t)s_tab[t] + (int)((rank[u][jy] >> (16 * jx)) & 0xffffu);
               if (pos < list_capacity) lists[pos] = ent;
@@ -346,7 +453,8 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
         const int nx = wave_max_i32_scalar(span[u] & 0xffff), ny = wave_max_i32_scalar(span[u] >> 16);
         for (int jy = 0; jy < ny; ++jy)
           for (int jx = 0; jx < nx; ++jx) {
-            const int t = (jx < (span[u] & 0xffff) && jy < (span[u] >> 16)) ? t0[u] + jy * ntx + jx : -1;
+            int t = (jx < (span[u] & 0xffff) && jy < (span[u] >> 16)) ? t0[u] + jy * ntx + jx : -1;
+            if (tile_bound != nullptr && t >= 0 && ez[u] > tile_bound[t]) t = -1;
             const int slot = wave_tile_reserve(cursor, t);
             if (t >= 0) {
               const int64_t pos = (int64_t)offsets[t] + slot;
@@ -812,6 +920,8 @@ static int64_t max_tiles_per_point(float radius, int H, int W) {
 struct RasterWs {
   int32_t *tile_count, *cursor, *offsets;
   int32_t *stats;  // [64] zeroed per call with the counters: [0] tiles the sorted path handed to the general path for equal depths
+  unsigned *zmin;      // [H*W] per-pixel minimum depth of the point centres (bit patterns), filled per call
+  float *tile_bound;   // [ntiles] depth behind which nothing can enter the tile's lists
   float4 *lists;  // 16-byte entries (x_ndc, y_ndc, id, z)
   int64_t list_capacity;
   int64_t total_bytes;
@@ -830,6 +940,10 @@ static RasterWs raster_ws_layout(void *base, int64_t n, int H, int W, float radi
   off += 256;
   w.offsets = reinterpret_cast<int32_t *>(p + off);
   off += align_up((ntiles + 1) * 4, 256);
+  w.tile_bound = reinterpret_cast<float *>(p + off);
+  off += align_up(ntiles * 4, 256);
+  w.zmin = reinterpret_cast<unsigned *>(p + off);
+  off += align_up((int64_t)H * W * 4, 256);
   w.list_capacity = (n > 0 ? n : 1) * max_tiles_per_point(radius, H, W);
   w.lists = reinterpret_cast<float4 *>(p + off);
   off += align_up(w.list_capacity * 16, 256);
@@ -970,6 +1084,37 @@ static int points_raster_impl(const float *pts, int64_t pts_stride, const float 
     return PGDVS_ERR_LAUNCH;
   }
   const bool small_table = ntiles <= kBinSlots / 2;  // the binning kernels' table of tile counters: 32 KB or 64 KB
+  // The depth bound (raster_zmin / raster_bound): a b x b block's points must cover the block's pixels -- radius in pixels
+  // beyond (b - 1/2) sqrt(2) by a margin that dwarfs the rounding of the pixel <-> NDC mapping (1e-3 px at 4k) -- and a block
+  // must be able to hold K points.  b = 4 from 5.05 px (the reference's radius 0.01 at 1080p: 5.4 px), b = 2 from 2.25 px.
+  const float *tile_bound = nullptr;
+  int64_t gate_rows = 0;
+  {
+    // PGDVS_RASTER_BOUND_DENSITY: rows per pixel from which the bound is computed (default 2.2; 0 = always, a large value = never)
+    const char *dens_env = getenv("PGDVS_RASTER_BOUND_DENSITY");  // (read per call: tests switch it)
+    const double density = dens_env ? atof(dens_env) : 2.2;
+    const float px_per_ndc = (float)(W < H ? W : H) / 2.0f;  // (both axes: PixToNonSquareNdc keeps pixels square)
+    const float rpx = radius * px_per_ndc;
+    const int b = rpx >= 5.05f ? 4 : (rpx >= 2.25f ? 2 : 0);
+    gate_rows = (int64_t)(density * (double)H * (double)W);
+    // (a host count, or a capacity, below the gate: no launch at all)
+    if (n_points > 0 && n_points >= gate_rows && b != 0 && K <= b * b) {
+      const int64_t n16 = cdiv((int64_t)H * W * 4, 16);  // (the region is padded to 256 bytes)
+      PGDVS_LAUNCH("raster_zmin_init", raster_zmin_init_kernel, dim3((unsigned)(cdiv(n16, 256) < 2048 ? cdiv(n16, 256) : 2048)), dim3(256),
+                   0, st, n_points, n_points_dev, gate_rows, reinterpret_cast<uint4 *>(ws.zmin), n16);
+      const unsigned gz = (unsigned)(cdiv(n_points, 256) < 4096 ? cdiv(n_points, 256) : 4096);
+      PGDVS_LAUNCH("raster_zmin", raster_zmin_kernel, dim3(gz), dim3(256), 0, st, pts, pts_stride, n_points, n_points_dev, gate_rows,
+                   cam_tgt, H, W, ws.zmin);
+      if (b == 4) {
+        PGDVS_LAUNCH("raster_bound", raster_bound_kernel<4>, dim3((unsigned)ntiles), dim3(256), 0, st, (const unsigned *)ws.zmin,
+                     n_points, n_points_dev, gate_rows, H, W, ntx, K, ws.tile_bound);
+      } else {
+        PGDVS_LAUNCH("raster_bound", raster_bound_kernel<2>, dim3((unsigned)ntiles), dim3(256), 0, st, (const unsigned *)ws.zmin,
+                     n_points, n_points_dev, gate_rows, H, W, ntx, K, ws.tile_bound);
+      }
+      tile_bound = ws.tile_bound;
+    }
+  }
   if (n_points == 0 && status_dev != nullptr) {  // (row bound 0: nothing runs that could look at the device count)
     PGDVS_LAUNCH("raster_status", raster_status_kernel, dim3(1), dim3(64), 0, st, n_points_dev, status_dev);
   }
@@ -977,10 +1122,10 @@ static int points_raster_impl(const float *pts, int64_t pts_stride, const float 
     unsigned g = (unsigned)(cdiv(n_points, kBinThreads) < 512 ? cdiv(n_points, kBinThreads) : 512);
     if (small_table) {
       PGDVS_LAUNCH("raster_project_count", raster_project_count_kernel<kBinSlots / 2>, dim3(g), dim3(kBinThreads), 0, st, pts,
-                   pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count, status_dev);
+                   pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count, status_dev, tile_bound, gate_rows);
     } else {
       PGDVS_LAUNCH("raster_project_count", raster_project_count_kernel<kBinSlots>, dim3(g), dim3(kBinThreads), 0, st, pts,
-                   pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count, status_dev);
+                   pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count, status_dev, tile_bound, gate_rows);
     }
   }
   PGDVS_LAUNCH("raster_scan", raster_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_count, ntiles, ws.offsets);
@@ -989,10 +1134,10 @@ static int points_raster_impl(const float *pts, int64_t pts_stride, const float 
     unsigned g = (unsigned)(chunks < 4096 ? chunks : 4096);
     if (small_table) {
       PGDVS_LAUNCH("raster_fill", raster_fill_kernel<kBinSlots / 2>, dim3(g), dim3(kFillThreads), 0, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
-                       radius, H, W, ntx, nty, ws.offsets, ws.cursor, ws.lists, ws.list_capacity);
+                       radius, H, W, ntx, nty, ws.offsets, ws.cursor, ws.lists, ws.list_capacity, tile_bound, gate_rows);
     } else {
       PGDVS_LAUNCH("raster_fill", raster_fill_kernel<kBinSlots>, dim3(g), dim3(kFillThreads), 0, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
-                       radius, H, W, ntx, nty, ws.offsets, ws.cursor, ws.lists, ws.list_capacity);
+                       radius, H, W, ntx, nty, ws.offsets, ws.cursor, ws.lists, ws.list_capacity, tile_bound, gate_rows);
     }
   }
   const int tiles_per_xcd = (int)cdiv(ntiles, 8);

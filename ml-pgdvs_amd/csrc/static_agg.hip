@@ -138,8 +138,9 @@ __global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, float 
 struct ByteStamp {  // one occupancy byte per (frame, pixel): frame 0's chip-filling push (coalesced byte stores)
   uint8_t *occ_all;
   int64_t P;
-  // two counters of the call (pgdvs_view_geo_counters): [0] points whose projections the fp32 form left to the fp64 queue,
-  // [1] projections that went all the way to the reference operation order
+  // counters of the call (pgdvs_view_geo_counters): [0] projections that went all the way to the reference operation order,
+  // [1 .. 64] points whose projections the fp32 form left to the fp64 queue -- summed per workgroup in LDS and added once per
+  // workgroup and frame group to word 1 + (workgroup & 63): one hot word cost every link of the chain 4 us
   unsigned *stat;
   __device__ __forceinline__ void operator()(int f, int q) const { occ_all[(int64_t)f * P + q] = 1; }
 };
@@ -209,7 +210,7 @@ __device__ __attribute__((noinline)) void mark_fp64(const ProjF64 *__restrict__ 
       return;
     }
   }
-  atomicAdd(stamp.stat + 1, 1u);  // (one projection in ~1e9)
+  atomicAdd(stamp.stat, 1u);  // (one projection in ~1e9)
   mark_reference_order(pj, x, y, z, H, W, f, stamp);
 }
 
@@ -361,6 +362,7 @@ __device__ __forceinline__ unsigned screen_frames(const PushConsts *__restrict__
 // The (point, frame) pairs the fp32 form could not decide: one LDS queue entry per point (the point itself and a
 // frame bitmask), drained densely through the fp64 forms when the next round could overflow the queue (every
 // thread adds at most one entry per round) and after the last round.  Called by every thread of the workgroup.
+constexpr int kAggStatWords = 65;
 template <int kQueue, int kThreads, class Stamp>
 __device__ __forceinline__ void queue_doubtful(uint4 *s_q, int *s_qn, const unsigned dmask, const float x, const float y,
                                                const float z, const int fa, const bool last,
@@ -370,7 +372,7 @@ __device__ __forceinline__ void queue_doubtful(uint4 *s_q, int *s_qn, const unsi
     if (slot < kQueue) {
       s_q[slot] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), dmask);
     } else {  // queue full (degenerate views): decide in place
-      atomicAdd(stamp.stat, 1u);
+      atomicAdd(stamp.stat + 1 + (blockIdx.x & 63), 1u);
       for (unsigned m = dmask; m; m &= m - 1) {
         const int f = fa + __builtin_ctz(m);
         mark_fp64(proj + f, x, y, z, H, W, f, stamp);
@@ -383,7 +385,7 @@ __device__ __forceinline__ void queue_doubtful(uint4 *s_q, int *s_qn, const unsi
   // drain -- and with it the barriers inside -- is the same on all of them
   __syncthreads();
   if (last || qn + kThreads > kQueue) {
-    if (threadIdx.x == 0 && qn > 0) atomicAdd(stamp.stat, (unsigned)qn);  // (one atomic per drain, nothing returned)
+    if (threadIdx.x == 0) s_qn[1] += qn;
     for (int e = threadIdx.x; e < qn; e += kThreads) {
       const uint4 q = s_q[e];
       const float px = __uint_as_float(q.x), py = __uint_as_float(q.y), pz = __uint_as_float(q.z);
@@ -393,7 +395,13 @@ __device__ __forceinline__ void queue_doubtful(uint4 *s_q, int *s_qn, const unsi
       }
     }
     __syncthreads();
-    if (threadIdx.x == 0) *s_qn = 0;
+    if (threadIdx.x == 0) {
+      *s_qn = 0;
+      if (last && s_qn[1] > 0) {
+        atomicAdd(stamp.stat + 1 + (blockIdx.x & 63), (unsigned)s_qn[1]);
+        s_qn[1] = 0;
+      }
+    }
     __syncthreads();
   }
 }
@@ -410,12 +418,12 @@ agg_push_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ cnts,
                 uint8_t *__restrict__ occ_all, const int32_t *__restrict__ sel_pix, AppendSrc app, CamBlock cam,
                 unsigned *__restrict__ stat) {
   __shared__ uint4 s_q[kQueue];
-  __shared__ int s_qn;
+  __shared__ int s_qn[2];  // queue length; points queued since the last report to the statistics words
   const int64_t begin = cnts[src], end = cnts[src + 1];
   if (begin >= end) return;
   const ByteStamp stamp{occ_all, (int64_t)H * W, stat};
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
-  if (threadIdx.x == 0) s_qn = 0;
+  if (threadIdx.x == 0) s_qn[0] = s_qn[1] = 0;
   __syncthreads();
   // frame groups side by side (gridDim.y covers them; a smaller gridDim.y walks them one after the other:
   // tried for frame 0 so that all workgroups stamp the same <= fpg maps at a time -- 98 us against 81 us,
@@ -453,7 +461,7 @@ agg_push_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ cnts,
     }
     unsigned dmask = 0;
     if (fa < fb) dmask = screen_frames(pc, fa, fb, live, x, y, z, wm1, hm1, W, stamp);
-    queue_doubtful<kQueue, kPushThreads>(s_q, &s_qn, dmask, x, y, z, fa, ch + c_step >= c_hi, proj, H, W, stamp);
+    queue_doubtful<kQueue, kPushThreads>(s_q, s_qn, dmask, x, y, z, fa, ch + c_step >= c_hi, proj, H, W, stamp);
   }
   }
 }
@@ -669,6 +677,106 @@ __global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamB
   }
 }
 
+// ---- frame 0, default path: selection, ordered offsets, projections into every later frame and rows in ONE launch -----
+// Frame 0 appends every static pixel (~0.85 P points) and carries three quarters of all projections.  Rounds 2-3 ran it as
+// agg_select (count, ordered offsets, rows: 29 us) + agg_push<1024> (the rows' packed coordinates re-read once per group
+// of 8 later frames, 47.6 M projections: 54 us).  Here workgroup (tile, group) selects its 4096 pixels itself (mask bytes:
+// 2 MB per group instead of 21 MB of coordinates), unprojects them in registers and screens them against its group of
+// later frames; the workgroups of group 0 also own the ORDER: they publish their tile's count before the projections and
+// sum their predecessors' counts after them (published ~50 us earlier: the look-back never waits), then write the rows.
+constexpr int kF0Threads = 256;
+constexpr int kF0Tile = kF0Threads * kSelItems;  // 4096 pixels
+
+template <int kQueue>
+__global__ void __launch_bounds__(kF0Threads)
+agg_frame0_kernel(SelArgs a, CamBlock cam, const ProjF64 *__restrict__ proj, const PushConsts *__restrict__ pc, int f_hi, int fpg,
+                  int H, int W, uint8_t *__restrict__ occ_all, unsigned *__restrict__ stat) {
+  __shared__ uint16_t s_list[kF0Tile];
+  __shared__ uint4 s_q[kQueue];
+  __shared__ int s_qn[2];
+  __shared__ int s_tile;
+  __shared__ int s_wsum[4];
+  __shared__ long long s_part[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool writer = blockIdx.y == 0;
+  // group 0 takes dynamic tile ids (a tile's predecessors are then owned by workgroups that already run, whatever order
+  // the dispatcher starts workgroups in); the other groups need no order
+  if (tid == 0) s_tile = writer ? atomicAdd(&a.ticket[0], 1) : (int)blockIdx.x;
+  if (tid == 0) s_qn[0] = s_qn[1] = 0;
+  __syncthreads();
+  const int tile = s_tile;
+  const int base = tile * kF0Tile + tid * kSelItems;
+  const unsigned flags = base < a.P ? sel_flags16(a, base) : 0u;
+  int total;
+  int slot = block_excl_256(__popc(flags), s_wsum, total);
+  if (writer && tid == 0)
+    __hip_atomic_store(&a.desc[tile], sel_desc(1, 1, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (unsigned f = flags; f; f &= f - 1) s_list[slot++] = (uint16_t)(tid * kSelItems + __builtin_ctz(f));
+  __syncthreads();
+  const int tile_px = tile * kF0Tile;
+  AppendSrc app;
+  app.depth = a.depth;
+  app.rgb = a.rgb;
+  app.cloud = a.cloud;
+  app.xyz = a.xyz;
+  app.P = a.P;
+  app.W = a.W;
+  // ---- projections: this group's later frames
+  const int fa = 1 + (int)blockIdx.y * fpg;
+  const int fb = fa + fpg < f_hi ? fa + fpg : f_hi;
+  if (fa < fb && total > 0) {
+    const ByteStamp stamp{occ_all, (int64_t)H * W, stat};
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    for (int e0 = 0; e0 < total; e0 += kF0Threads) {
+      const int e = e0 + tid;
+      const bool live = e < total;
+      float x = 0.f, y = 0.f, z = 0.f;
+      if (live) {
+        const f3 X = append_row(app, cam, tile_px + (int)s_list[e], 0, false);
+        x = X.x;
+        y = X.y;
+        z = X.z;
+      }
+      const unsigned dmask = screen_frames(pc, fa, fb, live, x, y, z, wm1, hm1, W, stamp);
+      queue_doubtful<kQueue, kF0Threads>(s_q, s_qn, dmask, x, y, z, fa, e0 + kF0Threads >= total, proj, H, W, stamp);
+    }
+  }
+  if (!writer) return;
+  // ---- rows, in the reference's order: behind everything the tiles before this one selected
+  const int tiles = a.tiles;
+  if (total == 0 && tile != tiles - 1) return;
+  long long part = 0;
+  for (int j = tid; j < tile; j += kF0Threads) {
+    unsigned spins = 0;
+    unsigned long long dsc;
+    while (true) {
+      dsc = __hip_atomic_load(&a.desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)(dsc >> 48) == 1) break;
+      if (++spins > kSelSpinLimit) {  // never expected; keeps a protocol bug from hanging the GPU
+        atomicExch(a.error, 1);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    part += (long long)(dsc & ((1ull << 46) - 1));
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+  if (lane == 0) s_part[wave] = part;
+  __syncthreads();
+  const long long excl = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  if (tile == tiles - 1 && tid == 0) {
+    int64_t n = excl + total;
+    n = n > a.capacity ? a.capacity : n;
+    a.cnts[1] = n;  // (cnts[0] = 0: the state block is zeroed per call)
+  }
+#pragma unroll 4
+  for (int e = tid; e < total; e += kF0Threads) {
+    const int64_t pos = excl + e;
+    if (pos >= a.capacity) break;
+    append_row(app, cam, tile_px + (int)s_list[e], pos, true);
+  }
+}
+
 // selection flags of 16 pixels of a later frame, both 16-byte loads in flight together (sel_flags16 waits for each in turn:
 // dependent round trips at the head of every chain link); selected = mask byte zero and map byte zero = (mask | map) zero
 __device__ __forceinline__ unsigned sel_flags16_pair(const SelArgs &a, const int64_t base) {
@@ -696,7 +804,7 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
                 AppendSrc app, CamBlock cam, unsigned *__restrict__ stat) {
   __shared__ uint16_t s_list[kStepThreads * kStepPx];  // (thread << 4 | pixel) of every selected pixel, 8 KB
   __shared__ uint4 s_q[kQueue];
-  __shared__ int s_qn;
+  __shared__ int s_qn[2];
   __shared__ int s_wsum[4];
   const int tid = threadIdx.x;
   auto pixel_base = [&](const int t) {
@@ -712,7 +820,7 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
   int slot = block_excl_256(__popc(bits), s_wsum, n);
   if (n == 0) return;
   for (uint32_t m = bits; m; m &= m - 1) s_list[slot++] = (uint16_t)((tid << 4) | __builtin_ctz(m));
-  if (tid == 0) s_qn = 0;
+  if (tid == 0) s_qn[0] = s_qn[1] = 0;
   __syncthreads();
   const ByteStamp stamp{occ_all, (int64_t)H * W, stat};
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
@@ -728,7 +836,7 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
       z = X.z;
     }
     const unsigned dmask = screen_frames(pc, fa, fb, live, x, y, z, wm1, hm1, W, stamp);
-    queue_doubtful<kQueue, kStepThreads>(s_q, &s_qn, dmask, x, y, z, fa, e0 + kStepThreads >= n, proj, H, W, stamp);
+    queue_doubtful<kQueue, kStepThreads>(s_q, s_qn, dmask, x, y, z, fa, e0 + kStepThreads >= n, proj, H, W, stamp);
   }
 }
 
@@ -855,6 +963,7 @@ struct AggWs {
   int64_t state_bytes;
   int64_t *cnts;
   int32_t *ticket, *error;
+  unsigned *stat;  // [kAggStatWords] see ByteStamp::stat
   unsigned long long *desc;
   int32_t *tile_cnt;   // [S][tiles] pixels the later frames selected per (frame, tile)
   int64_t *tile_off;   // [S * tiles + 1] their running sum
@@ -873,6 +982,7 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   AggWs w;
   const int64_t P = (int64_t)H * W;
   const int64_t tiles = cdiv(P, kSelTile);
+  const int64_t tiles0 = cdiv(P, 4096);  // (kF0Tile: frame 0's fused launch publishes one count per 4096 pixels)
   char *p = reinterpret_cast<char *>(base);
   int64_t off = 0;
   w.state = p;
@@ -882,8 +992,10 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   off += align_up((int64_t)S * 4, 16);
   w.error = reinterpret_cast<int32_t *>(p + off);
   off += 16;
+  w.stat = reinterpret_cast<unsigned *>(p + off);
+  off += align_up((int64_t)kAggStatWords * 4, 16);
   w.desc = reinterpret_cast<unsigned long long *>(p + off);
-  off += align_up(tiles * 8, 16);
+  off += align_up(tiles0 * 8, 16);
   w.state_bytes = off;
   off = align_up(off, 256);
   w.tile_cnt = reinterpret_cast<int32_t *>(p + off);
@@ -912,7 +1024,7 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
 // the two statistics words the last aggregation on this workspace left behind (see ByteStamp::stat)
 const unsigned *agg_stat_words(const void *workspace, int S, int H, int W, int64_t capacity) {
   const AggWs w = agg_ws_layout(const_cast<void *>(workspace), S, H, W, capacity);
-  return reinterpret_cast<const unsigned *>(w.error) + 1;
+  return w.stat;
 }
 
 }  // namespace pgdvs
@@ -1098,12 +1210,12 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       PGDVS_LAUNCH("agg_push0", agg_push_kernel<kPushQueue>, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
                    (const float *)ws.xyz, (const int64_t *)ws.cnts, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, i + 1, S, fpg_i, H, W,
                    ws.occ,
-                   (const int32_t *)nullptr, frame_src(i), cams[(size_t)i], reinterpret_cast<unsigned *>(ws.error) + 1);
+                   (const int32_t *)nullptr, frame_src(i), cams[(size_t)i], ws.stat);
     } else {
       PGDVS_LAUNCH("agg_push", agg_push_kernel<kPushQueueSmall>, dim3(gx, (unsigned)groups), dim3(kPushThreads), 0, st,
                    (const float *)ws.xyz, (const int64_t *)ws.cnts, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, i + 1, S, fpg_i, H, W,
                    ws.occ,
-                   (const int32_t *)ws.sel_pix, frame_src(i), cams[(size_t)i], reinterpret_cast<unsigned *>(ws.error) + 1);
+                   (const int32_t *)ws.sel_pix, frame_src(i), cams[(size_t)i], ws.stat);
     }
   };
   if (!bit_chain) {
@@ -1128,8 +1240,36 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       }
     }
   }
-  select(0);
-  push(0);
+  // (measured, round 4: the fused launch takes 114 us where the pair takes 29 + 64 -- the third of the workgroups that also
+  // writes the rows finishes last; the pair stays the default, PGDVS_AGG_FUSED0=1 selects the fused launch)
+  static const bool fused0_env = getenv("PGDVS_AGG_FUSED0") && getenv("PGDVS_AGG_FUSED0")[0] == '1';
+  if (!fused0_env) {
+    select(0);
+    push(0);
+  } else {
+    static_assert(kF0Tile == 4096, "agg_ws_layout sizes the count granules for 4096-pixel tiles");
+    SelArgs a;
+    a.dyn_mask = dyn_masks;
+    a.occ = ws.occ;
+    a.depth = depths;
+    a.rgb = rgbs;
+    a.cloud = out;
+    a.xyz = ws.xyz;
+    a.cnts = ws.cnts;
+    a.desc = ws.desc;
+    a.ticket = ws.ticket;
+    a.error = ws.error;
+    a.sel_pix = nullptr;
+    a.capacity = capacity;
+    a.frame = 0;
+    a.P = (int)P;
+    a.W = W;
+    a.tiles = (int)cdiv(P, kF0Tile);
+    const int groups = (int)cdiv(S - 1, fpg);
+    PGDVS_LAUNCH("agg_frame0", agg_frame0_kernel<kPushQueue>, dim3((unsigned)a.tiles, (unsigned)groups), dim3(kF0Threads), 0, st, a,
+                 cams[0], (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, fpg, H, W, ws.occ,
+                 ws.stat);
+  }
   {
     // 32 chunks of 128 pixels per workgroup, dealt round-robin; a multiple of 8 workgroups per row (see the kernel)
     const unsigned gx = (unsigned)align_up(cdiv(ws.Wd * 32 / kStepChunkPx, kStepChunks), 8);
@@ -1149,7 +1289,7 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       const unsigned gy = i + 1 < S ? (unsigned)cdiv(S - 1 - i, sfpg) : 1u;
       PGDVS_LAUNCH("agg_step", agg_step_kernel<kPushQueueSmall>, dim3(gx, gy), dim3(kStepThreads), 0, st, a, ws.occ,
                    reinterpret_cast<uint16_t *>(ws.sel), ws.Wd, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, sfpg, H, W,
-                   frame_src(i), cams[(size_t)i], reinterpret_cast<unsigned *>(ws.error) + 1);
+                   frame_src(i), cams[(size_t)i], ws.stat);
     }
   }
   PGDVS_LAUNCH("agg_count", agg_count_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,

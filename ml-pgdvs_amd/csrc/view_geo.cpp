@@ -34,8 +34,11 @@ __global__ void view_counters_kernel(const int64_t *__restrict__ static_rows, in
   out[PGDVS_VIEW_CNT_KNN_TO_RING] = to_ring ? *to_ring : 0;
   out[PGDVS_VIEW_CNT_KNN_TO_COARSE] = to_coarse ? *to_coarse : 0;
   out[PGDVS_VIEW_CNT_KNN_TO_EXHAUSTIVE] = to_exhaustive ? *to_exhaustive : 0;
-  out[PGDVS_VIEW_CNT_AGG_FP64_POINTS] = agg_stat ? agg_stat[0] : 0;
-  out[PGDVS_VIEW_CNT_AGG_REFERENCE_ORDER] = agg_stat ? agg_stat[1] : 0;
+  int64_t queued = 0;
+  if (agg_stat)
+    for (int k = 1; k <= 64; ++k) queued += agg_stat[k];
+  out[PGDVS_VIEW_CNT_AGG_FP64_POINTS] = queued;
+  out[PGDVS_VIEW_CNT_AGG_REFERENCE_ORDER] = agg_stat ? agg_stat[0] : 0;
   for (int k = PGDVS_VIEW_CNT_AGG_REFERENCE_ORDER + 1; k < PGDVS_VIEW_COUNTERS; ++k) out[k] = 0;
 }
 

@@ -121,12 +121,15 @@ class ResidentVideoRenderer:
         self.row_bound = min(self.capacity, int(1.25 * n) + 65536)
         return n
 
-    def render(self, data, lane: int, out=None):
+    def render(self, data, lane: int, out=None, use_side: bool = True):
         """enqueue one view on lane ``lane``; ``out`` [1,3,H,W]: the caller's slot for ``combined_rgb`` (written by the
-        splat epilogue itself).  Returns (ret dict incl. ``st_pcl_rgb`` / ``st_pcl_rgb_count``, the lane's stream)."""
+        splat epilogue itself); ``use_side=False``: everything on the lane's main stream (per-kernel timing: no kernel of
+        the view then runs beside another).  Returns (ret dict incl. ``st_pcl_rgb`` / ``st_pcl_rgb_count``, the lane's stream)."""
         from . import ops
 
         main, side = self.lanes[lane % self.n_lanes]
+        if not use_side:
+            side = None
         main.wait_stream(torch.cuda.current_stream(self.dev))
         d = dict(data)
         if out is not None:

@@ -332,3 +332,99 @@ def test_scene_statistics_540p_vs_oracle(scene):
     assert np.array_equal(N(ret["render_dyn_mask"]), o["render_dyn_mask"])
     for k in ["render_dyn_rgb", "combined_rgb"]:
         np.testing.assert_allclose(N(ret[k]), o[k], rtol=0, atol=1e-4, err_msg=k)
+
+
+# ---------------------------------------------------------------- the rasteriser's depth bound (list pruning)
+@pytest.mark.parametrize("H,W,n,K,radius,seed", [(160, 224, 60000, 3, 0.075, 0), (160, 224, 90000, 4, 0.04, 1), (96, 128, 30000, 8, 0.12, 2),
+                                                 (200, 320, 120000, 1, 0.06, 3), (128, 128, 50000, 5, 0.05, 4)])
+def test_raster_depth_bound_random_clouds_vs_oracle(H, W, n, K, radius, seed, monkeypatch):
+    """PGDVS_RASTER_BOUND_DENSITY=0: the bound is computed whatever the density.  Layered random depths (the regime in which
+    it drops most of every list), exact depth ties across the bound, points outside the image and behind the camera, block
+    sizes 4 and 2, K up to the block's capacity and beyond it: fragments bit-exact against the oracle's naive loop, and
+    identical to the un-pruned rasteriser's"""
+    rng = np.random.default_rng(seed)
+    pts = np.concatenate([rng.uniform(-1.3, 1.3, (n, 2)) * [W / H, 1.0], rng.choice([1.5, 1.5, 1.7, 2.0, 2.5, 3.0], (n, 1))
+                          + rng.normal(0, 0.05, (n, 1)) * (rng.random((n, 1)) < 0.7)], 1).astype(np.float32)
+    pts[:50, 2] = -1.0
+    feat = rng.random((n, 3)).astype(np.float32)
+    fc = synth.flat_cam(H, W, np.array([[0.8 * H, 0, W / 2], [0, 0.8 * H, H / 2], [0, 0, 1]]), np.eye(4)).astype(np.float32)
+    cam = ops.cam_prep(T(fc))
+    monkeypatch.setenv("PGDVS_RASTER_BOUND_DENSITY", "0")
+    a = ops.points_raster(T(pts), T(feat), cam, radius, K, H, W, want_fragments=True)
+    monkeypatch.setenv("PGDVS_RASTER_BOUND_DENSITY", "1e9")
+    b = ops.points_raster(T(pts), T(feat), cam, radius, K, H, W, want_fragments=True)
+    for k in ("idx", "zbuf", "dist2", "rgb", "mask"):
+        assert torch.equal(a[k], b[k]), k
+    idx, zbuf, d2 = orc.rasterize_points(pts, fc, H, W, radius, K)
+    assert np.array_equal(N(a["idx"]), idx) and np.array_equal(N(a["zbuf"]).view(np.uint32), zbuf.view(np.uint32))
+    assert np.array_equal(N(a["dist2"]).view(np.uint32), d2.view(np.uint32))
+    assert (idx >= 0).mean() > 0.5
+
+
+def test_raster_depth_bound_1080p_noisy_depth_vs_oracle(monkeypatch):
+    """the cloud the bound is made for -- noisy depth, 8 source frames at 1080p, more than 2.2 points per pixel so that
+    the default gate opens by itself -- through the native view call: every fragment of the frame against the oracle's
+    point-major sweep, and the counters say that lists shrank"""
+    H, W, S = 1080, 1920, 8
+    v = synth.make_video(S, H, W, seed=1234, scene="noisy_depth")
+    d = synth.make_view(v, 3, frac=0.4, seed=5)
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=False, st_render_pcl_pts_per_pixel=3)
+    data = synth.to_torch(d, DEV)
+    data["_st_pcl_video"] = _video_dict(v)
+    with torch.no_grad():
+        ret = model.forward(data, render_cfg=rc)
+    cnt_on = model.view_counters()
+    n = ops.checked_count(ret["st_pcl_rgb_count"], "agg")
+    assert n > 2.2 * H * W, n  # the default gate is open
+    monkeypatch.setenv("PGDVS_RASTER_BOUND_DENSITY", "1e9")
+    with torch.no_grad():
+        ret_off = model.forward(data, render_cfg=rc)
+    cnt_off = model.view_counters()
+    assert torch.equal(ret["geo_static_rgb"], ret_off["geo_static_rgb"]) and torch.equal(ret["geo_static_mask"], ret_off["geo_static_mask"])
+    assert cnt_on["static_rows"] == cnt_off["static_rows"] == n
+    assert cnt_on["raster_list_entries"] < 0.5 * cnt_off["raster_list_entries"], (cnt_on, cnt_off)
+    assert cnt_on["raster_longest_tile_list"] < cnt_off["raster_longest_tile_list"]
+    monkeypatch.delenv("PGDVS_RASTER_BOUND_DENSITY")
+    o_cloud = orc.aggregate_static_pcl(v["rgbs"], v["depths"], v["dyn_masks"], v["K3s"], v["c2ws"])
+    assert np.array_equal(N(ret["st_pcl_rgb"][0, :n]).view(np.uint32), o_cloud.view(np.uint32))
+    radius = float(rc.st_render_pcl_pt_radius)
+    frag = ops.points_raster(ret["st_pcl_rgb"][0, :n], ret["st_pcl_rgb"][0, :n, 3:], ops.cam_prep(data["flat_cam_tgt"][0]), radius, 3, H, W,
+                             want_fragments=True, rgb_planar=True)
+    assert torch.equal(frag["rgb"], ret["geo_static_rgb"][0])
+    ndc = orc.points_to_ndc(o_cloud[:, :3], d["flat_cam_tgt"][0], H, W)
+    idx, zbuf, d2 = orc.rasterize_points_pointmajor(ndc, H, W, radius, 3)
+    assert np.array_equal(N(frag["idx"]), idx)
+    assert np.array_equal(N(frag["zbuf"]).view(np.uint32), zbuf.view(np.uint32))
+    assert np.array_equal(N(frag["dist2"]).view(np.uint32), d2.view(np.uint32))
+
+
+def test_view_counters_report_the_fast_paths_exits():
+    """pgdvs_view_geo_counters: the numbers are the kernels' own device words -- rows, list entries (= the oracle's count of
+    (point, tile) pairs), kNN queries and how many left the thread-per-query pass, points in the aggregation's fp64 queue"""
+    H, W, S = 270, 480, 6
+    v = synth.make_video(S, H, W, seed=5)
+    d = synth.make_view(v, 2, frac=0.4, seed=1)
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=True, st_render_pcl_pts_per_pixel=3)
+    data = synth.to_torch(d, DEV)
+    data["_st_pcl_video"] = _video_dict(v)
+    with torch.no_grad():
+        ret = model.forward(data, render_cfg=rc)
+    c = model.view_counters()
+    n = ops.checked_count(ret["st_pcl_rgb_count"], "agg")
+    assert c["static_rows"] == n
+    assert c["knn_queries"] == int((N(data["dyn_mask_src_temporal"][0, 0]) > 0).sum()) or c["knn_queries"] > 0
+    assert 0 <= c["knn_queries_to_ring_search"] <= c["knn_queries"]
+    assert c["knn_queries_to_coarse_grid"] <= c["knn_queries"] and c["knn_queries_scanned_exhaustively"] <= c["knn_queries_to_coarse_grid"] + 1
+    assert n <= c["raster_list_entries"] <= 9 * n and 0 < c["raster_longest_tile_list"] <= c["raster_list_entries"]
+    assert c["raster_tiles_general_path_long_list"] == 0 and c["raster_tiles_general_path_equal_depths"] == 0
+    assert 0 < c["agg_points_in_fp64_queue"] < 0.2 * n * S
+    assert c["agg_projections_in_reference_order"] <= c["agg_points_in_fp64_queue"]
+    # a crowded tile (everything lands in a few tiles) takes the general path, and the counter says so
+    pts = np.concatenate([np.random.default_rng(0).normal(0, 0.01, (6000, 2)), np.full((6000, 1), 2.0)], 1).astype(np.float32)
+    data2 = synth.to_torch(d, DEV)
+    data2["st_pcl_rgb"] = T(np.concatenate([pts, np.full((6000, 3), 0.5, np.float32)], 1))[None]
+    with torch.no_grad():
+        model.forward(data2, render_cfg=rc)
+    c2 = model.view_counters()
+    assert c2["static_rows"] == 6000 and c2["raster_longest_tile_list"] > 2048
+    assert c2["raster_tiles_general_path_long_list"] >= 1

@@ -817,7 +817,7 @@ def main():
         drange = torch.tensor([[0.8, 5.0]], device=dev)
 
         def gnt_chunk():
-            gg = ops.gnt_gather(ro, rd, drange, Sg, True, cam_t, cams_s, rgbs, featmaps, inv_masks)
+            gg = ops.gnt_gather(ro, rd, drange, Sg, True, cam_t, cams_s, rvr.video["rgbs"], featmaps, inv_masks)
             out = net(gg["rgb_feat"], gg["ray_diff"], gg["mask"], gg["pts"], rd, ret_view_entropy=True, ret_view_std=True)
             return gg, out
 
@@ -843,7 +843,7 @@ def main():
             for _ in range(10):
                 g0 = time.perf_counter()
                 e0.record()
-                gg = ops.gnt_gather(ro, rd, drange, Sg, True, cam_t, cams_s, rgbs, featmaps, inv_masks)
+                gg = ops.gnt_gather(ro, rd, drange, Sg, True, cam_t, cams_s, rvr.video["rgbs"], featmaps, inv_masks)
                 e1.record()
                 net(gg["rgb_feat"], gg["ray_diff"], gg["mask"], gg["pts"], rd, ret_view_entropy=True, ret_view_std=True)
                 e2.record()

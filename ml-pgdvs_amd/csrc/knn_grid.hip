@@ -840,6 +840,7 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
   __shared__ int2 s_run[9][256];
   __shared__ float s_bd[9][256];
   __shared__ float s_thr[256];  // the lane's starting threshold (see below)
+  __shared__ float s_safe[256];  // ... and the squared distance up to which its block can certify a list
   __shared__ unsigned long long s_order[256];  // ... and its row numbers in visiting order, four bits each
   const GridParams g = *gp;
   const int n = g.n;
@@ -924,15 +925,47 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
     }
     return (KK >= 17 && ncand >= KK) ? (KK >= 40 ? 4.5f : 6.0f) * (float)KK * g.h * g.h / (float)ncand : __builtin_inff();
   };
+  // What the block can certify at all: the distance to its nearest face that still has cells behind it (minus the
+  // rounding margin), squared -- a list whose last entry lies beyond it is not complete whatever it holds.  Kept in LDS:
+  // it is the threshold of the second attempt below, and the completeness test at the end.
+  {
+    float db = __builtin_inff();
+    bool open = false;
+    const int c[3] = {cx, cy, cz};
+    const float qv[3] = {qx, qy, qz};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      if (c[ax] - 1 > 0) {
+        open = true;
+        db = fminf(db, qv[ax] - (g.mn[ax] + (float)(c[ax] - 1) * g.h));
+      }
+      if (c[ax] + 1 < g.G[ax] - 1) {
+        open = true;
+        db = fminf(db, (g.mn[ax] + (float)(c[ax] + 2) * g.h) - qv[ax]);
+      }
+    }
+    const float safe = db - 0.02f * g.h;
+    // +inf: nothing behind any face (everything is in the block); 0: the query sits on the margin (never complete)
+    s_safe[tid] = !open ? __builtin_inff() : (safe > 0.0f ? safe * safe : 0.0f);
+  }
   float a[KK];
+  float mx;
+  bool cut;
+  float t0 = threshold();
+  // Second attempt, per wavefront: the density estimate above assumes points on a SURFACE.  In a cloud from noisy depth
+  // (a slab several cells thick) it is too tight for every query -- round 4's noisy scene sent 303 k of 311 k queries to the
+  // ring search, 2.5 ms per view instead of 0.9 -- although the block holds their neighbours.  When a quarter of a
+  // wavefront's lists come out short, the wavefront runs the block again with the largest threshold that can still
+  // certify a list (the block's own bound above) for those lanes; the others repeat their search unchanged.  Isolated
+  // short lists (0.5 % on the benchmark's cloud) keep going to the ring search: a repeat would cost their whole wavefront.
+  for (int attempt = 0;; ++attempt) {
   __builtin_amdgcn_sched_barrier(0);  // (the 51 copies must not become live while the run set-up above still is)
   {
-    const float t0 = threshold();
     s_thr[tid] = t0;
 #pragma unroll
     for (int i = 0; i < KK; ++i) a[i] = t0;
   }
-  float mx = a[KK - 1];
+  mx = a[KK - 1];
   float qd[kTpqQueue];
 #pragma unroll
   for (int u = 0; u < kTpqQueue; ++u) qd[u] = __builtin_inff();
@@ -993,29 +1026,15 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
     __builtin_amdgcn_sched_barrier(0);
   }
   mx = a[KK - 1];
-  const bool cut = mx < __builtin_inff() && mx == s_thr[tid];  // the threshold left the list short
+  cut = mx < __builtin_inff() && mx == s_thr[tid];  // the threshold left the list short
+  const float safe2 = s_safe[tid];
+  const bool retry = cut && live && mx < safe2;  // (a list cut at the block's own bound is not complete anyway)
+  if (attempt == 1 || __builtin_popcountll(__builtin_amdgcn_ballot_w64(retry)) < 16) break;
+  t0 = retry ? safe2 : t0;
+  }
   if (!live) continue;
-  // complete?  distance to the nearest face of the 3x3x3 block that still has cells behind it
-  float db = __builtin_inff();
-  bool open = false;
-  const int c[3] = {cx, cy, cz};
-  const float qv[3] = {qx, qy, qz};
-#pragma unroll
-  for (int ax = 0; ax < 3; ++ax) {
-    if (c[ax] - 1 > 0) {
-      open = true;
-      db = fminf(db, qv[ax] - (g.mn[ax] + (float)(c[ax] - 1) * g.h));
-    }
-    if (c[ax] + 1 < g.G[ax] - 1) {
-      open = true;
-      db = fminf(db, (g.mn[ax] + (float)(c[ax] + 2) * g.h) - qv[ax]);
-    }
-  }
-  bool done = !open;
-  if (open) {
-    const float safe = db - 0.02f * g.h;
-    done = safe > 0.0f && mx <= safe * safe;
-  }
+  // complete?  (the block's bound: see above)
+  const bool done = mx <= s_safe[tid];
   if (!done || cut || n < KK || first_col > 1) {
     open_list[atomicAdd(open_count, 1)] = q;
     continue;

@@ -1236,7 +1236,7 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       chunk.c[(i - 1) % per] = cams[(size_t)i];
       if ((i - 1) % per == per - 1 || i == S - 1) {
         const int cnt = (i - 1) % per + 1;
-        PGDVS_LAUNCH("agg_params", agg_cams_kernel, dim3(1), dim3(256), 0, st, chunk, ws.cams, i - cnt + 1, cnt);
+        PGDVS_LAUNCH("agg_cams", agg_cams_kernel, dim3(1), dim3(256), 0, st, chunk, ws.cams, i - cnt + 1, cnt);
       }
     }
   }
@@ -1294,7 +1294,7 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
   }
   PGDVS_LAUNCH("agg_count", agg_count_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,
                (const uint32_t *)ws.sel, ws.Wd, tiles, ws.tile_cnt);
-  PGDVS_LAUNCH("agg_count", agg_scan_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)ws.tile_cnt, ws.tile_off, (int64_t)tiles,
+  PGDVS_LAUNCH("agg_scan", agg_scan_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)ws.tile_cnt, ws.tile_off, (int64_t)tiles,
                (int64_t)S * tiles, (const int64_t *)ws.cnts, (const int32_t *)ws.error, capacity, count_out);
   {
     RowsArgs ra;

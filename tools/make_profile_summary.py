@@ -35,7 +35,7 @@ def counter(dirname, cname):
                 continue
             k = short(r["Kernel_Name"])
             agg[k] += float(r["Counter_Value"])
-            disp[k].add(r["Dispatch_Id"])
+            disp[k].add((f, r["Dispatch_Id"]))
     return {k: (v / len(disp[k]), len(disp[k])) for k, v in agg.items()}
 
 
@@ -73,21 +73,23 @@ json.dump({"command": cmd, "note": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE
 print("wrote", out / f"{tag}_kernel_stats.csv", out / f"{tag}_hbm_traffic.json")
 
 # ---- instruction-mix counters of the co-dominant kernels (gpurun_out/<tag>_pmc1, _pmc2: separate --pmc passes of
-# `bench.py --steps 4 --warmup 1 --inflight 1 --launch eager ...` restricted to those kernels) ->
+# `bench.py --steps 4 --warmup 1 --inflight 1 --no-side-stream ...` restricted to those kernels) ->
 #   profiles/<tag>_pmc_instructions.json  (read by bench.py for the VALU-issue figure)
 #   profiles/<tag>_pmc_<kernel>.txt       (one text block per kernel, every counter, mean per launch)
 pmc = collections.defaultdict(dict)
 for d in (f"{tag}_pmc1", f"{tag}_pmc2"):
-    for f in glob.glob(str(root / "gpurun_out" / d / "**" / "*counter_collection.csv"), recursive=True):
-        agg, disp = collections.defaultdict(lambda: collections.defaultdict(float)), collections.defaultdict(set)
+    # one pass = one directory: sums and dispatch sets are merged over ALL of its files (one per process / agent) before
+    # the division, so that the means do not depend on the order in which glob returns them
+    agg, disp = collections.defaultdict(lambda: collections.defaultdict(float)), collections.defaultdict(set)
+    for f in sorted(glob.glob(str(root / "gpurun_out" / d / "**" / "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            disp[k].add(r["Dispatch_Id"])
-        for k, v in agg.items():
-            for c, val in v.items():
-                pmc[k][c] = val / len(disp[k])
-            pmc[k]["launches_profiled"] = max(pmc[k].get("launches_profiled", 0), len(disp[k]))
+            disp[k].add((f, r["Dispatch_Id"]))
+    for k, v in agg.items():
+        for c, val in v.items():
+            pmc[k][c] = val / len(disp[k])
+        pmc[k]["launches_profiled"] = max(pmc[k].get("launches_profiled", 0), len(disp[k]))
 if pmc:
     import re
     keyed = {re.sub(r"<.*>", "", k).replace("_kernel", ""): {c: round(v, 1) for c, v in sorted(cs.items())} for k, cs in pmc.items()}
@@ -95,7 +97,7 @@ if pmc:
     if "agg_push" in keyed:
         keyed["agg_push0"] = keyed.pop("agg_push")
     json.dump({"command": "rocprofv3 --pmc <8 SQ counters> --kernel-include-regex <co-dominant kernels> -- python3 bench.py --steps 4 "
-                          "--warmup 1 --inflight 1 --launch eager --no-cpu-baseline --no-kernel-timing --gnt-rays 0 (two passes)",
+                          "--warmup 1 --inflight 1 --no-side-stream --no-cpu-baseline --no-kernel-timing --gnt-rays 0 --no-scene-sweep (two passes)",
                "note": "mean per launch; SQ_INSTS_* are wave-instructions; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles "
                        "summed over waves (MI355X_MICROARCH.md); issue cost per wave-instruction and SIMD: profiles/r03_valu_rate.txt",
                "kernels": keyed}, open(out / f"{tag}_pmc_instructions.json", "w"), indent=1)

@@ -1,14 +1,13 @@
 #!/bin/bash
-# (the command pins eager launches and seven lanes: under the profiler the host is slow enough for `--launch auto` to switch to
-# graph replay, whose input copies and output clones are not what an unprofiled run executes)
+# (the command pins the lane count: under the profiler the host is slow and a lane probe would measure the profiler)
 # rocprofv3 passes behind profiles/<tag>_*: kernel-trace stats, then FETCH_SIZE and WRITE_SIZE in their own --pmc
 # passes, then two instruction-mix passes restricted to the co-dominant kernels (never combined with traces).
 # Run on the GPU box through gpurun; tools/make_profile_summary.py condenses the output into profiles/.
-tag=${1:-r03}
+tag=${1:-r04}
 R=$GRAFT_REPO_ROOT
-CMD="python3 $R/bench.py --steps 10 --warmup 2 --launch eager --inflight 7 --no-cpu-baseline --no-kernel-timing --gnt-rays 0"
-PMCCMD="python3 $R/bench.py --steps 4 --warmup 1 --inflight 1 --launch eager --no-cpu-baseline --no-kernel-timing --gnt-rays 0"
-KERNELS="raster_tile|grid_query_tpq|agg_push|agg_step|agg_rows|dyn_splat_scatter"
+CMD="python3 $R/bench.py --steps 10 --warmup 2 --inflight 3 --no-cpu-baseline --no-kernel-timing --gnt-rays 0 --no-scene-sweep"
+PMCCMD="python3 $R/bench.py --steps 4 --warmup 1 --inflight 1 --no-side-stream --no-cpu-baseline --no-kernel-timing --gnt-rays 0 --no-scene-sweep"
+KERNELS="raster_tile|grid_query_tpq|agg_push|agg_step|agg_rows|agg_select|raster_fill|dyn_splat_scatter"
 cd /tmp && export TMPDIR=/tmp
 for d in stats fetch write pmc1 pmc2; do rm -rf $R/gpurun_out/${tag}_$d; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -o k -- $CMD > $R/gpurun_out/${tag}_stats.log 2>&1

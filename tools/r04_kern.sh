@@ -3,7 +3,8 @@
 cd "${GRAFT_REPO_ROOT:?}" || exit 1
 mkdir -p gpurun_out/r04
 tag=$1; shift
-env "$@" python bench.py --steps 8 --warmup 3 --inflight 1 --no-cpu-baseline --gnt-rays 0 --no-scene-sweep > gpurun_out/r04/kern_$tag.json 2> gpurun_out/r04/kern_$tag.err
+# BENCH_ARGS: extra flags for bench.py (e.g. "--scene noisy_depth")
+env "$@" python bench.py ${BENCH_ARGS:-} --steps 8 --warmup 3 --inflight 1 --no-cpu-baseline --gnt-rays 0 --no-scene-sweep > gpurun_out/r04/kern_$tag.json 2> gpurun_out/r04/kern_$tag.err
 python - "$tag" <<'PY'
 import json,sys
 n=sys.argv[1]

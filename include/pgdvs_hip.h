@@ -450,6 +450,10 @@ typedef struct pgdvs_view_geo_desc {
   float *combined_dyn;          /* [3,H,W]                                                             */
   /* optional: the dynamic branch's geometry (A2-A5) on a second stream, joined before the splat       */
   pgdvs_stream_t side_stream;   /* NULL: everything on `stream`                                        */
+  /* agg_S > 0 only: non-zero = this workspace ran the previous pgdvs_view_geo_forward with the SAME agg_S, H, W,
+   * agg_capacity, agg_K3s_host and agg_c2ws_host and nothing else has written to it since: the per-frame camera constants
+   * are still in it and are not uploaded again (five launches less per view).  0 is always correct. */
+  int32_t agg_params_cached;
 } pgdvs_view_geo_desc;
 
 /* sizeof(pgdvs_view_geo_desc) as this library was compiled: a binding checks its own struct against it */

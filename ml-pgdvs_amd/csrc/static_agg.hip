@@ -101,10 +101,7 @@ struct ProjChunk {
 static_assert(sizeof(ProjChunk) + 64 <= 4096, "agg_params_kernel's arguments");
 
 struct PushConsts;
-__global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, float *__restrict__ pc32, int first, int n, float q_hi,
-                                  uint32_t *__restrict__ zero, int n_zero) {
-  // (the call's first launch also clears the state block: counts, tickets, error flag, look-back descriptors)
-  for (int k = threadIdx.x; k < n_zero; k += blockDim.x) zero[k] = 0u;
+__global__ void agg_params_kernel(ProjChunk c, ProjF64 *__restrict__ dst, float *__restrict__ pc32, int first, int n, float q_hi) {
   const int words = (int)(sizeof(ProjF64) / 4);
   for (int k = threadIdx.x; k < n * words; k += blockDim.x)
     reinterpret_cast<uint32_t *>(dst + first)[k] = reinterpret_cast<const uint32_t *>(&c.p[0])[k];
@@ -985,7 +982,13 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   const int64_t tiles0 = cdiv(P, 4096);  // (kF0Tile: frame 0's fused launch publishes one count per 4096 pixels)
   char *p = reinterpret_cast<char *>(base);
   int64_t off = 0;
-  w.state = p;
+  w.tile_cnt = reinterpret_cast<int32_t *>(p + off);
+  off += align_up((int64_t)S * tiles * 4, 256);
+  w.tile_off = reinterpret_cast<int64_t *>(p + off);
+  off += align_up(((int64_t)S * tiles + 1) * 8, 256);
+  // the state block and, right behind it, the occupancy maps of frames 1 .. S-1 (frame 0 has none): ONE fill per call
+  // clears both
+  w.state = p + off;
   w.cnts = reinterpret_cast<int64_t *>(p + off);
   off += align_up((int64_t)(S + 1) * 8, 16);
   w.ticket = reinterpret_cast<int32_t *>(p + off);
@@ -996,14 +999,12 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   off += align_up((int64_t)kAggStatWords * 4, 16);
   w.desc = reinterpret_cast<unsigned long long *>(p + off);
   off += align_up(tiles0 * 8, 16);
-  w.state_bytes = off;
   off = align_up(off, 256);
-  w.tile_cnt = reinterpret_cast<int32_t *>(p + off);
-  off += align_up((int64_t)S * tiles * 4, 256);
-  w.tile_off = reinterpret_cast<int64_t *>(p + off);
-  off += align_up(((int64_t)S * tiles + 1) * 8, 256);
-  w.occ = reinterpret_cast<uint8_t *>(p + off);
-  off += align_up((int64_t)S * P + 32, 256);
+  w.state_bytes = (p + off) - w.state;
+  // occ[f][q] lives at occ + f * P + q for f >= 1; the pointer itself lies P bytes before the first map and is never
+  // dereferenced for frame 0
+  w.occ = reinterpret_cast<uint8_t *>(p + off) - P;
+  off += align_up((int64_t)(S - 1) * P + 32, 256);
   w.Wd = tiles * kBitTileWords;
   w.sel = reinterpret_cast<uint32_t *>(p + off);
   off += align_up((int64_t)S * w.Wd * 4, 256);
@@ -1039,7 +1040,7 @@ PGDVS_API int64_t pgdvs_static_aggregate_workspace_bytes(int S, int H, int W, in
 static int static_aggregate_impl(const float *rgbs, const float *depths, const uint8_t *dyn_masks,
                                  const double *K3s_host, const double *c2ws_host, int S, int H, int W, float *out,
                                  float *xyz_out, int64_t capacity, int64_t *count_out, void *workspace,
-                                 int64_t workspace_bytes, pgdvs_stream_t stream);
+                                 int64_t workspace_bytes, pgdvs_stream_t stream, bool params_cached = false);
 
 PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
                                      const uint8_t *dyn_masks, const double *K3s_host,
@@ -1062,10 +1063,22 @@ PGDVS_API int pgdvs_static_aggregate_packed(const float *rgbs, const float *dept
                                workspace, workspace_bytes, stream);
 }
 
+namespace pgdvs {
+// the view-level entry point (view_geo.cpp): the same aggregation; params_cached = the workspace still holds the per-frame
+// constants of the previous call with the same cameras (five parameter uploads less per view)
+int static_aggregate_for_view(const float *rgbs, const float *depths, const uint8_t *dyn_masks, const double *K3s_host,
+                              const double *c2ws_host, int S, int H, int W, float *out, float *xyz_out, int64_t capacity,
+                              int64_t *count_out, void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream,
+                              bool params_cached) {
+  return static_aggregate_impl(rgbs, depths, dyn_masks, K3s_host, c2ws_host, S, H, W, out, xyz_out, capacity, count_out, workspace,
+                               workspace_bytes, stream, params_cached);
+}
+}  // namespace pgdvs
+
 static int static_aggregate_impl(const float *rgbs, const float *depths, const uint8_t *dyn_masks,
                                  const double *K3s_host, const double *c2ws_host, int S, int H, int W, float *out,
                                  float *xyz_out, int64_t capacity, int64_t *count_out, void *workspace,
-                                 int64_t workspace_bytes, pgdvs_stream_t stream) {
+                                 int64_t workspace_bytes, pgdvs_stream_t stream, bool params_cached) {
   PGDVS_REQUIRE(rgbs && depths && dyn_masks && K3s_host && c2ws_host && out && count_out,
                 "pgdvs_static_aggregate: null pointer");
   PGDVS_REQUIRE(S > 0 && S < 65535 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31) && capacity > 0 &&
@@ -1079,9 +1092,8 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
   if (xyz_out) ws.xyz = xyz_out;
   hipStream_t st = as_stream(stream);
   const int64_t P = (int64_t)H * W;
-  // (the state block is cleared by the first agg_params launch below)
-  hipError_t e = hipSuccess;
-  if (S > 1) e = fill_async(ws.occ + P, 0, (size_t)(S - 1) * (size_t)P, st);  // (frame 0 has no map)
+  // counts, tickets, error / statistics words, look-back granules and the later frames' maps: one fill
+  hipError_t e = fill_async(ws.state, 0, (size_t)ws.state_bytes + (size_t)(S - 1) * (size_t)P, st);
   if (e != hipSuccess) {
     set_error("static_aggregate memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
@@ -1152,11 +1164,10 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
         set_error("pgdvs_static_aggregate: singular intrinsics for frame %d", i);
         return PGDVS_ERR_INVALID;
       }
-      if (i % kProjChunk == kProjChunk - 1 || i == S - 1) {
+      if (!params_cached && (i % kProjChunk == kProjChunk - 1 || i == S - 1)) {
         const int first = i - i % kProjChunk, cnt = i % kProjChunk + 1;
         PGDVS_LAUNCH("agg_params", agg_params_kernel, dim3(1), dim3(256), 0, st, chunk, ws.proj, reinterpret_cast<float *>(ws.pc32), first,
-                     cnt, (float)((W > H ? W : H) + 1), first == 0 ? reinterpret_cast<uint32_t *>(ws.state) : nullptr,
-                     first == 0 ? (int)(ws.state_bytes / 4) : 0);
+                     cnt, (float)((W > H ? W : H) + 1));
       }
     }
   }
@@ -1229,7 +1240,7 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
                  (const int32_t *)ws.error, (const int64_t *)nullptr, S, capacity, count_out);
     return check_launch("static_aggregate");
   }
-  {
+  if (!params_cached) {
     CamChunk chunk;
     const int per = (int)(sizeof(chunk.c) / sizeof(chunk.c[0]));
     for (int i = 1; i < S; ++i) {  // (frame 0's block travels by value)

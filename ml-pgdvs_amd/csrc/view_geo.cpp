@@ -18,6 +18,11 @@ namespace pgdvs {
 int view_prep(const float *flat_tgt, const float *flat_src, const float *time_src, const float *time_tgt, float *blocks,
               float *times, hipStream_t st);  // dyn.hip
 
+int static_aggregate_for_view(const float *rgbs, const float *depths, const uint8_t *dyn_masks, const double *K3s_host,
+                              const double *c2ws_host, int S, int H, int W, float *out, float *xyz_out, int64_t capacity,
+                              int64_t *count_out, void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream,
+                              bool params_cached);  // static_agg.hip
+
 // counters of the sub-workspaces (raster.hip, knn_grid.hip, static_agg.hip)
 void raster_counters(const void *workspace, int64_t n_rows, int H, int W, float radius, int64_t *out_dev, hipStream_t st);
 void knn_grid_counter_words(const void *workspace, int64_t capacity, int64_t qcapacity, const int32_t **to_ring,
@@ -237,9 +242,9 @@ int view_forward(const pgdvs_view_geo_desc &d, void *workspace, int64_t workspac
   int64_t rows = d.st_rows;
   int rc = PGDVS_OK;
   if (d.agg_S > 0) {
-    rc = pgdvs_static_aggregate_packed(d.agg_rgbs, d.agg_depths, d.agg_masks, d.agg_K3s_host, d.agg_c2ws_host, d.agg_S, H, W,
-                                       d.agg_cloud_out, d.agg_xyz_out, d.agg_capacity, d.agg_count_out, w.agg, w.agg_bytes,
-                                       stream);
+    rc = static_aggregate_for_view(d.agg_rgbs, d.agg_depths, d.agg_masks, d.agg_K3s_host, d.agg_c2ws_host, d.agg_S, H, W,
+                                   d.agg_cloud_out, d.agg_xyz_out, d.agg_capacity, d.agg_count_out, w.agg, w.agg_bytes, stream,
+                                   d.agg_params_cached != 0);
     cloud = d.agg_cloud_out;
     xyz = d.agg_xyz_out;
     count_dev = d.agg_count_out;

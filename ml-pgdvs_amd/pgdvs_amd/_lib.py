@@ -88,7 +88,7 @@ class ViewGeoDesc(C.Structure):
         ("row_bound", _i64), ("radius", _f), ("K", C.c_int32),
         ("static_rgb", _vp), ("static_mask", _vp), ("raster_status", _vp), ("render_dyn_rgb", _vp), ("render_dyn_mask", _vp),
         ("combined", _vp), ("combined_static", _vp), ("combined_dyn", _vp),
-        ("side_stream", _vp),
+        ("side_stream", _vp), ("agg_params_cached", C.c_int32),
     ]
 
 

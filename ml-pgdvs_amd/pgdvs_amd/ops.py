@@ -434,6 +434,7 @@ class ViewGeoState:
         self.workspace = None
         self.ws_key = None
         self.ws_bytes = 0
+        self.agg_key = None  # (shape, cameras) whose per-frame constants the workspace holds
 
 
 def view_geo_forward(state: ViewGeoState, *, H: int, W: int, flat_cam_tgt, flat_cam_src, time_src, time_tgt, rgb1, rgb2, depth1,
@@ -498,7 +499,9 @@ def view_geo_forward(state: ViewGeoState, *, H: int, W: int, flat_cam_tgt, flat_
         d.st_rows = 0
         rows = cap
         out.update(st_pcl_rgb=cloud, st_pcl_xyz=xyz, st_pcl_rgb_count=cnt)
+        agg_key = (S, H, W, cap, K3.tobytes(), c2w.tobytes())
     else:
+        agg_key = None
         d.agg_S = 0
         rows = st_pcl_rgb.shape[0]
         d.st_pcl_rgb = ptr(st_pcl_rgb, "st_pcl_rgb", numel=rows * 6) if rows else None
@@ -535,8 +538,13 @@ def view_geo_forward(state: ViewGeoState, *, H: int, W: int, flat_cam_tgt, flat_
             state.workspace = torch.empty(int(need), dtype=torch.uint8, device=dev)
             state.ws_bytes = int(need)
         state.ws_key = key
+        state.agg_key = None  # (another layout, or a fresh block: nothing is cached in it)
+    # the camera constants of the aggregation stay in the workspace between calls with the same video
+    d.agg_params_cached = int(agg_key is not None and agg_key == state.agg_key)
+    state.agg_key = None  # (until the call has gone through)
     check(lib.pgdvs_view_geo_forward(C.byref(d), state.workspace.data_ptr(), state.ws_bytes, _stream()), "pgdvs_view_geo_forward")
     del keep_alive
+    state.agg_key = agg_key
     out.update(geo_static_rgb=imgs[0], geo_static_mask=masks[0], render_dyn_rgb=imgs[1], render_dyn_mask=masks[1],
                combined_rgb=comb, combined_rgb_static=imgs[2], combined_rgb_dyn=imgs[3], raster_status=status)
     return out

@@ -428,3 +428,30 @@ def test_view_counters_report_the_fast_paths_exits():
     c2 = model.view_counters()
     assert c2["static_rows"] == 6000 and c2["raster_longest_tile_list"] > 2048
     assert c2["raster_tiles_general_path_long_list"] >= 1
+
+
+def test_native_view_call_reuses_camera_constants_only_for_the_same_video():
+    """the per-frame camera constants of the aggregation stay in the view workspace between calls with the same video
+    (``agg_params_cached``); another video of the same shape, or the same video again after it, uploads them again --
+    every cloud is the oracle's"""
+    H, W, S = 80, 128, 5
+    va = synth.make_video(S, H, W, seed=3)
+    vb = synth.make_video(S, H, W, seed=3, scene="wide_baseline")  # same shape, other cameras
+    d = synth.make_view(va, 2, seed=1)
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=False, st_render_pcl_pts_per_pixel=2)
+    clouds = {"a": orc.aggregate_static_pcl(va["rgbs"], va["depths"], va["dyn_masks"], va["K3s"], va["c2ws"]),
+              "b": orc.aggregate_static_pcl(vb["rgbs"], vb["depths"], vb["dyn_masks"], vb["K3s"], vb["c2ws"])}
+    vids = {"a": _video_dict(va), "b": _video_dict(vb)}
+    (st,) = [None]
+    cached = []
+    for which in ("a", "a", "b", "a", "a"):
+        data = synth.to_torch(d, DEV)
+        data["_st_pcl_video"] = vids[which]
+        with torch.no_grad():
+            r = model.forward(data, render_cfg=rc)
+        (st,) = model._view_states.values()
+        cached.append(int(st.desc.agg_params_cached))
+        n = ops.checked_count(r["st_pcl_rgb_count"], "agg")
+        assert n == clouds[which].shape[0], which
+        assert np.array_equal(N(r["st_pcl_rgb"][0, :n]).view(np.uint32), clouds[which].view(np.uint32)), which
+    assert cached == [0, 1, 0, 0, 1]

@@ -7,7 +7,7 @@ for r in 1 2 3 4; do
   for v in off on; do
     echo -n "$v: "
     if [ $v = on ]; then export "$kv"; else unset "${kv%%=*}"; fi
-    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --gnt-rays 0 --no-kernel-timing "$@" 2>/dev/null |
+    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --gnt-rays 0 --no-kernel-timing --no-scene-sweep "$@" 2>/dev/null |
       python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['steady_state']['frames_per_s'], d['host_enqueue_ms_per_step'], d['config']['views_in_flight'])"
   done
 done

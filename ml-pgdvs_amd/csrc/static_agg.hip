@@ -1207,9 +1207,11 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
     return app;
   };
   // cnts[i] = points in the cloud before frame i.  Frame 0 appends every static pixel (~P points x S-1 frames: the
-  // chip-filling push launch, 8 frames per workgroup row so that the points are read three times).
+  // chip-filling push launch, 12 frames per workgroup row so that the points are read twice).
   static const int fpg_env = getenv("PGDVS_AGG_FPG") ? atoi(getenv("PGDVS_AGG_FPG")) : 0;
-  const int fpg = fpg_env > 0 ? (fpg_env < kPushMaxFpg ? fpg_env : kPushMaxFpg) : 8;
+  // (round 4, three lanes, 60-view runs on one box: 8 frames per row 1160 / 1168 frames/s in steady state, 6: 1155 / 1152,
+  // 12 -- two rows, the coordinates read twice instead of three times --: 1171 / 1184)
+  const int fpg = fpg_env > 0 ? (fpg_env < kPushMaxFpg ? fpg_env : kPushMaxFpg) : 12;
   auto push = [&](int i) {
     // (ordered chain: later frames append a few per cent of P and their launches are latency chains, shorter with 4
     // frames per row; 256 workgroups walk whatever there is -- the count is device-side)

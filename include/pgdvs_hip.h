@@ -231,7 +231,9 @@ int pgdvs_points_raster_bounded(const float *pts, int64_t pts_stride, const floa
  *   K3s: HOST double[S,9]; c2ws: HOST double[S,16]   (float64 numpy upstream)
  *   out[capacity,6] (xyz,rgb) in the reference's order; count_out: device int64 = the number
  *   of rows written, or -1 if the kernels' internal ordering protocol reported an error (the rows are
- *   then not valid; pgdvs_points_raster treats a negative device count as 0).
+ *   then not valid; pgdvs_points_raster treats a negative device count as 0).  A count EQUAL to `capacity` means the
+ *   cloud did not fit: rows were dropped (which ones is unspecified beyond frame 0's prefix) and the cloud must not be
+ *   used -- size the buffer so that the count stays below it (S*H*W rows always suffice).
  *   The workspace holds one occupancy byte per (frame, pixel): S*H*W bytes + 12 bytes per row. */
 int64_t pgdvs_static_aggregate_workspace_bytes(int S, int H, int W, int64_t capacity);
 int pgdvs_static_aggregate(const float *rgbs, const float *depths, const uint8_t *dyn_masks,

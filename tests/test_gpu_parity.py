@@ -434,7 +434,10 @@ def test_static_aggregation_capacity_clamp():
     cap = n - 1000
     part, cnt2 = ops.static_aggregate(T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]).view(torch.uint8), v["K3s"], v["c2ws"],
                                       capacity=cap)
-    assert int(cnt2.item()) <= cap
+    # overflow: both chains (this test also runs under PGDVS_AGG_ORDERED=1) report count == capacity -- the signal that rows
+    # may have been dropped and the cloud must not be used (harness.eval_step and bench.py raise on it); which rows of the
+    # later frames survive differs between the chains, frame 0's prefix does not
+    assert int(cnt2.item()) == cap
     k = min(cap, 54 * 96 // 2)  # rows appended before the clamp bit are unaffected
     assert torch.equal(part[:k], full[:k])
 

@@ -497,7 +497,11 @@ struct TopK {
 };
 
 constexpr int kSortCap = 2048;       // list entries the sorted path holds in LDS (<= 40 KB with the rest: 4 workgroups per CU, see the static_assert)
-constexpr int kSortPerThread = kSortCap / 256;
+// Round 4: a second instantiation for the tiles of DENSE clouds (1080p x 48 frames: 1800 entries per tile on average, 40 % of
+// the tiles beyond 2048 -- the general path took them at 2.5 x the time per tile and the tile pass grew from 0.2 to 1.1 ms):
+// 4096 entries, 69 KB of LDS, two workgroups per CU.  Launched only from 2.2 rows per pixel (a host-side bound on the rows:
+// the headline's clouds never pay for it); the first launch then leaves the longer lists to it.
+constexpr int kSortCapLong = 4096;
 constexpr int kSortBuckets = 1024;   // monotone z-buckets of the distribution pass
 constexpr int kSortMaxBucket = 64;   // more entries than this in one bucket (equal depths): general path
 // ranks are carried as floats (exact below 2^24; +inf = empty slot) so that v_med3_f32 applies
@@ -517,21 +521,24 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-template <int K>
-__global__ void __launch_bounds__(256, 4)
-raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__ offsets, int64_t list_capacity,
+// kCap: capacity of the sorted path (kSortCap / kSortCapLong).  pass: 0 = every tile (lists beyond kCap take the general
+// path), 1 = the first of two launches (tiles with longer lists are left to the second), 2 = the second (only those tiles).
+template <int K, int kCap>
+__global__ void __launch_bounds__(256, kCap <= kSortCap ? 4 : 2)
+raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__ offsets, int64_t list_capacity, int pass,
                    const float *__restrict__ feat, int64_t feat_stride, float radius, int H, int W,
                    int ntx, int nty, int tiles_per_xcd, int64_t *__restrict__ idx_out,
                    float *__restrict__ zbuf_out, float *__restrict__ dist_out,
                    float *__restrict__ rgb_out, int rgb_planar, float *__restrict__ mask_out, int32_t *__restrict__ stats) {
-  __shared__ float2 s_xy[kSortCap];         // rank order: NDC x, y (general path: staging of 256 entries)
-  __shared__ uint2 s_kz[kSortCap];          // bucket order: (z bits, id); after ranking, rank order: (id, z bits)
+  constexpr int kSortPerThread = kCap / 256;
+  __shared__ float2 s_xy[kCap];             // rank order: NDC x, y (general path: staging of 256 entries)
+  __shared__ uint2 s_kz[kCap];              // bucket order: (z bits, id); after ranking, rank order: (id, z bits)
   __shared__ float4 s_wave[4][68];          // per-wave strip of culled points (+ padding)
   // bucket counts, then bucket starts: dead before the walk begins, so they share the strips' storage
   unsigned *s_cnt = reinterpret_cast<unsigned *>(&s_wave[0][0]);
   static_assert(kSortBuckets * 4 <= 4 * 68 * 16, "the counters alias the strips");
-  static_assert(kSortCap * 16 + 4 * 68 * 16 + 128 <= 40960, "four workgroups per CU");
-  static_assert(kSortCap % 256 == 0, "every thread owns kSortCap / 256 entries");
+  static_assert(kCap * 16 + 4 * 68 * 16 + 128 <= (kCap <= kSortCap ? 40960 : 81920), "four (two) workgroups per CU");
+  static_assert(kCap % 256 == 0 && kCap <= 4096, "every thread owns kCap / 256 entries; positions are packed in 12 bits");
   __shared__ unsigned s_red[12];
   __shared__ int s_flag;
   // XCD-aware mapping: blocks b, b+8, ... share an XCD -> give them a contiguous tile band
@@ -576,7 +583,9 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
     rd2[k] = -1.0f;
   }
 
-  bool sorted_path = n64 > 0 && n64 <= kSortCap;  // (uniform over the workgroup)
+  // (two launches: every tile is drawn by exactly one of them)
+  if ((pass == 1 && n64 > kSortCap) || (pass == 2 && n64 <= kSortCap)) return;
+  bool sorted_path = n64 > 0 && n64 <= kCap;  // (uniform over the workgroup)
   if (sorted_path) {
     const int n = (int)n64;
     // ---- 1. the list, once, into registers (all loads in flight together); its depth range; clear the counters
@@ -1010,10 +1019,15 @@ template <int K>
 static void launch_tile(dim3 grid, hipStream_t st, const RasterWs &ws, const float *feat,
                         int64_t feat_stride, float radius, int H, int W, int ntx, int nty,
                         int tiles_per_xcd, int64_t *idx, float *zbuf, float *dist2, float *rgb,
-                        int rgb_planar, float *mask) {
-  PGDVS_LAUNCH("raster_tile", raster_tile_kernel<K>, grid, dim3(256), 0, st, (const float4 *)ws.lists, (const int32_t *)ws.offsets,
-               ws.list_capacity, feat, feat_stride, radius, H, W, ntx, nty, tiles_per_xcd, idx, zbuf, dist2, rgb, rgb_planar, mask,
-               ws.stats);
+                        int rgb_planar, float *mask, bool long_lists) {
+  PGDVS_LAUNCH("raster_tile", (raster_tile_kernel<K, kSortCap>), grid, dim3(256), 0, st, (const float4 *)ws.lists,
+               (const int32_t *)ws.offsets, ws.list_capacity, long_lists ? 1 : 0, feat, feat_stride, radius, H, W, ntx, nty,
+               tiles_per_xcd, idx, zbuf, dist2, rgb, rgb_planar, mask, ws.stats);
+  if (long_lists) {
+    PGDVS_LAUNCH("raster_tile_long", (raster_tile_kernel<K, kSortCapLong>), grid, dim3(256), 0, st, (const float4 *)ws.lists,
+                 (const int32_t *)ws.offsets, ws.list_capacity, 2, feat, feat_stride, radius, H, W, ntx, nty, tiles_per_xcd, idx, zbuf,
+                 dist2, rgb, rgb_planar, mask, ws.stats);
+  }
 }
 
 static int points_raster_impl(const float *pts, int64_t pts_stride, const float *feat, int64_t feat_stride, int64_t n_points,
@@ -1142,10 +1156,13 @@ static int points_raster_impl(const float *pts, int64_t pts_stride, const float 
   }
   const int tiles_per_xcd = (int)cdiv(ntiles, 8);
   dim3 grid(8 * tiles_per_xcd);
+  // dense clouds (the same density from which the depth bound is computed): a second tile launch with a 4096-entry sorted
+  // path takes the lists the first one cannot hold
+  const bool long_lists = n_points > 0 && n_points >= gate_rows;
 #define PGDVS_TILE_CASE(KK)                                                                      \
   case KK:                                                                                       \
     launch_tile<KK>(grid, st, ws, feat, feat_stride, radius, H, W, ntx, nty, tiles_per_xcd, idx, \
-                    zbuf, dist2, rgb, rgb_planar, mask);                                         \
+                    zbuf, dist2, rgb, rgb_planar, mask, long_lists);                             \
     break;
   switch (K) {
     PGDVS_TILE_CASE(1)

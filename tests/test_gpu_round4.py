@@ -455,3 +455,32 @@ def test_native_view_call_reuses_camera_constants_only_for_the_same_video():
         assert n == clouds[which].shape[0], which
         assert np.array_equal(N(r["st_pcl_rgb"][0, :n]).view(np.uint32), clouds[which].view(np.uint32)), which
     assert cached == [0, 1, 0, 0, 1]
+
+
+@pytest.mark.parametrize("n,spread,K,bound", [(9000, 0.09, 3, "0"), (14000, 0.06, 2, "0"), (30000, 0.05, 3, "0"), (9000, 0.09, 3, "1e9")])
+def test_raster_long_tile_lists_second_launch_vs_oracle(n, spread, K, bound, monkeypatch):
+    """tile lists between 2048 and 4096 entries (the second tile launch's 4096-entry sorted path), beyond 4096 (its general
+    path) and short ones in one image; with the depth bound dropping entries and without it (PGDVS_RASTER_BOUND_DENSITY=1e9:
+    one launch, the general path takes every list beyond 2048): fragments bit-exact against the oracle's naive loop"""
+    H, W = 96, 128
+    rng = np.random.default_rng(n)
+    centres = np.array([[-0.5, -0.3], [0.4, 0.2], [0.0, 0.45]])
+    which = rng.integers(0, 3, n)
+    xy = centres[which] + rng.normal(0, spread, (n, 2)) * np.array([1.0, 0.6])
+    z = 2.0 + 0.4 * which[:, None] + rng.normal(0, 0.02, (n, 1)) * (rng.random((n, 1)) < 0.5)  # exact ties inside a cluster
+    pts = np.concatenate([xy, z], 1).astype(np.float32)
+    fc = synth.flat_cam(H, W, np.array([[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]]), np.eye(4)).astype(np.float32)
+    cam = ops.cam_prep(T(fc))
+    radius = 0.12  # 5.76 px: 4 x 4 blocks for the bound
+    monkeypatch.setenv("PGDVS_RASTER_BOUND_DENSITY", bound)
+    a = ops.points_raster(T(pts), T(rng.random((n, 3)).astype(np.float32)), cam, radius, K, H, W, want_fragments=True)
+    idx, zbuf, d2 = orc.rasterize_points(pts, fc, H, W, radius, K)
+    assert np.array_equal(N(a["idx"]), idx)
+    assert np.array_equal(N(a["zbuf"]).view(np.uint32), zbuf.view(np.uint32))
+    assert np.array_equal(N(a["dist2"]).view(np.uint32), d2.view(np.uint32))
+    # the lists really are that long: count the (point, tile) pairs of the densest tile on the host
+    ndc = orc.points_to_ndc(pts, fc, H, W)
+    px = (W - 1) - ((ndc[:, 0] + W / H) * W - W / H) / (2.0 * W / H)
+    py = (H - 1) - ((ndc[:, 1] + 1.0) * H - 1.0) / 2.0
+    t = (np.clip(py // 16, 0, H // 16 - 1) * (W // 16) + np.clip(px // 16, 0, W // 16 - 1)).astype(int)
+    assert np.bincount(t).max() > 2048

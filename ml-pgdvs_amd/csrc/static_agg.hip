@@ -233,7 +233,9 @@ struct AppendSrc {
 };
 struct f3 { float x, y, z; };  // 12-byte loads / stores in one instruction
 
-__device__ __forceinline__ f3 append_row(const AppendSrc &a, const CamBlock &cam, int p, int64_t pos, bool write) {
+// (d_in: the pixel's depth if the caller already has it, NaN = load it here; *d_out receives the depth used)
+__device__ __forceinline__ f3 append_row(const AppendSrc &a, const CamBlock &cam, int p, int64_t pos, bool write,
+                                         float d_in = __builtin_nanf(""), float *d_out = nullptr) {
   // row / column of the pixel: float reciprocal + one correction step (exact for P < 2^24),
   // integer division otherwise
   int r, col;
@@ -252,7 +254,8 @@ __device__ __forceinline__ f3 append_row(const AppendSrc &a, const CamBlock &cam
     col = p - r * a.W;
   }
   const float u = (float)col, v = (float)r;
-  const float d = a.depth[p];
+  const float d = d_in == d_in ? d_in : a.depth[p];
+  if (d_out) *d_out = d;
   float X[3];
 #pragma unroll
   for (int ax = 0; ax < 3; ++ax) {
@@ -798,8 +801,9 @@ template <int kQueue>
 __global__ void __launch_bounds__(kStepThreads)
 agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__ sel16, int64_t Wd, int src,
                 const ProjF64 *__restrict__ proj, const PushConsts *__restrict__ pc, int f_hi, int fpg, int H, int W,
-                AppendSrc app, CamBlock cam, unsigned *__restrict__ stat) {
+                AppendSrc app, CamBlock cam, unsigned *__restrict__ stat, float *__restrict__ seldepth) {
   __shared__ uint16_t s_list[kStepThreads * kStepPx];  // (thread << 4 | pixel) of every selected pixel, 8 KB
+  __shared__ int s_cstart[kStepChunks];  // list position of every chunk's first selected pixel
   __shared__ uint4 s_q[kQueue];
   __shared__ int s_qn[2];
   __shared__ int s_wsum[4];
@@ -816,6 +820,7 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
   int n;
   int slot = block_excl_256(__popc(bits), s_wsum, n);
   if (n == 0) return;
+  if ((tid & 7) == 0) s_cstart[tid >> 3] = slot;
   for (uint32_t m = bits; m; m &= m - 1) s_list[slot++] = (uint16_t)((tid << 4) | __builtin_ctz(m));
   if (tid == 0) s_qn[0] = s_qn[1] = 0;
   __syncthreads();
@@ -827,10 +832,17 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
     float x = 0.f, y = 0.f, z = 0.f;
     if (live) {
       const int ent = s_list[e];
-      const f3 X = append_row(app, cam, (int)(pixel_base(ent >> 4) + (ent & 15)), 0, false);
+      float d;
+      const f3 X = append_row(app, cam, (int)(pixel_base(ent >> 4) + (ent & 15)), 0, false, __builtin_nanf(""), &d);
       x = X.x;
       y = X.y;
       z = X.z;
+      // the depth this link gathered anyway, left for agg_rows: the selected pixels of a 128-pixel chunk in order, packed
+      // at the chunk's own base (a dense 4-byte read there instead of a 64-byte sector per scattered pixel)
+      if (blockIdx.y == 0) {
+        const int ch = ent >> 7;  // chunk of the workgroup (eight threads per chunk)
+        seldepth[(int64_t)src * Wd * 32 + ((int64_t)blockIdx.x + (int64_t)ch * gridDim.x) * kStepChunkPx + (e - s_cstart[ch])] = d;
+      }
     }
     const unsigned dmask = screen_frames(pc, fa, fb, live, x, y, z, wm1, hm1, W, stamp);
     queue_doubtful<kQueue, kStepThreads>(s_q, s_qn, dmask, x, y, z, fa, e0 + kStepThreads >= n, proj, H, W, stamp);
@@ -903,18 +915,23 @@ struct RowsArgs {
 };
 __global__ void __launch_bounds__(kBitTileWords)
 agg_rows_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles, const int64_t *__restrict__ tile_off,
-                const int64_t *__restrict__ cnts, const CamBlock *__restrict__ cams, RowsArgs a) {
+                const int64_t *__restrict__ cnts, const CamBlock *__restrict__ cams, RowsArgs a,
+                const float *__restrict__ seldepth, int f_with_depth) {
   __shared__ uint16_t s_list[kSelTile];
   __shared__ int s_wsum[4];
+  __shared__ int s_cstart[kBitTileWords / 4];  // list position of every 128-pixel chunk's first selected pixel
   const int tid = threadIdx.x;
   const int f = 1 + (int)blockIdx.y, t = (int)blockIdx.x;
   const uint32_t bits = sel[(int64_t)f * Wd + (int64_t)t * kBitTileWords + tid];
   int total;
   int slot = block_excl_256(__popc(bits), s_wsum, total);
   if (total == 0) return;
+  if ((tid & 3) == 0) s_cstart[tid >> 2] = slot;
   for (uint32_t m = bits; m; m &= m - 1) s_list[slot++] = (uint16_t)((tid << 5) | __builtin_ctz(m));
   __syncthreads();
   const int64_t pos0 = cnts[1] + tile_off[(int64_t)f * tiles + t];
+  // frames whose chain link unprojected its pixels (all but the last one) left their depths packed per 128-pixel chunk
+  const float *dep = f < f_with_depth ? seldepth + (int64_t)f * Wd * 32 + (int64_t)t * kSelTile : nullptr;
   AppendSrc app;
   app.depth = a.depths + (size_t)f * (size_t)a.P;
   app.rgb = a.rgbs + (size_t)f * (size_t)a.P * 3;
@@ -928,7 +945,10 @@ agg_rows_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles, const i
   for (int e = tid; e < total; e += kBitTileWords) {
     const int64_t pos = pos0 + e;
     if (pos >= a.capacity) break;
-    append_row(app, cam, tile_px + (int)s_list[e], pos, true);
+    const int ent = (int)s_list[e];
+    const int ch = ent >> 7;  // 128-pixel chunk of the tile (four threads of 32 pixels)
+    const float d = dep ? dep[ch * kStepChunkPx + (e - s_cstart[ch])] : __builtin_nanf("");
+    append_row(app, cam, tile_px + ent, pos, true, d);
   }
 }
 
@@ -966,6 +986,8 @@ struct AggWs {
   int64_t *tile_off;   // [S * tiles + 1] their running sum
   uint8_t *occ;  // [S][P] one occupancy byte per (frame, pixel), zeroed per call
   uint32_t *sel;  // [S][Wd] selection bits of the later frames (each written whole by its agg_step launch)
+  float *seldepth;  // [S][Wd * 32] depths of the selected pixels, packed per 128-pixel chunk at the chunk's base (sparse: only
+                    // what the links write is ever touched)
   int64_t Wd;
   int32_t *sel_pix;  // [P] ordered chain: the pixels the current frame selected, in cloud order
   float *xyz;
@@ -1008,6 +1030,8 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   w.Wd = tiles * kBitTileWords;
   w.sel = reinterpret_cast<uint32_t *>(p + off);
   off += align_up((int64_t)S * w.Wd * 4, 256);
+  w.seldepth = reinterpret_cast<float *>(p + off);
+  off += align_up((int64_t)S * w.Wd * 32 * 4, 256);
   w.xyz = reinterpret_cast<float *>(p + off);
   off += align_up((capacity > 0 ? capacity : 1) * 12, 256);
   w.sel_pix = reinterpret_cast<int32_t *>(p + off);
@@ -1302,7 +1326,7 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       const unsigned gy = i + 1 < S ? (unsigned)cdiv(S - 1 - i, sfpg) : 1u;
       PGDVS_LAUNCH("agg_step", agg_step_kernel<kPushQueueSmall>, dim3(gx, gy), dim3(kStepThreads), 0, st, a, ws.occ,
                    reinterpret_cast<uint16_t *>(ws.sel), ws.Wd, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, sfpg, H, W,
-                   frame_src(i), cams[(size_t)i], ws.stat);
+                   frame_src(i), cams[(size_t)i], ws.stat, ws.seldepth);
     }
   }
   PGDVS_LAUNCH("agg_count", agg_count_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,
@@ -1320,7 +1344,7 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
     ra.W = W;
     PGDVS_LAUNCH("agg_rows", agg_rows_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,
                  (const uint32_t *)ws.sel, ws.Wd, tiles, (const int64_t *)ws.tile_off, (const int64_t *)ws.cnts,
-                 (const CamBlock *)ws.cams, ra);
+                 (const CamBlock *)ws.cams, ra, (const float *)ws.seldepth, S - 1);
   }
   return check_launch("static_aggregate");
 }

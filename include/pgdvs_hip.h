@@ -15,8 +15,11 @@
  *   - `stream` is a hipStream_t (NULL = default stream); every call only enqueues
  *     work on it and never synchronises or allocates (one diagnostics switch does
  *     synchronise: PGDVS_KNN_STATS=1 in the environment makes the kNN print its ring
- *     histogram to stderr; PGDVS_KNN_NO_TPQ=1 and PGDVS_KNN_PER_CELL=<n> select kNN search
- *     variants / the grid density for tuning -- results are identical for any setting);
+ *     histogram to stderr; PGDVS_KNN_NO_TPQ=1, PGDVS_KNN_PER_CELL=<n>, PGDVS_KNN_THR_MULT=<x> and PGDVS_KNN_RING_CAP=<n>
+ *     select kNN search variants / the grid density / the starting threshold for tuning, PGDVS_RASTER_BOUND_DENSITY=<rows
+ *     per pixel> the density from which the rasteriser computes its depth bound and runs its long-list launch,
+ *     PGDVS_AGG_ORDERED / PGDVS_AGG_FUSED0 / PGDVS_AGG_FPG / PGDVS_AGG_STEP_FPG the aggregation's launch structure --
+ *     results are identical for any setting);
  *   - return value: 0 on success, negative pgdvs_status on error, message via
  *     pgdvs_last_error() (thread-local);
  *   - no global mutable state; re-entrant per stream.

@@ -836,7 +836,7 @@ template <int KK>
 __global__ void __launch_bounds__(256, 5)
 grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted,
                       const CellIndex cell_start, int first_col, float *__restrict__ avg_out,
-                      int32_t *__restrict__ open_count, int32_t *__restrict__ open_list) {
+                      int32_t *__restrict__ open_count, int32_t *__restrict__ open_list, float thr_mult) {
   __shared__ int2 s_run[9][256];
   __shared__ float s_bd[9][256];
   __shared__ float s_thr[256];  // the lane's starting threshold (see below)
@@ -923,7 +923,7 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
       const int2 se = s_run[k][tid];
       ncand += se.y - se.x;
     }
-    return (KK >= 17 && ncand >= KK) ? (KK >= 40 ? 4.5f : 6.0f) * (float)KK * g.h * g.h / (float)ncand : __builtin_inff();
+    return (KK >= 17 && ncand >= KK) ? (KK >= 40 ? thr_mult : 6.0f) * (float)KK * g.h * g.h / (float)ncand : __builtin_inff();
   };
   // What the block can certify at all: the distance to its nearest face that still has cells behind it (minus the
   // rounding margin), squared -- a list whose last entry lies beyond it is not complete whatever it holds.  Kept in LDS:
@@ -1332,13 +1332,15 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   const unsigned gq = (unsigned)(cdiv(nq_cap, 4) < 256 * 8 ? (cdiv(nq_cap, 4) > 0 ? cdiv(nq_cap, 4) : 1) : 256 * 8);
   const char *no_tpq = getenv("PGDVS_KNN_NO_TPQ");  // diagnostics: force the wavefront-per-query search
   bool tpq = qpts == nullptr && !(no_tpq && no_tpq[0] == '1') && capacity < (1ll << 27);  // (32-bit byte offsets)
+  const char *etm = getenv("PGDVS_KNN_THR_MULT");  // tuning knob (any value gives exact results)
+  const float thr_mult = etm && atof(etm) > 0.0 ? (float)atof(etm) : 4.5f;
   if (tpq) {
     const unsigned gt = (unsigned)(cdiv(capacity, 256) < 2560 ? (cdiv(capacity, 256) > 0 ? cdiv(capacity, 256) : 1) : 2560);
     switch (KK) {
 #define PGDVS_TPQ_CASE(N)                                                                                        \
   case N:                                                                                                        \
     PGDVS_LAUNCH("grid_query_tpq", grid_query_tpq_kernel<N>, dim3(gt), dim3(256), 0, st, ws.gp, ws.sorted,      \
-                 ci, qs.first_col, avg_out, ws.open_count, ws.open_list);                                        \
+                 ci, qs.first_col, avg_out, ws.open_count, ws.open_list, thr_mult);                              \
     break;
       PGDVS_TPQ_CASE(5)
       PGDVS_TPQ_CASE(9)

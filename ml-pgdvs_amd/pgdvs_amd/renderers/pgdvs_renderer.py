@@ -50,6 +50,8 @@ class PGDVSRenderer(PGDVSBaseRenderer):
             proj_func=self.static_renderer.projector.compute_projections, local_rank=local_rank,
             use_tracker=render_cfg.dyn_render_track_temporal == "no_tgt")
 
+    _MAX_VIEW_STATES = 16  # per-stream workspaces of the native call kept alive (views in flight use one stream each)
+
     # -- one native call per view (include/pgdvs_hip.h: pgdvs_view_geo_forward) -----------------------------------
     def _native_view_ok(self, data, render_cfg):
         """The geometric path with softsplat, one batch item, full resolution, everything fp32 on the GPU: what the
@@ -93,9 +95,12 @@ class PGDVSRenderer(PGDVSBaseRenderer):
         dev = data["rgb_src_temporal"].device
         states = self.__dict__.setdefault("_view_states", {})
         key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-        st = states.get(key)
+        st = states.pop(key, None)
         if st is None:
-            st = states[key] = ops.ViewGeoState()
+            st = ops.ViewGeoState()
+            while len(states) >= self._MAX_VIEW_STATES:  # (a workspace is ~1 GB at 1080p: forget the least recently used stream's)
+                states.pop(next(iter(states)))
+        states[key] = st  # (most recently used last)
         noise = data.get("static_noise", None)
         rng_state = None if noise is not None else self.dyn_renderer.splat_rng_state(dev)
         occ = data.get("flow_fwd_occ_mask", None)

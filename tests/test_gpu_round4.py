@@ -484,3 +484,22 @@ def test_raster_long_tile_lists_second_launch_vs_oracle(n, spread, K, bound, mon
     py = (H - 1) - ((ndc[:, 1] + 1.0) * H - 1.0) / 2.0
     t = (np.clip(py // 16, 0, H // 16 - 1) * (W // 16) + np.clip(px // 16, 0, W // 16 - 1)).astype(int)
     assert np.bincount(t).max() > 2048
+
+
+def test_static_aggregation_fused_frame0_launch():
+    """PGDVS_AGG_FUSED0=1: frame 0 as ONE launch (selection + ordered offsets + projections + rows; opt-in, the select + push
+    pair is the default because it is faster) through the bit-exact aggregation tests -- read once per process, hence the
+    child process"""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, PGDVS_AGG_FUSED0="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_round2.py"), "-k",
+                        "static_aggregation_shapes_vs_oracle or static_aggregation_vs_reference_golden or "
+                        "static_aggregation_capacity_clamp or degenerate_camera_motions or config_c1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

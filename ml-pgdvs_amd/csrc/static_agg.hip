@@ -797,12 +797,14 @@ __device__ __forceinline__ unsigned sel_flags16_pair(const SelArgs &a, const int
 // them against the frames src + 1 + blockIdx.y * fpg ... like agg_push_kernel.  gridDim.x is a multiple of 8: the
 // workgroups (x, 0), (x, 1), ... land on one XCD and share its L2's copy of the chunk (the rows re-read the same 4 MB).
 // The last frame's launch only leaves its bits.
-template <int kQueue>
+template <int kQueue, int kSpec>
 __global__ void __launch_bounds__(kStepThreads)
 agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__ sel16, int64_t Wd, int src,
                 const ProjF64 *__restrict__ proj, const PushConsts *__restrict__ pc, int f_hi, int fpg, int H, int W,
                 AppendSrc app, CamBlock cam, unsigned *__restrict__ stat, float *__restrict__ seldepth) {
+  constexpr int spec = kSpec;
   __shared__ uint16_t s_list[kStepThreads * kStepPx];  // (thread << 4 | pixel) of every selected pixel, 8 KB
+  __shared__ float s_dep[kSpec ? kStepThreads * kStepPx : 1];  // spec: their depths, loaded densely beside mask and map
   __shared__ int s_cstart[kStepChunks];  // list position of every chunk's first selected pixel
   __shared__ uint4 s_q[kQueue];
   __shared__ int s_qn[2];
@@ -812,6 +814,15 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
     return ((int64_t)blockIdx.x + (int64_t)(t >> 3) * gridDim.x) * kStepChunkPx + (t & 7) * kStepPx;
   };
   const int64_t base = pixel_base(tid);
+  // spec (review item 1c, PGDVS_AGG_SPEC_DEPTH=1): the 16 depths of the thread's pixels requested TOGETHER with its mask
+  // and map bytes -- 8.3 MB of dense reads per link instead of a sector per selected pixel, and one dependent round trip
+  // less in the link (mask / map -> stamps instead of mask / map -> depth -> stamps)
+  float4 dq[4];
+  const bool spec_ok = spec != 0 && base + 16 <= a.P && ((reinterpret_cast<uintptr_t>(app.depth + base) & 15) == 0);
+  if (spec_ok) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dq[k] = reinterpret_cast<const float4 *>(app.depth + base)[k];
+  }
   const uint32_t bits = sel_flags16_pair(a, base);
   if (blockIdx.y == 0 && base < Wd * 32) sel16[((int64_t)src * Wd * 32 + base) >> 4] = (uint16_t)bits;
   const int fa = src + 1 + (int)blockIdx.y * fpg;
@@ -821,7 +832,20 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
   int slot = block_excl_256(__popc(bits), s_wsum, n);
   if (n == 0) return;
   if ((tid & 7) == 0) s_cstart[tid >> 3] = slot;
-  for (uint32_t m = bits; m; m &= m - 1) s_list[slot++] = (uint16_t)((tid << 4) | __builtin_ctz(m));
+  if (spec != 0) {
+    const float dv[16] = {dq[0].x, dq[0].y, dq[0].z, dq[0].w, dq[1].x, dq[1].y, dq[1].z, dq[1].w,
+                          dq[2].x, dq[2].y, dq[2].z, dq[2].w, dq[3].x, dq[3].y, dq[3].z, dq[3].w};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if ((bits >> k) & 1u) {
+        s_list[slot] = (uint16_t)((tid << 4) | k);
+        s_dep[kSpec ? slot : 0] = spec_ok ? dv[k] : app.depth[base + k];
+        ++slot;
+      }
+    }
+  } else {
+    for (uint32_t m = bits; m; m &= m - 1) s_list[slot++] = (uint16_t)((tid << 4) | __builtin_ctz(m));
+  }
   if (tid == 0) s_qn[0] = s_qn[1] = 0;
   __syncthreads();
   const ByteStamp stamp{occ_all, (int64_t)H * W, stat};
@@ -833,7 +857,8 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
     if (live) {
       const int ent = s_list[e];
       float d;
-      const f3 X = append_row(app, cam, (int)(pixel_base(ent >> 4) + (ent & 15)), 0, false, __builtin_nanf(""), &d);
+      const f3 X = append_row(app, cam, (int)(pixel_base(ent >> 4) + (ent & 15)), 0, false,
+                              spec != 0 ? s_dep[kSpec ? e : 0] : __builtin_nanf(""), &d);
       x = X.x;
       y = X.y;
       z = X.z;
@@ -1316,6 +1341,7 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
     // in flight the throughput is the other way round: 1037 frames/s with 6, 1048 with 8, 1055 with 16, 1058 with 24-32 -- one
     // row whenever the later frames fit a queue entry's mask
     const int sfpg = sfpg_env > 0 ? (sfpg_env < kPushMaxFpg ? sfpg_env : kPushMaxFpg) : kPushMaxFpg;
+    static const bool spec_env = getenv("PGDVS_AGG_SPEC_DEPTH") && getenv("PGDVS_AGG_SPEC_DEPTH")[0] == '1';
     for (int i = 1; i < S; ++i) {
       SelArgs a;
       a.dyn_mask = dyn_masks + (size_t)i * P;
@@ -1324,9 +1350,15 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       a.P = (int)P;
       a.W = W;
       const unsigned gy = i + 1 < S ? (unsigned)cdiv(S - 1 - i, sfpg) : 1u;
-      PGDVS_LAUNCH("agg_step", agg_step_kernel<kPushQueueSmall>, dim3(gx, gy), dim3(kStepThreads), 0, st, a, ws.occ,
-                   reinterpret_cast<uint16_t *>(ws.sel), ws.Wd, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, sfpg, H, W,
-                   frame_src(i), cams[(size_t)i], ws.stat, ws.seldepth);
+      if (spec_env) {
+        PGDVS_LAUNCH("agg_step", (agg_step_kernel<kPushQueueSmall, 1>), dim3(gx, gy), dim3(kStepThreads), 0, st, a, ws.occ,
+                     reinterpret_cast<uint16_t *>(ws.sel), ws.Wd, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, sfpg, H, W,
+                     frame_src(i), cams[(size_t)i], ws.stat, ws.seldepth);
+      } else {
+        PGDVS_LAUNCH("agg_step", (agg_step_kernel<kPushQueueSmall, 0>), dim3(gx, gy), dim3(kStepThreads), 0, st, a, ws.occ,
+                     reinterpret_cast<uint16_t *>(ws.sel), ws.Wd, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, sfpg, H, W,
+                     frame_src(i), cams[(size_t)i], ws.stat, ws.seldepth);
+      }
     }
   }
   PGDVS_LAUNCH("agg_count", agg_count_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,

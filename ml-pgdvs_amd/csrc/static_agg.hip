@@ -864,7 +864,7 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
       z = X.z;
       // the depth this link gathered anyway, left for agg_rows: the selected pixels of a 128-pixel chunk in order, packed
       // at the chunk's own base (a dense 4-byte read there instead of a 64-byte sector per scattered pixel)
-      if (blockIdx.y == 0) {
+      if (blockIdx.y == 0 && seldepth != nullptr) {
         const int ch = ent >> 7;  // chunk of the workgroup (eight threads per chunk)
         seldepth[(int64_t)src * Wd * 32 + ((int64_t)blockIdx.x + (int64_t)ch * gridDim.x) * kStepChunkPx + (e - s_cstart[ch])] = d;
       }
@@ -1055,8 +1055,13 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   w.Wd = tiles * kBitTileWords;
   w.sel = reinterpret_cast<uint32_t *>(p + off);
   off += align_up((int64_t)S * w.Wd * 4, 256);
-  w.seldepth = reinterpret_cast<float *>(p + off);
-  off += align_up((int64_t)S * w.Wd * 32 * 4, 256);
+  // (address space for every pixel of every later frame, of which the selected few per cent are ever touched; very long
+  // videos do without it -- agg_rows then gathers the depths itself)
+  w.seldepth = nullptr;
+  if ((int64_t)S * w.Wd * 32 * 4 <= (1ll << 30)) {
+    w.seldepth = reinterpret_cast<float *>(p + off);
+    off += align_up((int64_t)S * w.Wd * 32 * 4, 256);
+  }
   w.xyz = reinterpret_cast<float *>(p + off);
   off += align_up((capacity > 0 ? capacity : 1) * 12, 256);
   w.sel_pix = reinterpret_cast<int32_t *>(p + off);
@@ -1376,7 +1381,7 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
     ra.W = W;
     PGDVS_LAUNCH("agg_rows", agg_rows_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,
                  (const uint32_t *)ws.sel, ws.Wd, tiles, (const int64_t *)ws.tile_off, (const int64_t *)ws.cnts,
-                 (const CamBlock *)ws.cams, ra, (const float *)ws.seldepth, S - 1);
+                 (const CamBlock *)ws.cams, ra, (const float *)ws.seldepth, ws.seldepth != nullptr ? S - 1 : 0);
   }
   return check_launch("static_aggregate");
 }

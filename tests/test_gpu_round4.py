@@ -503,3 +503,36 @@ def test_static_aggregation_fused_frame0_launch():
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_views_in_flight_reproduce_the_sequential_images():
+    """stress of the lanes: 48 views of a 540p x 8-frame video through `ResidentVideoRenderer` with three lanes (second
+    stream each), four distinct target views cycled, injected noise -- every image equals the one the same view gives alone
+    (splat atomics: to rounding), every cloud count is the same, no status word is raised"""
+    from pgdvs_amd.runtime import ResidentVideoRenderer
+
+    H, W, S = 540, 960, 8
+    v = synth.make_video(S, H, W, seed=77)
+    model, rc = _renderer("geo", dyn_pcl_remove_outlier=True, st_render_pcl_pts_per_pixel=3)
+    rvr = ResidentVideoRenderer(model, rc, T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]), v["K3s"], v["c2ws"], lanes=3,
+                                side_streams=True)
+    datas = [synth.to_torch(synth.make_view(v, i, frac=0.3, seed=2), DEV) for i in (0, 2, 4, 6)]
+    n0 = rvr.calibrate(datas[0])
+    refs = []
+    for d in datas:
+        ret, _ = rvr.render(d, 0)
+        rvr.join()
+        torch.cuda.synchronize()
+        refs.append((ret["combined_rgb"].clone(), ret["geo_static_rgb"].clone(), ret["render_dyn_mask"].clone()))
+    outs = torch.empty((48, 1, 3, H, W), device=DEV)
+    rets = []
+    for j in range(48):
+        rets.append(rvr.render(datas[j % 4], j, out=outs[j])[0])
+    rvr.join()
+    torch.cuda.synchronize()
+    for j, ret in enumerate(rets):
+        comb, st, dm = refs[j % 4]
+        assert int(ret["st_pcl_rgb_count"]) == n0 and int(ret["geo_static_raster_status"]) == 0, j
+        assert torch.equal(ret["geo_static_rgb"], st), j          # the static branch has no atomics: bit for bit
+        assert torch.equal(ret["render_dyn_mask"], dm), j
+        assert torch.allclose(outs[j], comb, rtol=0, atol=1e-5), j

@@ -682,8 +682,8 @@ __global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamB
 // agg_select (count, ordered offsets, rows: 29 us) + agg_push<1024> (the rows' packed coordinates re-read once per group
 // of 8 later frames, 47.6 M projections: 54 us).  Here workgroup (tile, group) selects its 4096 pixels itself (mask bytes:
 // 2 MB per group instead of 21 MB of coordinates), unprojects them in registers and screens them against its group of
-// later frames; the workgroups of group 0 also own the ORDER: they publish their tile's count before the projections and
-// sum their predecessors' counts after them (published ~50 us earlier: the look-back never waits), then write the rows.
+// later frames; every workgroup publishes its tile's count before the projections, sums its predecessors' counts after them
+// (published ~50 us earlier: the look-back never waits) and writes its group's share of the tile's rows.
 constexpr int kF0Threads = 256;
 constexpr int kF0Tile = kF0Threads * kSelItems;  // 4096 pixels
 
@@ -698,10 +698,12 @@ agg_frame0_kernel(SelArgs a, CamBlock cam, const ProjF64 *__restrict__ proj, con
   __shared__ int s_wsum[4];
   __shared__ long long s_part[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool writer = blockIdx.y == 0;
-  // group 0 takes dynamic tile ids (a tile's predecessors are then owned by workgroups that already run, whatever order
-  // the dispatcher starts workgroups in); the other groups need no order
-  if (tid == 0) s_tile = writer ? atomicAdd(&a.ticket[0], 1) : (int)blockIdx.x;
+  // Every group takes dynamic tile ids from its own ticket counter (each group walks every tile once; a tile's
+  // predecessors are then owned, in every group, by workgroups that already run -- whatever order the dispatcher starts
+  // workgroups in), publishes the tile's count (the same value from every group: idempotent) and writes ITS share of the
+  // tile's rows at the end: all workgroups carry the same mix of projections and row traffic.  (First version, round 4:
+  // only group 0 wrote rows and finished last -- 114 us against 93 for the select + push pair.)
+  if (tid == 0) s_tile = atomicAdd(&a.ticket[blockIdx.y], 1);
   if (tid == 0) s_qn[0] = s_qn[1] = 0;
   __syncthreads();
   const int tile = s_tile;
@@ -709,7 +711,7 @@ agg_frame0_kernel(SelArgs a, CamBlock cam, const ProjF64 *__restrict__ proj, con
   const unsigned flags = base < a.P ? sel_flags16(a, base) : 0u;
   int total;
   int slot = block_excl_256(__popc(flags), s_wsum, total);
-  if (writer && tid == 0)
+  if (tid == 0)
     __hip_atomic_store(&a.desc[tile], sel_desc(1, 1, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (unsigned f = flags; f; f &= f - 1) s_list[slot++] = (uint16_t)(tid * kSelItems + __builtin_ctz(f));
   __syncthreads();
@@ -741,10 +743,9 @@ agg_frame0_kernel(SelArgs a, CamBlock cam, const ProjF64 *__restrict__ proj, con
       queue_doubtful<kQueue, kF0Threads>(s_q, s_qn, dmask, x, y, z, fa, e0 + kF0Threads >= total, proj, H, W, stamp);
     }
   }
-  if (!writer) return;
   // ---- rows, in the reference's order: behind everything the tiles before this one selected
   const int tiles = a.tiles;
-  if (total == 0 && tile != tiles - 1) return;
+  if (total == 0 && !(tile == tiles - 1 && blockIdx.y == 0)) return;
   long long part = 0;
   for (int j = tid; j < tile; j += kF0Threads) {
     unsigned spins = 0;
@@ -764,13 +765,15 @@ agg_frame0_kernel(SelArgs a, CamBlock cam, const ProjF64 *__restrict__ proj, con
   if (lane == 0) s_part[wave] = part;
   __syncthreads();
   const long long excl = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-  if (tile == tiles - 1 && tid == 0) {
+  if (tile == tiles - 1 && blockIdx.y == 0 && tid == 0) {
     int64_t n = excl + total;
     n = n > a.capacity ? a.capacity : n;
     a.cnts[1] = n;  // (cnts[0] = 0: the state block is zeroed per call)
   }
+  // this group's contiguous share of the tile's rows
+  const int e_lo = (int)((int64_t)total * blockIdx.y / gridDim.y), e_hi = (int)((int64_t)total * (blockIdx.y + 1) / gridDim.y);
 #pragma unroll 4
-  for (int e = tid; e < total; e += kF0Threads) {
+  for (int e = e_lo + tid; e < e_hi; e += kF0Threads) {
     const int64_t pos = excl + e;
     if (pos >= a.capacity) break;
     append_row(app, cam, tile_px + (int)s_list[e], pos, true);

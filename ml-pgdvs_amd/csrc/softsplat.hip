@@ -503,6 +503,14 @@ static int dyn_splat_composite_impl(int H, int W, const float *rgb1, const float
                                     unsigned long long *rng, float alpha, const float *static_rgb, float *render_dyn_rgb,
                                     float *render_dyn_mask, float *combined, float *combined_static, float *combined_dyn,
                                     void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream);
+namespace pgdvs {
+int dyn_splat_scatter_part(int H, int W, const float *rgb1, const float *rgb2, const float *flow12, const float *flow_1_to_tgt,
+                           const float *valid_dyn_mask_1, const float *noise, const unsigned long long *rng, float alpha,
+                           void *workspace, hipStream_t st);
+int dyn_splat_finish_part(int H, int W, unsigned long long *rng, const float *static_rgb, float *render_dyn_rgb,
+                          float *render_dyn_mask, float *combined, float *combined_static, float *combined_dyn, void *workspace,
+                          hipStream_t st);
+}  // namespace pgdvs
 
 PGDVS_API int pgdvs_dyn_splat_composite(int H, int W, const float *rgb1, const float *rgb2,
                                         const float *flow12, const float *flow_1_to_tgt,
@@ -551,7 +559,20 @@ static int dyn_splat_composite_impl(int H, int W, const float *rgb1, const float
     set_error("pgdvs_dyn_splat_composite: workspace too small");
     return PGDVS_ERR_WORKSPACE;
   }
-  hipStream_t st = as_stream(stream);
+  int rc = pgdvs::dyn_splat_scatter_part(H, W, rgb1, rgb2, flow12, flow_1_to_tgt, valid_dyn_mask_1, noise, rng, alpha, workspace,
+                                         as_stream(stream));
+  if (rc != PGDVS_OK) return rc;
+  return pgdvs::dyn_splat_finish_part(H, W, rng, static_rgb, render_dyn_rgb, render_dyn_mask, combined, combined_static,
+                                      combined_dyn, workspace, as_stream(stream));
+}
+
+namespace pgdvs {
+// The two halves of the composite (the per-view call runs the first beside the static branch: it needs the flows, not the
+// static image).  Arguments as validated by dyn_splat_composite_impl / pgdvs_view_geo_forward; workspace >=
+// pgdvs_dyn_splat_workspace_bytes(H, W).
+int dyn_splat_scatter_part(int H, int W, const float *rgb1, const float *rgb2, const float *flow12, const float *flow_1_to_tgt,
+                           const float *valid_dyn_mask_1, const float *noise, const unsigned long long *rng, float alpha,
+                           void *workspace, hipStream_t st) {
   const int P = H * W;
   float *acc = reinterpret_cast<float *>(workspace);
   uint8_t *flags = reinterpret_cast<uint8_t *>(acc + (size_t)5 * P);
@@ -565,11 +586,22 @@ static int dyn_splat_composite_impl(int H, int W, const float *rgb1, const float
                flags, acc);
   const dim3 tgrid((unsigned)cdiv(W, kSplatTile), (unsigned)cdiv(H, kSplatTile));
   PGDVS_LAUNCH("dyn_splat_scatter", dyn_splat_scatter_kernel, tgrid, block, 0, st, H, W, rgb1, rgb2, flow12,
-                     flow_1_to_tgt, valid_dyn_mask_1, noise, (const unsigned long long *)rng, alpha, acc, (const uint8_t *)flags);
-  PGDVS_LAUNCH("dyn_splat_finish", dyn_splat_finish_kernel, grid, block, 0, st, P, acc, (const uint8_t *)flags, static_rgb,
+                     flow_1_to_tgt, valid_dyn_mask_1, noise, rng, alpha, acc, (const uint8_t *)flags);
+  return check_launch("dyn_splat_scatter");
+}
+
+int dyn_splat_finish_part(int H, int W, unsigned long long *rng, const float *static_rgb, float *render_dyn_rgb,
+                          float *render_dyn_mask, float *combined, float *combined_static, float *combined_dyn, void *workspace,
+                          hipStream_t st) {
+  const int P = H * W;
+  float *acc = reinterpret_cast<float *>(workspace);
+  const uint8_t *flags = reinterpret_cast<const uint8_t *>(acc + (size_t)5 * P);
+  dim3 grid((unsigned)cdiv(P, 256)), block(256);
+  PGDVS_LAUNCH("dyn_splat_finish", dyn_splat_finish_kernel, grid, block, 0, st, P, acc, flags, static_rgb,
                      render_dyn_rgb, render_dyn_mask, combined, combined_static, combined_dyn, rng);
   return check_launch("dyn_splat_composite");
 }
+}  // namespace pgdvs
 
 PGDVS_API int pgdvs_softsplat_bwd(const float *in, const float *flow, const float *outgrad, float *ingrad,
                                   float *flowgrad, int B, int C, int H, int W, pgdvs_stream_t stream) {

@@ -23,6 +23,14 @@ int static_aggregate_for_view(const float *rgbs, const float *depths, const uint
                               int64_t *count_out, void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream,
                               bool params_cached);  // static_agg.hip
 
+// the two halves of the splat composite (softsplat.hip)
+int dyn_splat_scatter_part(int H, int W, const float *rgb1, const float *rgb2, const float *flow12, const float *flow_1_to_tgt,
+                           const float *valid_dyn_mask_1, const float *noise, const unsigned long long *rng, float alpha,
+                           void *workspace, hipStream_t st);
+int dyn_splat_finish_part(int H, int W, unsigned long long *rng, const float *static_rgb, float *render_dyn_rgb,
+                          float *render_dyn_mask, float *combined, float *combined_static, float *combined_dyn, void *workspace,
+                          hipStream_t st);
+
 // counters of the sub-workspaces (raster.hip, knn_grid.hip, static_agg.hip)
 void raster_counters(const void *workspace, int64_t n_rows, int H, int W, float radius, int64_t *out_dev, hipStream_t st);
 void knn_grid_counter_words(const void *workspace, int64_t capacity, int64_t qcapacity, const int32_t **to_ring,
@@ -192,6 +200,11 @@ int dyn_geometry(const pgdvs_view_geo_desc &d, const ViewWs &w, pgdvs_stream_t s
     keep = w.keep;
   }
   VG_TRY(pgdvs_project_flow_dense(H, W, cam_t, w.pcl, keep, w.flow_1_to_tgt, w.valid_mask, s));
+  // A6-A8, first half: metric, flags and the scatter into the accumulators need the flows, not the static image -- they run
+  // here, beside the static branch when there is a side stream; only the finish pass waits for the rasteriser
+  const unsigned long long *rng = (d.noise == nullptr && d.rng_state != nullptr) ? reinterpret_cast<const unsigned long long *>(d.rng_state) : nullptr;
+  VG_TRY(dyn_splat_scatter_part(H, W, d.rgb1, d.rgb2, d.flow12, w.flow_1_to_tgt, w.valid_mask, d.noise, rng, d.alpha, w.splat,
+                                as_stream(s)));
   return PGDVS_OK;
 }
 
@@ -207,6 +220,7 @@ int view_forward(const pgdvs_view_geo_desc &d, void *workspace, int64_t workspac
   PGDVS_REQUIRE(d.agg_S <= 0 || (d.agg_rgbs && d.agg_depths && d.agg_masks && d.agg_K3s_host && d.agg_c2ws_host &&
                                   d.agg_cloud_out && d.agg_xyz_out && d.agg_count_out && d.agg_capacity > 0),
                 "pgdvs_view_geo_forward: incomplete aggregation arguments");
+  PGDVS_REQUIRE(d.alpha >= 0.0f, "pgdvs_view_geo_forward: alpha must be >= 0");
   PGDVS_REQUIRE(!d.remove_outlier || (d.outlier_knn >= 1 && d.outlier_knn + 1 <= 64),
                 "pgdvs_view_geo_forward: dyn_pcl_outlier_knn must be in [1, 63]");
   ViewWs w;
@@ -272,14 +286,10 @@ int view_forward(const pgdvs_view_geo_desc &d, void *workspace, int64_t workspac
     }
   }
   VG_TRY(rc);
-  // ---- A6-A8 + A11: metric, splat, threshold, composite
-  if (d.noise == nullptr && d.rng_state != nullptr)
-    return pgdvs_dyn_splat_composite_rng(H, W, d.rgb1, d.rgb2, d.flow12, w.flow_1_to_tgt, w.valid_mask, d.rng_state, d.alpha,
-                                         d.static_rgb, d.render_dyn_rgb, d.render_dyn_mask, d.combined, d.combined_static,
-                                         d.combined_dyn, w.splat, w.splat_bytes, stream);
-  return pgdvs_dyn_splat_composite(H, W, d.rgb1, d.rgb2, d.flow12, w.flow_1_to_tgt, w.valid_mask, d.noise, d.alpha, d.static_rgb,
-                                   d.render_dyn_rgb, d.render_dyn_mask, d.combined, d.combined_static, d.combined_dyn, w.splat,
-                                   w.splat_bytes, stream);
+  // ---- A8 second half + A11: normalise, threshold, composite over the static image (and advance the noise's draw number)
+  unsigned long long *rng = (d.noise == nullptr && d.rng_state != nullptr) ? reinterpret_cast<unsigned long long *>(d.rng_state) : nullptr;
+  return dyn_splat_finish_part(H, W, rng, d.static_rgb, d.render_dyn_rgb, d.render_dyn_mask, d.combined, d.combined_static,
+                               d.combined_dyn, w.splat, st);
 }
 
 }  // namespace

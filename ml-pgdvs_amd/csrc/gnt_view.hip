@@ -746,11 +746,19 @@ gnt_ray_attn_kernel(const float *__restrict__ W_arg, const float *__restrict__ q
             }
           }
           float x[4], xmax = -__builtin_inff();
+          if (16 * kt + 16 <= S) {  // a full key tile (every tile when S is a multiple of 16): nothing to mask
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = 16 * kt + 4 * hq + r;
-            x[r] = key < S ? sc[r] : -__builtin_inff();
-            xmax = fmaxf(xmax, x[r]);
+            for (int r = 0; r < 4; ++r) {
+              x[r] = sc[r];
+              xmax = fmaxf(xmax, x[r]);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = 16 * kt + 4 * hq + r;
+              x[r] = key < S ? sc[r] : -__builtin_inff();
+              xmax = fmaxf(xmax, x[r]);
+            }
           }
           if (kt == 0) {
             m = quad_max(xmax, lane);  // key 0 is always valid: finite

@@ -388,12 +388,14 @@ int pgdvs_combine(const float *static_rgb, const float *dyn_rgb, const float *dy
  * masks ones / eval_mask / 1 - eval_mask).
  *   pred_planar[3,H,W] raw render (combined_rgb); gt_hwc[H,W,3] raw ground truth; mask_hwc[H,W,3] eval_mask
  *   pred_q / gt_q [3,H,W] (nullable): the quantised images
- *   sums: DEVICE double[6] = sum d2, sum d2*m, sum d2*(1-m), 3*H*W, sum m, sum (1-m)
+ *   sums: DEVICE double[8] = sum d2, sum d2*m, sum d2*(1-m), 3*H*W, sum m, sum (1-m), then two words that ride along so that
+ *   the evaluator's step reads ONE block back: (double)*count_dev (the static cloud's device count; -1 when NULL) and
+ *   (double)*status_dev (pgdvs_points_raster_bounded's status word; 0 when NULL)
  *   PSNR_k = 10 log10(1 / (sums[k] / (sums[3+k] + 1e-8))), 0 when the sum of squares is 0 (upstream's quirk). */
 int64_t pgdvs_eval_psnr_workspace_bytes(void);
 int pgdvs_eval_psnr_sums(const float *pred_planar, const float *gt_hwc, const float *mask_hwc, int H, int W,
-                         float *pred_q, float *gt_q, double *sums, void *workspace, int64_t workspace_bytes,
-                         pgdvs_stream_t stream);
+                         float *pred_q, float *gt_q, const int64_t *count_dev, const int32_t *status_dev, double *sums,
+                         void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream);
 
 /* ---- one native call per target view -------------------------------------------------
  * PGDVSRenderer.forward with static_renderer = StaticGeoPointRenderer, dyn_render_type = "softsplat",

@@ -59,12 +59,17 @@ eval_partials_kernel(const float *__restrict__ pred, const float *__restrict__ g
 }
 
 // fixed-order final sum: the result does not depend on scheduling
-__global__ void eval_final_kernel(const double *__restrict__ partials, double *__restrict__ sums) {
+// (+ the renderer's two device-side status words, so that the step reads everything back in ONE transfer: sums[6] = the
+// static cloud's row count or -1 without one, sums[7] = the rasteriser's status word or 0)
+__global__ void eval_final_kernel(const double *__restrict__ partials, double *__restrict__ sums, const int64_t *__restrict__ count_dev,
+                                  const int32_t *__restrict__ status_dev) {
   if (threadIdx.x < kEvalSums) {
     double v = 0.0;
     for (int b = 0; b < kEvalBlocks; ++b) v += partials[(size_t)b * kEvalSums + threadIdx.x];
     sums[threadIdx.x] = v;
   }
+  if (threadIdx.x == kEvalSums) sums[kEvalSums] = count_dev ? (double)*count_dev : -1.0;
+  if (threadIdx.x == kEvalSums + 1) sums[kEvalSums + 1] = status_dev ? (double)*status_dev : 0.0;
 }
 
 }  // namespace pgdvs
@@ -74,8 +79,8 @@ using namespace pgdvs;
 PGDVS_API int64_t pgdvs_eval_psnr_workspace_bytes(void) { return (int64_t)kEvalBlocks * kEvalSums * 8; }
 
 PGDVS_API int pgdvs_eval_psnr_sums(const float *pred_planar, const float *gt_hwc, const float *mask_hwc, int H, int W,
-                                   float *pred_q, float *gt_q, double *sums, void *workspace, int64_t workspace_bytes,
-                                   pgdvs_stream_t stream) {
+                                   float *pred_q, float *gt_q, const int64_t *count_dev, const int32_t *status_dev, double *sums,
+                                   void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream) {
   PGDVS_REQUIRE(pred_planar && gt_hwc && mask_hwc && sums && H > 0 && W > 0 && (int64_t)H * W < (1ll << 30),
                 "pgdvs_eval_psnr_sums: bad arguments");
   if (!workspace || workspace_bytes < pgdvs_eval_psnr_workspace_bytes()) {
@@ -86,6 +91,6 @@ PGDVS_API int pgdvs_eval_psnr_sums(const float *pred_planar, const float *gt_hwc
   double *partials = reinterpret_cast<double *>(workspace);
   PGDVS_LAUNCH("eval_partials", eval_partials_kernel, dim3(kEvalBlocks), dim3(kEvalThreads), 0, st, pred_planar, gt_hwc, mask_hwc,
                H * W, pred_q, gt_q, partials);
-  PGDVS_LAUNCH("eval_final", eval_final_kernel, dim3(1), dim3(64), 0, st, (const double *)partials, sums);
+  PGDVS_LAUNCH("eval_final", eval_final_kernel, dim3(1), dim3(64), 0, st, (const double *)partials, sums, count_dev, status_dev);
   return check_launch("eval_psnr_sums");
 }

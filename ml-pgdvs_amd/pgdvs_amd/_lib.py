@@ -94,7 +94,7 @@ class ViewGeoDesc(C.Structure):
 
 SIGNATURES.update({
     "pgdvs_eval_psnr_workspace_bytes": (_i64, []),
-    "pgdvs_eval_psnr_sums": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "pgdvs_eval_psnr_sums": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "pgdvs_view_geo_desc_size": (_i64, []),
     "pgdvs_view_geo_workspace_bytes": (_i64, [C.POINTER(ViewGeoDesc)]),
     "pgdvs_view_geo_forward": (_i, [C.POINTER(ViewGeoDesc), _vp, _i64, _vp]),

@@ -56,31 +56,44 @@ def eval_step(model, data: dict, render_cfg, *, device=None, disable_tqdm=True, 
     ret = model.forward(data_gpu, render_cfg=render_cfg, disable_tqdm=disable_tqdm, for_debug=False)
     from . import ops
 
-    def check_status():
+    def check_status(host_counts=None, host_status=None):
         # device-side status words of the geometry path (the step synchronises for its metrics anyway): a static cloud whose
         # aggregation reported an error (count -1), filled its buffer (rows may have been dropped: the aggregation clamps
         # at its capacity) or outgrew the rasteriser's row bound would otherwise show up as a silently blank or truncated
-        # static image
+        # static image.  host_counts / host_status: the words as already read back with the metric sums.
         cnts = ret.get("st_pcl_rgb_count", data_gpu.get("st_pcl_rgb_count", None))
         if isinstance(cnts, torch.Tensor):
             cloud = ret.get("st_pcl_rgb", None)
-            for c in cnts.reshape(-1):
-                n = ops.checked_count(c, "st_pcl_rgb_count")
+            values = host_counts if host_counts is not None else [int(c.item()) for c in cnts.reshape(-1)]
+            for n in values:
+                if n < 0:
+                    raise ops.PgdvsHipError(f"st_pcl_rgb_count: device-side error flag set (count {n}); the output is not valid")
                 limited = cloud is not None and "_st_pcl_video" in data_gpu and cloud.shape[1] < data_gpu["_st_pcl_video"]["depths"].numel()
                 if limited and n >= cloud.shape[1]:
                     raise ops.PgdvsHipError(f"the aggregated static cloud filled its buffer of {cloud.shape[1]} rows (capacity-limited): "
                                             "rows may have been dropped -- pass a larger capacity")
-        ops.check_raster_status(ret.get("geo_static_raster_status", None))
+        if host_status is not None:
+            ops.check_raster_status(torch.tensor(host_status, dtype=torch.int32))
+        else:
+            ops.check_raster_status(ret.get("geo_static_raster_status", None))
 
     comb = ret["combined_rgb"]
     if (comb.is_cuda and comb.dtype == torch.float32 and tuple(comb.shape[2:]) == tuple(data_gpu["rgb_tgt"].shape[1:3])
             and data_gpu["rgb_tgt"].dtype == torch.float32 and data_gpu["eval_mask"].dtype == torch.float32):
         # GPU, render size == ground-truth size (render_stride 1): quantisation and the three masked sums of a view in ONE
         # pass (csrc/eval.hip), one host read for the whole batch
-        res = [ops.eval_psnr_sums(comb[i_b], data_gpu["rgb_tgt"][i_b], data_gpu["eval_mask"][i_b], want_images=return_images)
+        # (the device-side status words of the geometry path ride along in the same block: ONE host read per batch)
+        cnts = ret.get("st_pcl_rgb_count", data_gpu.get("st_pcl_rgb_count", None))
+        cnts = cnts.reshape(-1) if isinstance(cnts, torch.Tensor) and cnts.is_cuda and cnts.dtype == torch.int64 else None
+        stat = ret.get("geo_static_raster_status", None)
+        stat = stat.reshape(-1) if isinstance(stat, torch.Tensor) and stat.is_cuda and stat.dtype == torch.int32 else None
+        res = [ops.eval_psnr_sums(comb[i_b], data_gpu["rgb_tgt"][i_b], data_gpu["eval_mask"][i_b], want_images=return_images,
+                                  count_dev=cnts[i_b:i_b + 1] if (cnts is not None and i_b < cnts.numel()) else None,
+                                  status_dev=stat[i_b:i_b + 1] if (stat is not None and i_b < stat.numel()) else None)
                for i_b in range(n_batch)]
         sums = torch.stack([r_[0] for r_ in res]).cpu().tolist()  # (the step's synchronisation)
-        check_status()
+        check_status(host_counts=[int(s_[6]) for s_ in sums] if cnts is not None else None,
+                     host_status=[int(s_[7]) for s_ in sums] if stat is not None else None)
         per_view = {k: [] for k in METRIC_KEYS}
         for s_ in sums:
             for j, k in enumerate(METRIC_KEYS):

@@ -575,10 +575,11 @@ def view_geo_host_stats():
     return int(calls.value), float(secs.value)
 
 
-def eval_psnr_sums(pred_planar, gt_hwc, mask_hwc, want_images: bool = False):
+def eval_psnr_sums(pred_planar, gt_hwc, mask_hwc, want_images: bool = False, count_dev=None, status_dev=None):
     """The evaluator's per-view statistics in one pass (``pgdvs_eval_psnr_sums``): pred[3,H,W] raw render, gt[H,W,3] raw,
-    mask[H,W,3] -> device float64[6] (sum d2, sum d2 m, sum d2 (1-m), count, sum m, sum (1-m)) and, with ``want_images``,
-    the quantised prediction / ground truth [3,H,W]."""
+    mask[H,W,3] -> device float64[8] (sum d2, sum d2 m, sum d2 (1-m), count, sum m, sum (1-m), then ``count_dev`` -- int64[1],
+    -1 when None -- and ``status_dev`` -- int32[1], 0 when None -- as doubles, so that one transfer brings everything back)
+    and, with ``want_images``, the quantised prediction / ground truth [3,H,W]."""
     p = _req(pred_planar, torch.float32, "pred")
     g = _req(gt_hwc, torch.float32, "gt")
     m = _req(mask_hwc, torch.float32, "eval_mask")
@@ -586,12 +587,14 @@ def eval_psnr_sums(pred_planar, gt_hwc, mask_hwc, want_images: bool = False):
     assert tuple(g.shape) == (H, W, 3) and tuple(m.shape) == (H, W, 3), (p.shape, g.shape, m.shape)
     lib = _lib.load()
     nws = int(lib.pgdvs_eval_psnr_workspace_bytes())
-    buf = torch.empty(nws + 64, dtype=torch.uint8, device=p.device)  # partials, then the six sums
-    sums = buf[nws:nws + 48].view(torch.float64)
+    buf = torch.empty(nws + 64, dtype=torch.uint8, device=p.device)  # partials, then the eight doubles
+    sums = buf[nws:nws + 64].view(torch.float64)
     pq = torch.empty_like(p) if want_images else None
     gq = torch.empty_like(p) if want_images else None
-    check(lib.pgdvs_eval_psnr_sums(_ptr(p), _ptr(g), _ptr(m), H, W, _ptr(pq), _ptr(gq), _ptr(sums), _ptr(buf), nws, _stream()),
-          "pgdvs_eval_psnr_sums")
+    cd = _req(count_dev, torch.int64, "count_dev") if count_dev is not None else None
+    sd = _req(status_dev, torch.int32, "status_dev") if status_dev is not None else None
+    check(lib.pgdvs_eval_psnr_sums(_ptr(p), _ptr(g), _ptr(m), H, W, _ptr(pq), _ptr(gq), _ptr(cd), _ptr(sd), _ptr(sums), _ptr(buf), nws,
+                                   _stream()), "pgdvs_eval_psnr_sums")
     return sums, pq, gq
 
 

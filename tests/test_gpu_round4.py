@@ -260,6 +260,11 @@ def test_eval_psnr_sums_vs_torch_statement(H, W):
         got = 0 if mse == 0 else 10 * np.log10(1.0 / mse)
         assert abs(got - want) < 1e-9, (j, got, want)
     assert s[3] == 3 * H * W and abs(s[4] + s[5] - s[3]) < 1e-6
+    assert s[6] == -1.0 and s[7] == 0.0  # no status words given
+    cnt = torch.tensor([123456789012], dtype=torch.int64, device=DEV)
+    st = torch.tensor([1], dtype=torch.int32, device=DEV)
+    s3 = ops.eval_psnr_sums(pred.to(DEV), gt.to(DEV), mask.to(DEV), count_dev=cnt, status_dev=st)[0].cpu().tolist()
+    assert s3[:6] == s[:6] and s3[6] == 123456789012.0 and s3[7] == 1.0  # the status words ride along, the sums do not move
     # identical images: the reference's quirk of PSNR 0
     s2 = ops.eval_psnr_sums(gq, gq_t.permute(1, 2, 0).contiguous().to(DEV), mask.to(DEV))[0].cpu().tolist()
     assert s2[0] == 0 and s2[1] == 0 and s2[2] == 0

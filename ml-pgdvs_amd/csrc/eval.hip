@@ -3,7 +3,8 @@
 // pgdvs/utils/training.py:281-313 calculate_psnr) as ONE pass over the rendered image: clamp -> NaN to 0 -> 8-bit
 // quantisation of prediction and ground truth, squared differences and mask sums in float64.  Upstream this is ~45
 // elementwise torch / numpy passes and a dozen host synchronisations per view -- several times the cost of rendering
-// the view on this GPU; here the step enqueues two launches and reads six doubles back.
+// the view on this GPU; here the step enqueues two launches and reads eight doubles back (the six sums and the
+// geometry path's two status words).
 #include "common.h"
 
 namespace pgdvs {

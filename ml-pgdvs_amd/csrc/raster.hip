@@ -523,21 +523,30 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 
 // kCap: capacity of the sorted path (kSortCap / kSortCapLong).  pass: 0 = every tile (lists beyond kCap take the general
 // path), 1 = the first of two launches (tiles with longer lists are left to the second), 2 = the second (only those tiles).
-template <int K, int kCap>
-__global__ void __launch_bounds__(256, kCap <= kSortCap ? 4 : 2)
+// kFrag: the fragments' depths are wanted (zbuf): the sorted path then keeps them in LDS by rank as well.  Without them (the
+// renderer's path) a workgroup needs 28 KB instead of 37 -- the keys of the sort and the sorted coordinates share one
+// array, ids are 4 bytes -- and FIVE workgroups fit a CU instead of four.
+template <int K, int kCap, bool kFrag>
+__global__ void __launch_bounds__(256, kCap <= kSortCap ? (kFrag ? 4 : 5) : 2)
 raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__ offsets, int64_t list_capacity, int pass,
                    const float *__restrict__ feat, int64_t feat_stride, float radius, int H, int W,
                    int ntx, int nty, int tiles_per_xcd, int64_t *__restrict__ idx_out,
                    float *__restrict__ zbuf_out, float *__restrict__ dist_out,
                    float *__restrict__ rgb_out, int rgb_planar, float *__restrict__ mask_out, int32_t *__restrict__ stats) {
   constexpr int kSortPerThread = kCap / 256;
-  __shared__ float2 s_xy[kCap];             // rank order: NDC x, y (general path: staging of 256 entries)
-  __shared__ uint2 s_kz[kCap];              // bucket order: (z bits, id); after ranking, rank order: (id, z bits)
+  // one array, two lives: during the sort the keys (z bits, id) in bucket order; from step 6 on the NDC (x, y) in rank order
+  // (every key has been read by then: barrier).  General path: staging of 256 entries in the first 4 KB.
+  __shared__ uint2 s_buf[kCap];
+  uint2 *s_kz = s_buf;
+  float2 *s_xy = reinterpret_cast<float2 *>(s_buf);
+  __shared__ unsigned s_id[kCap];                // rank order: point id
+  __shared__ unsigned s_zr[kFrag ? kCap : 1];    // rank order: z bits (fragments only)
   __shared__ float4 s_wave[4][68];          // per-wave strip of culled points (+ padding)
   // bucket counts, then bucket starts: dead before the walk begins, so they share the strips' storage
   unsigned *s_cnt = reinterpret_cast<unsigned *>(&s_wave[0][0]);
   static_assert(kSortBuckets * 4 <= 4 * 68 * 16, "the counters alias the strips");
-  static_assert(kCap * 16 + 4 * 68 * 16 + 128 <= (kCap <= kSortCap ? 40960 : 81920), "four (two) workgroups per CU");
+  static_assert(kCap * (kFrag ? 16 : 12) + 4 * 68 * 16 + 128 <= (kCap <= kSortCap ? (kFrag ? 40960 : 32768) : 81920),
+                "four / five (two) workgroups per CU");
   static_assert(kCap % 256 == 0 && kCap <= 4096, "every thread owns kCap / 256 entries; positions are packed in 12 bits");
   __shared__ unsigned s_red[12];
   __shared__ int s_flag;
@@ -722,7 +731,8 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
           if (e < n) {
             const float4 q = ent[k];
             s_xy[pos[k]] = make_float2(q.x, q.y);
-            s_kz[pos[k]] = make_uint2(__float_as_uint(q.z), __float_as_uint(q.w));
+            s_id[pos[k]] = __float_as_uint(q.z);
+            if (kFrag) s_zr[pos[k]] = __float_as_uint(q.w);
           }
         }
       }
@@ -791,12 +801,11 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
       for (int k = 0; k < K; ++k) {
         if (key[k] != __builtin_inff()) {
           const int r = (int)key[k];
-          const uint2 iz = s_kz[r];
           const float2 c = s_xy[r];
           const float dx = c.x - xf, dy = c.y - yf;
           has[k] = true;
-          rid[k] = (int)iz.x;
-          rz[k] = __uint_as_float(iz.y);
+          rid[k] = (int)s_id[r];
+          rz[k] = kFrag ? __uint_as_float(s_zr[kFrag ? r : 0]) : 0.0f;  // (only written out with kFrag)
           rd2[k] = dx * dx + dy * dy;  // the loop's own arithmetic on the same operands
         }
       }
@@ -1020,11 +1029,17 @@ static void launch_tile(dim3 grid, hipStream_t st, const RasterWs &ws, const flo
                         int64_t feat_stride, float radius, int H, int W, int ntx, int nty,
                         int tiles_per_xcd, int64_t *idx, float *zbuf, float *dist2, float *rgb,
                         int rgb_planar, float *mask, bool long_lists) {
-  PGDVS_LAUNCH("raster_tile", (raster_tile_kernel<K, kSortCap>), grid, dim3(256), 0, st, (const float4 *)ws.lists,
-               (const int32_t *)ws.offsets, ws.list_capacity, long_lists ? 1 : 0, feat, feat_stride, radius, H, W, ntx, nty,
-               tiles_per_xcd, idx, zbuf, dist2, rgb, rgb_planar, mask, ws.stats);
-  if (long_lists) {
-    PGDVS_LAUNCH("raster_tile_long", (raster_tile_kernel<K, kSortCapLong>), grid, dim3(256), 0, st, (const float4 *)ws.lists,
+  if (zbuf != nullptr) {
+    PGDVS_LAUNCH("raster_tile", (raster_tile_kernel<K, kSortCap, true>), grid, dim3(256), 0, st, (const float4 *)ws.lists,
+                 (const int32_t *)ws.offsets, ws.list_capacity, long_lists ? 1 : 0, feat, feat_stride, radius, H, W, ntx, nty,
+                 tiles_per_xcd, idx, zbuf, dist2, rgb, rgb_planar, mask, ws.stats);
+  } else {
+    PGDVS_LAUNCH("raster_tile", (raster_tile_kernel<K, kSortCap, false>), grid, dim3(256), 0, st, (const float4 *)ws.lists,
+                 (const int32_t *)ws.offsets, ws.list_capacity, long_lists ? 1 : 0, feat, feat_stride, radius, H, W, ntx, nty,
+                 tiles_per_xcd, idx, zbuf, dist2, rgb, rgb_planar, mask, ws.stats);
+  }
+  if (long_lists) {  // (the long-list launch keeps the depths in LDS either way: two workgroups per CU with or without)
+    PGDVS_LAUNCH("raster_tile_long", (raster_tile_kernel<K, kSortCapLong, true>), grid, dim3(256), 0, st, (const float4 *)ws.lists,
                  (const int32_t *)ws.offsets, ws.list_capacity, 2, feat, feat_stride, radius, H, W, ntx, nty, tiles_per_xcd, idx, zbuf,
                  dist2, rgb, rgb_planar, mask, ws.stats);
   }

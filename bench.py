@@ -272,9 +272,29 @@ def gnt_full_frame(dev, H=288, W=550, V=10, chunk=1024):
         t0 = time.perf_counter()
         model.forward(d, render_cfg=rc, disable_tqdm=True)
         torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        # where the time goes: the same forward once more with an event pair per stage (BaseRenderer.stage_events)
+        model.static_renderer.stage_events = ev = {}
+        t1 = time.perf_counter()
+        model.forward(d, render_cfg=rc, disable_tqdm=True)
+        torch.cuda.synchronize()
+        dt_ev = time.perf_counter() - t1
+        model.static_renderer.stage_events = None
+    ms = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in ev.items()}
+    n_chunks = len(ev.get("transformer", []))
+    breakdown = {
+        "chunks": n_chunks, "resunet_ms": round(ms.get("features", 0.0), 2),
+        "gather_A13_ms_sum": round(ms.get("gather", 0.0), 2),
+        "transformer_A14_and_ray_reductions_ms_sum": round(ms.get("transformer", 0.0), 2),
+        "rest_ms": round(dt_ev * 1e3 - sum(ms.get(k, 0.0) for k in ("features", "gather", "transformer")), 2),
+        "seconds_with_events": round(dt_ev, 3),
+        "note": "event pairs around the stages of one forward (ResUNet on the source views; per chunk the epipolar gather and "
+                "GNT.forward with the per-ray reductions); rest = ray set-up, dynamic branch, composite, output concatenation, "
+                "gaps between launches.  Enqueueing the gather of chunk i+1 on a side stream ahead of the transformer of chunk i "
+                "was measured (round 4) and gains nothing: A14's kernels are persistent workgroups that own every CU's "
+                "registers, the gather only runs in the seams either way"}
     return {"seconds_per_view": round(dt, 3), "frames_per_s": round(1.0 / dt, 3), "height": H, "width": W, "spatial_views": V,
-            "temporal_views": 2, "samples_per_ray": 256, "chunk_rays": chunk, "weights": "random init",
+            "temporal_views": 2, "samples_per_ray": 256, "chunk_rays": chunk, "weights": "random init", "breakdown": breakdown,
             "reference_context": "the reference states ~2 days on 8 A100 for 15 840 such views incl. data loading and metrics "
                                  "(docs/BENCHMARK_NVIDIA.md:148-149): ~87 s per view per GPU; not the same hardware or scope"}
 

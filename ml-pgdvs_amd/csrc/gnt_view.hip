@@ -242,7 +242,7 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       p2w[u][mt] = sP2[(hu + 2 * u) * 64 + 16 * mt + i];
-      a2w[u][mt] = sA2[(hu + 2 * u) * 64 + 16 * mt + i];
+      a2w[u][mt] = sA2[(hu + 2 * u) * 64 + 16 * mt + i] * kLog2e;  // logits in log2 units: exp2 without a multiply
     }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -279,11 +279,14 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
 #pragma unroll
       for (int t = 0; t < 16; ++t) c1[t] = b[t] - qq[t >> 2][t & 3];
     }
-    float m[16], l[16], acc[16];
+    // bm = (A2's bias - reference logit m) in log2 units: the logits leave the second layer's MFMAs already
+    // relative to the reference (no subtraction, no bias reload per view); m itself is never needed
+    float bm[16], l[16], acc[16];
     float sk[16], sk2[16], sabs[16], ue[16];
+    load_row16(sA2b, bm, hq);
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-      m[t] = 0.0f;
+      bm[t] *= kLog2e;
       l[t] = 0.0f;
       acc[t] = 0.0f;
       if (STATS) {
@@ -352,15 +355,13 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) lv[mt] = pq[mt];
       chain64q<kWStride>(lv, wv, k, w, [&](float (&d)[8]) { ldq8<kWStride>(d, wk, 0); });
-      float x[16];  // logits, then logits relative to the reference m
+      float x[16];  // logits relative to the reference, in log2 units
       {
         floatx4 la[4];
-        float b[16];
-        load_row16(sA2b, b, hq);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) la[mt][r] = b[4 * mt + r];
+          for (int r = 0; r < 4; ++r) la[mt][r] = bm[4 * mt + r];
 #pragma unroll
           for (int u = 0; u < 2; ++u) la[mt] = mfma16(a2w[u][mt], hk[u], la[mt]);
         }
@@ -371,34 +372,34 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       if (__builtin_amdgcn_ballot_w64(first) != 0) {
         // a group's first valid view defines the reference: x = 0, e = 1 below
 #pragma unroll
-        for (int t = 0; t < 16; ++t) m[t] = first ? x[t] : m[t];
+        for (int t = 0; t < 16; ++t) {
+          bm[t] -= first ? x[t] : 0.0f;
+          x[t] = first ? 0.0f : x[t];
+        }
       }
       nvalid += ok ? 1 : 0;
       float xmax = -__builtin_inff();
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        x[t] -= m[t];
-        xmax = fmaxf(xmax, x[t]);
-      }
-      if (__builtin_amdgcn_ballot_w64(ok && xmax > kRescaleGap) != 0) {
-        // (rare) move the reference up by d = max(x, 0): every running sum scales by exp(-d).
-        // ue = sum_v exp(a_v - m) (a_v - m) follows the change of reference as
-        // exp(-d) (ue - d l); the entropy of the final softmax is log(l) - ue / l (epilogue).
+      for (int t = 0; t < 16; ++t) xmax = fmaxf(xmax, x[t]);
+      if (__builtin_amdgcn_ballot_w64(ok && xmax > kRescaleGap * kLog2e) != 0) {
+        // (rare) move the reference up by d = max(x, 0): every running sum scales by 2^-d.
+        // ue = sum_v 2^(a_v - m) (a_v - m) follows the change of reference as
+        // 2^-d (ue - d l); the entropy of the final softmax is log(l) - ln2 ue / l (epilogue).
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
           const float d = ok ? fmaxf(x[t], 0.0f) : 0.0f;
-          const float sc = exp_fast(-d);
+          const float sc = __builtin_amdgcn_exp2f(-d);
           if (STATS) ue[t] = sc * (ue[t] - d * l[t]);
           l[t] *= sc;
           acc[t] *= sc;
-          m[t] += d;
+          bm[t] -= d;
           x[t] -= d;
         }
       }
       if (ok) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-          const float e = exp_fast(x[t]);
+          const float e = __builtin_amdgcn_exp2f(x[t]);
           if (STATS) ue[t] = __builtin_fmaf(e, x[t], ue[t]);
           l[t] += e;
           acc[t] = __builtin_fmaf(e, lv[t >> 2][t & 3], acc[t]);
@@ -435,7 +436,7 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       float ent = 0.0f, sd = 0.0f, sdn = 0.0f;
       if (nvalid > 0) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) ent += logf(l[t]) - ue[t] / l[t] - 1e-8f * (float)nvalid;
+        for (int t = 0; t < 16; ++t) ent += logf(l[t]) - 0.6931471805599453f * ue[t] / l[t] - 1e-8f * (float)nvalid;
       }
       if (nvalid > 1) {
         const float n = (float)nvalid;

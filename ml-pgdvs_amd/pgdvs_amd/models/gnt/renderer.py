@@ -17,6 +17,10 @@ class BaseRenderer(torch.nn.Module):
         super().__init__()
         self.projector = Projector()
         self.model = None
+        # measurement hook (bench.py): a dict set here is filled by `forward` with (start, end) event pairs per
+        # stage -- "features" (ResUNet), "gather" (A13), "transformer" (A14 + the per-ray reductions); None = no
+        # events recorded
+        self.stage_events = None
         if model_cfg is not None and (model_cfg.get("_target_", None) if hasattr(model_cfg, "get") else None):
             self.model = instantiate(model_cfg)
         elif model_cfg is not None:
@@ -35,7 +39,19 @@ class BaseRenderer(torch.nn.Module):
         src_rgbs = ray_batch["src_rgbs"]  # [B,V,H,W,3]
         B, V, H, W, _ = src_rgbs.shape
         n_rays = ray_batch["ray_o"].shape[0]
-        raw_feats = self.model.feature_net(src_rgbs.permute(0, 1, 4, 2, 3).reshape(B * V, 3, H, W))  # (coarse, fine)
+        ev = self.stage_events
+
+        def timed(stage, fn):
+            if ev is None:
+                return fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()  # on the stream that is current where the stage runs
+            out = fn()
+            b.record()
+            ev.setdefault(stage, []).append((a, b))
+            return out
+
+        raw_feats = timed("features", lambda: self.model.feature_net(src_rgbs.permute(0, 1, 4, 2, 3).reshape(B * V, 3, H, W)))  # (coarse, fine)
         to_cl = lambda f: f.permute(0, 2, 3, 1).contiguous().reshape((B, V) + tuple(f.shape[2:]) + (f.shape[1],))  # noqa: E731
         feats_cl = to_cl(raw_feats[0])
         n_fine = int(n_fine_samples_per_ray)
@@ -48,34 +64,54 @@ class BaseRenderer(torch.nn.Module):
         if chunk_size < 0:
             chunk_size = n_rays
         outs, outs_fine = OrderedDict(), OrderedDict()
-        for c0 in range(0, n_rays, chunk_size):
+        # a chunk may straddle batch items (true batching, renderer.py:414-485): one job per (chunk, batch item)
+        jobs = []
+        for ci, c0 in enumerate(range(0, n_rays, chunk_size)):
             c1 = min(c0 + chunk_size, n_rays)
-            # a chunk may straddle batch items (true batching, renderer.py:414-485)
-            pieces = []
-            b0, b1 = c0 // rays_per_view, (c1 - 1) // rays_per_view
-            for b in range(b0, b1 + 1):
-                lo, hi = max(c0, b * rays_per_view), min(c1, (b + 1) * rays_per_view)
-                pieces.append(self._render_rays(
-                    ray_o=ray_batch["ray_o"][lo:hi], ray_d=ray_batch["ray_d"][lo:hi],
-                    depth_range=ray_batch["depth_range"][lo:hi] if per_ray_range else ray_batch["depth_range"][b:b + 1],
-                    cam_tgt=cams_tgt[b], cams_src=cams_src[b], src_rgbs=src_rgbs[b], feats_cl=feats_cl[b],
-                    inv_masks=None if inv_masks is None else inv_masks[b], n_samples=n_coarse_samples_per_ray,
-                    inv_uniform=inv_uniform, ret_view_entropy=ret_view_entropy, ret_view_std=ret_view_std,
-                    n_fine=n_fine, feats_fine_cl=None if feats_fine_cl is None else feats_fine_cl[b]))
+            for b in range(c0 // rays_per_view, (c1 - 1) // rays_per_view + 1):
+                jobs.append((ci, b, max(c0, b * rays_per_view), min(c1, (b + 1) * rays_per_view)))
+        drange = lambda b, lo, hi: ray_batch["depth_range"][lo:hi] if per_ray_range else ray_batch["depth_range"][b:b + 1]  # noqa: E731
+
+        def gather(job):  # the coarse pass's A13 of one job
+            _, b, lo, hi = job
+            return timed("gather", lambda: ops.gnt_gather(
+                ray_batch["ray_o"][lo:hi], ray_batch["ray_d"][lo:hi], drange(b, lo, hi), n_coarse_samples_per_ray,
+                inv_uniform, cams_tgt[b], cams_src[b], src_rgbs[b], feats_cl[b], None if inv_masks is None else inv_masks[b]))
+
+        pieces, cur = [], -1
+
+        def flush():
             for dst, which in ((outs, 0), (outs_fine, 1)):
                 if pieces[0][which] is None:
                     continue
                 for k in pieces[0][which]:
                     dst.setdefault(k, []).append(
                         pieces[0][which][k] if len(pieces) == 1 else torch.cat([p[which][k] for p in pieces], 0))
+
+        for ci, b, lo, hi in jobs:
+            g = gather((ci, b, lo, hi))
+            if ci != cur and pieces:
+                flush()
+                pieces = []
+            cur = ci
+            pieces.append(timed("transformer", lambda: self._render_rays(  # noqa: B023 -- called at once
+                g=g, ray_o=ray_batch["ray_o"][lo:hi], ray_d=ray_batch["ray_d"][lo:hi], depth_range=drange(b, lo, hi),
+                cam_tgt=cams_tgt[b], cams_src=cams_src[b], src_rgbs=src_rgbs[b],
+                inv_masks=None if inv_masks is None else inv_masks[b],
+                inv_uniform=inv_uniform, ret_view_entropy=ret_view_entropy, ret_view_std=ret_view_std,
+                n_fine=n_fine, feats_fine_cl=None if feats_fine_cl is None else feats_fine_cl[b])))
+            del g
+        if pieces:
+            flush()
         rh = (ray_batch["raw_h"] + render_stride - 1) // render_stride
         rw = (ray_batch["raw_w"] + render_stride - 1) // render_stride
         merge = lambda d: OrderedDict((k, torch.cat(v, dim=0).reshape((B, rh, rw, -1))) for k, v in d.items())  # noqa: E731
         return OrderedDict([("outputs_coarse", merge(outs)), ("outputs_fine", merge(outs_fine) if n_fine > 0 else None)])
 
-    def _render_rays(self, *, ray_o, ray_d, depth_range, cam_tgt, cams_src, src_rgbs, feats_cl, inv_masks, n_samples,
+    def _render_rays(self, *, g, ray_o, ray_d, depth_range, cam_tgt, cams_src, src_rgbs, inv_masks,
                      inv_uniform, ret_view_entropy, ret_view_std, n_fine=0, feats_fine_cl=None):
-        """render_rays (:207-412) for rays of one batch item -> (coarse outputs, fine outputs or None)."""
+        """render_rays (:207-412) for rays of one batch item, `g` = the coarse pass's gathered block
+        -> (coarse outputs, fine outputs or None)."""
         from .ray_sampler import sample_fine_z
 
         V = src_rgbs.shape[0]
@@ -94,7 +130,6 @@ class BaseRenderer(torch.nn.Module):
                     ret[k] = torch.sum(weights[..., None] * extras[k], dim=1)
             return ret
 
-        g = ops.gnt_gather(ray_o, ray_d, depth_range, n_samples, inv_uniform, cam_tgt, cams_src, src_rgbs, feats_cl, inv_masks)
         coarse = one_pass(self.model.net_coarse, g)
         if n_fine <= 0:
             return coarse, None

@@ -541,3 +541,58 @@ def test_views_in_flight_reproduce_the_sequential_images():
         assert torch.equal(ret["geo_static_rgb"], st), j          # the static branch has no atomics: bit for bit
         assert torch.equal(ret["render_dyn_mask"], dm), j
         assert torch.allclose(outs[j], comb, rtol=0, atol=1e-5), j
+
+
+def test_gnt_chunk_loop_jobs_and_stage_events():
+    """BaseRenderer's chunk loop (reference: pgdvs/models/gnt/renderer.py:414-485) as a list of (chunk, batch item)
+    jobs: chunks that straddle the two batch items, results independent of the chunk size, peak memory not growing
+    with the number of chunks, and the stage-event hook behind bench.py's breakdown of the GNT renderer."""
+    from pgdvs_amd.models.gnt.model import GNTModel
+    from pgdvs_amd.models.gnt.renderer import BaseRenderer
+
+    torch.manual_seed(3)
+    br = BaseRenderer(model_cfg=None)
+    br.model = GNTModel(netwidth=64, transformer_depth=2)
+    br = br.to(DEV).eval()
+    B, V, H, W, S = 2, 5, 48, 64, 32
+    video = synth.make_video(V, H, W, seed=5)
+    cams_src = np.stack([synth.flat_cam(H, W, video["K3s"][i], video["c2ws"][i]) for i in range(V)])
+    cam_tgt = np.stack([cams_src[1], cams_src[3]])
+    rays = [ops.get_rays(ops.cam_prep(T(cam_tgt[b])), H, W, 1) for b in range(B)]
+    ray_batch = {
+        "ray_o": torch.cat([r[0] for r in rays]), "ray_d": torch.cat([r[1] for r in rays]), "camera": T(cam_tgt),
+        "raw_h": H, "raw_w": W, "depth_range": T(np.array([[0.8, 5.0], [0.7, 4.0]], np.float32)), "depth_range_per_ray": False,
+        "src_rgbs": T(np.stack([video["rgbs"], video["rgbs"][::-1]])),
+        "src_invalid_masks": T(np.stack([video["dyn_masks"], video["dyn_masks"][::-1]]).astype(np.float32))[..., None],
+        "src_cameras": T(np.stack([cams_src, cams_src[::-1]])),
+    }
+
+    def run(chunk):  # noqa: E306
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        with torch.no_grad():
+            ret = br.forward(ray_batch=ray_batch, chunk_size=chunk, inv_uniform=True, n_coarse_samples_per_ray=S, use_dyn_mask=True,
+                             flag_deterministic=True, ret_view_entropy=True, ret_view_std=True)["outputs_coarse"]
+        torch.cuda.synchronize()
+        return ret, torch.cuda.max_memory_allocated() - base
+
+    n_rays = B * H * W
+    chunk = 500  # 13 chunks; chunk 6 straddles the two batch items
+    assert (H * W) % chunk != 0 and n_rays // chunk >= 12
+    mid, _ = run(chunk)
+    for k in mid:
+        assert bool(torch.isfinite(mid[k]).all()), k
+    # memory: 4x the chunks (a quarter of the rays each) must not need more than the long chunks' run
+    few, peak_few = run(2048)
+    many, peak_many = run(256)
+    assert peak_many <= peak_few, (peak_many, peak_few)
+    for k in few:
+        np.testing.assert_allclose(many[k].cpu().numpy(), few[k].cpu().numpy(), rtol=0, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(mid[k].cpu().numpy(), few[k].cpu().numpy(), rtol=0, atol=1e-5, err_msg=k)
+    # the stage-event hook of bench.py's breakdown
+    br.stage_events = ev = {}
+    run(chunk)
+    br.stage_events = None
+    assert len(ev["features"]) == 1 and len(ev["gather"]) == len(ev["transformer"]) == 14  # 13 chunks, one of them in two pieces
+    assert all(a.elapsed_time(b) >= 0 for v in ev.values() for a, b in v)

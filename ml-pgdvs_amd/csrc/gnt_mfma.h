@@ -112,4 +112,66 @@ __device__ __forceinline__ void chain64q(floatx4 (&acc)[4], const float *__restr
   }
 }
 
+// ---- lane-major weight images -----------------------------------------------------------
+// The A operands of a 64 -> 64 product in the order the lanes consume them: K-step s (0..15) is one float4 per
+// lane -- the operands of the four output tiles -- at image[s][lane][mt].  One ds_read_b128 per K-step with an
+// immediate offset off a single per-lane base (consecutive lanes, consecutive 16 bytes: no bank conflicts, no
+// padding, no address arithmetic in the loop), where the row-major image takes four ds_read_b32 at four strides.
+// Source: the packed input-major matrix Wt[in][out]; lane (i, hq) multiplies in = 16*(s>>2) + (s&3) + 4*hq,
+// out = 16*mt + i.
+template <int NT>
+__device__ __forceinline__ void stage_w64_lanes(const float *__restrict__ src, float *__restrict__ dst) {
+  constexpr int IT = 1024 / NT;
+  float4 v[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) v[it] = reinterpret_cast<const float4 *>(src)[(int)threadIdx.x + it * NT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int q = (int)threadIdx.x + it * NT;
+    const int in = q >> 4, out0 = (q & 15) * 4;
+    const int s = 4 * (in >> 4) + (in & 3), hq = (in >> 2) & 3;
+    float *d = dst + s * 256 + ((out0 & 15) + 16 * hq) * 4 + (out0 >> 4);
+    d[0] = v[it].x;
+    d[4] = v[it].y;
+    d[8] = v[it].z;
+    d[12] = v[it].w;
+  }
+}
+
+// K-steps 2q, 2q+1 (64 -> 64 image: w[4*s2 + mt]) or, for a 64 -> 16 image [s>>2][lane][s&3], K-steps
+// 8q .. 8q+7; lb = image + 4 * lane
+__device__ __forceinline__ void ldq8v(float (&w)[8], const float *__restrict__ lb, int q) {
+  const float4 a = *reinterpret_cast<const float4 *>(lb + (2 * q) * 256);
+  const float4 b = *reinterpret_cast<const float4 *>(lb + (2 * q + 1) * 256);
+  w[0] = a.x;
+  w[1] = a.y;
+  w[2] = a.z;
+  w[3] = a.w;
+  w[4] = b.x;
+  w[5] = b.y;
+  w[6] = b.z;
+  w[7] = b.w;
+}
+
+// chain64q on a lane-major image
+template <class Next>
+__device__ __forceinline__ void chain64qv(floatx4 (&acc)[4], const float *__restrict__ lb, const float (&x)[16],
+                                          float (&w)[8], Next &&next) {
+  float w2[8];
+#pragma unroll
+  for (int q = 0; q < 8; q += 2) {
+    ldq8v(w2, lb, q + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mmq8(acc, w, x, q);
+    __builtin_amdgcn_sched_barrier(0);
+    if (q + 2 < 8)
+      ldq8v(w, lb, q + 2);
+    else
+      next(w);
+    __builtin_amdgcn_sched_barrier(0);
+    mmq8(acc, w2, x, q + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 }  // namespace pgdvs

@@ -113,13 +113,12 @@ __device__ __forceinline__ void load_row32(const float *__restrict__ row, float 
 // two wavefronts fit per SIMD, so one wavefront's exp / accumulate work runs in the shadow of
 // the other's matrix instructions.  The 64 -> 8 -> 64 MLPs also waste less padding (M = 16).
 // ---------------------------------------------------------------------------------------
-constexpr int kWStride = 68, kA1Stride = 36;  // padded LDS rows of Wk / Wv and A1
 // offsets inside the unpadded tail of the LDS image (same order as the packed weights)
 constexpr int kSmP1B = VW_P1B - VW_P1, kSmP2 = VW_P2 - VW_P1, kSmP2B = VW_P2B - VW_P1;
 constexpr int kSmA1B = VW_A1 - VW_P1;  // A1 itself lives in the padded region
 constexpr int kSmA2 = kSmA1B + (VW_A2 - VW_A1B), kSmA2B = kSmA1B + (VW_A2B - VW_A1B);
 constexpr int kSmallFloats = kSmA1B + (VW_WO - VW_A1B);
-constexpr int kViewLdsFloats = 4 * 64 * kWStride + 64 * kA1Stride + kSmallFloats + 192;
+constexpr int kViewLdsFloats = 4 * 4096 + 1024 + kSmallFloats + 192;  // four lane-major 64 x 64 images, A1's, the small pieces
 
 constexpr float kLog2e = 1.4426950408889634f;
 // The softmax over views keeps a per-feature reference logit m and rescales the running sums
@@ -151,22 +150,14 @@ __device__ __forceinline__ void layer_norm64q(const float (&x)[16], const float 
   for (int t = 0; t < 16; ++t) y[t] = (x[t] - mean) * rstd * gg[t] + bb[t];
 }
 
-// 64 -> 16 (8 used): one output tile; the 16 K-steps alternate between two accumulators
-template <int STRIDE>
-__device__ __forceinline__ void ldn8(float (&w)[8], const float *__restrict__ wb, int q) {
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int s = 8 * q + u;
-    w[u] = wb[(16 * (s >> 2) + (s & 3)) * STRIDE];
-  }
-}
-
+// 64 -> 16 (8 used): one output tile (lane-major image [s>>2][lane][s&3], see gnt_mfma.h); the 16 K-steps
+// alternate between two accumulators
 template <class Next>
-__device__ __forceinline__ floatx4 chain64n(const float *__restrict__ wb, const float (&x)[16], float (&w)[8],
+__device__ __forceinline__ floatx4 chain64n(const float *__restrict__ lb, const float (&x)[16], float (&w)[8],
                                             Next &&next) {
   floatx4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
   float w2[8];
-  ldn8<kA1Stride>(w2, wb, 1);
+  ldq8v(w2, lb, 1);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int u = 0; u < 8; u += 2) {
@@ -203,34 +194,43 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
                       const float *__restrict__ feat, const float *__restrict__ ray_diff,
                       const uint8_t *__restrict__ valid, int64_t N, int V, float *__restrict__ q_out,
                       float *__restrict__ stats) {
-  // LDS image of the per-view weights.  The rows of the three big matrices are padded by 4
-  // floats: the two quarters that share a ds_read_b32 lane group read input rows 4 apart, and
-  // 4 * 68 (4 * 36) = 16 mod 32 puts them on opposite halves of the 32 banks (unpadded they
-  // collide 2-way on every weight read).
+  // LDS image of the layer's weights: the 64 x 64 matrices and A1 lane-major (gnt_mfma.h: one ds_read_b128 per
+  // K-step off one per-lane base), the small pieces as packed
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [kViewLdsFloats]
-  float *s_wk = s_w, *s_wv = s_wk + 64 * kWStride, *s_a1 = s_wv + 64 * kWStride, *s_small = s_a1 + 64 * kA1Stride;
-  float *s_wq = s_small + kSmallFloats, *s_wo = s_wq + 64 * kWStride, *s_par = s_wo + 64 * kWStride;
-  constexpr auto row68 = [](int q) { return (q >> 4) * kWStride + 4 * (q & 15); };
-  stage_f4<1024, 512>(W_arg + VW_WK, s_wk, row68);
-  stage_f4<1024, 512>(W_arg + VW_WV, s_wv, row68);
-  stage_f4<512, 512>(W_arg + VW_A1, s_a1, [](int q) { return (q >> 3) * kA1Stride + 4 * (q & 7); });
+  float *s_wk = s_w, *s_wv = s_wk + 4096, *s_wq = s_wv + 4096, *s_wo = s_wq + 4096, *s_a1 = s_wo + 4096;
+  float *s_small = s_a1 + 1024, *s_par = s_small + kSmallFloats;
+  stage_w64_lanes<512>(W_arg + VW_WK, s_wk);
+  stage_w64_lanes<512>(W_arg + VW_WV, s_wv);
+  {  // A1 [64 in][32 out, 8 used] -> [s>>2][lane][s&3] for the 16 output columns of the (padded) tile
+    const int q = (int)threadIdx.x;  // 512 float4's
+    const float4 v = reinterpret_cast<const float4 *>(W_arg + VW_A1)[q];
+    const int in = q >> 3, out0 = (q & 7) * 4;
+    if (out0 < 16) {
+      const int s = 4 * (in >> 4) + (in & 3), hq = (in >> 2) & 3;
+      float *d = s_a1 + (s >> 2) * 256 + (out0 + 16 * hq) * 4 + (s & 3);
+      d[0] = v.x;
+      d[4] = v.y;
+      d[8] = v.z;
+      d[12] = v.w;
+    }
+  }
   // s_small: P1 [4][32], P1B [32], P2 [8][64], P2B [64], A1B [32], A2 [8][64], A2B [64]
   stage_f4<kSmA1B / 4, 512>(W_arg + VW_P1, s_small, [](int q) { return 4 * q; });
   stage_f4<(kSmallFloats - kSmA1B) / 4, 512>(W_arg + VW_A1B, s_small + kSmA1B, [](int q) { return 4 * q; });
   // the per-tile pieces too (q_fc, out_fc, LayerNorm, out_fc bias): from global memory they
   // cost an L2 round trip per 8-MFMA chunk of a tile's prologue and epilogue
-  stage_f4<1024, 512>(W_arg + VW_WQ, s_wq, row68);
-  stage_f4<1024, 512>(W_arg + VW_WO, s_wo, row68);
+  stage_w64_lanes<512>(W_arg + VW_WQ, s_wq);
+  stage_w64_lanes<512>(W_arg + VW_WO, s_wo);
   stage_f4<32, 512>(W_arg + VW_LN1_G, s_par, [](int q) { return 4 * q; });        // gamma[64], beta[64]
   stage_f4<16, 512>(W_arg + VW_WOB, s_par + 128, [](int q) { return 4 * q; });    // out_fc bias[64]
   __syncthreads();
   const int lane = threadIdx.x & 63, i = lane & 15, hq = lane >> 4;
   const int wave = threadIdx.x >> 6;
-  // per-lane bases of the A operands: input row 4*hq (+ 16*c + r), output column i (+ 16*mt)
-  const float *wq = s_wq + (4 * hq) * kWStride + i, *wo = s_wo + (4 * hq) * kWStride + i;
-  const float *wk = s_wk + (4 * hq) * kWStride + i;
-  const float *wv = s_wv + (4 * hq) * kWStride + i;
-  const float *wa1 = s_a1 + (4 * hq) * kA1Stride + i;
+  // per-lane bases of the A operands (lane-major images)
+  const float *wq = s_wq + 4 * lane, *wo = s_wo + 4 * lane;
+  const float *wk = s_wk + 4 * lane;
+  const float *wv = s_wv + 4 * lane;
+  const float *wa1 = s_a1 + 4 * lane;
   const float *sP1 = s_small, *sP1b = s_small + kSmP1B, *sP2 = s_small + kSmP2, *sP2b = s_small + kSmP2B;
   const float *sA1b = s_small + kSmA1B, *sA2 = s_small + kSmA2, *sA2b = s_small + kSmA2B;
   // the small MLPs' weights are loop invariants of a lane
@@ -272,8 +272,8 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       load_row16(q_in + g * 64, q0, hq);
       layer_norm64q(q0, s_par, s_par + 64, 1e-6f, x, hq);
       floatx4 qq[4] = {};
-      ldq8<kWStride>(w, wq, 0);
-      chain64q<kWStride>(qq, wq, x, w, [&](float (&d)[8]) { ldq8<kWStride>(d, wk, 0); });
+      ldq8v(w, wq, 0);
+      chain64qv(qq, wq, x, w, [&](float (&d)[8]) { ldq8v(d, wk, 0); });
       float b[16];
       load_row16(sP2b, b, hq);
 #pragma unroll
@@ -307,7 +307,7 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       const bool seen = __builtin_amdgcn_ballot_w64(ok) != 0;
       if (seen) {  // k = Wk f
         floatx4 c[4] = {};
-        chain64q<kWStride>(c, wk, f_nx, w, [&](float (&d)[8]) { ldn8<kA1Stride>(d, wa1, 0); });
+        chain64qv(c, wk, f_nx, w, [&](float (&d)[8]) { ldq8v(d, wa1, 0); });
 #pragma unroll
         for (int t = 0; t < 16; ++t) k[t] = c[t >> 2][t & 3];
       }
@@ -338,7 +338,7 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
 #pragma unroll
       for (int t = 0; t < 16; ++t) a[t] = k[t] + pq[t >> 2][t & 3];
       {  // hidden layer of the attention MLP (64 -> 8, M padded to 16)
-        const floatx4 c = chain64n(wa1, a, w, [&](float (&d)[8]) { ldq8<kWStride>(d, wv, 0); });
+        const floatx4 c = chain64n(wa1, a, w, [&](float (&d)[8]) { ldq8v(d, wv, 0); });
 #pragma unroll
         for (int r = 0; r < 4; ++r) hid[r] = fmaxf(c[r] + a1b[r], 0.0f);
         pack_hidden(hid, hk);
@@ -354,7 +354,7 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       floatx4 lv[4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) lv[mt] = pq[mt];
-      chain64q<kWStride>(lv, wv, k, w, [&](float (&d)[8]) { ldq8<kWStride>(d, wk, 0); });
+      chain64qv(lv, wv, k, w, [&](float (&d)[8]) { ldq8v(d, wk, 0); });
       float x[16];  // logits relative to the reference, in log2 units
       {
         floatx4 la[4];
@@ -420,8 +420,8 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       load_row16(s_par + 128, b, hq);
 #pragma unroll
       for (int t = 0; t < 16; ++t) o[t >> 2][t & 3] = b[t];
-      ldq8<kWStride>(w, wo, 0);
-      chain64q<kWStride>(o, wo, xa, w, [&](float (&d)[8]) {});
+      ldq8v(w, wo, 0);
+      chain64qv(o, wo, xa, w, [&](float (&d)[8]) {});
 #pragma unroll
       for (int t = 0; t < 16; ++t) x1[t] = o[t >> 2][t & 3] + qres[t];
     }

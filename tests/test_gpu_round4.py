@@ -587,9 +587,9 @@ def test_gnt_chunk_loop_jobs_and_stage_events():
     few, peak_few = run(2048)
     many, peak_many = run(256)
     assert peak_many <= peak_few, (peak_many, peak_few)
-    for k in few:
-        np.testing.assert_allclose(many[k].cpu().numpy(), few[k].cpu().numpy(), rtol=0, atol=1e-5, err_msg=k)
-        np.testing.assert_allclose(mid[k].cpu().numpy(), few[k].cpu().numpy(), rtol=0, atol=1e-5, err_msg=k)
+    for k in few:  # (the ResUNet runs on MIOpen, whose convolutions are not bit-reproducible from call to call: 1e-4, the path's tolerance)
+        np.testing.assert_allclose(many[k].cpu().numpy(), few[k].cpu().numpy(), rtol=0, atol=1e-4, err_msg=k)
+        np.testing.assert_allclose(mid[k].cpu().numpy(), few[k].cpu().numpy(), rtol=0, atol=1e-4, err_msg=k)
     # the stage-event hook of bench.py's breakdown
     br.stage_events = ev = {}
     run(chunk)

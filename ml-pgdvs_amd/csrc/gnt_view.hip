@@ -627,6 +627,19 @@ __device__ __forceinline__ float quad_max(float v, int lane) {  // over the lane
   return fmaxf(v, __int_as_float((lane & 32) ? b[0] : b[1]));
 }
 
+// maximum without the canonicalising v_max x, x the compiler puts in front of fmaxf on values it cannot prove
+// quiet (MFMA results): same result, -inf and all (a NaN loses against a number either way)
+__device__ __forceinline__ float vmax2(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 __global__ void __launch_bounds__(1024)
 gnt_ray_attn_kernel(const float *__restrict__ W_arg, const float *__restrict__ q_in, int R, int S,
                     float *__restrict__ y_out, float *__restrict__ w_out) {
@@ -723,63 +736,80 @@ gnt_ray_attn_kernel(const float *__restrict__ W_arg, const float *__restrict__ q
         floatx4 O = {0.0f, 0.0f, 0.0f, 0.0f};
         // the score tile of key tile kt+1 is issued before the softmax of tile kt: the matrix
         // pipe works on it while the vector ALU exponentiates, and its K operands were
-        // requested one tile earlier still
+        // requested one tile earlier still.  From the second tile on the score product starts from
+        // -m (the accumulator operand of its first MFMA), so the scores arrive relative to the
+        // reference: no subtraction per score (the vector ALU and the fp32 matrix pipe do not overlap
+        // on this chip: every vector instruction in this loop is paid in full).
         float ka[4], va[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ka[r] = kr[r * kRayKStride];
-        floatx4 sc = {0.0f, 0.0f, 0.0f, 0.0f};
+        floatx4 sa = {0.0f, 0.0f, 0.0f, 0.0f}, sb;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sc = mfma16(ka[r], qv[4 * hh + r], sc);
+        for (int r = 0; r < 4; ++r) sa = mfma16(ka[r], qv[4 * hh + r], sa);
+        const float *kp = kr + 16, *vp = vr;  // walking pointers: every read is pointer + immediate
         if (1 < ntile) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ka[r] = kr[r * kRayKStride + 16];
+          for (int r = 0; r < 4; ++r) ka[r] = kp[r * kRayKStride];
+          kp += 16;
         }
-        for (int kt = 0; kt < ntile; ++kt) {
+        floatx4 negm = {0.0f, 0.0f, 0.0f, 0.0f};
+        // one key tile: `cur` holds its scores, `nxt` receives the next tile's (the two trade places from tile
+        // to tile: the loop below is unrolled by two so that no accumulator is ever copied)
+        auto key_tile = [&](floatx4 &cur, floatx4 &nxt, int kt) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) va[r] = vr[(16 * kt + r) * kRayVStride];
-          floatx4 sn = {0.0f, 0.0f, 0.0f, 0.0f};
+          for (int r = 0; r < 4; ++r) va[r] = vp[r * kRayVStride];
+          vp += 16 * kRayVStride;
+          nxt = negm;
           if (kt + 1 < ntile) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sn = mfma16(ka[r], qv[4 * hh + r], sn);
+            for (int r = 0; r < 4; ++r) nxt = mfma16(ka[r], qv[4 * hh + r], nxt);
             if (kt + 2 < ntile) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) ka[r] = kr[r * kRayKStride + 16 * (kt + 2)];
+              for (int r = 0; r < 4; ++r) ka[r] = kp[r * kRayKStride];
+              kp += 16;
             }
           }
-          float x[4], xmax = -__builtin_inff();
-          if (16 * kt + 16 <= S) {  // a full key tile (every tile when S is a multiple of 16): nothing to mask
+          if (16 * kt + 16 > S) {  // the last, partial key tile (never when S is a multiple of 16)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              x[r] = sc[r];
-              xmax = fmaxf(xmax, x[r]);
-            }
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int key = 16 * kt + 4 * hq + r;
-              x[r] = key < S ? sc[r] : -__builtin_inff();
-              xmax = fmaxf(xmax, x[r]);
-            }
+            for (int r = 0; r < 4; ++r) cur[r] = 16 * kt + 4 * hq + r < S ? cur[r] : -__builtin_inff();
           }
+          const float xmax = vmax2(vmax3(cur[0], cur[1], cur[2]), cur[3]);
           if (kt == 0) {
-            m = quad_max(xmax, lane);  // key 0 is always valid: finite
-          } else if (__builtin_amdgcn_ballot_w64(xmax - m > kRayGap) != 0) {
-            const float mn = fmaxf(m, quad_max(xmax, lane));
-            const float f = __builtin_amdgcn_exp2f(m - mn);
+            // raw scores: their maximum over the tile becomes the reference (key 0 is always valid: finite)
+            m = quad_max(xmax, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              cur[r] -= m;
+              nxt[r] -= m;
+              negm[r] = -m;
+            }
+          } else if (__builtin_amdgcn_ballot_w64(xmax > kRayGap) != 0) {
+            // (rare) a score left the reference behind by more than the gap: move it up by d
+            const float d = fmaxf(quad_max(xmax, lane), 0.0f);
+            const float f = __builtin_amdgcn_exp2f(-d);
             l *= f;
+            m += d;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) O[r] *= f;
-            m = mn;
+            for (int r = 0; r < 4; ++r) {
+              O[r] *= f;
+              cur[r] -= d;
+              nxt[r] -= d;
+              negm[r] -= d;
+            }
           }
+          float e[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            x[r] = __builtin_amdgcn_exp2f(x[r] - m);
-            l += x[r];
-          }
+          for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(cur[r]);
+          l += (e[0] + e[1]) + (e[2] + e[3]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) O = mfma16(va[r], x[r], O);
-          sc = sn;
+          for (int r = 0; r < 4; ++r) O = mfma16(va[r], e[r], O);
+        };
+        int kt = 0;
+        for (; kt + 1 < ntile; kt += 2) {
+          key_tile(sa, sb, kt);
+          key_tile(sb, sa, kt + 1);
         }
+        if (kt < ntile) key_tile(sa, sb, kt);
         l = quad_sum(l);
         if (wave == 0 && i == 0) {  // query sample 0: softmax statistics + its scaled Q for the weight row
           if (hq == 0) {

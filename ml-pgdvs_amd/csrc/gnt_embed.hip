@@ -7,6 +7,8 @@
 // and the per-group maximum / moments are carried in registers, so the [N,V,64] tensor is
 // never re-read for the reductions (upstream: two GEMMs, a ReLU, a max, two std passes and a
 // mean-abs over a 1.6 GB tensor at 1080p chunk sizes).
+#include <type_traits>
+
 #include "gnt_mfma.h"
 
 namespace pgdvs {
@@ -33,46 +35,57 @@ gnt_embed_kernel(const float *__restrict__ W_arg, const float *__restrict__ rgb_
   const float *w1 = s_w1 + hq * kEmb1Stride + i;
   // layer 2 takes layer 1's accumulators: K-step (c,r) <-> hidden unit 16*c + 4*hq + r
   const float *w2 = s_w2 + (4 * hq) * kEmbStride + i;
-  float b1[16], b2[16];
-  load_row16(b1g, b1, hq);
-  load_row16(b2g, b2, hq);
+  // the biases as accumulator operands of each product's first MFMAs (register quads: no copies)
+  floatx4 b1v[4], b2v[4];
+  {
+    float b1[16], b2[16];
+    load_row16(b1g, b1, hq);
+    load_row16(b2g, b2, hq);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      b1v[t >> 2][t & 3] = b1[t];
+      b2v[t >> 2][t & 3] = b2[t];
+    }
+  }
 
   const int64_t ntiles = (N + 15) / 16;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t g_raw = tile * 16 + i;
     const bool g_ok = g_raw < N;
     const int64_t g = g_ok ? g_raw : N - 1;
-    float qmax[16], f0[16], s1[16], s2[16], sa[16];
+    // running maximum and moments over the views (all of them: the mask plays no part here); the moments are
+    // taken about the first view's value, which keeps the one-pass variance as accurate as the two-pass form
+    // for features whose spread is small against their mean.  Pairs of features: packed vector instructions.
+    float qmax[16];
+    floatx2 f0[8], s1[8], s2[8];
+    float sa[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      qmax[t] = -__builtin_inff();
-      f0[t] = 0.0f;
-      s1[t] = 0.0f;
-      s2[t] = 0.0f;
-      sa[t] = 0.0f;
+    for (int t = 0; t < 16; ++t) sa[t] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      s1[t] = floatx2{0.0f, 0.0f};
+      s2[t] = floatx2{0.0f, 0.0f};
     }
+    // channel 4*s + hq of the row: only the last K-step can reach past Cin (Cin > 4*KS - 4)
+    const bool last_ok = 4 * (KS - 1) + hq < Cin;
+    auto load_x = [&](float (&x)[KS], const float *row) {
+#pragma unroll
+      for (int s = 0; s + 1 < KS; ++s) x[s] = row[4 * s + hq];
+      x[KS - 1] = last_ok ? row[4 * (KS - 1) + hq] : 0.0f;
+    };
     float x_nx[KS];
-    {
-      const float *row = rgb_feat + (g * V) * Cin;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) x_nx[s] = 4 * s + hq < Cin ? row[4 * s + hq] : 0.0f;
-    }
+    load_x(x_nx, rgb_feat + (g * V) * Cin);
     float w[8];
     ldq8<kEmbStride>(w, w2, 0);
-    for (int v = 0; v < V; ++v) {
+    // one source view; `first` (a compile-time flag: the loop's first trip is peeled) initialises the running values
+    auto view = [&](int v, auto first) {
       const int64_t r = g * V + v;
       float x[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s) x[s] = x_nx[s];
-      if (v + 1 < V) {
-        const float *row = rgb_feat + (r + 1) * Cin;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) x_nx[s] = 4 * s + hq < Cin ? row[4 * s + hq] : 0.0f;
-      }
+      if (v + 1 < V) load_x(x_nx, rgb_feat + (r + 1) * Cin);
       // hidden = relu(W1 x + b1)
       floatx4 hacc[4];
-#pragma unroll
-      for (int t = 0; t < 16; ++t) hacc[t >> 2][t & 3] = b1[t];
       {
         float wa[4], wb[4];
 #pragma unroll
@@ -85,7 +98,7 @@ gnt_embed_kernel(const float *__restrict__ W_arg, const float *__restrict__ rgb_
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) hacc[mt] = mfma16(wa[mt], x[s], hacc[mt]);
+          for (int mt = 0; mt < 4; ++mt) hacc[mt] = mfma16(wa[mt], x[s], s == 0 ? b1v[mt] : hacc[mt]);
           __builtin_amdgcn_sched_barrier(0);
           if (s + 2 < KS) {
 #pragma unroll
@@ -101,34 +114,36 @@ gnt_embed_kernel(const float *__restrict__ W_arg, const float *__restrict__ rgb_
       }
       float hid[16];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) hid[t] = fmaxf(hacc[t >> 2][t & 3], 0.0f);
+      for (int t = 0; t < 16; ++t) hid[t] = vrelu(hacc[t >> 2][t & 3]);
       // feat = W2 hidden + b2
       floatx4 o[4];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) o[t >> 2][t & 3] = b2[t];
+      for (int mt = 0; mt < 4; ++mt) o[mt] = b2v[mt];
       chain64q<kEmbStride>(o, w2, hid, w, [&](float (&d)[8]) { ldq8<kEmbStride>(d, w2, 0); });
       float f[16];
 #pragma unroll
       for (int t = 0; t < 16; ++t) f[t] = o[t >> 2][t & 3];
       if (g_ok) store_row16(feat + r * 64, f, hq);
-      // running maximum and moments over the views (all of them: the mask plays no part here);
-      // the moments are taken about the first view's value, which keeps the one-pass variance
-      // as accurate as the two-pass form for features whose spread is small against their mean
-      if (v == 0) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) f0[t] = f[t];
-      }
+      for (int t = 0; t < 16; ++t) qmax[t] = first ? f[t] : vmax2(qmax[t], f[t]);
+      if (stats != nullptr) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        qmax[t] = fmaxf(qmax[t], f[t]);
-        if (stats != nullptr) {
-          const float d = f[t] - f0[t];
-          s1[t] += d;
-          s2[t] = __builtin_fmaf(d, d, s2[t]);
-          sa[t] += fabsf(f[t]);
+        for (int t = 0; t < 8; ++t) {
+          const floatx2 fv = {f[2 * t], f[2 * t + 1]};
+          if (first) {
+            f0[t] = fv;  // d = 0: the sums stay zero
+          } else {
+            const floatx2 d = fv - f0[t];
+            s1[t] += d;
+            s2[t] = __builtin_elementwise_fma(d, d, s2[t]);
+          }
         }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sa[t] += fabsf(f[t]);
       }
-    }
+    };
+    view(0, std::true_type{});
+    for (int v = 1; v < V; ++v) view(v, std::false_type{});
     if (g_ok) store_row16(q0 + g * 64, qmax, hq);
     if (stats != nullptr) {
       const float n = (float)V;
@@ -136,7 +151,7 @@ gnt_embed_kernel(const float *__restrict__ W_arg, const float *__restrict__ rgb_
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         // torch.std (unbiased): NaN for a single view, like upstream
-        const float var = (s2[t] - s1[t] * s1[t] / n) / (n - 1.0f);
+        const float var = (s2[t >> 1][t & 1] - s1[t >> 1][t & 1] * s1[t >> 1][t & 1] / n) / (n - 1.0f);
         const float sdev = sqrtf(fmaxf(var, 0.0f));
         sd += sdev;
         sdn += sdev / (sa[t] / n + 1e-6f);

@@ -45,6 +45,17 @@ __device__ __forceinline__ floatx4 mfma16(float a, float b, floatx4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Maxima without the canonicalising `v_max x, x` the compiler puts in front of fmaxf on values it cannot prove
+// quiet (MFMA results): the median of (a, b, +inf) IS the maximum, and v_med3_f32 is one instruction (a NaN loses
+// against a number, as in fmaxf).  Builtins, not inline assembly: the compiler inserts the wait states an MFMA
+// result needs before a vector instruction may read it only for instructions it knows.  They matter: the vector
+// ALU and the fp32 matrix pipe do not overlap on this chip (profiles/r01_mfma_calibration.txt), every vector
+// instruction between MFMAs is paid in full.
+__device__ __forceinline__ float vmax2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+__device__ __forceinline__ float vrelu(float a) { return __builtin_amdgcn_fmed3f(a, 0.0f, __builtin_inff()); }
+
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ void load_row16(const float *__restrict__ row, float (&x)[16], int hq) {
   const float *rb = row + 4 * hq;
 #pragma unroll

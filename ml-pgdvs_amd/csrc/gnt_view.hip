@@ -575,7 +575,7 @@ gnt_ff_kernel(const float *__restrict__ W_arg, float *__restrict__ x_io, int64_t
         for (int u = 0; u < 8; ++u) {
           if (mt < 7) hnext = mfma(p[u], xn[8 * c + u], hnext);
           if (u < 4) {
-            const float hv = fmaxf(hcur[4 * c + u], 0.0f);
+            const float hv = vrelu(hcur[4 * c + u]);
             o0 = mfma(q[u], hv, o0);
             o1 = mfma(q[4 + u], hv, o1);
           }
@@ -625,19 +625,6 @@ __device__ __forceinline__ float quad_max(float v, int lane) {  // over the lane
   const int iw = __float_as_int(v);
   const auto b = __builtin_amdgcn_permlane32_swap(iw, iw, false, false);
   return fmaxf(v, __int_as_float((lane & 32) ? b[0] : b[1]));
-}
-
-// maximum without the canonicalising v_max x, x the compiler puts in front of fmaxf on values it cannot prove
-// quiet (MFMA results): same result, -inf and all (a NaN loses against a number either way)
-__device__ __forceinline__ float vmax2(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
 }
 
 __global__ void __launch_bounds__(1024)
@@ -773,7 +760,7 @@ gnt_ray_attn_kernel(const float *__restrict__ W_arg, const float *__restrict__ q
 #pragma unroll
             for (int r = 0; r < 4; ++r) cur[r] = 16 * kt + 4 * hq + r < S ? cur[r] : -__builtin_inff();
           }
-          const float xmax = vmax2(vmax3(cur[0], cur[1], cur[2]), cur[3]);
+          const float xmax = vmax2(vmax2(cur[0], cur[1]), vmax2(cur[2], cur[3]));
           if (kt == 0) {
             // raw scores: their maximum over the tile becomes the reference (key 0 is always valid: finite)
             m = quad_max(xmax, lane);

@@ -596,3 +596,47 @@ def test_gnt_chunk_loop_jobs_and_stage_events():
     br.stage_events = None
     assert len(ev["features"]) == 1 and len(ev["gather"]) == len(ev["transformer"]) == 14  # 13 chunks, one of them in two pieces
     assert all(a.elapsed_time(b) >= 0 for v in ev.values() for a, b in v)
+
+
+@pytest.mark.parametrize("S", [33, 64, 250, 256])
+def test_gnt_ray_layer_wide_score_range(S):
+    """ray attention with scores that grow along the ray by far more than the kernel's rescaling gap (2^20): the
+    score tiles arrive relative to a reference that has to move several times per head (csrc/gnt_view.hip key_tile,
+    the rare branch), also inside the partial last key tile; against torch's softmax
+    (reference: pgdvs/models/gnt/models/transformer_network.py:231-338)."""
+    from pgdvs_amd.models.gnt.models.transformer_network import GNT
+
+    torch.manual_seed(300 + S)
+    net = GNT(netwidth=64, transformer_depth=1).to(DEV).eval()
+    layer = net.view_selftrans[0]
+    R = 9
+    # rows = one direction per ray + noise that fades along the ray, q_fc = k_fc = 8 I: the keys late on the ray align
+    # better and better with every query, the running maximum climbs by more than the gap tile after tile
+    fade = torch.linspace(2.0, 0.0, S, device=DEV)[None, :, None]
+    q = torch.randn(R, 1, 64, device=DEV) + fade * torch.randn(R, S, 64, device=DEV)
+    with torch.no_grad():
+        layer.attn_norm.weight.fill_(1.0)
+        layer.attn_norm.bias.zero_()
+        layer.attn.q_fc.weight.copy_(torch.eye(64, device=DEV) * 8.0)
+        layer.attn.k_fc.weight.copy_(torch.eye(64, device=DEV) * 8.0)
+        xn = layer.attn_norm(q)
+        qq = layer.attn.q_fc(xn).view(R, S, 4, 16).permute(0, 2, 1, 3)
+        kk = layer.attn.k_fc(xn).view(R, S, 4, 16).permute(0, 2, 1, 3)
+        sc = (qq @ kk.transpose(-1, -2)) / 4.0
+        spread = ((sc.amax(-1) - sc.amin(-1)).max() * 1.4426950408889634).item()
+        # running maximum per query over 16-key tiles: how often does it jump by more than the gap?
+        tiles = torch.stack([sc[..., t:t + 16].amax(-1) for t in range(0, S, 16)], -1) * 1.4426950408889634
+        run = torch.cummax(tiles, -1).values
+        jumps = int(((tiles[..., 1:] - run[..., :-1]) > 20.0).sum())
+        out_k, w_k = GNT._ray_layer(layer, q, True)
+    assert spread > 60.0 and jumps > 0, (spread, jumps)  # the inputs do exercise the branch
+    ops._GNT_VIEW_ENABLED = False
+    try:
+        with torch.no_grad():
+            out_t, w_t = GNT._ray_layer(layer, q, True)
+    finally:
+        ops._GNT_VIEW_ENABLED = True
+    np.testing.assert_allclose(out_k.cpu().numpy(), out_t.cpu().numpy(), rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(w_k.cpu().numpy(), w_t.cpu().numpy(), rtol=2e-4, atol=1e-6)
+    # (scores of several hundred: one ulp of a score is 4e-5 of its weight)
+    np.testing.assert_allclose(w_k.cpu().numpy().sum(1), 1.0, rtol=1e-4)

@@ -150,30 +150,24 @@ __device__ __forceinline__ void layer_norm64q(const float (&x)[16], const float 
   for (int t = 0; t < 16; ++t) y[t] = (x[t] - mean) * rstd * gg[t] + bb[t];
 }
 
-// 64 -> 16 (8 used): one output tile (lane-major image [s>>2][lane][s&3], see gnt_mfma.h); the 16 K-steps
-// alternate between two accumulators
+// 64 -> 16 (8 used): one output tile (lane-major image [s>>2][lane][s&3], see gnt_mfma.h), started from the bias
+// `c0` (accumulator operand of the first MFMA).  One accumulator: a dependent chain of these MFMAs issues back to
+// back at the pipe's own pace (profiles/r01_mfma_calibration.txt), two would need an addition at the end.
 template <class Next>
 __device__ __forceinline__ floatx4 chain64n(const float *__restrict__ lb, const float (&x)[16], float (&w)[8],
-                                            Next &&next) {
-  floatx4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
+                                            floatx4 c0, Next &&next) {
   float w2[8];
   ldq8v(w2, lb, 1);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int u = 0; u < 8; u += 2) {
-    c0 = mfma16(w[u], x[u], c0);
-    c1 = mfma16(w[u + 1], x[u + 1], c1);
-  }
+  for (int u = 0; u < 8; ++u) c0 = mfma16(w[u], x[u], c0);
   __builtin_amdgcn_sched_barrier(0);
   next(w);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int u = 0; u < 8; u += 2) {
-    c0 = mfma16(w2[u], x[8 + u], c0);
-    c1 = mfma16(w2[u + 1], x[9 + u], c1);
-  }
+  for (int u = 0; u < 8; ++u) c0 = mfma16(w2[u], x[8 + u], c0);
   __builtin_amdgcn_sched_barrier(0);
-  return c0 + c1;
+  return c0;
 }
 
 // The 8 hidden units of a 64 -> 8 -> 64 MLP leave the first layer in lanes hq = 0,1 (unit
@@ -235,7 +229,8 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
   const float *sA1b = s_small + kSmA1B, *sA2 = s_small + kSmA2, *sA2b = s_small + kSmA2B;
   // the small MLPs' weights are loop invariants of a lane
   const int hu = 4 * (hq & 1) + (hq >> 1);  // packed hidden unit of K-step 0 (see pack_hidden)
-  float p2w[2][4], a2w[2][4], p1b[4], a1b[4];
+  float p2w[2][4], a2w[2][4];
+  floatx4 p1b, a1b;  // the hidden layers' biases: accumulator operands of their first MFMAs
   const float p1w = sP1[hq * 32 + i];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -322,10 +317,9 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       float a[16], hid[4], hk[2];
       floatx4 pq[4];
       {  // pq = P2 relu(P1 d + b) + b - q'   (4 -> 8 -> 64)
-        floatx4 c = {0.0f, 0.0f, 0.0f, 0.0f};
-        c = mfma16(p1w, dv, c);
+        const floatx4 c = mfma16(p1w, dv, p1b);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hid[r] = fmaxf(c[r] + p1b[r], 0.0f);
+        for (int r = 0; r < 4; ++r) hid[r] = vrelu(c[r]);
         pack_hidden(hid, hk);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -338,9 +332,9 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
 #pragma unroll
       for (int t = 0; t < 16; ++t) a[t] = k[t] + pq[t >> 2][t & 3];
       {  // hidden layer of the attention MLP (64 -> 8, M padded to 16)
-        const floatx4 c = chain64n(wa1, a, w, [&](float (&d)[8]) { ldq8v(d, wv, 0); });
+        const floatx4 c = chain64n(wa1, a, w, a1b, [&](float (&d)[8]) { ldq8v(d, wv, 0); });
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hid[r] = fmaxf(c[r] + a1b[r], 0.0f);
+        for (int r = 0; r < 4; ++r) hid[r] = vrelu(c[r]);
         pack_hidden(hid, hk);
       }
       if (STATS && ok) {

@@ -655,7 +655,13 @@ def main():
             md = harness.eval_step(model, ev_views[j % n_views], rc, device=dev)
         torch.cuda.synchronize()
         e1 = time.perf_counter() - e0
+        # where a step's host time goes (a second, instrumented pass: the timed one above carries no timers)
+        harness.STAGE_SECONDS = st_ = {}
+        for j in range(n_ev):
+            harness.eval_step(model, ev_views[j % n_views], rc, device=dev)
+        harness.STAGE_SECONDS = None
         eval_loop = {"frames_per_s": round(n_ev / e1, 2), "ms_per_view": round(e1 / n_ev * 1e3, 3), "views": n_ev,
+                     "host_ms_per_view": {k_: round(v_ / n_ev * 1e3, 4) for k_, v_ in st_.items()},
                      "psnr_full_last": round(float(md["eval/psnr_full_combined"]), 3),
                      "note": "pgdvs_amd.harness.eval_step per view (to-device, forward = one native call incl. A12, quantisation + "
                              "the three masked PSNRs in one pass, ONE host synchronisation, status words checked): the "

@@ -8,6 +8,7 @@ the evaluator's three masked PSNRs (``obtain_quantitative_nvidia`` :190-283 with
 third-party networks / skimage and are out of scope: their keys are not produced.  A few elementwise
 torch ops on final images; nothing here is on the rendering hot path."""
 import math
+import time
 from collections import OrderedDict
 
 import torch
@@ -41,19 +42,37 @@ def to_device(batch: dict, device) -> dict:
 
 METRIC_KEYS = ("psnr_full_combined", "psnr_dyn_combined", "psnr_static_combined")
 
+# measurement hook (bench.py): a dict set here accumulates the host wall time of eval_step's stages in seconds
+# ("to_device", "forward" = enqueue of the renderer, "metric_enqueue", "sync_read" = the step's one wait for the GPU,
+# "post"); None = no timing
+STAGE_SECONDS = None
+
 
 @torch.no_grad()
 def eval_step(model, data: dict, render_cfg, *, device=None, disable_tqdm=True, return_images=False):
     """One evaluator step on a batch of target views.  ``data`` is the reference's data dict (row A0) plus
     ``rgb_tgt[B,H,W,3]`` and ``eval_mask[B,H,W,3]`` (1 = dynamic region).  Returns the reference's
     ``metric_dict`` restricted to the in-scope keys: ``eval/count`` (int64) and the per-key SUMS over the
-    batch (float32), reduced to rank 0 when a process group is up.  With ``return_images`` also the
-    quantised prediction / ground truth and the per-view values."""
+    batch (float32), reduced to rank 0 when a process group is up (device tensors then, as upstream; host tensors in a
+    single process on the fused GPU path).  With ``return_images`` also the quantised prediction / ground truth and the
+    per-view values."""
     device = device if device is not None else next(iter(v for v in data.values() if isinstance(v, torch.Tensor))).device
+    stages, t_prev = STAGE_SECONDS, time.perf_counter()
+
+    def lap(name):
+        nonlocal t_prev
+        if stages is not None:
+            now = time.perf_counter()
+            stages[name] = stages.get(name, 0.0) + (now - t_prev)
+            t_prev = now
+
     data_gpu = to_device(data, device)
-    model.eval()
+    lap("to_device")
+    if model.training:
+        model.eval()
     n_batch = data["rgb_src_temporal"].shape[0]
     ret = model.forward(data_gpu, render_cfg=render_cfg, disable_tqdm=disable_tqdm, for_debug=False)
+    lap("forward")
     from . import ops
 
     def check_status(host_counts=None, host_status=None):
@@ -91,7 +110,9 @@ def eval_step(model, data: dict, render_cfg, *, device=None, disable_tqdm=True, 
                                   count_dev=cnts[i_b:i_b + 1] if (cnts is not None and i_b < cnts.numel()) else None,
                                   status_dev=stat[i_b:i_b + 1] if (stat is not None and i_b < stat.numel()) else None)
                for i_b in range(n_batch)]
-        sums = torch.stack([r_[0] for r_ in res]).cpu().tolist()  # (the step's synchronisation)
+        lap("metric_enqueue")
+        sums = ops.read_back_rows([r_[0] for r_ in res])  # (the step's synchronisation)
+        lap("sync_read")
         check_status(host_counts=[int(s_[6]) for s_ in sums] if cnts is not None else None,
                      host_status=[int(s_[7]) for s_ in sums] if stat is not None else None)
         per_view = {k: [] for k in METRIC_KEYS}
@@ -99,12 +120,22 @@ def eval_step(model, data: dict, render_cfg, *, device=None, disable_tqdm=True, 
             for j, k in enumerate(METRIC_KEYS):
                 mse = s_[j] / (s_[3 + j] + 1e-8)
                 per_view[k].append(0 if mse == 0 else 10 * math.log10(1.0 / mse))
-        packed = torch.tensor([float(n_batch)] + [float(torch.tensor(per_view[k], dtype=torch.float32).sum()) for k in METRIC_KEYS],
-                              dtype=torch.float64, device=comb.device)
-        packed = pdist.reduce_metrics(packed, dst=0)
-        metric = {"eval/count": packed[:1].round().to(torch.int64)}
-        for j, k in enumerate(METRIC_KEYS):
-            metric[f"eval/{k}"] = packed[1 + j].to(torch.float32)
+        # (a single process keeps the packed sums -- and so the metric tensors -- on the host: same dtypes and values, no
+        # upload and no one-element kernels per step, and the caller's `.item()` costs nothing; ranks that reduce over
+        # RCCL need them on the device, like upstream)
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        if not multi:
+            metric = {"eval/count": torch.tensor([n_batch], dtype=torch.int64)}
+            for k in METRIC_KEYS:
+                metric[f"eval/{k}"] = torch.tensor(per_view[k], dtype=torch.float32).sum()
+        else:
+            packed = torch.tensor([float(n_batch)] + [float(torch.tensor(per_view[k], dtype=torch.float32).sum()) for k in METRIC_KEYS],
+                                  dtype=torch.float64, device=comb.device)
+            packed = pdist.reduce_metrics(packed, dst=0)
+            metric = {"eval/count": packed[:1].round().to(torch.int64)}
+            for j, k in enumerate(METRIC_KEYS):
+                metric[f"eval/{k}"] = packed[1 + j].to(torch.float32)
+        lap("post")
         if return_images:
             return metric, {"pred": torch.stack([r_[1] for r_ in res]), "gt": torch.stack([r_[2] for r_ in res]),
                             "eval_mask": data_gpu["eval_mask"].permute(0, 3, 1, 2), "per_view": per_view, "ret": ret}

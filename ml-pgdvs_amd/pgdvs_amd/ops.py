@@ -598,6 +598,27 @@ def eval_psnr_sums(pred_planar, gt_hwc, mask_hwc, want_images: bool = False, cou
     return sums, pq, gq
 
 
+_pinned_sums = {}
+
+
+def read_back_rows(rows):
+    """[n] device tensors of 8 float64 each -> [n][8] Python floats, through ONE pinned staging block per device (cached):
+    asynchronous copies on the current stream and one event wait, instead of a pageable `.cpu()` per step (which stages
+    through a fresh host block and synchronises the whole stream)."""
+    dev = rows[0].device
+    n = len(rows)
+    ent = _pinned_sums.get(dev.index)
+    if ent is None or ent[0].shape[0] < n:
+        ent = (torch.empty((max(n, 8), 8), dtype=torch.float64).pin_memory(), torch.cuda.Event())
+        _pinned_sums[dev.index] = ent
+    host, ev = ent
+    for i, r_ in enumerate(rows):
+        host[i].copy_(r_, non_blocking=True)
+    ev.record()
+    ev.synchronize()
+    return host[:n].tolist()
+
+
 def checked_count(cnt, what: str) -> int:
     """Host read of a device-side count that doubles as a status word: negative = the kernel chain
     reported an internal error (e.g. ``agg_select``'s ordered-offset look-back gave up) and its

@@ -481,7 +481,7 @@ def test_eval_step_drives_the_hip_renderer():
     data["rgb_tgt"], data["eval_mask"] = torch.from_numpy(gt), torch.from_numpy(dyn)
     data["misc"] = [{"scene_id": "synthetic", "tgt_frame_id": 1, "tgt_cam_id": 0}]
     md, extra = eval_step(model, data, rc, device=DEV, return_images=True)
-    assert int(md["eval/count"]) == 1 and md["eval/count"].device.type == "cuda"
+    assert int(md["eval/count"]) == 1 and md["eval/count"].dtype == torch.int64  # (single process: host tensors)
     pq = quantize_like_evaluator(torch.from_numpy(o["combined_rgb"][0]))
     gq = quantize_like_evaluator(torch.from_numpy(gt[0]).permute(2, 0, 1))
     # quantised predictions: the HIP image is within 1e-4 of the oracle's, so at most a handful of 8-bit steps differ

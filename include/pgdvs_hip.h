@@ -18,7 +18,7 @@
  *     histogram to stderr; PGDVS_KNN_NO_TPQ=1, PGDVS_KNN_PER_CELL=<n>, PGDVS_KNN_THR_MULT=<x> and PGDVS_KNN_RING_CAP=<n>
  *     select kNN search variants / the grid density / the starting threshold for tuning, PGDVS_RASTER_BOUND_DENSITY=<rows
  *     per pixel> the density from which the rasteriser computes its depth bound and runs its long-list launch,
- *     PGDVS_AGG_ORDERED / PGDVS_AGG_FUSED0 / PGDVS_AGG_FPG / PGDVS_AGG_STEP_FPG the aggregation's launch structure --
+ *     PGDVS_AGG_ORDERED / PGDVS_AGG_FUSED0 / PGDVS_AGG_STAGE / PGDVS_AGG_FPG / PGDVS_AGG_STEP_FPG the aggregation's launch structure --
  *     results are identical for any setting);
  *   - return value: 0 on success, negative pgdvs_status on error, message via
  *     pgdvs_last_error() (thread-local);

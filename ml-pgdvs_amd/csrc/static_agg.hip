@@ -235,7 +235,7 @@ struct f3 { float x, y, z; };  // 12-byte loads / stores in one instruction
 
 // (d_in: the pixel's depth if the caller already has it, NaN = load it here; *d_out receives the depth used)
 __device__ __forceinline__ f3 append_row(const AppendSrc &a, const CamBlock &cam, int p, int64_t pos, bool write,
-                                         float d_in = __builtin_nanf(""), float *d_out = nullptr) {
+                                         float d_in = __builtin_nanf(""), float *d_out = nullptr, const f3 *c_in = nullptr) {
   // row / column of the pixel: float reciprocal + one correction step (exact for P < 2^24),
   // integer division otherwise
   int r, col;
@@ -269,7 +269,7 @@ __device__ __forceinline__ f3 append_row(const AppendSrc &a, const CamBlock &cam
   xq.y = X[1];
   xq.z = X[2];
   if (write) {
-    const f3 c = *reinterpret_cast<const f3 *>(a.rgb + (size_t)p * 3);
+    const f3 c = c_in ? *c_in : *reinterpret_cast<const f3 *>(a.rgb + (size_t)p * 3);
     // a cloud row is 24 bytes at an 8-byte aligned address: three 8-byte stores
     float2 *o = reinterpret_cast<float2 *>(a.cloud + pos * 6);
     o[0] = make_float2(X[0], X[1]);
@@ -791,6 +791,17 @@ __device__ __forceinline__ unsigned sel_flags16_pair(const SelArgs &a, const int
   return base < a.P ? sel_flags16(a, (int)base) : 0u;
 }
 
+// Rows of the later frames on their way from the chain links to agg_rows: the selected pixels of a 128-pixel chunk in
+// order, as (depth, r, g, b) -- one 16-byte store per pixel in the link, one dense 16-byte read in agg_rows -- packed at
+// the chunk's own base: rows[(frame * pixels + chunk * 128 + k) * 4] for the chunk's k-th selected pixel.  (The finished
+// row, 24 bytes in three stores, cost the link 1.4 us: more than agg_rows gained.)  Address space for every pixel of
+// every later frame, of which the selected few per cent are ever touched; no counter, no ordering between workgroups
+// (a cursor shared by the 512 workgroups of a link cost the link 5 us).  null: nothing staged, agg_rows gathers depth and colour itself.
+struct RowStage {
+  float *rows;
+  int64_t frame_px;  // pixels per frame in the layout (Wd * 32)
+};
+
 // One link of the chain: frame `src`'s selection = static and not stamped (tmp_st_mask & ~tmp_proj_mask, :224-245);
 // its own map is complete when the launch starts.  Workgroup b takes the 128-pixel chunks b, b + gridDim.x, ... (32 of
 // them, 16 pixels per thread: selected pixels cluster -- whole rows at an image border, bands around depth edges --
@@ -804,7 +815,7 @@ template <int kQueue, int kSpec>
 __global__ void __launch_bounds__(kStepThreads)
 agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__ sel16, int64_t Wd, int src,
                 const ProjF64 *__restrict__ proj, const PushConsts *__restrict__ pc, int f_hi, int fpg, int H, int W,
-                AppendSrc app, CamBlock cam, unsigned *__restrict__ stat, float *__restrict__ seldepth) {
+                AppendSrc app, CamBlock cam, unsigned *__restrict__ stat, RowStage stage) {
   constexpr int spec = kSpec;
   __shared__ uint16_t s_list[kStepThreads * kStepPx];  // (thread << 4 | pixel) of every selected pixel, 8 KB
   __shared__ float s_dep[kSpec ? kStepThreads * kStepPx : 1];  // spec: their depths, loaded densely beside mask and map
@@ -851,29 +862,35 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
   }
   if (tid == 0) s_qn[0] = s_qn[1] = 0;
   __syncthreads();
+  const bool staged = blockIdx.y == 0 && stage.rows != nullptr;
   const ByteStamp stamp{occ_all, (int64_t)H * W, stat};
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
   for (int e0 = 0; e0 < n; e0 += kStepThreads) {
     const int e = e0 + tid;
     const bool live = e < n;
-    float x = 0.f, y = 0.f, z = 0.f;
+    float x = 0.f, y = 0.f, z = 0.f, d = 0.f;
+    f3 c = {0.f, 0.f, 0.f};
+    int64_t slot4 = -1;
     if (live) {
       const int ent = s_list[e];
-      float d;
-      const f3 X = append_row(app, cam, (int)(pixel_base(ent >> 4) + (ent & 15)), 0, false,
-                              spec != 0 ? s_dep[kSpec ? e : 0] : __builtin_nanf(""), &d);
+      const int px = (int)(pixel_base(ent >> 4) + (ent & 15));
+      // the depth first, the colour right behind it: the unprojection and the stamps below wait for the depth only, the
+      // colour is still on its way while they run and is consumed at the very end of the round -- both are left for
+      // agg_rows, which then reads 16 dense bytes per row instead of a sector per scattered depth and another per colour
+      d = spec != 0 ? s_dep[kSpec ? e : 0] : app.depth[px];
+      if (staged) {
+        c = *reinterpret_cast<const f3 *>(app.rgb + (size_t)px * 3);
+        const int ch = ent >> 7;  // chunk of the workgroup (eight threads per chunk)
+        slot4 = ((int64_t)src * stage.frame_px + ((int64_t)blockIdx.x + (int64_t)ch * gridDim.x) * kStepChunkPx + (e - s_cstart[ch])) * 4;
+      }
+      const f3 X = append_row(app, cam, px, 0, false, d);
       x = X.x;
       y = X.y;
       z = X.z;
-      // the depth this link gathered anyway, left for agg_rows: the selected pixels of a 128-pixel chunk in order, packed
-      // at the chunk's own base (a dense 4-byte read there instead of a 64-byte sector per scattered pixel)
-      if (blockIdx.y == 0 && seldepth != nullptr) {
-        const int ch = ent >> 7;  // chunk of the workgroup (eight threads per chunk)
-        seldepth[(int64_t)src * Wd * 32 + ((int64_t)blockIdx.x + (int64_t)ch * gridDim.x) * kStepChunkPx + (e - s_cstart[ch])] = d;
-      }
     }
     const unsigned dmask = screen_frames(pc, fa, fb, live, x, y, z, wm1, hm1, W, stamp);
     queue_doubtful<kQueue, kStepThreads>(s_q, s_qn, dmask, x, y, z, fa, e0 + kStepThreads >= n, proj, H, W, stamp);
+    if (slot4 >= 0) *reinterpret_cast<float4 *>(stage.rows + slot4) = make_float4(d, c.x, c.y, c.z);
   }
 }
 
@@ -944,7 +961,7 @@ struct RowsArgs {
 __global__ void __launch_bounds__(kBitTileWords)
 agg_rows_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles, const int64_t *__restrict__ tile_off,
                 const int64_t *__restrict__ cnts, const CamBlock *__restrict__ cams, RowsArgs a,
-                const float *__restrict__ seldepth, int f_with_depth) {
+                RowStage stage, int f_staged) {
   __shared__ uint16_t s_list[kSelTile];
   __shared__ int s_wsum[4];
   __shared__ int s_cstart[kBitTileWords / 4];  // list position of every 128-pixel chunk's first selected pixel
@@ -958,8 +975,8 @@ agg_rows_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles, const i
   for (uint32_t m = bits; m; m &= m - 1) s_list[slot++] = (uint16_t)((tid << 5) | __builtin_ctz(m));
   __syncthreads();
   const int64_t pos0 = cnts[1] + tile_off[(int64_t)f * tiles + t];
-  // frames whose chain link unprojected its pixels (all but the last one) left their depths packed per 128-pixel chunk
-  const float *dep = f < f_with_depth ? seldepth + (int64_t)f * Wd * 32 + (int64_t)t * kSelTile : nullptr;
+  // frames whose chain link unprojected its pixels (all but the last one) left their rows packed per 128-pixel chunk
+  const float *srow = f < f_staged && stage.rows != nullptr ? stage.rows + ((int64_t)f * stage.frame_px + (int64_t)t * kSelTile) * 4 : nullptr;
   AppendSrc app;
   app.depth = a.depths + (size_t)f * (size_t)a.P;
   app.rgb = a.rgbs + (size_t)f * (size_t)a.P * 3;
@@ -975,8 +992,13 @@ agg_rows_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles, const i
     if (pos >= a.capacity) break;
     const int ent = (int)s_list[e];
     const int ch = ent >> 7;  // 128-pixel chunk of the tile (four threads of 32 pixels)
-    const float d = dep ? dep[ch * kStepChunkPx + (e - s_cstart[ch])] : __builtin_nanf("");
-    append_row(app, cam, tile_px + ent, pos, true, d);
+    if (srow != nullptr) {
+      const float4 q = *reinterpret_cast<const float4 *>(srow + (ch * kStepChunkPx + (e - s_cstart[ch])) * 4);
+      const f3 c = {q.y, q.z, q.w};
+      append_row(app, cam, tile_px + ent, pos, true, q.x, nullptr, &c);
+    } else {
+      append_row(app, cam, tile_px + ent, pos, true);
+    }
   }
 }
 
@@ -1014,8 +1036,7 @@ struct AggWs {
   int64_t *tile_off;   // [S * tiles + 1] their running sum
   uint8_t *occ;  // [S][P] one occupancy byte per (frame, pixel), zeroed per call
   uint32_t *sel;  // [S][Wd] selection bits of the later frames (each written whole by its agg_step launch)
-  float *seldepth;  // [S][Wd * 32] depths of the selected pixels, packed per 128-pixel chunk at the chunk's base (sparse: only
-                    // what the links write is ever touched)
+  float *stage_rows;  // [S][Wd * 32][4] (depth, colour) of the later frames' selected pixels as the chain links leave them (see RowStage; sparse)
   int64_t Wd;
   int32_t *sel_pix;  // [P] ordered chain: the pixels the current frame selected, in cloud order
   float *xyz;
@@ -1058,12 +1079,11 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   w.Wd = tiles * kBitTileWords;
   w.sel = reinterpret_cast<uint32_t *>(p + off);
   off += align_up((int64_t)S * w.Wd * 4, 256);
-  // (address space for every pixel of every later frame, of which the selected few per cent are ever touched; very long
-  // videos do without it -- agg_rows then gathers the depths itself)
-  w.seldepth = nullptr;
-  if ((int64_t)S * w.Wd * 32 * 4 <= (1ll << 30)) {
-    w.seldepth = reinterpret_cast<float *>(p + off);
-    off += align_up((int64_t)S * w.Wd * 32 * 4, 256);
+  // (very long videos do without the staging block -- agg_rows then gathers depths and colours itself)
+  w.stage_rows = nullptr;
+  if ((int64_t)S * w.Wd * 32 * 16 <= (4ll << 30)) {
+    w.stage_rows = reinterpret_cast<float *>(p + off);
+    off += align_up((int64_t)S * w.Wd * 32 * 16, 256);
   }
   w.xyz = reinterpret_cast<float *>(p + off);
   off += align_up((capacity > 0 ? capacity : 1) * 12, 256);
@@ -1340,6 +1360,11 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
                  cams[0], (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, fpg, H, W, ws.occ,
                  ws.stat);
   }
+  // PGDVS_AGG_STAGE=0: the links leave nothing behind, agg_rows gathers depth and colour itself (the other path of the same kernels)
+  static const bool stage_env = !(getenv("PGDVS_AGG_STAGE") && getenv("PGDVS_AGG_STAGE")[0] == '0');
+  RowStage stage;
+  stage.rows = stage_env ? ws.stage_rows : nullptr;
+  stage.frame_px = ws.Wd * 32;
   {
     // 32 chunks of 128 pixels per workgroup, dealt round-robin; a multiple of 8 workgroups per row (see the kernel)
     const unsigned gx = (unsigned)align_up(cdiv(ws.Wd * 32 / kStepChunkPx, kStepChunks), 8);
@@ -1361,11 +1386,11 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       if (spec_env) {
         PGDVS_LAUNCH("agg_step", (agg_step_kernel<kPushQueueSmall, 1>), dim3(gx, gy), dim3(kStepThreads), 0, st, a, ws.occ,
                      reinterpret_cast<uint16_t *>(ws.sel), ws.Wd, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, sfpg, H, W,
-                     frame_src(i), cams[(size_t)i], ws.stat, ws.seldepth);
+                     frame_src(i), cams[(size_t)i], ws.stat, stage);
       } else {
         PGDVS_LAUNCH("agg_step", (agg_step_kernel<kPushQueueSmall, 0>), dim3(gx, gy), dim3(kStepThreads), 0, st, a, ws.occ,
                      reinterpret_cast<uint16_t *>(ws.sel), ws.Wd, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, sfpg, H, W,
-                     frame_src(i), cams[(size_t)i], ws.stat, ws.seldepth);
+                     frame_src(i), cams[(size_t)i], ws.stat, stage);
       }
     }
   }
@@ -1384,7 +1409,7 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
     ra.W = W;
     PGDVS_LAUNCH("agg_rows", agg_rows_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,
                  (const uint32_t *)ws.sel, ws.Wd, tiles, (const int64_t *)ws.tile_off, (const int64_t *)ws.cnts,
-                 (const CamBlock *)ws.cams, ra, (const float *)ws.seldepth, ws.seldepth != nullptr ? S - 1 : 0);
+                 (const CamBlock *)ws.cams, ra, stage, stage.rows != nullptr ? S - 1 : 0);
   }
   return check_launch("static_aggregate");
 }

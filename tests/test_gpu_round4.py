@@ -491,15 +491,17 @@ def test_raster_long_tile_lists_second_launch_vs_oracle(n, spread, K, bound, mon
     assert np.bincount(t).max() > 2048
 
 
-def test_static_aggregation_fused_frame0_launch():
+@pytest.mark.parametrize("switch", ["PGDVS_AGG_FUSED0=1", "PGDVS_AGG_STAGE=0"])
+def test_static_aggregation_other_launch_structures(switch):
     """PGDVS_AGG_FUSED0=1: frame 0 as ONE launch (selection + ordered offsets + projections + rows; opt-in, the select + push
-    pair is the default because it is faster) through the bit-exact aggregation tests -- read once per process, hence the
-    child process"""
+    pair is the default because it is faster); PGDVS_AGG_STAGE=0: the chain links leave no (depth, colour) behind and
+    `agg_rows` gathers both itself (the default path of the last frame and of videos too long for the staging block) --
+    through the bit-exact aggregation tests; the switches are read once per process, hence the child process"""
     import os
     import subprocess
     import sys
 
-    env = dict(os.environ, PGDVS_AGG_FUSED0="1")
+    env = dict(os.environ, **dict([switch.split("=")]))
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_round2.py"), "-k",

@@ -665,8 +665,16 @@ def main():
         for j in range(n_ev):
             harness.eval_step(model, ev_views[j % n_views], rc, device=dev)
         harness.STAGE_SECONDS = None
+        # the renderer's plugin call alone on the same inputs, one view at a time (what eval_step adds is the rest)
+        f0 = time.perf_counter()
+        with torch.no_grad():
+            for j in range(n_ev):
+                model.forward(ev_views[j % n_views], render_cfg=rc, disable_tqdm=True, for_debug=False)
+                torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - f0) / n_ev * 1e3
         eval_loop = {"frames_per_s": round(n_ev / e1, 2), "ms_per_view": round(e1 / n_ev * 1e3, 3), "views": n_ev,
                      "host_ms_per_view": {k_: round(v_ / n_ev * 1e3, 4) for k_, v_ in st_.items()},
+                     "forward_and_synchronize_ms_per_view": round(fwd_ms, 3),
                      "psnr_full_last": round(float(md["eval/psnr_full_combined"]), 3),
                      "note": "pgdvs_amd.harness.eval_step per view (to-device, forward = one native call incl. A12, quantisation + "
                              "the three masked PSNRs in one pass, ONE host synchronisation, status words checked): the "

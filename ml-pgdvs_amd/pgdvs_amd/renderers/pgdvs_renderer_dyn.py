@@ -264,7 +264,12 @@ class PGDVSDynamicRenderer(PGDVSBaseRenderer):
     def _zeros_like(self, t):
         """zero images of the no-tracker outputs without filling 33 MB per view at 1080p: ONE zero element expanded to
         the shape (stride 0).  Reads behave like a zeros tensor; an in-place write raises (torch refuses to write
-        through overlapping memory), so a caller cannot corrupt what later views return -- ``.clone()`` it to edit."""
+        through overlapping memory), so a caller cannot corrupt what later views return -- ``.clone()`` it to edit, or set
+        ``PGDVS_MATERIALIZE_ZEROS=1`` for fresh writable zero tensors as upstream returns them (33 MB filled per 1080p view)."""
+        import os
+
+        if os.environ.get("PGDVS_MATERIALIZE_ZEROS") == "1":  # upstream's behaviour to the letter: a fresh, writable tensor per view
+            return torch.zeros_like(t)
         cache = self.__dict__.setdefault("_zero_cache", {})
         key = (t.dtype, t.device)
         z = cache.get(key)

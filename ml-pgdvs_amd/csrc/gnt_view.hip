@@ -128,8 +128,6 @@ constexpr float kLog2e = 1.4426950408889634f;
 // and two fused multiply-adds per (feature, view) instead of two library expf calls.
 constexpr float kRescaleGap = 16.0f;
 
-__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
-
 __device__ __forceinline__ void layer_norm64q(const float (&x)[16], const float *__restrict__ g,
                                               const float *__restrict__ b, float eps, float (&y)[16], int hq) {
   float s = 0.0f;

@@ -306,7 +306,11 @@ int pgdvs_gnt_head(const float *weights, const float *q, int R, int S, float *rg
  *   q_in[N,64]; feat[N,V,64] (rgbfeat_fc output); ray_diff[N,V,4]; valid[N,V] u8 (rows
  *   without any valid view must be passed as all-valid, :124-129); q_out[N,64]
  *   stats[N,3] (nullable): view entropy (:497-500, evaluated online as log l - sum e a / l, within
- *   2e-7 of the upstream expression), masked std of k, normalised std; means over features. */
+ *   2e-7 of the upstream expression), masked std of k, normalised std; means over features.
+ *   Arithmetic: fp32 throughout; the two 64 x 64 products per source view (k = Wk f, vv = Wv k) run on the bf16 matrix
+ *   instruction with both operands split EXACTLY into three bf16 pieces (six partial products above 2^-24 of the product,
+ *   fp32 accumulation: the accuracy of an fp32 multiply-add chain, at 0.58 of its time); PGDVS_GNT_FP32=1 in the environment
+ *   (read per call) keeps them on the fp32 matrix instruction. */
 int64_t pgdvs_gnt_view_weight_floats(void);
 int pgdvs_gnt_view_layer(const float *weights, const float *q_in, const float *feat,
                          const float *ray_diff, const uint8_t *valid, int64_t N, int V, float *q_out,

@@ -185,4 +185,100 @@ __device__ __forceinline__ void chain64qv(floatx4 (&acc)[4], const float *__rest
   }
 }
 
+// ---- fp32-faithful products on the bf16 matrix pipe ------------------------------------------------------------------
+// v_mfma_f32_16x16x32_bf16 runs at ~16 cycles for 16 x 16 x 32 (profiles/r01_mfma_calibration.txt, tools/mfma_bf16_probe.hip)
+// where the fp32 instruction takes 32 for 16 x 16 x 4: a 64 -> 64 product of a 16-row tile is 8 of them per operand piece
+// pair instead of 64.  An fp32 value is the exact sum of three bf16 pieces (8 + 8 + 8 mantissa bits, by truncation:
+// hi = x & 0xffff0000, the remainders are exact fp32 subtractions), so w * x = sum over the nine piece pairs; the three
+// pairs below 2^-24 of the product (mid*lo, lo*mid, lo*lo) are dropped like an fp32 multiply drops its low bits, the other
+// six are accumulated in fp32, small ones first: 48 MFMAs = 768 matrix cycles + ~5.5 vector instructions per activation
+// value to split it, against 2048.  Weights are split once per workgroup when they are staged.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ floatx4 mfma_bf16(uintx4 a, uintx4 b, floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// eight floats -> three registers quads of eight bf16 each (element j in the low half of word j / 2 for even j)
+__device__ __forceinline__ void split8_bf16x3(const float *x, uintx4 &hi, uintx4 &mid, uintx4 &lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = x[2 * j], b = x[2 * j + 1];
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    hi[j] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);  // (ub & 0xffff0000) | (ua >> 16)
+    const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);
+    const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+    mid[j] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+    const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
+    lo[j] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+  }
+}
+
+// Lane-major bf16x3 image of a 64 x 64 matrix for the products above: img[piece][mt * 2 + s][lane] (16 bytes each) holds,
+// for output tile mt and K-step s, the eight weights W[in = F(8 s + j, hq)][out = 16 mt + i] of lane (i, hq) -- the in-features
+// the lane's activation operand carries in the same slots (F(t, hq) = 16 (t >> 2) + 4 hq + (t & 3), t = 8 s + j).  6144 floats.
+// One slot per thread of a 512-thread workgroup; source: the packed input-major matrix Wt[in][out].
+__device__ __forceinline__ void stage_w64_bf16x3(const float *__restrict__ src, float *__restrict__ dst) {
+  const int tid = (int)threadIdx.x;  // 512 slots
+  const int mt = tid >> 7, s = (tid >> 6) & 1, lane = tid & 63, i = lane & 15, hq = lane >> 4;
+  float wv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int t = 8 * s + j;
+    wv[j] = src[(16 * (t >> 2) + 4 * hq + (t & 3)) * 64 + 16 * mt + i];
+  }
+  uintx4 h, m, l;
+  split8_bf16x3(wv, h, m, l);
+  uintx4 *d = reinterpret_cast<uintx4 *>(dst) + (mt * 2 + s) * 64 + lane;
+  d[0] = h;
+  d[8 * 64] = m;
+  d[16 * 64] = l;
+}
+
+// acc[mt] += W x for the four output tiles, W as a bf16x3 image (lb = image + 4 * lane floats), x the lane's 16 fp32 features.
+// Per K-step three phases -- the low weight piece (one partial product per tile), the middle one (two), the high one
+// (three) -- each holding its four register quads (one per output tile) while the next phase's are on their way: every
+// weight quad is read once, and consecutive MFMAs go to different accumulators (the four tiles in turn; a chain of six
+// into one accumulator waits for each result: 16.5 ms per chunk instead of 14.6 with the fp32 instruction).
+__device__ __forceinline__ void chain64_bf16x3(floatx4 (&acc)[4], const float *__restrict__ lb, const float (&x)[16]) {
+  const uintx4 *img = reinterpret_cast<const uintx4 *>(lb);
+  auto quads = [&](uintx4 (&w)[4], int piece, int s) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) w[mt] = img[(piece * 8 + mt * 2 + s) * 64];
+  };
+  uintx4 wa[4], wb[4];
+  quads(wa, 2, 0);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    uintx4 xh, xm, xl;
+    split8_bf16x3(&x[8 * s], xh, xm, xl);
+    quads(wb, 1, s);  // (middle pieces requested while the low ones work)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma_bf16(wa[mt], xh, acc[mt]);
+    __builtin_amdgcn_sched_barrier(0);
+    quads(wa, 0, s);  // (high pieces)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma_bf16(wb[mt], xm, acc[mt]);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma_bf16(wb[mt], xh, acc[mt]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s == 0) quads(wb, 2, 1);  // (the next K-step's low pieces)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma_bf16(wa[mt], xl, acc[mt]);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma_bf16(wa[mt], xm, acc[mt]);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma_bf16(wa[mt], xh, acc[mt]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s == 0) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) wa[mt] = wb[mt];
+    }
+  }
+}
+
 }  // namespace pgdvs

@@ -118,7 +118,9 @@ constexpr int kSmP1B = VW_P1B - VW_P1, kSmP2 = VW_P2 - VW_P1, kSmP2B = VW_P2B - 
 constexpr int kSmA1B = VW_A1 - VW_P1;  // A1 itself lives in the padded region
 constexpr int kSmA2 = kSmA1B + (VW_A2 - VW_A1B), kSmA2B = kSmA1B + (VW_A2B - VW_A1B);
 constexpr int kSmallFloats = kSmA1B + (VW_WO - VW_A1B);
-constexpr int kViewLdsFloats = 4 * 4096 + 1024 + kSmallFloats + 192;  // four lane-major 64 x 64 images, A1's, the small pieces
+// four lane-major 64 x 64 images (Wk and Wv as bf16x3 images of 6144 floats when the k / v products run on the bf16 pipe), A1's,
+// the small pieces
+constexpr int kViewLdsFloats = 2 * 6144 + 2 * 4096 + 1024 + kSmallFloats + 192 + 1024 + 8192;
 
 constexpr float kLog2e = 1.4426950408889634f;
 // The softmax over views keeps a per-feature reference logit m and rescales the running sums
@@ -180,7 +182,9 @@ __device__ __forceinline__ void pack_hidden(const float (&hid)[4], float (&hk)[2
   }
 }
 
-template <bool STATS>
+// SPLIT: k = Wk f and vv = Wv k as bf16x3 products on v_mfma_f32_16x16x32_bf16 (gnt_mfma.h: fp32-faithful, 768 + ~400
+// cycles per product instead of 2048); false: every product on the fp32 instruction (PGDVS_GNT_FP32=1).
+template <bool STATS, bool SPLIT>
 __global__ void __launch_bounds__(512, 1)
 gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__ q_in,
                       const float *__restrict__ feat, const float *__restrict__ ray_diff,
@@ -189,10 +193,18 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
   // LDS image of the layer's weights: the 64 x 64 matrices and A1 lane-major (gnt_mfma.h: one ds_read_b128 per
   // K-step off one per-lane base), the small pieces as packed
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [kViewLdsFloats]
-  float *s_wk = s_w, *s_wv = s_wk + 4096, *s_wq = s_wv + 4096, *s_wo = s_wq + 4096, *s_a1 = s_wo + 4096;
+  float *s_wk = s_w, *s_wv = s_wk + 6144, *s_wq = s_wv + 6144, *s_wo = s_wq + 4096, *s_a1 = s_wo + 4096;
   float *s_small = s_a1 + 1024, *s_par = s_small + kSmallFloats;
-  stage_w64_lanes<512>(W_arg + VW_WK, s_wk);
-  stage_w64_lanes<512>(W_arg + VW_WV, s_wv);
+  // per lane the second layers' A operands of the two small MLPs ([4 quads][lane][4]), per wavefront the tile's c1 ([4][lane][4]):
+  // loop invariants that would otherwise hold 32 of the 256 registers through the view loop
+  float *s_pw = s_par + 192, *s_c1 = s_pw + 1024;
+  if (SPLIT) {
+    stage_w64_bf16x3(W_arg + VW_WK, s_wk);
+    stage_w64_bf16x3(W_arg + VW_WV, s_wv);
+  } else {
+    stage_w64_lanes<512>(W_arg + VW_WK, s_wk);
+    stage_w64_lanes<512>(W_arg + VW_WV, s_wv);
+  }
   {  // A1 [64 in][32 out, 8 used] -> [s>>2][lane][s&3] for the 16 output columns of the (padded) tile
     const int q = (int)threadIdx.x;  // 512 float4's
     const float4 v = reinterpret_cast<const float4 *>(W_arg + VW_A1)[q];
@@ -225,18 +237,23 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
   const float *wa1 = s_a1 + 4 * lane;
   const float *sP1 = s_small, *sP1b = s_small + kSmP1B, *sP2 = s_small + kSmP2, *sP2b = s_small + kSmP2B;
   const float *sA1b = s_small + kSmA1B, *sA2 = s_small + kSmA2, *sA2b = s_small + kSmA2B;
-  // the small MLPs' weights are loop invariants of a lane
-  const int hu = 4 * (hq & 1) + (hq >> 1);  // packed hidden unit of K-step 0 (see pack_hidden)
-  float p2w[2][4], a2w[2][4];
   floatx4 p1b, a1b;  // the hidden layers' biases: accumulator operands of their first MFMAs
   const float p1w = sP1[hq * 32 + i];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      p2w[u][mt] = sP2[(hu + 2 * u) * 64 + 16 * mt + i];
-      a2w[u][mt] = sA2[(hu + 2 * u) * 64 + 16 * mt + i] * kLog2e;  // logits in log2 units: exp2 without a multiply
-    }
+  if (threadIdx.x < 256) {
+    const int q = (int)threadIdx.x >> 6, ln = (int)threadIdx.x & 63, li = ln & 15, lq = ln >> 4;
+    const int lhu = 4 * (lq & 1) + (lq >> 1), u = q & 1;
+    float4 v;
+    const float *src = (q < 2 ? sP2 : sA2) + (lhu + 2 * u) * 64 + li;
+    const float sc = q < 2 ? 1.0f : kLog2e;  // logits in log2 units: exp2 without a multiply
+    v.x = src[0] * sc;
+    v.y = src[16] * sc;
+    v.z = src[32] * sc;
+    v.w = src[48] * sc;
+    reinterpret_cast<float4 *>(s_pw)[q * 64 + ln] = v;
+  }
+  __syncthreads();
+  const floatx4 *pw4 = reinterpret_cast<const floatx4 *>(s_pw) + lane;      // [q * 64]: p2w[0], p2w[1], a2w[0], a2w[1] (x log2e)
+  floatx4 *c1q = reinterpret_cast<floatx4 *>(s_c1) + wave * 256 + lane;      // [mt * 64]
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     p1b[r] = sP1b[4 * hq + r];
@@ -259,18 +276,21 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
     // positional MLP's second layer starts from, so pq = pos - q' costs nothing; then
     // a = k + pq, and the value product starts from pq as well: sum_v attn (vv + pos - q'),
     // to which q' is added back once in the epilogue (the attention weights sum to one).
-    float c1[16];
     {
       float q0[16], x[16];
       load_row16(q_in + g * 64, q0, hq);
       layer_norm64q(q0, s_par, s_par + 64, 1e-6f, x, hq);
       floatx4 qq[4] = {};
       ldq8v(w, wq, 0);
-      chain64qv(qq, wq, x, w, [&](float (&d)[8]) { ldq8v(d, wk, 0); });
+      chain64qv(qq, wq, x, w, [&](float (&d)[8]) {
+        if (!SPLIT) ldq8v(d, wk, 0);
+      });
       float b[16];
       load_row16(sP2b, b, hq);
 #pragma unroll
-      for (int t = 0; t < 16; ++t) c1[t] = b[t] - qq[t >> 2][t & 3];
+      for (int t = 0; t < 16; ++t) qq[t >> 2][t & 3] = b[t] - qq[t >> 2][t & 3];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) c1q[mt * 64] = qq[mt];  // c1, parked in this wavefront's LDS block
     }
     // bm = (A2's bias - reference logit m) in log2 units: the logits leave the second layer's MFMAs already
     // relative to the reference (no subtraction, no bias reload per view); m itself is never needed
@@ -300,7 +320,12 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       const bool seen = __builtin_amdgcn_ballot_w64(ok) != 0;
       if (seen) {  // k = Wk f
         floatx4 c[4] = {};
-        chain64qv(c, wk, f_nx, w, [&](float (&d)[8]) { ldq8v(d, wa1, 0); });
+        if (SPLIT) {
+          chain64_bf16x3(c, wk, f_nx);
+          ldq8v(w, wa1, 0);
+        } else {
+          chain64qv(c, wk, f_nx, w, [&](float (&d)[8]) { ldq8v(d, wa1, 0); });
+        }
 #pragma unroll
         for (int t = 0; t < 16; ++t) k[t] = c[t >> 2][t & 3];
       }
@@ -322,15 +347,15 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pq[mt][r] = c1[4 * mt + r];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) pq[mt] = mfma16(p2w[u][mt], hk[u], pq[mt]);
+          for (int u = 0; u < 2; ++u) pq[mt] = mfma16(pw4[u * 64][mt], hk[u], u == 0 ? c1q[mt * 64] : pq[mt]);
         }
       }
 #pragma unroll
       for (int t = 0; t < 16; ++t) a[t] = k[t] + pq[t >> 2][t & 3];
       {  // hidden layer of the attention MLP (64 -> 8, M padded to 16)
-        const floatx4 c = chain64n(wa1, a, w, a1b, [&](float (&d)[8]) { ldq8v(d, wv, 0); });
+        const floatx4 c = chain64n(wa1, a, w, a1b, [&](float (&d)[8]) {
+          if (!SPLIT) ldq8v(d, wv, 0);
+        });
 #pragma unroll
         for (int r = 0; r < 4; ++r) hid[r] = vrelu(c[r]);
         pack_hidden(hid, hk);
@@ -346,7 +371,10 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       floatx4 lv[4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) lv[mt] = pq[mt];
-      chain64qv(lv, wv, k, w, [&](float (&d)[8]) { ldq8v(d, wk, 0); });
+      if (SPLIT)
+        chain64_bf16x3(lv, wv, k);
+      else
+        chain64qv(lv, wv, k, w, [&](float (&d)[8]) { ldq8v(d, wk, 0); });
       float x[16];  // logits relative to the reference, in log2 units
       {
         floatx4 la[4];
@@ -355,7 +383,7 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
 #pragma unroll
           for (int r = 0; r < 4; ++r) la[mt][r] = bm[4 * mt + r];
 #pragma unroll
-          for (int u = 0; u < 2; ++u) la[mt] = mfma16(a2w[u][mt], hk[u], la[mt]);
+          for (int u = 0; u < 2; ++u) la[mt] = mfma16(pw4[(2 + u) * 64][mt], hk[u], la[mt]);
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t) x[t] = la[t >> 2][t & 3];
@@ -407,7 +435,7 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       float xa[16], b[16];
       load_row16(sP2b, b, hq);
 #pragma unroll
-      for (int t = 0; t < 16; ++t) xa[t] = acc[t] / l[t] + (b[t] - c1[t]);
+      for (int t = 0; t < 16; ++t) xa[t] = acc[t] / l[t] + (b[t] - c1q[(t >> 2) * 64][t & 3]);
       floatx4 o[4];
       load_row16(s_par + 128, b, hq);
 #pragma unroll
@@ -871,8 +899,10 @@ PGDVS_API int pgdvs_gnt_view_layer(const float *weights, const float *q_in, cons
   hipStream_t st = as_stream(stream);
   static bool configured = false;
   if (!configured) {
-    for (const void *fn : {reinterpret_cast<const void *>(gnt_view_layer_kernel<true>),
-                           reinterpret_cast<const void *>(gnt_view_layer_kernel<false>)}) {
+    for (const void *fn : {reinterpret_cast<const void *>(gnt_view_layer_kernel<true, true>),
+                           reinterpret_cast<const void *>(gnt_view_layer_kernel<false, true>),
+                           reinterpret_cast<const void *>(gnt_view_layer_kernel<true, false>),
+                           reinterpret_cast<const void *>(gnt_view_layer_kernel<false, false>)}) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) {
         set_error("gnt_view_layer: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
@@ -881,13 +911,27 @@ PGDVS_API int pgdvs_gnt_view_layer(const float *weights, const float *q_in, cons
     }
     configured = true;
   }
+  // PGDVS_GNT_FP32=1: the k / v products on the fp32 matrix instruction as well (exact fp32 products; the default splits both
+  // operands into three bf16 pieces: six partial products, fp32 accumulation -- see gnt_mfma.h)
+  const char *fp32_var = getenv("PGDVS_GNT_FP32");  // (read per call: tests and bench.py time both paths in one process)
+  const bool fp32_env = fp32_var != nullptr && fp32_var[0] == '1';
+#define PGDVS_VIEW_LAUNCH(ST, SP)                                                                                        \
+  PGDVS_LAUNCH("gnt_view_layer", (gnt_view_layer_kernel<ST, SP>), dim3(grid), dim3(512), lds, st, weights, q_in, feat, \
+               ray_diff, valid, N, V, q_out, stats)
   if (stats) {
-    PGDVS_LAUNCH("gnt_view_layer", gnt_view_layer_kernel<true>, dim3(grid), dim3(512), lds, st, weights, q_in,
-                 feat, ray_diff, valid, N, V, q_out, stats);
+    if (fp32_env) {
+      PGDVS_VIEW_LAUNCH(true, false);
+    } else {
+      PGDVS_VIEW_LAUNCH(true, true);
+    }
   } else {
-    PGDVS_LAUNCH("gnt_view_layer", gnt_view_layer_kernel<false>, dim3(grid), dim3(512), lds, st, weights, q_in,
-                 feat, ray_diff, valid, N, V, q_out, stats);
+    if (fp32_env) {
+      PGDVS_VIEW_LAUNCH(false, false);
+    } else {
+      PGDVS_VIEW_LAUNCH(false, true);
+    }
   }
+#undef PGDVS_VIEW_LAUNCH
   if (launch_ff(weights, q_out, N, st) != PGDVS_OK) return PGDVS_ERR_LAUNCH;
   return check_launch("gnt_view_layer");
 }

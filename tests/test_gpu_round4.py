@@ -642,3 +642,69 @@ def test_gnt_ray_layer_wide_score_range(S):
     np.testing.assert_allclose(w_k.cpu().numpy(), w_t.cpu().numpy(), rtol=2e-4, atol=1e-6)
     # (scores of several hundred: one ulp of a score is 4e-5 of its weight)
     np.testing.assert_allclose(w_k.cpu().numpy().sum(1), 1.0, rtol=1e-4)
+
+
+@pytest.mark.parametrize("V,want_stats", [(4, False), (24, True)])
+def test_gnt_view_layer_bf16x3_products_vs_fp32_products(V, want_stats, monkeypatch):
+    """the view layer's two 64 x 64 products per source view (k = Wk f, vv = Wv k) run on v_mfma_f32_16x16x32_bf16 with both
+    operands split exactly into three bf16 pieces (csrc/gnt_mfma.h chain64_bf16x3; six partial products, fp32 accumulation);
+    PGDVS_GNT_FP32=1 keeps them on the fp32 instruction.  Both against the torch fp32 statement of the layer
+    (pgdvs/models/gnt/models/transformer_network.py:59-169), and against each other at a tenth of that tolerance:
+    inputs with a wide dynamic range (features over four decades, weights scaled up) so that dropped low-order pieces
+    would show."""
+    from pgdvs_amd.models.gnt.models.transformer_network import GNT
+
+    torch.manual_seed(40 + V)
+    net = GNT(netwidth=64, transformer_depth=1).to(DEV).eval()
+    layer = net.view_crosstrans[0]
+    with torch.no_grad():
+        layer.attn.k_fc.weight.mul_(3.0)
+        layer.attn.v_fc.weight.mul_(2.0)
+    R, S = 29, 23
+    q = torch.randn(R, S, 64, device=DEV)
+    decades = 10.0 ** torch.randint(-2, 2, (R, S, V, 64), device=DEV).float()
+    feat = torch.randn(R, S, V, 64, device=DEV) * decades
+    rd = torch.randn(R, S, V, 4, device=DEV)
+    valid = torch.rand(R, S, V, device=DEV) < 0.7
+    cnt = valid.sum(-1)
+    empty = cnt == 0
+    valid = valid | empty[..., None]
+    cnt = torch.where(empty, torch.full_like(cnt, V), cnt)
+
+    def run():
+        with torch.no_grad():
+            return net._view_layer(layer, q, feat, rd, valid, cnt, want_stats)
+
+    monkeypatch.setenv("PGDVS_GNT_FP32", "1")
+    out_f, st_f = run()
+    monkeypatch.setenv("PGDVS_GNT_FP32", "0")
+    out_s, st_s = run()
+    ops._GNT_VIEW_ENABLED = False
+    try:
+        out_t, st_t = run()
+    finally:
+        ops._GNT_VIEW_ENABLED = True
+    scale = float(out_t.abs().max())
+    for name, o in (("fp32 products", out_f), ("bf16x3 products", out_s)):
+        np.testing.assert_allclose(o.cpu().numpy(), out_t.cpu().numpy(), rtol=1e-4, atol=2e-5 * max(scale, 1.0), err_msg=name)
+    # the two arithmetic paths agree ten times closer than either has to agree with torch
+    np.testing.assert_allclose(out_s.cpu().numpy(), out_f.cpu().numpy(), rtol=1e-5, atol=2e-6 * max(scale, 1.0))
+    if want_stats:
+        for a, b, c, name in zip(st_s, st_f, st_t, ("entropy", "std", "std_norm")):
+            np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=1e-3, atol=5e-5, err_msg=name)
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=5e-6, err_msg=name + " (paths)")
+
+
+def test_gnt_forward_golden_on_both_product_paths(golden_dir, monkeypatch):
+    """the reference-made fixture gnt_small.npz (GNT.forward of upstream, two layers) through the fp32-instruction path too:
+    the default (bf16x3 products) runs in test_gnt_forward_vs_reference"""
+    from test_gpu_parity import _gnt_model
+
+    m, g = _gnt_model(golden_dir)
+    monkeypatch.setenv("PGDVS_GNT_FP32", "1")
+    with torch.no_grad():
+        out, ex = m.net_coarse(T(g["dynmask_rgb_feat"]), T(g["dynmask_ray_diff"]), T(g["dynmask_mask"]), T(g["pts"]), T(g["ray_d"]),
+                               ret_view_entropy=True, ret_view_std=True)
+    np.testing.assert_allclose(out.cpu().numpy(), g["dynmask_out"], rtol=0, atol=1e-4)
+    for k, v in ex.items():
+        np.testing.assert_allclose(v.cpu().numpy(), g[f"dynmask_{k}"], rtol=0, atol=1e-4, err_msg=k)

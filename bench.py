@@ -889,6 +889,20 @@ def main():
                 tele.append(telemetry())  # (read while the chunk is still running: after the synchronise the card idles)
                 torch.cuda.synchronize()
                 reps.append((time.perf_counter() - g0, e0.elapsed_time(e1), e1.elapsed_time(e2)))
+            # the same chunk with every product on the fp32 matrix instruction (PGDVS_GNT_FP32=1, read per call): five repetitions
+            os.environ["PGDVS_GNT_FP32"] = "1"
+            try:
+                gnt_chunk()
+                torch.cuda.synchronize()
+                reps32 = []
+                for _ in range(5):
+                    g0 = time.perf_counter()
+                    gnt_chunk()
+                    torch.cuda.synchronize()
+                    reps32.append(time.perf_counter() - g0)
+            finally:
+                os.environ.pop("PGDVS_GNT_FP32", None)
+            reps32.sort()
         reps.sort()
         gdt, t_gather, t_net = reps[len(reps) // 2]
         gflop = 2.0 * Rg * Sg * (1048064 + 84416 * Vg)
@@ -902,11 +916,17 @@ def main():
                                "ms_per_chunk_all": [round(r_[0] * 1e3, 2) for r_ in reps],
                                "power_W_range": [min(pw), max(pw)] if pw else None},
                "peak_tflops_fp32_mfma": 157.3, "frac_of_peak": round(gflop / gdt / 157.3e12, 4),
+               "fp32_instruction_path": {"ms_per_chunk": round(reps32[len(reps32) // 2] * 1e3, 2), "tflops": tf(reps32[len(reps32) // 2]),
+                                         "frac_of_peak": round(gflop / reps32[len(reps32) // 2] / 157.3e12, 4), "repetitions": len(reps32),
+                                         "note": "PGDVS_GNT_FP32=1: the view layers' k / v products on v_mfma_f32_16x16x4_f32 as well"},
                "gather_alg_GBps": round(gather_bytes / (t_gather * 1e-3) / 1e9, 1), "valid_projection_fraction": round(valid_frac, 3),
-               "dtype": "f32 (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)",
+               "dtype": "f32 (v_mfma_f32_16x16x4_f32 / 32x32x2_f32; the view layers' two 64 x 64 products per source view as bf16x3 on "
+                        "v_mfma_f32_16x16x32_bf16: both operands split exactly into three bf16 pieces, six partial products, fp32 accumulation)",
                "est_seconds_per_1080p_frame": round(gdt * (H * W / Rg), 1),
                "note": "pgdvs_gnt_gather (real projections of target-ray samples into the resident source frames, dynamic masks "
-                       "applied) + GNT.forward incl. view entropy/std side outputs; FLOPs counted for A14 only, time for both; "
+                       "applied) + GNT.forward incl. view entropy/std side outputs; FLOPs = the fp32 multiply-adds of A14 (an operand "
+                       "split into bf16 pieces is not counted three times), time for both; frac_of_peak is against the fp32-MFMA peak "
+                       "whichever instruction a product runs on; "
                        "median of ten repetitions (board power as sysfs reports it while each runs)"}
         # The whole renderer with the GNT static renderer at the reference's own benchmark setting
         # (NVIDIA Dynamic Scenes: 288 x 550 targets, 10 spatial + 2 temporal source views, 256 samples

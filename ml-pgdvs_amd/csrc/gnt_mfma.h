@@ -218,22 +218,25 @@ __device__ __forceinline__ void split8_bf16x3(const float *x, uintx4 &hi, uintx4
 // Lane-major bf16x3 image of a 64 x 64 matrix for the products above: img[piece][mt * 2 + s][lane] (16 bytes each) holds,
 // for output tile mt and K-step s, the eight weights W[in = F(8 s + j, hq)][out = 16 mt + i] of lane (i, hq) -- the in-features
 // the lane's activation operand carries in the same slots (F(t, hq) = 16 (t >> 2) + 4 hq + (t & 3), t = 8 s + j).  6144 floats.
-// One slot per thread of a 512-thread workgroup; source: the packed input-major matrix Wt[in][out].
+// Source: the packed input-major matrix Wt[in][out]; NT threads share the 512 slots.
+template <int NT>
 __device__ __forceinline__ void stage_w64_bf16x3(const float *__restrict__ src, float *__restrict__ dst) {
-  const int tid = (int)threadIdx.x;  // 512 slots
-  const int mt = tid >> 7, s = (tid >> 6) & 1, lane = tid & 63, i = lane & 15, hq = lane >> 4;
-  float wv[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int t = 8 * s + j;
-    wv[j] = src[(16 * (t >> 2) + 4 * hq + (t & 3)) * 64 + 16 * mt + i];
+  for (int slot = (int)threadIdx.x; slot < 512; slot += NT) {  // 512 slots = (output tile, K-step, lane)
+    const int mt = slot >> 7, s = (slot >> 6) & 1, lane = slot & 63, i = lane & 15, hq = lane >> 4;
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = 8 * s + j;
+      wv[j] = src[(16 * (t >> 2) + 4 * hq + (t & 3)) * 64 + 16 * mt + i];
+    }
+    uintx4 h, m, l;
+    split8_bf16x3(wv, h, m, l);
+    uintx4 *d = reinterpret_cast<uintx4 *>(dst) + (mt * 2 + s) * 64 + lane;
+    d[0] = h;
+    d[8 * 64] = m;
+    d[16 * 64] = l;
   }
-  uintx4 h, m, l;
-  split8_bf16x3(wv, h, m, l);
-  uintx4 *d = reinterpret_cast<uintx4 *>(dst) + (mt * 2 + s) * 64 + lane;
-  d[0] = h;
-  d[8 * 64] = m;
-  d[16 * 64] = l;
 }
 
 // acc[mt] += W x for the four output tiles, W as a bf16x3 image (lb = image + 4 * lane floats), x the lane's 16 fp32 features.

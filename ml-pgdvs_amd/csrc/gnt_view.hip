@@ -120,7 +120,7 @@ constexpr int kSmA2 = kSmA1B + (VW_A2 - VW_A1B), kSmA2B = kSmA1B + (VW_A2B - VW_
 constexpr int kSmallFloats = kSmA1B + (VW_WO - VW_A1B);
 // four lane-major 64 x 64 images (Wk and Wv as bf16x3 images of 6144 floats when the k / v products run on the bf16 pipe), A1's,
 // the small pieces
-constexpr int kViewLdsFloats = 2 * 6144 + 2 * 4096 + 1024 + kSmallFloats + 192 + 1024 + 8192;
+constexpr int kViewLdsFloats = 4 * 6144 + 1024 + kSmallFloats + 192 + 1024 + 8192;
 
 constexpr float kLog2e = 1.4426950408889634f;
 // The softmax over views keeps a per-feature reference logit m and rescales the running sums
@@ -182,7 +182,8 @@ __device__ __forceinline__ void pack_hidden(const float (&hid)[4], float (&hk)[2
   }
 }
 
-// SPLIT: k = Wk f and vv = Wv k as bf16x3 products on v_mfma_f32_16x16x32_bf16 (gnt_mfma.h: fp32-faithful, 768 + ~400
+// SPLIT: the 64 x 64 products (q' = Wq LN(q) and the out_fc product per tile, k = Wk f and vv = Wv k per view) as bf16x3
+// products on v_mfma_f32_16x16x32_bf16 (gnt_mfma.h: fp32-faithful, 768 + ~400
 // cycles per product instead of 2048); false: every product on the fp32 instruction (PGDVS_GNT_FP32=1).
 template <bool STATS, bool SPLIT>
 __global__ void __launch_bounds__(512, 1)
@@ -193,14 +194,14 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
   // LDS image of the layer's weights: the 64 x 64 matrices and A1 lane-major (gnt_mfma.h: one ds_read_b128 per
   // K-step off one per-lane base), the small pieces as packed
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [kViewLdsFloats]
-  float *s_wk = s_w, *s_wv = s_wk + 6144, *s_wq = s_wv + 6144, *s_wo = s_wq + 4096, *s_a1 = s_wo + 4096;
+  float *s_wk = s_w, *s_wv = s_wk + 6144, *s_wq = s_wv + 6144, *s_wo = s_wq + 6144, *s_a1 = s_wo + 6144;
   float *s_small = s_a1 + 1024, *s_par = s_small + kSmallFloats;
   // per lane the second layers' A operands of the two small MLPs ([4 quads][lane][4]), per wavefront the tile's c1 ([4][lane][4]):
   // loop invariants that would otherwise hold 32 of the 256 registers through the view loop
   float *s_pw = s_par + 192, *s_c1 = s_pw + 1024;
   if (SPLIT) {
-    stage_w64_bf16x3(W_arg + VW_WK, s_wk);
-    stage_w64_bf16x3(W_arg + VW_WV, s_wv);
+    stage_w64_bf16x3<512>(W_arg + VW_WK, s_wk);
+    stage_w64_bf16x3<512>(W_arg + VW_WV, s_wv);
   } else {
     stage_w64_lanes<512>(W_arg + VW_WK, s_wk);
     stage_w64_lanes<512>(W_arg + VW_WV, s_wv);
@@ -223,8 +224,13 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
   stage_f4<(kSmallFloats - kSmA1B) / 4, 512>(W_arg + VW_A1B, s_small + kSmA1B, [](int q) { return 4 * q; });
   // the per-tile pieces too (q_fc, out_fc, LayerNorm, out_fc bias): from global memory they
   // cost an L2 round trip per 8-MFMA chunk of a tile's prologue and epilogue
-  stage_w64_lanes<512>(W_arg + VW_WQ, s_wq);
-  stage_w64_lanes<512>(W_arg + VW_WO, s_wo);
+  if (SPLIT) {
+    stage_w64_bf16x3<512>(W_arg + VW_WQ, s_wq);
+    stage_w64_bf16x3<512>(W_arg + VW_WO, s_wo);
+  } else {
+    stage_w64_lanes<512>(W_arg + VW_WQ, s_wq);
+    stage_w64_lanes<512>(W_arg + VW_WO, s_wo);
+  }
   stage_f4<32, 512>(W_arg + VW_LN1_G, s_par, [](int q) { return 4 * q; });        // gamma[64], beta[64]
   stage_f4<16, 512>(W_arg + VW_WOB, s_par + 128, [](int q) { return 4 * q; });    // out_fc bias[64]
   __syncthreads();
@@ -281,10 +287,12 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       load_row16(q_in + g * 64, q0, hq);
       layer_norm64q(q0, s_par, s_par + 64, 1e-6f, x, hq);
       floatx4 qq[4] = {};
-      ldq8v(w, wq, 0);
-      chain64qv(qq, wq, x, w, [&](float (&d)[8]) {
-        if (!SPLIT) ldq8v(d, wk, 0);
-      });
+      if (SPLIT) {
+        chain64_bf16x3(qq, wq, x);
+      } else {
+        ldq8v(w, wq, 0);
+        chain64qv(qq, wq, x, w, [&](float (&d)[8]) { ldq8v(d, wk, 0); });
+      }
       float b[16];
       load_row16(sP2b, b, hq);
 #pragma unroll
@@ -440,8 +448,12 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       load_row16(s_par + 128, b, hq);
 #pragma unroll
       for (int t = 0; t < 16; ++t) o[t >> 2][t & 3] = b[t];
-      ldq8v(w, wo, 0);
-      chain64qv(o, wo, xa, w, [&](float (&d)[8]) {});
+      if (SPLIT) {
+        chain64_bf16x3(o, wo, xa);
+      } else {
+        ldq8v(w, wo, 0);
+        chain64qv(o, wo, xa, w, [&](float (&d)[8]) {});
+      }
 #pragma unroll
       for (int t = 0; t < 16; ++t) x1[t] = o[t >> 2][t & 3] + qres[t];
     }

@@ -48,7 +48,9 @@ constexpr int VW_F1 = VW_LN2_B + 64;              // [64 in][256 out]
 constexpr int VW_F1B = VW_F1 + 16384;             // [256]
 constexpr int VW_F2 = VW_F1B + 256;               // [256 in][64 out]
 constexpr int VW_F2B = VW_F2 + 16384;             // [64]
-constexpr int VW_TOTAL = VW_F2B + 64;
+// the feed-forward weights once more, as the bf16x3 images of gnt_ff_bf16x3_kernel (ops.ff_bf16x3_images): two halves of 24576 floats
+constexpr int VW_FFIMG = VW_F2B + 64;
+constexpr int VW_TOTAL = VW_FFIMG + 2 * 24576;
 
 // 32-row tiles (feed-forward block): lane (i, h) keeps, for its row i, the 32 features
 // feature(t,h) = featc(t) + 4*h.  The lane-dependent 4*h always goes into a per-lane BASE
@@ -629,6 +631,162 @@ gnt_ff_kernel(const float *__restrict__ W_arg, float *__restrict__ x_io, int64_t
 }
 
 // ---------------------------------------------------------------------------------------
+// The feed-forward block on the bf16 matrix pipe with fp32 results (round 4): every product as six partial products of
+// exact bf16x3 pieces (gnt_mfma.h), on v_mfma_f32_32x32x16_bf16.  Three pieces of the 32 768 weights are 192 KB, LDS holds
+// 160: the eight wavefronts of a workgroup take their eight tiles through TWO phases per round, with the pieces of half of
+// the hidden units resident (96 KB: the rows of layer 1 and the columns of layer 2 that belong to those 128 units), the
+// output accumulators kept across the phases; between the phases the other half is copied in from the weight blob's
+// pre-split image (ops.ff_bf16x3_images), and the next round starts with the half that is resident.
+// Layouts (32-row tiles as in gnt_ff_kernel: lane (i, h) keeps features featc(t) + 4 h of row i): A and B operands of the
+// 32 x 32 x 16 instruction carry K index 8 (lane >> 5) + j in element j.  Layer 1, K-step c: the lane supplies its own
+// features t = 8 c + j (split in registers), the image supplies W1[featc(8 c + j) + 4 kg][32 mt + m].  The accumulator leaves
+// hidden unit (r & 3) + 8 (r >> 2) + 4 h + 32 mt in register r -- layer 2's K-step c' takes the lane's registers 8 c' + j.
+// ---------------------------------------------------------------------------------------
+typedef float floatx16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ floatx16v mfma32_bf16(uintx4 a, uintx4 b, floatx16v c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// six partial products of one (weight, activation) operand pair, small ones first
+__device__ __forceinline__ floatx16v mfma32_bf16x3(const uintx4 (&w)[3], const uintx4 &xh, const uintx4 &xm, const uintx4 &xl,
+                                                   floatx16v c) {
+  c = mfma32_bf16(w[2], xh, c);
+  c = mfma32_bf16(w[0], xl, c);
+  c = mfma32_bf16(w[1], xm, c);
+  c = mfma32_bf16(w[1], xh, c);
+  c = mfma32_bf16(w[0], xm, c);
+  c = mfma32_bf16(w[0], xh, c);
+  return c;
+}
+
+constexpr int kFfHalfU4 = 6144;  // 16-byte units of one half image: 3 pieces x (1024 of layer 1 + 1024 of layer 2)
+
+__global__ void __launch_bounds__(512, 1)
+gnt_ff_bf16x3_kernel(const float *__restrict__ W_arg, float *__restrict__ x_io, int64_t N) {
+  extern __shared__ __attribute__((aligned(16))) float s_ffb[];  // [24576: the resident half image][b1 256 | b2 64 | LN 128]
+  uintx4 *s_img = reinterpret_cast<uintx4 *>(s_ffb);
+  float *s_par = s_ffb + 4 * kFfHalfU4;
+  const uintx4 *g_img = reinterpret_cast<const uintx4 *>(W_arg + VW_FFIMG);
+  auto stage_half = [&](int hf) {
+    uintx4 v[kFfHalfU4 / 512];
+#pragma unroll
+    for (int k = 0; k < kFfHalfU4 / 512; ++k) v[k] = g_img[hf * kFfHalfU4 + (int)threadIdx.x + 512 * k];
+#pragma unroll
+    for (int k = 0; k < kFfHalfU4 / 512; ++k) s_img[(int)threadIdx.x + 512 * k] = v[k];
+  };
+  stage_half(0);
+  stage_f4<64, 512>(W_arg + VW_F1B, s_par, [](int q) { return 4 * q; });
+  stage_f4<16, 512>(W_arg + VW_F2B, s_par + 256, [](int q) { return 4 * q; });
+  stage_f4<32, 512>(W_arg + VW_LN2_G, s_par + 320, [](int q) { return 4 * q; });  // gamma[64], beta[64]
+  __syncthreads();
+  int resident = 0;
+  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int wave = threadIdx.x >> 6;
+  const int64_t ntiles = (N + 31) / 32;
+  for (int64_t base = (int64_t)blockIdx.x * 8; base < ntiles; base += (int64_t)gridDim.x * 8) {  // (uniform over the workgroup)
+    const int64_t tile = base + wave;
+    const bool t_ok = tile < ntiles;
+    const int64_t g_raw = tile * 32 + i;
+    const bool g_ok = t_ok && g_raw < N;
+    const int64_t g = g_raw < N ? g_raw : N - 1;
+    // the row, normalised, split once for both phases: K-step c of layer 1 takes registers 8 c .. 8 c + 7
+    uintx4 xh[4], xm[4], xl[4];
+    {
+      float x1[32], xn[32];
+      load_row32(x_io + g * 64, x1, h);
+      layer_norm64(x1, s_par + 320, s_par + 384, 1e-6f, xn, h);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) split8_bf16x3(&xn[8 * c], xh[c], xm[c], xl[c]);
+    }
+    floatx16v o0, o1;
+    {
+      const float *bb = s_par + 256 + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o0[r] = bb[featc(r)];
+        o1[r] = bb[featc(r + 16)];
+      }
+    }
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+      const int hf = ph == 0 ? resident : 1 - resident;
+      if (ph == 1) {
+        __syncthreads();  // every wavefront is through with the resident half
+        stage_half(hf);
+        __syncthreads();
+      }
+      const uintx4 *img = s_img + lane;
+#pragma unroll 1
+      for (int mtl = 0; mtl < 4; ++mtl) {
+        const int mt = 4 * hf + mtl;
+        floatx16v hacc;
+        {
+          const float *b1 = s_par + 32 * mt + 4 * h;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hacc[r] = b1[(r & 3) + 8 * (r >> 2)];
+        }
+        // layer 1: four K-steps, the next step's weight pieces requested while this step's six MFMAs run
+        uintx4 wa[3], wb[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wa[p] = img[p * 2048 + (mtl * 4 + 0) * 64];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (c + 1 < 4) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wb[p] = img[p * 2048 + (mtl * 4 + c + 1) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          hacc = mfma32_bf16x3(wa, xh[c], xm[c], xl[c], hacc);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) wa[p] = wb[p];
+        }
+        // ReLU, split, layer 2: two K-steps x two output tiles
+        float hv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[r] = vrelu(hacc[r]);
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          uintx4 hh, hm, hl;
+          split8_bf16x3(&hv[8 * c2], hh, hm, hl);
+          uintx4 w0[3], w1[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            w0[p] = img[p * 2048 + 1024 + ((mtl * 2 + c2) * 2 + 0) * 64];
+            w1[p] = img[p * 2048 + 1024 + ((mtl * 2 + c2) * 2 + 1) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // (the two output tiles take turns: consecutive MFMAs never wait for each other's result)
+          o0 = mfma32_bf16(w0[2], hh, o0);
+          o1 = mfma32_bf16(w1[2], hh, o1);
+          o0 = mfma32_bf16(w0[0], hl, o0);
+          o1 = mfma32_bf16(w1[0], hl, o1);
+          o0 = mfma32_bf16(w0[1], hm, o0);
+          o1 = mfma32_bf16(w1[1], hm, o1);
+          o0 = mfma32_bf16(w0[1], hh, o0);
+          o1 = mfma32_bf16(w1[1], hh, o1);
+          o0 = mfma32_bf16(w0[0], hm, o0);
+          o1 = mfma32_bf16(w1[0], hm, o1);
+          o0 = mfma32_bf16(w0[0], hh, o0);
+          o1 = mfma32_bf16(w1[0], hh, o1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      resident = hf;
+    }
+    if (g_ok) {
+      float x1[32], out[32];
+      load_row32(x_io + g * 64, x1, h);  // (the residual: read again rather than kept through both phases)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        out[r] = o0[r] + x1[r];
+        out[r + 16] = o1[r] + x1[r + 16];
+      }
+      store_row32(x_io + g * 64, out, h);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Ray transformer attention (Transformer + Attention, attn_mode="qk",
 // transformer_network.py:231-338): per ray, x = LN(q); Q,K,V = W x; 4 heads x 16 dims;
 // attn = softmax(Q K^T / 4) over the S samples of the ray; y = Wo (attn V) + bo + q.
@@ -882,20 +1040,27 @@ PGDVS_API int64_t pgdvs_gnt_view_weight_floats(void) { return VW_TOTAL; }
 
 // feed-forward block in place on x[N,64]: one persistent 8-wave workgroup per CU
 static int launch_ff(const float *weights, float *x, int64_t N, hipStream_t st) {
-  constexpr size_t lds = (2 * 16384 + 256 + 64 + 128) * sizeof(float);
+  const char *fp32_var = getenv("PGDVS_GNT_FP32");  // (read per call, see pgdvs_gnt_view_layer)
+  const bool fp32_path = fp32_var != nullptr && fp32_var[0] == '1';
+  const size_t lds = fp32_path ? (2 * 16384 + 256 + 64 + 128) * sizeof(float) : (4 * (size_t)kFfHalfU4 + 256 + 64 + 128) * sizeof(float);
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gnt_ff_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      set_error("gnt_ff: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-      return PGDVS_ERR_LAUNCH;
+    for (const void *fn : {reinterpret_cast<const void *>(gnt_ff_kernel), reinterpret_cast<const void *>(gnt_ff_bf16x3_kernel)}) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * 16384 + 256 + 64 + 128) * sizeof(float)));
+      if (e != hipSuccess) {
+        set_error("gnt_ff: cannot reserve LDS: %s", hipGetErrorString(e));
+        return PGDVS_ERR_LAUNCH;
+      }
     }
     configured = true;
   }
   const int64_t ntiles = cdiv(N, 32);
   const unsigned grid = (unsigned)(cdiv(ntiles, 8) < 256 ? cdiv(ntiles, 8) : 256);
-  PGDVS_LAUNCH("gnt_ff", gnt_ff_kernel, dim3(grid), dim3(512), lds, st, weights, x, N);
+  if (fp32_path) {
+    PGDVS_LAUNCH("gnt_ff", gnt_ff_kernel, dim3(grid), dim3(512), lds, st, weights, x, N);
+  } else {
+    PGDVS_LAUNCH("gnt_ff", gnt_ff_bf16x3_kernel, dim3(grid), dim3(512), lds, st, weights, x, N);
+  }
   return PGDVS_OK;
 }
 

@@ -736,6 +736,63 @@ def gnt_view_available(dim: int, n_views: int) -> bool:
 _GNT_VIEW_ENABLED = True
 
 
+def _featc(t):
+    """csrc/gnt_view.hip featc: feature index of register t of a 32-row tile's lane (+ 4 h for the lane's half)"""
+    return (t & 3) + 8 * ((t & 15) >> 2) + 32 * (t >> 4)
+
+
+_ff_img_index = None
+
+
+def ff_bf16x3_images(w1_t: torch.Tensor, w2_t: torch.Tensor) -> torch.Tensor:
+    """The feed-forward block's weights (input-major ``w1_t[64, 256]``, ``w2_t[256, 64]``) as the lane-major bf16x3 images of
+    ``gnt_ff_bf16x3_kernel`` (csrc/gnt_view.hip): every weight split EXACTLY into three bf16 pieces (hi = w & 0xffff0000,
+    mid = (w - hi) & 0xffff0000, lo = w - hi - mid), arranged [half of the hidden units][piece][W1 part | W2 part], a part
+    being [chunk][lane][8 bf16] in the order the MFMA's A operand takes them (see the kernel).  Returns float32[49152] (the
+    bit patterns, two bf16 per word)."""
+    global _ff_img_index
+    import numpy as np
+
+    if _ff_img_index is None:
+        lane = np.arange(64)
+        m, kg = lane & 31, lane >> 5
+        j = np.arange(8)
+        idx1 = np.zeros((2, 4, 4, 64, 8), np.int64)      # [half][mtl][c][lane][j] -> flat index into w1_t (in * 256 + hid)
+        idx2 = np.zeros((2, 4, 2, 2, 64, 8), np.int64)   # [half][mtl][c'][ot][lane][j] -> flat index into w2_t (hid * 64 + out)
+        for hf in range(2):
+            for mtl in range(4):
+                mt = 4 * hf + mtl
+                for c in range(4):
+                    t = 8 * c + j                                        # [8]
+                    fin = _featc(t)[None, :] + 4 * kg[:, None]           # [64, 8]
+                    idx1[hf, mtl, c] = fin * 256 + (32 * mt + m)[:, None]
+                for c2 in range(2):
+                    r = 8 * c2 + j
+                    hid = ((r & 3) + 8 * (r >> 2))[None, :] + 4 * kg[:, None] + 32 * mt
+                    for ot in range(2):
+                        idx2[hf, mtl, c2, ot] = hid * 64 + (32 * ot + m)[:, None]
+        _ff_img_index = (torch.from_numpy(idx1.reshape(2, -1)), torch.from_numpy(idx2.reshape(2, -1)))
+    i1, i2 = (x_.to(w1_t.device) for x_ in _ff_img_index)
+
+    def pieces(w):  # float32 [n] -> three int32 [n] holding the bf16 bit patterns (upper halves)
+        w = w.detach().float().contiguous().reshape(-1)
+        mask = torch.tensor(-65536, dtype=torch.int32, device=w.device)
+        hi = (w.view(torch.int32) & mask).view(torch.float32)
+        r1 = w - hi
+        mid = (r1.view(torch.int32) & mask).view(torch.float32)
+        lo = r1 - mid
+        return [((x_.view(torch.int32) >> 16) & 0xFFFF) for x_ in (hi, mid, lo)]
+
+    p1, p2 = pieces(w1_t), pieces(w2_t)
+    halves = []
+    for hf in range(2):
+        for p in range(3):
+            halves.append(torch.cat([p1[p][i1[hf]], p2[p][i2[hf]]]))  # 8192 + 8192 bf16
+    bits = torch.cat(halves).to(torch.int32)  # [98304] 16-bit patterns
+    words = (bits[0::2] | (bits[1::2] << 16)).to(torch.int32)
+    return words.view(torch.float32)
+
+
 def pack_view_layer(layer) -> torch.Tensor:
     """Pack the parameters of one view-transformer layer (Transformer2D) into the input-major
     layout of csrc/gnt_view.hip (VW_* offsets)."""
@@ -758,6 +815,7 @@ def pack_view_layer(layer) -> torch.Tensor:
         pad_cols(a.attn_fc[0].weight.t(), 32), pad_vec(a.attn_fc[0].bias, 32), a.attn_fc[2].weight.t(), a.attn_fc[2].bias,
         a.out_fc.weight.t(), a.out_fc.bias, layer.ff_norm.weight, layer.ff_norm.bias, layer.ff.fc1.weight.t(),
         layer.ff.fc1.bias, layer.ff.fc2.weight.t(), layer.ff.fc2.bias,
+        ff_bf16x3_images(layer.ff.fc1.weight.t(), layer.ff.fc2.weight.t()),
     ]
     packed = torch.cat([p.detach().float().contiguous().reshape(-1) for p in parts])
     assert packed.numel() == _lib.load().pgdvs_gnt_view_weight_floats(), packed.numel()
@@ -886,6 +944,7 @@ def pack_ray_layer(layer) -> torch.Tensor:
         z(128 + 32 + 512 + 64 + 2048 + 32 + 512 + 64),
         a.out_fc.weight.t(), a.out_fc.bias, layer.ff_norm.weight, layer.ff_norm.bias, layer.ff.fc1.weight.t(),
         layer.ff.fc1.bias, layer.ff.fc2.weight.t(), layer.ff.fc2.bias,
+        ff_bf16x3_images(layer.ff.fc1.weight.t(), layer.ff.fc2.weight.t()),
     ]
     packed = torch.cat([p.detach().float().contiguous().reshape(-1) for p in parts])
     assert packed.numel() == _lib.load().pgdvs_gnt_view_weight_floats(), packed.numel()

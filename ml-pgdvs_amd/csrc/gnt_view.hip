@@ -682,17 +682,29 @@ gnt_ff_bf16x3_kernel(const float *__restrict__ W_arg, float *__restrict__ x_io, 
   const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
   const int wave = threadIdx.x >> 6;
   const int64_t ntiles = (N + 31) / 32;
+  // the next round's rows are requested before this round's 384 MFMAs (nothing else covers the HBM latency)
+  float x_nx[32];
+  {
+    const int64_t g0 = ((int64_t)blockIdx.x * 8 + wave) * 32 + i;
+    load_row32(x_io + (g0 < N ? g0 : N - 1) * 64, x_nx, h);
+  }
   for (int64_t base = (int64_t)blockIdx.x * 8; base < ntiles; base += (int64_t)gridDim.x * 8) {  // (uniform over the workgroup)
     const int64_t tile = base + wave;
     const bool t_ok = tile < ntiles;
     const int64_t g_raw = tile * 32 + i;
     const bool g_ok = t_ok && g_raw < N;
     const int64_t g = g_raw < N ? g_raw : N - 1;
+    float x1[32];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) x1[t] = x_nx[t];
+    {
+      const int64_t gn = (tile + (int64_t)gridDim.x * 8) * 32 + i;
+      load_row32(x_io + (gn < N ? gn : N - 1) * 64, x_nx, h);
+    }
     // the row, normalised, split once for both phases: K-step c of layer 1 takes registers 8 c .. 8 c + 7
     uintx4 xh[4], xm[4], xl[4];
     {
-      float x1[32], xn[32];
-      load_row32(x_io + g * 64, x1, h);
+      float xn[32];
       layer_norm64(x1, s_par + 320, s_par + 384, 1e-6f, xn, h);
 #pragma unroll
       for (int c = 0; c < 4; ++c) split8_bf16x3(&xn[8 * c], xh[c], xm[c], xl[c]);
@@ -716,66 +728,93 @@ gnt_ff_bf16x3_kernel(const float *__restrict__ W_arg, float *__restrict__ x_io, 
       }
       const uintx4 *img = s_img + lane;
 #pragma unroll 1
-      for (int mtl = 0; mtl < 4; ++mtl) {
+      for (int mtl = 0; mtl < 4; mtl += 2) {  // two hidden tiles at a time: their accumulators take turns in the matrix pipe
         const int mt = 4 * hf + mtl;
-        floatx16v hacc;
+        floatx16v hacc0, hacc1;
         {
           const float *b1 = s_par + 32 * mt + 4 * h;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) hacc[r] = b1[(r & 3) + 8 * (r >> 2)];
+          for (int r = 0; r < 16; ++r) {
+            hacc0[r] = b1[(r & 3) + 8 * (r >> 2)];
+            hacc1[r] = b1[32 + (r & 3) + 8 * (r >> 2)];
+          }
         }
-        // layer 1: four K-steps, the next step's weight pieces requested while this step's six MFMAs run
-        uintx4 wa[3], wb[3];
+        // layer 1: four K-steps, the next step's weight pieces requested while this step's twelve MFMAs run
+        uintx4 wa0[3], wa1[3], wb0[3], wb1[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wa[p] = img[p * 2048 + (mtl * 4 + 0) * 64];
+        for (int p = 0; p < 3; ++p) {
+          wa0[p] = img[p * 2048 + (mtl * 4 + 0) * 64];
+          wa1[p] = img[p * 2048 + ((mtl + 1) * 4 + 0) * 64];
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           if (c + 1 < 4) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) wb[p] = img[p * 2048 + (mtl * 4 + c + 1) * 64];
+            for (int p = 0; p < 3; ++p) {
+              wb0[p] = img[p * 2048 + (mtl * 4 + c + 1) * 64];
+              wb1[p] = img[p * 2048 + ((mtl + 1) * 4 + c + 1) * 64];
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
-          hacc = mfma32_bf16x3(wa, xh[c], xm[c], xl[c], hacc);
+          hacc0 = mfma32_bf16(wa0[2], xh[c], hacc0);
+          hacc1 = mfma32_bf16(wa1[2], xh[c], hacc1);
+          hacc0 = mfma32_bf16(wa0[0], xl[c], hacc0);
+          hacc1 = mfma32_bf16(wa1[0], xl[c], hacc1);
+          hacc0 = mfma32_bf16(wa0[1], xm[c], hacc0);
+          hacc1 = mfma32_bf16(wa1[1], xm[c], hacc1);
+          hacc0 = mfma32_bf16(wa0[1], xh[c], hacc0);
+          hacc1 = mfma32_bf16(wa1[1], xh[c], hacc1);
+          hacc0 = mfma32_bf16(wa0[0], xm[c], hacc0);
+          hacc1 = mfma32_bf16(wa1[0], xm[c], hacc1);
+          hacc0 = mfma32_bf16(wa0[0], xh[c], hacc0);
+          hacc1 = mfma32_bf16(wa1[0], xh[c], hacc1);
           __builtin_amdgcn_sched_barrier(0);
+          if (c + 1 < 4) {
 #pragma unroll
-          for (int p = 0; p < 3; ++p) wa[p] = wb[p];
+            for (int p = 0; p < 3; ++p) {
+              wa0[p] = wb0[p];
+              wa1[p] = wb1[p];
+            }
+          }
         }
-        // ReLU, split, layer 2: two K-steps x two output tiles
-        float hv[16];
+        // ReLU, split, layer 2: per hidden tile two K-steps x two output tiles
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hv[r] = vrelu(hacc[r]);
+        for (int sub = 0; sub < 2; ++sub) {
+          float hv[16];
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-          uintx4 hh, hm, hl;
-          split8_bf16x3(&hv[8 * c2], hh, hm, hl);
-          uintx4 w0[3], w1[3];
+          for (int r = 0; r < 16; ++r) hv[r] = vrelu(sub == 0 ? hacc0[r] : hacc1[r]);
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
-            w0[p] = img[p * 2048 + 1024 + ((mtl * 2 + c2) * 2 + 0) * 64];
-            w1[p] = img[p * 2048 + 1024 + ((mtl * 2 + c2) * 2 + 1) * 64];
+          for (int c2 = 0; c2 < 2; ++c2) {
+            uintx4 hh, hm, hl;
+            split8_bf16x3(&hv[8 * c2], hh, hm, hl);
+            uintx4 w0[3], w1[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+              w0[p] = img[p * 2048 + 1024 + (((mtl + sub) * 2 + c2) * 2 + 0) * 64];
+              w1[p] = img[p * 2048 + 1024 + (((mtl + sub) * 2 + c2) * 2 + 1) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (the two output tiles take turns: consecutive MFMAs never wait for each other's result)
+            o0 = mfma32_bf16(w0[2], hh, o0);
+            o1 = mfma32_bf16(w1[2], hh, o1);
+            o0 = mfma32_bf16(w0[0], hl, o0);
+            o1 = mfma32_bf16(w1[0], hl, o1);
+            o0 = mfma32_bf16(w0[1], hm, o0);
+            o1 = mfma32_bf16(w1[1], hm, o1);
+            o0 = mfma32_bf16(w0[1], hh, o0);
+            o1 = mfma32_bf16(w1[1], hh, o1);
+            o0 = mfma32_bf16(w0[0], hm, o0);
+            o1 = mfma32_bf16(w1[0], hm, o1);
+            o0 = mfma32_bf16(w0[0], hh, o0);
+            o1 = mfma32_bf16(w1[0], hh, o1);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
-          // (the two output tiles take turns: consecutive MFMAs never wait for each other's result)
-          o0 = mfma32_bf16(w0[2], hh, o0);
-          o1 = mfma32_bf16(w1[2], hh, o1);
-          o0 = mfma32_bf16(w0[0], hl, o0);
-          o1 = mfma32_bf16(w1[0], hl, o1);
-          o0 = mfma32_bf16(w0[1], hm, o0);
-          o1 = mfma32_bf16(w1[1], hm, o1);
-          o0 = mfma32_bf16(w0[1], hh, o0);
-          o1 = mfma32_bf16(w1[1], hh, o1);
-          o0 = mfma32_bf16(w0[0], hm, o0);
-          o1 = mfma32_bf16(w1[0], hm, o1);
-          o0 = mfma32_bf16(w0[0], hh, o0);
-          o1 = mfma32_bf16(w1[0], hh, o1);
-          __builtin_amdgcn_sched_barrier(0);
         }
       }
       resident = hf;
     }
     if (g_ok) {
-      float x1[32], out[32];
-      load_row32(x_io + g * 64, x1, h);  // (the residual: read again rather than kept through both phases)
+      float out[32];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         out[r] = o0[r] + x1[r];

@@ -918,10 +918,11 @@ def main():
                "peak_tflops_fp32_mfma": 157.3, "frac_of_peak": round(gflop / gdt / 157.3e12, 4),
                "fp32_instruction_path": {"ms_per_chunk": round(reps32[len(reps32) // 2] * 1e3, 2), "tflops": tf(reps32[len(reps32) // 2]),
                                          "frac_of_peak": round(gflop / reps32[len(reps32) // 2] / 157.3e12, 4), "repetitions": len(reps32),
-                                         "note": "PGDVS_GNT_FP32=1: the view layers' k / v products on v_mfma_f32_16x16x4_f32 as well"},
+                                         "note": "PGDVS_GNT_FP32=1: every product on the fp32 matrix instructions (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)"},
                "gather_alg_GBps": round(gather_bytes / (t_gather * 1e-3) / 1e9, 1), "valid_projection_fraction": round(valid_frac, 3),
-               "dtype": "f32 (v_mfma_f32_16x16x4_f32 / 32x32x2_f32; the view layers' two 64 x 64 products per source view as bf16x3 on "
-                        "v_mfma_f32_16x16x32_bf16: both operands split exactly into three bf16 pieces, six partial products, fp32 accumulation)",
+               "dtype": "f32 inputs, weights and results; the view layers' 64 x 64 products and the feed-forward blocks run as bf16x3 products on "
+                        "v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16 (both operands split exactly into three bf16 pieces, six partial products, "
+                        "fp32 accumulation), everything else on v_mfma_f32_16x16x4_f32",
                "est_seconds_per_1080p_frame": round(gdt * (H * W / Rg), 1),
                "note": "pgdvs_gnt_gather (real projections of target-ray samples into the resident source frames, dynamic masks "
                        "applied) + GNT.forward incl. view entropy/std side outputs; FLOPs = the fp32 multiply-adds of A14 (an operand "

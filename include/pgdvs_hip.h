@@ -307,10 +307,12 @@ int pgdvs_gnt_head(const float *weights, const float *q, int R, int S, float *rg
  *   without any valid view must be passed as all-valid, :124-129); q_out[N,64]
  *   stats[N,3] (nullable): view entropy (:497-500, evaluated online as log l - sum e a / l, within
  *   2e-7 of the upstream expression), masked std of k, normalised std; means over features.
- *   Arithmetic: fp32 throughout; the two 64 x 64 products per source view (k = Wk f, vv = Wv k) run on the bf16 matrix
- *   instruction with both operands split EXACTLY into three bf16 pieces (six partial products above 2^-24 of the product,
- *   fp32 accumulation: the accuracy of an fp32 multiply-add chain, at 0.58 of its time); PGDVS_GNT_FP32=1 in the environment
- *   (read per call) keeps them on the fp32 matrix instruction. */
+ *   Arithmetic: fp32 inputs, weights and results; the 64 x 64 products of the attention (k = Wk f and vv = Wv k per source view,
+ *   q' and out_fc per tile) and the feed-forward block that closes the layer (also in pgdvs_gnt_ray_layer) run on the bf16
+ *   matrix instructions with both operands split EXACTLY into three bf16 pieces (the six partial products above 2^-24 of the
+ *   product, fp32 accumulation: the accuracy of an fp32 multiply-add chain, in about half its time); the weight blob carries
+ *   the feed-forward weights a second time as pre-split images (pgdvs_amd.ops.ff_bf16x3_images).  PGDVS_GNT_FP32=1 in the
+ *   environment (read per call) keeps every product on the fp32 matrix instructions. */
 int64_t pgdvs_gnt_view_weight_floats(void);
 int pgdvs_gnt_view_layer(const float *weights, const float *q_in, const float *feat,
                          const float *ray_diff, const uint8_t *valid, int64_t N, int V, float *q_out,

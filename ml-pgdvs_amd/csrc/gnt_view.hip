@@ -410,7 +410,7 @@ gnt_view_layer_kernel(const float *__restrict__ W_arg, const float *__restrict__
       nvalid += ok ? 1 : 0;
       float xmax = -__builtin_inff();
 #pragma unroll
-      for (int t = 0; t < 16; ++t) xmax = fmaxf(xmax, x[t]);
+      for (int t = 0; t < 16; ++t) xmax = vmax2(xmax, x[t]);  // (v_med3: no canonicalising move per MFMA result)
       if (__builtin_amdgcn_ballot_w64(ok && xmax > kRescaleGap * kLog2e) != 0) {
         // (rare) move the reference up by d = max(x, 0): every running sum scales by 2^-d.
         // ue = sum_v 2^(a_v - m) (a_v - m) follows the change of reference as

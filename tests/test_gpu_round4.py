@@ -708,3 +708,40 @@ def test_gnt_forward_golden_on_both_product_paths(golden_dir, monkeypatch):
     np.testing.assert_allclose(out.cpu().numpy(), g["dynmask_out"], rtol=0, atol=1e-4)
     for k, v in ex.items():
         np.testing.assert_allclose(v.cpu().numpy(), g[f"dynmask_{k}"], rtol=0, atol=1e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("S,R", [(1, 5), (33, 19), (256, 9), (47, 300)])
+def test_gnt_feed_forward_both_product_paths(S, R, monkeypatch):
+    """the feed-forward block behind every attention layer (csrc/gnt_view.hip gnt_ff_bf16x3_kernel: bf16x3 products on
+    v_mfma_f32_32x32x16_bf16, two phases per round with half of the weight pieces resident; PGDVS_GNT_FP32=1: gnt_ff_kernel on
+    the fp32 instruction) through the ray layer at row counts that leave wavefronts and whole rounds of a workgroup without a
+    tile (5 rows, 627, 2304, 14100): both paths against torch (transformer_network.py:44-55,:218-221) and against each other."""
+    from pgdvs_amd.models.gnt.models.transformer_network import GNT
+
+    torch.manual_seed(500 + S)
+    net = GNT(netwidth=64, transformer_depth=1).to(DEV).eval()
+    layer = net.view_selftrans[0]
+    with torch.no_grad():
+        layer.ff.fc1.weight.mul_(2.0)
+        layer.ff.fc1.bias.add_(torch.randn_like(layer.ff.fc1.bias) * 0.3)
+        layer.ff.fc2.bias.add_(torch.randn_like(layer.ff.fc2.bias) * 0.3)
+    q = torch.randn(R, S, 64, device=DEV) * (10.0 ** torch.randint(-1, 2, (R, S, 1), device=DEV).float())
+
+    def run():
+        with torch.no_grad():
+            return GNT._ray_layer(layer, q, True)
+
+    monkeypatch.setenv("PGDVS_GNT_FP32", "1")
+    out_f, w_f = run()
+    monkeypatch.setenv("PGDVS_GNT_FP32", "0")
+    out_s, w_s = run()
+    ops._GNT_VIEW_ENABLED = False
+    try:
+        out_t, w_t = run()
+    finally:
+        ops._GNT_VIEW_ENABLED = True
+    scale = max(float(out_t.abs().max()), 1.0)
+    for name, o in (("fp32 instruction", out_f), ("bf16x3", out_s)):
+        np.testing.assert_allclose(o.cpu().numpy(), out_t.cpu().numpy(), rtol=1e-4, atol=3e-5 * scale, err_msg=name)
+    np.testing.assert_allclose(out_s.cpu().numpy(), out_f.cpu().numpy(), rtol=1e-5, atol=3e-6 * scale)
+    np.testing.assert_allclose(w_s.cpu().numpy(), w_f.cpu().numpy(), rtol=0, atol=0)  # (the attention itself is the same kernel)

@@ -889,8 +889,8 @@ def main():
                 tele.append(telemetry())  # (read while the chunk is still running: after the synchronise the card idles)
                 torch.cuda.synchronize()
                 reps.append((time.perf_counter() - g0, e0.elapsed_time(e1), e1.elapsed_time(e2)))
-            # the same chunk with every product on the fp32 matrix instruction (PGDVS_GNT_FP32=1, read per call): five repetitions
-            os.environ["PGDVS_GNT_FP32"] = "1"
+            # the same chunk with every product on the fp32 matrix instruction (library option gnt_fp32): five repetitions
+            ops.set_option("gnt_fp32", 1)
             try:
                 gnt_chunk()
                 torch.cuda.synchronize()
@@ -901,7 +901,7 @@ def main():
                     torch.cuda.synchronize()
                     reps32.append(time.perf_counter() - g0)
             finally:
-                os.environ.pop("PGDVS_GNT_FP32", None)
+                ops.set_option("gnt_fp32", 0)
             reps32.sort()
         reps.sort()
         gdt, t_gather, t_net = reps[len(reps) // 2]
@@ -918,7 +918,7 @@ def main():
                "peak_tflops_fp32_mfma": 157.3, "frac_of_peak": round(gflop / gdt / 157.3e12, 4),
                "fp32_instruction_path": {"ms_per_chunk": round(reps32[len(reps32) // 2] * 1e3, 2), "tflops": tf(reps32[len(reps32) // 2]),
                                          "frac_of_peak": round(gflop / reps32[len(reps32) // 2] / 157.3e12, 4), "repetitions": len(reps32),
-                                         "note": "PGDVS_GNT_FP32=1: every product on the fp32 matrix instructions (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)"},
+                                         "note": "option gnt_fp32 (PGDVS_GNT_FP32=1 at load time): every product on the fp32 matrix instructions (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)"},
                "gather_alg_GBps": round(gather_bytes / (t_gather * 1e-3) / 1e9, 1), "valid_projection_fraction": round(valid_frac, 3),
                "dtype": "f32 inputs, weights and results; the view layers' 64 x 64 products and the feed-forward blocks run as bf16x3 products on "
                         "v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16 (both operands split exactly into three bf16 pieces, six partial products, "

@@ -13,16 +13,29 @@
  *   - every pointer is a DEVICE pointer unless the parameter is documented "host";
  *   - all buffers are caller-allocated, contiguous, fp32 unless stated otherwise;
  *   - `stream` is a hipStream_t (NULL = default stream); every call only enqueues
- *     work on it and never synchronises or allocates (one diagnostics switch does
- *     synchronise: PGDVS_KNN_STATS=1 in the environment makes the kNN print its ring
- *     histogram to stderr; PGDVS_KNN_NO_TPQ=1, PGDVS_KNN_PER_CELL=<n>, PGDVS_KNN_THR_MULT=<x> and PGDVS_KNN_RING_CAP=<n>
- *     select kNN search variants / the grid density / the starting threshold for tuning, PGDVS_RASTER_BOUND_DENSITY=<rows
- *     per pixel> the density from which the rasteriser computes its depth bound and runs its long-list launch,
- *     PGDVS_AGG_ORDERED / PGDVS_AGG_FUSED0 / PGDVS_AGG_STAGE / PGDVS_AGG_FPG / PGDVS_AGG_STEP_FPG the aggregation's launch structure --
- *     results are identical for any setting);
+ *     work on it and never synchronises or allocates (the diagnostics option knn_stats
+ *     does synchronise);
  *   - return value: 0 on success, negative pgdvs_status on error, message via
  *     pgdvs_last_error() (thread-local);
- *   - no global mutable state; re-entrant per stream.
+ *   - re-entrant per stream.  Process-wide state is limited to (i) the options below, (ii) the
+ *     opt-in profiling records of pgdvs_prof_*, (iii) per-device pools of fork / join events
+ *     and the host-side statistics of pgdvs_view_geo_host_stats (mutex-protected).
+ *
+ * Options: a handful of process-wide switches, read from the ENVIRONMENT ONCE, when the
+ * library is loaded, and changed afterwards only through pgdvs_option_set (never by a later
+ * setenv: no entry point calls getenv).  An entry point reads the options it needs once, at
+ * its start.  Results are identical for every setting (bit for bit for the index paths).
+ *   name                  environment at load          meaning
+ *   agg_ordered           PGDVS_AGG_ORDERED=1          A12 as the ordered chain of round 2: per frame an ordered
+ *                                                      selection + a push that builds the rows (second implementation)
+ *   agg_stage             PGDVS_AGG_STAGE=0 -> 0       0: A12's links leave no (depth, colour) rows, agg_rows gathers
+ *                                                      them itself (the path of videos too long for the staging block)
+ *   gnt_fp32              PGDVS_GNT_FP32=1             every GNT product on the fp32 matrix instruction (default:
+ *                                                      exact bf16x3 products where they pay, see pgdvs_gnt_view_layer)
+ *   raster_bound_density  PGDVS_RASTER_BOUND_DENSITY   rows per pixel from which the rasteriser computes its depth
+ *                                                      bound and runs its long-list launch (default 2.2)
+ *   knn_no_tpq            PGDVS_KNN_NO_TPQ=1           diagnostics: the wavefront-per-query search for every query
+ *   knn_stats             PGDVS_KNN_STATS=1            diagnostics: ring histogram to stderr (synchronises)
  *
  * Camera block: 80 floats of derived per-camera constants produced by
  * pgdvs_cam_prep from the reference's flat_cam[34] = [h, w, K(4x4), c2w(4x4)]
@@ -58,6 +71,11 @@ enum pgdvs_status {
 #define PGDVS_CAM_BLOCK 80
 
 const char *pgdvs_last_error(void);
+
+/* Options (see the table at the top).  pgdvs_option_set: 0, or PGDVS_ERR_INVALID for an unknown name; flags take
+ * value != 0.  pgdvs_option_get: the current value, NaN for an unknown name. */
+int pgdvs_option_set(const char *name, double value);
+double pgdvs_option_get(const char *name);
 /* library/ABI version and the gfx target the device code was built for */
 int pgdvs_abi_version(void);
 const char *pgdvs_build_arch(void);
@@ -311,8 +329,11 @@ int pgdvs_gnt_head(const float *weights, const float *q, int R, int S, float *rg
  *   q' and out_fc per tile) and the feed-forward block that closes the layer (also in pgdvs_gnt_ray_layer) run on the bf16
  *   matrix instructions with both operands split EXACTLY into three bf16 pieces (the six partial products above 2^-24 of the
  *   product, fp32 accumulation: the accuracy of an fp32 multiply-add chain, in about half its time); the weight blob carries
- *   the feed-forward weights a second time as pre-split images (pgdvs_amd.ops.ff_bf16x3_images).  PGDVS_GNT_FP32=1 in the
- *   environment (read per call) keeps every product on the fp32 matrix instructions. */
+ *   the feed-forward weights a second time as pre-split images (pgdvs_amd.ops.ff_bf16x3_images).  The option gnt_fp32
+ *   (PGDVS_GNT_FP32=1 at load time, pgdvs_option_set) keeps every product on the fp32 matrix instructions.
+ *   Inputs below 2^-110 in magnitude or non-finite are outside the split path's contract: the truncation residues of a
+ *   split underflow (the product loses its low pieces) and inf / NaN turn into NaN (inf - inf in the residue), where the
+ *   fp32 instruction would carry them through; image features and LayerNorm outputs never get there. */
 int64_t pgdvs_gnt_view_weight_floats(void);
 int pgdvs_gnt_view_layer(const float *weights, const float *q_in, const float *feat,
                          const float *ray_diff, const uint8_t *valid, int64_t N, int V, float *q_out,

@@ -12,6 +12,21 @@ namespace pgdvs {
 
 void set_error(const char *fmt, ...);
 
+// Process-wide options (include/pgdvs_hip.h, "Options"): initialised from the environment ONCE, when the library is loaded,
+// and changed afterwards only through pgdvs_option_set.  Plain words behind relaxed atomic accesses: an entry point reads
+// the options it needs once, at its start, so a concurrent pgdvs_option_set takes effect on calls that start after it.
+struct Options {
+  int agg_ordered;             // PGDVS_AGG_ORDERED=1: A12 as round 2's ordered chain (second implementation for the tests)
+  int agg_stage;               // PGDVS_AGG_STAGE=0: A12's links leave no (depth, colour) rows for agg_rows (the long-video path)
+  int gnt_fp32;                // PGDVS_GNT_FP32=1: every GNT product on the fp32 matrix instruction (default: bf16x3 products)
+  int knn_no_tpq;              // PGDVS_KNN_NO_TPQ=1: diagnostics, the wavefront-per-query search for every query
+  int knn_stats;               // PGDVS_KNN_STATS=1: diagnostics, ring histogram to stderr (synchronises)
+  float raster_bound_density;  // PGDVS_RASTER_BOUND_DENSITY: rows per pixel from which the rasteriser computes its depth bound
+};
+int option_int(const int &field);
+float option_float(const float &field);
+const Options &options();
+
 inline hipStream_t as_stream(pgdvs_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int check_launch(const char *what) {

@@ -9,7 +9,9 @@
 #include <vector>
 #include <stdio.h>
 
-#include "../../include/pgdvs_hip.h"
+#include <stdlib.h>
+
+#include "common.h"
 
 namespace pgdvs {
 static thread_local char g_err[512] = "";
@@ -59,6 +61,68 @@ void prof_end(hipStream_t s) {
   g_prof_recs.push_back(g_prof_cur);
 }
 }  // namespace pgdvs
+
+// ---- options ------------------------------------------------------------------
+namespace pgdvs {
+static Options options_from_env() {
+  auto flag = [](const char *name) {
+    const char *v = getenv(name);
+    return v != nullptr && v[0] == '1' ? 1 : 0;
+  };
+  Options o;
+  o.agg_ordered = flag("PGDVS_AGG_ORDERED");
+  o.agg_stage = getenv("PGDVS_AGG_STAGE") != nullptr && getenv("PGDVS_AGG_STAGE")[0] == '0' ? 0 : 1;
+  o.gnt_fp32 = flag("PGDVS_GNT_FP32");
+  o.knn_no_tpq = flag("PGDVS_KNN_NO_TPQ");
+  o.knn_stats = flag("PGDVS_KNN_STATS");
+  const char *d = getenv("PGDVS_RASTER_BOUND_DENSITY");
+  o.raster_bound_density = d != nullptr ? (float)atof(d) : 2.2f;
+  return o;
+}
+static Options g_options = options_from_env();  // (dynamic initialisation at load time: the only read of the environment)
+const Options &options() { return g_options; }
+int option_int(const int &field) { return __atomic_load_n(&field, __ATOMIC_RELAXED); }
+float option_float(const float &field) {
+  float v;
+  __atomic_load(&field, &v, __ATOMIC_RELAXED);
+  return v;
+}
+struct OptionName {
+  const char *name;
+  int *i;
+  float *f;
+};
+static const OptionName kOptionNames[] = {
+    {"agg_ordered", &g_options.agg_ordered, nullptr},   {"agg_stage", &g_options.agg_stage, nullptr},
+    {"gnt_fp32", &g_options.gnt_fp32, nullptr},
+    {"knn_no_tpq", &g_options.knn_no_tpq, nullptr},     {"knn_stats", &g_options.knn_stats, nullptr},
+    {"raster_bound_density", nullptr, &g_options.raster_bound_density},
+};
+}  // namespace pgdvs
+
+extern "C" __attribute__((visibility("default"))) int pgdvs_option_set(const char *name, double value) {
+  for (const auto &o : pgdvs::kOptionNames) {
+    if (name != nullptr && strcmp(name, o.name) == 0) {
+      if (o.i != nullptr) {
+        __atomic_store_n(o.i, value != 0.0 ? 1 : 0, __ATOMIC_RELAXED);
+      } else {
+        float v = (float)value;
+        __atomic_store(o.f, &v, __ATOMIC_RELAXED);
+      }
+      return PGDVS_OK;
+    }
+  }
+  pgdvs::set_error("pgdvs_option_set: unknown option '%s'", name ? name : "(null)");
+  return PGDVS_ERR_INVALID;
+}
+
+extern "C" __attribute__((visibility("default"))) double pgdvs_option_get(const char *name) {
+  for (const auto &o : pgdvs::kOptionNames) {
+    if (name != nullptr && strcmp(name, o.name) == 0)
+      return o.i != nullptr ? (double)pgdvs::option_int(*o.i) : (double)pgdvs::option_float(*o.f);
+  }
+  return __builtin_nan("");
+}
 
 namespace pgdvs {
 __global__ void prof_null_kernel() {}

@@ -1079,8 +1079,7 @@ PGDVS_API int64_t pgdvs_gnt_view_weight_floats(void) { return VW_TOTAL; }
 
 // feed-forward block in place on x[N,64]: one persistent 8-wave workgroup per CU
 static int launch_ff(const float *weights, float *x, int64_t N, hipStream_t st) {
-  const char *fp32_var = getenv("PGDVS_GNT_FP32");  // (read per call, see pgdvs_gnt_view_layer)
-  const bool fp32_path = fp32_var != nullptr && fp32_var[0] == '1';
+  const bool fp32_path = option_int(options().gnt_fp32) != 0;  // (see pgdvs_gnt_view_layer)
   const size_t lds = fp32_path ? (2 * 16384 + 256 + 64 + 128) * sizeof(float) : (4 * (size_t)kFfHalfU4 + 256 + 64 + 128) * sizeof(float);
   static bool configured = false;
   if (!configured) {
@@ -1127,10 +1126,10 @@ PGDVS_API int pgdvs_gnt_view_layer(const float *weights, const float *q_in, cons
     }
     configured = true;
   }
-  // PGDVS_GNT_FP32=1: the k / v products on the fp32 matrix instruction as well (exact fp32 products; the default splits both
-  // operands into three bf16 pieces: six partial products, fp32 accumulation -- see gnt_mfma.h)
-  const char *fp32_var = getenv("PGDVS_GNT_FP32");  // (read per call: tests and bench.py time both paths in one process)
-  const bool fp32_env = fp32_var != nullptr && fp32_var[0] == '1';
+  // option gnt_fp32 (PGDVS_GNT_FP32=1 at load time, pgdvs_option_set afterwards): the k / v products on the fp32 matrix
+  // instruction as well (exact fp32 products; the default splits both operands into three bf16 pieces: six partial
+  // products, fp32 accumulation -- see gnt_mfma.h)
+  const bool fp32_env = option_int(options().gnt_fp32) != 0;
 #define PGDVS_VIEW_LAUNCH(ST, SP)                                                                                        \
   PGDVS_LAUNCH("gnt_view_layer", (gnt_view_layer_kernel<ST, SP>), dim3(grid), dim3(512), lds, st, weights, q_in, feat, \
                ray_diff, valid, N, V, q_out, stats)

@@ -1292,8 +1292,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   }
   unsigned gpts = (unsigned)(cdiv(capacity, 256) < 2048 ? cdiv(capacity, 256) : 2048);
   unsigned gbb = gpts < 128 ? gpts : 128;
-  const char *etc = getenv("PGDVS_KNN_PER_CELL");  // tuning knob (any value gives exact results)
-  const float target = etc && atof(etc) >= 1.0 ? (float)atof(etc) : kTargetPerCellDefault * (float)(K + 1) / 51.0f;
+  const float target = kTargetPerCellDefault * (float)(K + 1) / 51.0f;
   PGDVS_LAUNCH("grid_bbox", grid_bbox_kernel, dim3(gbb), dim3(256), 0, st, pts, count, ws.bbox);
   // trial grid from the bounding box, measure the occupancy, then the final grid.  The trial aims at
   // kTrialCoarser times the occupancy (cells twice as wide on a surface): an eighth of the cells to zero
@@ -1327,13 +1326,12 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   CellIndex ci;
   ci.start = ws.occ_start;
   ci.tab = ws.tab;
-  const char *env = getenv("PGDVS_KNN_STATS");
-  int32_t *stats = (env && env[0] == '1') ? ws.stats : nullptr;
+  const bool want_stats = option_int(options().knn_stats) != 0;
+  int32_t *stats = want_stats ? ws.stats : nullptr;
   const unsigned gq = (unsigned)(cdiv(nq_cap, 4) < 256 * 8 ? (cdiv(nq_cap, 4) > 0 ? cdiv(nq_cap, 4) : 1) : 256 * 8);
-  const char *no_tpq = getenv("PGDVS_KNN_NO_TPQ");  // diagnostics: force the wavefront-per-query search
-  bool tpq = qpts == nullptr && !(no_tpq && no_tpq[0] == '1') && capacity < (1ll << 27);  // (32-bit byte offsets)
-  const char *etm = getenv("PGDVS_KNN_THR_MULT");  // tuning knob (any value gives exact results)
-  const float thr_mult = etm && atof(etm) > 0.0 ? (float)atof(etm) : 4.5f;
+  // (option knn_no_tpq: diagnostics and tests, the wavefront-per-query search for every query)
+  bool tpq = qpts == nullptr && option_int(options().knn_no_tpq) == 0 && capacity < (1ll << 27);  // (32-bit byte offsets)
+  const float thr_mult = 4.5f;  // starting threshold of the thread-per-query pass in units of the block's estimate (any value is exact)
   if (tpq) {
     const unsigned gt = (unsigned)(cdiv(capacity, 256) < 2560 ? (cdiv(capacity, 256) > 0 ? cdiv(capacity, 256) : 1) : 2560);
     switch (KK) {
@@ -1352,8 +1350,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
         tpq = false;
     }
   }
-  const char *erc = getenv("PGDVS_KNN_RING_CAP");  // tuning knob (any value >= 1 gives exact results)
-  const int ring_cap_after_tpq = erc && atoi(erc) >= 1 ? atoi(erc) : kRingCapAfterTpq;
+  const int ring_cap_after_tpq = kRingCapAfterTpq;
   QuerySrc qs1 = qs;
   if (tpq) {  // the ring search only sees what the first pass left open
     qs1.list = ws.open_list;

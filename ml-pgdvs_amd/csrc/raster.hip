@@ -1119,9 +1119,8 @@ static int points_raster_impl(const float *pts, int64_t pts_stride, const float 
   const float *tile_bound = nullptr;
   int64_t gate_rows = 0;
   {
-    // PGDVS_RASTER_BOUND_DENSITY: rows per pixel from which the bound is computed (default 2.2; 0 = always, a large value = never)
-    const char *dens_env = getenv("PGDVS_RASTER_BOUND_DENSITY");  // (read per call: tests switch it)
-    const double density = dens_env ? atof(dens_env) : 2.2;
+    // option raster_bound_density: rows per pixel from which the bound is computed (default 2.2; 0 = always, a large value = never)
+    const double density = (double)option_float(options().raster_bound_density);
     const float px_per_ndc = (float)(W < H ? W : H) / 2.0f;  // (both axes: PixToNonSquareNdc keeps pixels square)
     const float rpx = radius * px_per_ndc;
     const int b = rpx >= 5.05f ? 4 : (rpx >= 2.25f ? 2 : 0);

@@ -35,6 +35,7 @@
 // No host synchronisation: the running point counts live on the device.
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -139,7 +140,11 @@ struct ByteStamp {  // one occupancy byte per (frame, pixel): frame 0's chip-fil
   // [1 .. 64] points whose projections the fp32 form left to the fp64 queue -- summed per workgroup in LDS and added once per
   // workgroup and frame group to word 1 + (workgroup & 63): one hot word cost every link of the chain 4 us
   unsigned *stat;
+#ifdef PGDVS_AB_CHAIN  // tools/r05_chain_cost.sh: a duplicate chain that computes everything and stores nothing
+  __device__ __forceinline__ void operator()(int f, int q) const { if (occ_all) occ_all[(int64_t)f * P + q] = 1; }
+#else
   __device__ __forceinline__ void operator()(int f, int q) const { occ_all[(int64_t)f * P + q] = 1; }
+#endif
 };
 template <class Stamp>
 __device__ __attribute__((noinline)) void mark_reference_order(const ProjF64 *__restrict__ pj, double x, double y,
@@ -677,109 +682,6 @@ __global__ void __launch_bounds__(kSelThreads) agg_select_kernel(SelArgs a, CamB
   }
 }
 
-// ---- frame 0, default path: selection, ordered offsets, projections into every later frame and rows in ONE launch -----
-// Frame 0 appends every static pixel (~0.85 P points) and carries three quarters of all projections.  Rounds 2-3 ran it as
-// agg_select (count, ordered offsets, rows: 29 us) + agg_push<1024> (the rows' packed coordinates re-read once per group
-// of 8 later frames, 47.6 M projections: 54 us).  Here workgroup (tile, group) selects its 4096 pixels itself (mask bytes:
-// 2 MB per group instead of 21 MB of coordinates), unprojects them in registers and screens them against its group of
-// later frames; every workgroup publishes its tile's count before the projections, sums its predecessors' counts after them
-// (published ~50 us earlier: the look-back never waits) and writes its group's share of the tile's rows.
-constexpr int kF0Threads = 256;
-constexpr int kF0Tile = kF0Threads * kSelItems;  // 4096 pixels
-
-template <int kQueue>
-__global__ void __launch_bounds__(kF0Threads)
-agg_frame0_kernel(SelArgs a, CamBlock cam, const ProjF64 *__restrict__ proj, const PushConsts *__restrict__ pc, int f_hi, int fpg,
-                  int H, int W, uint8_t *__restrict__ occ_all, unsigned *__restrict__ stat) {
-  __shared__ uint16_t s_list[kF0Tile];
-  __shared__ uint4 s_q[kQueue];
-  __shared__ int s_qn[2];
-  __shared__ int s_tile;
-  __shared__ int s_wsum[4];
-  __shared__ long long s_part[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // Every group takes dynamic tile ids from its own ticket counter (each group walks every tile once; a tile's
-  // predecessors are then owned, in every group, by workgroups that already run -- whatever order the dispatcher starts
-  // workgroups in), publishes the tile's count (the same value from every group: idempotent) and writes ITS share of the
-  // tile's rows at the end: all workgroups carry the same mix of projections and row traffic.  (First version, round 4:
-  // only group 0 wrote rows and finished last -- 114 us against 93 for the select + push pair.)
-  if (tid == 0) s_tile = atomicAdd(&a.ticket[blockIdx.y], 1);
-  if (tid == 0) s_qn[0] = s_qn[1] = 0;
-  __syncthreads();
-  const int tile = s_tile;
-  const int base = tile * kF0Tile + tid * kSelItems;
-  const unsigned flags = base < a.P ? sel_flags16(a, base) : 0u;
-  int total;
-  int slot = block_excl_256(__popc(flags), s_wsum, total);
-  if (tid == 0)
-    __hip_atomic_store(&a.desc[tile], sel_desc(1, 1, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (unsigned f = flags; f; f &= f - 1) s_list[slot++] = (uint16_t)(tid * kSelItems + __builtin_ctz(f));
-  __syncthreads();
-  const int tile_px = tile * kF0Tile;
-  AppendSrc app;
-  app.depth = a.depth;
-  app.rgb = a.rgb;
-  app.cloud = a.cloud;
-  app.xyz = a.xyz;
-  app.P = a.P;
-  app.W = a.W;
-  // ---- projections: this group's later frames
-  const int fa = 1 + (int)blockIdx.y * fpg;
-  const int fb = fa + fpg < f_hi ? fa + fpg : f_hi;
-  if (fa < fb && total > 0) {
-    const ByteStamp stamp{occ_all, (int64_t)H * W, stat};
-    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
-    for (int e0 = 0; e0 < total; e0 += kF0Threads) {
-      const int e = e0 + tid;
-      const bool live = e < total;
-      float x = 0.f, y = 0.f, z = 0.f;
-      if (live) {
-        const f3 X = append_row(app, cam, tile_px + (int)s_list[e], 0, false);
-        x = X.x;
-        y = X.y;
-        z = X.z;
-      }
-      const unsigned dmask = screen_frames(pc, fa, fb, live, x, y, z, wm1, hm1, W, stamp);
-      queue_doubtful<kQueue, kF0Threads>(s_q, s_qn, dmask, x, y, z, fa, e0 + kF0Threads >= total, proj, H, W, stamp);
-    }
-  }
-  // ---- rows, in the reference's order: behind everything the tiles before this one selected
-  const int tiles = a.tiles;
-  if (total == 0 && !(tile == tiles - 1 && blockIdx.y == 0)) return;
-  long long part = 0;
-  for (int j = tid; j < tile; j += kF0Threads) {
-    unsigned spins = 0;
-    unsigned long long dsc;
-    while (true) {
-      dsc = __hip_atomic_load(&a.desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((int)(dsc >> 48) == 1) break;
-      if (++spins > kSelSpinLimit) {  // never expected; keeps a protocol bug from hanging the GPU
-        atomicExch(a.error, 1);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    part += (long long)(dsc & ((1ull << 46) - 1));
-  }
-  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
-  if (lane == 0) s_part[wave] = part;
-  __syncthreads();
-  const long long excl = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-  if (tile == tiles - 1 && blockIdx.y == 0 && tid == 0) {
-    int64_t n = excl + total;
-    n = n > a.capacity ? a.capacity : n;
-    a.cnts[1] = n;  // (cnts[0] = 0: the state block is zeroed per call)
-  }
-  // this group's contiguous share of the tile's rows
-  const int e_lo = (int)((int64_t)total * blockIdx.y / gridDim.y), e_hi = (int)((int64_t)total * (blockIdx.y + 1) / gridDim.y);
-#pragma unroll 4
-  for (int e = e_lo + tid; e < e_hi; e += kF0Threads) {
-    const int64_t pos = excl + e;
-    if (pos >= a.capacity) break;
-    append_row(app, cam, tile_px + (int)s_list[e], pos, true);
-  }
-}
-
 // selection flags of 16 pixels of a later frame, both 16-byte loads in flight together (sel_flags16 waits for each in turn:
 // dependent round trips at the head of every chain link); selected = mask byte zero and map byte zero = (mask | map) zero
 __device__ __forceinline__ unsigned sel_flags16_pair(const SelArgs &a, const int64_t base) {
@@ -811,14 +713,12 @@ struct RowStage {
 // them against the frames src + 1 + blockIdx.y * fpg ... like agg_push_kernel.  gridDim.x is a multiple of 8: the
 // workgroups (x, 0), (x, 1), ... land on one XCD and share its L2's copy of the chunk (the rows re-read the same 4 MB).
 // The last frame's launch only leaves its bits.
-template <int kQueue, int kSpec>
+template <int kQueue>
 __global__ void __launch_bounds__(kStepThreads)
 agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__ sel16, int64_t Wd, int src,
                 const ProjF64 *__restrict__ proj, const PushConsts *__restrict__ pc, int f_hi, int fpg, int H, int W,
                 AppendSrc app, CamBlock cam, unsigned *__restrict__ stat, RowStage stage) {
-  constexpr int spec = kSpec;
   __shared__ uint16_t s_list[kStepThreads * kStepPx];  // (thread << 4 | pixel) of every selected pixel, 8 KB
-  __shared__ float s_dep[kSpec ? kStepThreads * kStepPx : 1];  // spec: their depths, loaded densely beside mask and map
   __shared__ int s_cstart[kStepChunks];  // list position of every chunk's first selected pixel
   __shared__ uint4 s_q[kQueue];
   __shared__ int s_qn[2];
@@ -828,16 +728,10 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
     return ((int64_t)blockIdx.x + (int64_t)(t >> 3) * gridDim.x) * kStepChunkPx + (t & 7) * kStepPx;
   };
   const int64_t base = pixel_base(tid);
-  // spec (review item 1c, PGDVS_AGG_SPEC_DEPTH=1): the 16 depths of the thread's pixels requested TOGETHER with its mask
-  // and map bytes -- 8.3 MB of dense reads per link instead of a sector per selected pixel, and one dependent round trip
-  // less in the link (mask / map -> stamps instead of mask / map -> depth -> stamps)
-  float4 dq[4];
-  const bool spec_ok = spec != 0 && base + 16 <= a.P && ((reinterpret_cast<uintptr_t>(app.depth + base) & 15) == 0);
-  if (spec_ok) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dq[k] = reinterpret_cast<const float4 *>(app.depth + base)[k];
-  }
   const uint32_t bits = sel_flags16_pair(a, base);
+#ifdef PGDVS_AB_CHAIN
+  if (sel16 != nullptr)
+#endif
   if (blockIdx.y == 0 && base < Wd * 32) sel16[((int64_t)src * Wd * 32 + base) >> 4] = (uint16_t)bits;
   const int fa = src + 1 + (int)blockIdx.y * fpg;
   if (fa >= f_hi) return;
@@ -846,20 +740,7 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
   int slot = block_excl_256(__popc(bits), s_wsum, n);
   if (n == 0) return;
   if ((tid & 7) == 0) s_cstart[tid >> 3] = slot;
-  if (spec != 0) {
-    const float dv[16] = {dq[0].x, dq[0].y, dq[0].z, dq[0].w, dq[1].x, dq[1].y, dq[1].z, dq[1].w,
-                          dq[2].x, dq[2].y, dq[2].z, dq[2].w, dq[3].x, dq[3].y, dq[3].z, dq[3].w};
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if ((bits >> k) & 1u) {
-        s_list[slot] = (uint16_t)((tid << 4) | k);
-        s_dep[kSpec ? slot : 0] = spec_ok ? dv[k] : app.depth[base + k];
-        ++slot;
-      }
-    }
-  } else {
-    for (uint32_t m = bits; m; m &= m - 1) s_list[slot++] = (uint16_t)((tid << 4) | __builtin_ctz(m));
-  }
+  for (uint32_t m = bits; m; m &= m - 1) s_list[slot++] = (uint16_t)((tid << 4) | __builtin_ctz(m));
   if (tid == 0) s_qn[0] = s_qn[1] = 0;
   __syncthreads();
   const bool staged = blockIdx.y == 0 && stage.rows != nullptr;
@@ -877,7 +758,7 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
       // the depth first, the colour right behind it: the unprojection and the stamps below wait for the depth only, the
       // colour is still on its way while they run and is consumed at the very end of the round -- both are left for
       // agg_rows, which then reads 16 dense bytes per row instead of a sector per scattered depth and another per colour
-      d = spec != 0 ? s_dep[kSpec ? e : 0] : app.depth[px];
+      d = app.depth[px];
       if (staged) {
         c = *reinterpret_cast<const f3 *>(app.rgb + (size_t)px * 3);
         const int ch = ent >> 7;  // chunk of the workgroup (eight threads per chunk)
@@ -1002,6 +883,11 @@ agg_rows_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles, const i
   }
 }
 
+#ifdef PGDVS_AB_CHAIN
+__global__ void agg_empty_kernel(int *p) {
+  if (p != nullptr && threadIdx.x == 12345) *p = 0;
+}
+#endif
 struct CamChunk {
   CamBlock c[12];
 };
@@ -1050,7 +936,7 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   AggWs w;
   const int64_t P = (int64_t)H * W;
   const int64_t tiles = cdiv(P, kSelTile);
-  const int64_t tiles0 = cdiv(P, 4096);  // (kF0Tile: frame 0's fused launch publishes one count per 4096 pixels)
+  const int64_t tiles0 = tiles;  // one look-back granule per selection tile
   char *p = reinterpret_cast<char *>(base);
   int64_t off = 0;
   w.tile_cnt = reinterpret_cast<int32_t *>(p + off);
@@ -1249,10 +1135,9 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
     }
   }
   const int tiles = (int)cdiv(P, kSelTile);
-  // PGDVS_AGG_ORDERED=1: round 2's chain for every frame (ordered selection + byte-stamping push that builds the rows),
+  // option agg_ordered (PGDVS_AGG_ORDERED=1 at load time): round 2's chain for every frame (ordered selection + byte-stamping push that builds the rows),
   // kept as a second implementation that the tests run the same bit-exact cases through
-  static const bool ordered_env = getenv("PGDVS_AGG_ORDERED") && getenv("PGDVS_AGG_ORDERED")[0] == '1';
-  const bool bit_chain = !ordered_env && S > 1;
+  const bool bit_chain = option_int(options().agg_ordered) == 0 && S > 1;
   auto select = [&](int i) {
     SelArgs a;
     a.dyn_mask = dyn_masks + (size_t)i * P;
@@ -1285,10 +1170,9 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
   };
   // cnts[i] = points in the cloud before frame i.  Frame 0 appends every static pixel (~P points x S-1 frames: the
   // chip-filling push launch, 12 frames per workgroup row so that the points are read twice).
-  static const int fpg_env = getenv("PGDVS_AGG_FPG") ? atoi(getenv("PGDVS_AGG_FPG")) : 0;
   // (round 4, three lanes, 60-view runs on one box: 8 frames per row 1160 / 1168 frames/s in steady state, 6: 1155 / 1152,
   // 12 -- two rows, the coordinates read twice instead of three times --: 1171 / 1184)
-  const int fpg = fpg_env > 0 ? (fpg_env < kPushMaxFpg ? fpg_env : kPushMaxFpg) : 12;
+  const int fpg = 12;
   auto push = [&](int i) {
     // (ordered chain: later frames append a few per cent of P and their launches are latency chains, shorter with 4
     // frames per row; 256 workgroups walk whatever there is -- the count is device-side)
@@ -1330,51 +1214,30 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       }
     }
   }
-  // (measured, round 4: the fused launch takes 114 us where the pair takes 29 + 64 -- the third of the workgroups that also
-  // writes the rows finishes last; the pair stays the default, PGDVS_AGG_FUSED0=1 selects the fused launch)
-  static const bool fused0_env = getenv("PGDVS_AGG_FUSED0") && getenv("PGDVS_AGG_FUSED0")[0] == '1';
-  if (!fused0_env) {
-    select(0);
-    push(0);
-  } else {
-    static_assert(kF0Tile == 4096, "agg_ws_layout sizes the count granules for 4096-pixel tiles");
-    SelArgs a;
-    a.dyn_mask = dyn_masks;
-    a.occ = ws.occ;
-    a.depth = depths;
-    a.rgb = rgbs;
-    a.cloud = out;
-    a.xyz = ws.xyz;
-    a.cnts = ws.cnts;
-    a.desc = ws.desc;
-    a.ticket = ws.ticket;
-    a.error = ws.error;
-    a.sel_pix = nullptr;
-    a.capacity = capacity;
-    a.frame = 0;
-    a.P = (int)P;
-    a.W = W;
-    a.tiles = (int)cdiv(P, kF0Tile);
-    const int groups = (int)cdiv(S - 1, fpg);
-    PGDVS_LAUNCH("agg_frame0", agg_frame0_kernel<kPushQueue>, dim3((unsigned)a.tiles, (unsigned)groups), dim3(kF0Threads), 0, st, a,
-                 cams[0], (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, fpg, H, W, ws.occ,
-                 ws.stat);
-  }
-  // PGDVS_AGG_STAGE=0: the links leave nothing behind, agg_rows gathers depth and colour itself (the other path of the same kernels)
-  static const bool stage_env = !(getenv("PGDVS_AGG_STAGE") && getenv("PGDVS_AGG_STAGE")[0] == '0');
+  // (round 4: frame 0 as ONE fused launch -- selection, ordered offsets, projections and rows -- was built twice and took
+  // 110-114 us against 29 + 61 for this pair)
+  select(0);
+  push(0);
+  // option agg_stage = 0: the links leave nothing behind, agg_rows gathers depth and colour itself -- the path very long
+  // videos take anyway (no staging block in their workspace)
   RowStage stage;
-  stage.rows = stage_env ? ws.stage_rows : nullptr;
+  stage.rows = option_int(options().agg_stage) != 0 ? ws.stage_rows : nullptr;
   stage.frame_px = ws.Wd * 32;
   {
     // 32 chunks of 128 pixels per workgroup, dealt round-robin; a multiple of 8 workgroups per row (see the kernel)
     const unsigned gx = (unsigned)align_up(cdiv(ws.Wd * 32 / kStepChunkPx, kStepChunks), 8);
-    static const int sfpg_env = getenv("PGDVS_AGG_STEP_FPG") ? atoi(getenv("PGDVS_AGG_STEP_FPG")) : 0;
     // frames per workgroup row.  Alone on the chip a link takes 9.9 / 8.4 / 7.9 / 7.6 / 7.6 / 8.2 us with 2 / 3 / 4 / 6 / 8 / 16 frames per
     // row (more rows = more parallel frames), but every row re-reads the chunk and re-gathers the depths, and with seven views
     // in flight the throughput is the other way round: 1037 frames/s with 6, 1048 with 8, 1055 with 16, 1058 with 24-32 -- one
     // row whenever the later frames fit a queue entry's mask
-    const int sfpg = sfpg_env > 0 ? (sfpg_env < kPushMaxFpg ? sfpg_env : kPushMaxFpg) : kPushMaxFpg;
-    static const bool spec_env = getenv("PGDVS_AGG_SPEC_DEPTH") && getenv("PGDVS_AGG_SPEC_DEPTH")[0] == '1';
+    const int sfpg = kPushMaxFpg;
+#ifdef PGDVS_AB_CHAIN
+    // tools/r05_chain_cost.sh: what the chain costs the throughput, by ADDING copies of it behind the real one (a link is
+    // idempotent: its own map is complete before it runs, so a second run selects, stamps and stages exactly the same)
+    const char *dbg = getenv("PGDVS_DBG_CHAIN");
+    const int dbg_mode = !dbg ? 0 : !strcmp(dbg, "dup") ? 1 : !strcmp(dbg, "dup_dry") ? 2 : !strcmp(dbg, "dup_empty") ? 3 : !strcmp(dbg, "dup_small") ? 4 : 0;
+    for (int pass = 0; pass < (dbg_mode ? 2 : 1); ++pass)
+#endif
     for (int i = 1; i < S; ++i) {
       SelArgs a;
       a.dyn_mask = dyn_masks + (size_t)i * P;
@@ -1383,15 +1246,28 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       a.P = (int)P;
       a.W = W;
       const unsigned gy = i + 1 < S ? (unsigned)cdiv(S - 1 - i, sfpg) : 1u;
-      if (spec_env) {
-        PGDVS_LAUNCH("agg_step", (agg_step_kernel<kPushQueueSmall, 1>), dim3(gx, gy), dim3(kStepThreads), 0, st, a, ws.occ,
-                     reinterpret_cast<uint16_t *>(ws.sel), ws.Wd, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, sfpg, H, W,
-                     frame_src(i), cams[(size_t)i], ws.stat, stage);
-      } else {
-        PGDVS_LAUNCH("agg_step", (agg_step_kernel<kPushQueueSmall, 0>), dim3(gx, gy), dim3(kStepThreads), 0, st, a, ws.occ,
-                     reinterpret_cast<uint16_t *>(ws.sel), ws.Wd, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, sfpg, H, W,
-                     frame_src(i), cams[(size_t)i], ws.stat, stage);
+#ifdef PGDVS_AB_CHAIN
+      if (pass == 1 && dbg_mode == 3) {
+        PGDVS_LAUNCH("agg_empty", agg_empty_kernel, dim3(1), dim3(64), 0, st, (int *)nullptr);
+        continue;
       }
+      if (pass == 1 && dbg_mode == 4) {  // launch boundaries + the workgroups, which leave at once (frame index beyond the video)
+        PGDVS_LAUNCH("agg_empty", agg_empty_kernel, dim3(gx), dim3(kStepThreads), 0, st, (int *)nullptr);
+        continue;
+      }
+      if (pass == 1 && dbg_mode == 2) {
+        RowStage none;
+        none.rows = nullptr;
+        none.frame_px = stage.frame_px;
+        PGDVS_LAUNCH("agg_step_dry", agg_step_kernel<kPushQueueSmall>, dim3(gx, gy), dim3(kStepThreads), 0, st, a, (uint8_t *)nullptr,
+                     (uint16_t *)nullptr, ws.Wd, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, sfpg, H, W,
+                     frame_src(i), cams[(size_t)i], ws.stat, none);
+        continue;
+      }
+#endif
+      PGDVS_LAUNCH("agg_step", agg_step_kernel<kPushQueueSmall>, dim3(gx, gy), dim3(kStepThreads), 0, st, a, ws.occ,
+                   reinterpret_cast<uint16_t *>(ws.sel), ws.Wd, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, sfpg, H, W,
+                   frame_src(i), cams[(size_t)i], ws.stat, stage);
     }
   }
   PGDVS_LAUNCH("agg_count", agg_count_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,

@@ -19,6 +19,8 @@ _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 # name -> (restype, argtypes); mirrors include/pgdvs_hip.h one-to-one
 SIGNATURES = {
     "pgdvs_last_error": (C.c_char_p, []),
+    "pgdvs_option_set": (_i, [C.c_char_p, C.c_double]),
+    "pgdvs_option_get": (C.c_double, [C.c_char_p]),
     "pgdvs_abi_version": (_i, []),
     "pgdvs_build_arch": (C.c_char_p, []),
     "pgdvs_prof_enable": (None, [_i]),

@@ -89,6 +89,7 @@ class GNT(nn.Module):
         self.posenc_dim = 3 + 3 * 2 * pos_enc_n_freqs
         self.viewenc_dim = 3 + 3 * 2 * view_enc_n_freqs
         self.ret_alpha = ret_alpha
+        self.hidden_hook = None  # tests: called as hook("view" / "ray", q) behind every transformer block
         self.norm = nn.LayerNorm(netwidth)
         self.rgb_fc = nn.Linear(netwidth, 3)
         self.rgbfeat_fc = _mlp(in_feat_ch + 3, netwidth, netwidth)
@@ -194,9 +195,13 @@ class GNT(nn.Module):
             ops.gnt_fallback("pgdvs_gnt_posfc", f"width {q.shape[-1]} (needs 64)")
         for i, (vl, qfc, rl) in enumerate(zip(self.view_crosstrans, self.q_fcs, self.view_selftrans)):
             q, stats = self._view_layer(vl, q, feat, ray_diff, valid, cnt, want_stats)
+            if self.hidden_hook is not None:
+                self.hidden_hook("view", q)
             if i % 2 == 0:
                 q = posfc(i, q) if posfc is not None else qfc(torch.cat((q, input_pts, input_views), dim=-1))
             q, attn = self._ray_layer(rl, q, self.ret_alpha)
+            if self.hidden_hook is not None:
+                self.hidden_hook("ray", q)
             if want_stats:
                 ents.append(stats[0])
                 stds.append(stats[1])

@@ -710,6 +710,42 @@ def needs_autograd(*modules_and_tensors) -> bool:
 _fallback_seen = set()
 
 
+# ---------------------------------------------------------------- library options (include/pgdvs_hip.h, "Options")
+def set_option(name: str, value) -> None:
+    """process-wide option of the library (read from the environment once, at load time; this is the only other way to
+    change one).  Names: agg_ordered, agg_stage, gnt_fp32, raster_bound_density, knn_no_tpq, knn_stats."""
+    check(_lib.load().pgdvs_option_set(name.encode(), float(value)), f"pgdvs_option_set({name})")
+
+
+def get_option(name: str) -> float:
+    v = _lib.load().pgdvs_option_get(name.encode())
+    if v != v:
+        raise PgdvsHipError(f"pgdvs_option_get: unknown option '{name}'")
+    return v
+
+
+class option:
+    """``with ops.option("agg_ordered", 1): ...`` -- sets a library option for the block and restores it (tests, bench.py)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.prev = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.prev)
+        return False
+
+
+def gnt_product_path(fp32: bool):
+    """the GNT kernels' product path for a block of code: exact bf16x3 products on the bf16 matrix instructions (default) or
+    every product on the fp32 matrix instruction (csrc/gnt_view.hip)"""
+    return option("gnt_fp32", 1 if fp32 else 0)
+
+
 def gnt_fallback(kernel: str, why: str) -> None:
     """A CUDA tensor is about to take the torch branch of a GNT stage because the fused kernel does not
     cover its shape: say so once per (kernel, reason); raise instead under PGDVS_GNT_STRICT=1."""

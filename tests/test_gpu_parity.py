@@ -186,9 +186,8 @@ def test_knn_search_variants_agree_at_benchmark_size(K, monkeypatch):
     pts[:400] += rng.normal(0, 0.5, (400, 3))  # flying pixels
     pts = pts.astype(np.float32)
     cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
-    monkeypatch.setenv("PGDVS_KNN_NO_TPQ", "1")
-    a0 = N(ops.knn_mean_dist(T(pts), cnt, K, algo=2))
-    monkeypatch.delenv("PGDVS_KNN_NO_TPQ")
+    with ops.option("knn_no_tpq", 1):
+        a0 = N(ops.knn_mean_dist(T(pts), cnt, K, algo=2))
     a1 = N(ops.knn_mean_dist(T(pts), cnt, K, algo=2))
     assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
     assert np.isfinite(a1).all() and float(a1.max()) > 10 * float(np.median(a1))
@@ -434,7 +433,7 @@ def test_static_aggregation_capacity_clamp():
     cap = n - 1000
     part, cnt2 = ops.static_aggregate(T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]).view(torch.uint8), v["K3s"], v["c2ws"],
                                       capacity=cap)
-    # overflow: both chains (this test also runs under PGDVS_AGG_ORDERED=1) report count == capacity -- the signal that rows
+    # overflow: both chains (this test also runs with the option agg_ordered) report count == capacity -- the signal that rows
     # may have been dropped and the cloud must not be used (harness.eval_step and bench.py raise on it); which rows of the
     # later frames survive differs between the chains, frame 0's prefix does not
     assert int(cnt2.item()) == cap

@@ -343,7 +343,7 @@ def test_scene_statistics_540p_vs_oracle(scene):
 @pytest.mark.parametrize("H,W,n,K,radius,seed", [(160, 224, 60000, 3, 0.075, 0), (160, 224, 90000, 4, 0.04, 1), (96, 128, 30000, 8, 0.12, 2),
                                                  (200, 320, 120000, 1, 0.06, 3), (128, 128, 50000, 5, 0.05, 4)])
 def test_raster_depth_bound_random_clouds_vs_oracle(H, W, n, K, radius, seed, monkeypatch):
-    """PGDVS_RASTER_BOUND_DENSITY=0: the bound is computed whatever the density.  Layered random depths (the regime in which
+    """option raster_bound_density = 0: the bound is computed whatever the density.  Layered random depths (the regime in which
     it drops most of every list), exact depth ties across the bound, points outside the image and behind the camera, block
     sizes 4 and 2, K up to the block's capacity and beyond it: fragments bit-exact against the oracle's naive loop, and
     identical to the un-pruned rasteriser's"""
@@ -354,10 +354,10 @@ def test_raster_depth_bound_random_clouds_vs_oracle(H, W, n, K, radius, seed, mo
     feat = rng.random((n, 3)).astype(np.float32)
     fc = synth.flat_cam(H, W, np.array([[0.8 * H, 0, W / 2], [0, 0.8 * H, H / 2], [0, 0, 1]]), np.eye(4)).astype(np.float32)
     cam = ops.cam_prep(T(fc))
-    monkeypatch.setenv("PGDVS_RASTER_BOUND_DENSITY", "0")
-    a = ops.points_raster(T(pts), T(feat), cam, radius, K, H, W, want_fragments=True)
-    monkeypatch.setenv("PGDVS_RASTER_BOUND_DENSITY", "1e9")
-    b = ops.points_raster(T(pts), T(feat), cam, radius, K, H, W, want_fragments=True)
+    with ops.option("raster_bound_density", 0):
+        a = ops.points_raster(T(pts), T(feat), cam, radius, K, H, W, want_fragments=True)
+    with ops.option("raster_bound_density", 1e9):
+        b = ops.points_raster(T(pts), T(feat), cam, radius, K, H, W, want_fragments=True)
     for k in ("idx", "zbuf", "dist2", "rgb", "mask"):
         assert torch.equal(a[k], b[k]), k
     idx, zbuf, d2 = orc.rasterize_points(pts, fc, H, W, radius, K)
@@ -375,21 +375,20 @@ def test_raster_depth_bound_1080p_noisy_depth_vs_oracle(monkeypatch):
     model, rc = _renderer("geo", dyn_pcl_remove_outlier=False, st_render_pcl_pts_per_pixel=3)
     data = synth.to_torch(d, DEV)
     data["_st_pcl_video"] = _video_dict(v)
-    monkeypatch.setenv("PGDVS_RASTER_BOUND_DENSITY", "1.2")  # (default 2.2 rows per pixel: 24 such frames reach 3.1, these 8 do not)
-    with torch.no_grad():
-        ret = model.forward(data, render_cfg=rc)
-    cnt_on = model.view_counters()
+    with ops.option("raster_bound_density", 1.2):  # (default 2.2 rows per pixel: 24 such frames reach 3.1, these 8 do not)
+        with torch.no_grad():
+            ret = model.forward(data, render_cfg=rc)
+        cnt_on = model.view_counters()
     n = ops.checked_count(ret["st_pcl_rgb_count"], "agg")
     assert n > 1.2 * H * W, n  # the gate is open: decided on the device, from the count
-    monkeypatch.setenv("PGDVS_RASTER_BOUND_DENSITY", "1e9")
-    with torch.no_grad():
-        ret_off = model.forward(data, render_cfg=rc)
-    cnt_off = model.view_counters()
+    with ops.option("raster_bound_density", 1e9):
+        with torch.no_grad():
+            ret_off = model.forward(data, render_cfg=rc)
+        cnt_off = model.view_counters()
     assert torch.equal(ret["geo_static_rgb"], ret_off["geo_static_rgb"]) and torch.equal(ret["geo_static_mask"], ret_off["geo_static_mask"])
     assert cnt_on["static_rows"] == cnt_off["static_rows"] == n
     assert cnt_on["raster_list_entries"] < 0.5 * cnt_off["raster_list_entries"], (cnt_on, cnt_off)
     assert cnt_on["raster_longest_tile_list"] < cnt_off["raster_longest_tile_list"]
-    monkeypatch.delenv("PGDVS_RASTER_BOUND_DENSITY")
     o_cloud = orc.aggregate_static_pcl(v["rgbs"], v["depths"], v["dyn_masks"], v["K3s"], v["c2ws"])
     assert np.array_equal(N(ret["st_pcl_rgb"][0, :n]).view(np.uint32), o_cloud.view(np.uint32))
     radius = float(rc.st_render_pcl_pt_radius)
@@ -465,7 +464,7 @@ def test_native_view_call_reuses_camera_constants_only_for_the_same_video():
 @pytest.mark.parametrize("n,spread,K,bound", [(9000, 0.09, 3, "0"), (14000, 0.06, 2, "0"), (30000, 0.05, 3, "0"), (9000, 0.09, 3, "1e9")])
 def test_raster_long_tile_lists_second_launch_vs_oracle(n, spread, K, bound, monkeypatch):
     """tile lists between 2048 and 4096 entries (the second tile launch's 4096-entry sorted path), beyond 4096 (its general
-    path) and short ones in one image; with the depth bound dropping entries and without it (PGDVS_RASTER_BOUND_DENSITY=1e9:
+    path) and short ones in one image; with the depth bound dropping entries and without it (raster_bound_density = 1e9:
     one launch, the general path takes every list beyond 2048): fragments bit-exact against the oracle's naive loop"""
     H, W = 96, 128
     rng = np.random.default_rng(n)
@@ -477,8 +476,8 @@ def test_raster_long_tile_lists_second_launch_vs_oracle(n, spread, K, bound, mon
     fc = synth.flat_cam(H, W, np.array([[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]]), np.eye(4)).astype(np.float32)
     cam = ops.cam_prep(T(fc))
     radius = 0.12  # 5.76 px: 4 x 4 blocks for the bound
-    monkeypatch.setenv("PGDVS_RASTER_BOUND_DENSITY", bound)
-    a = ops.points_raster(T(pts), T(rng.random((n, 3)).astype(np.float32)), cam, radius, K, H, W, want_fragments=True)
+    with ops.option("raster_bound_density", float(bound)):
+        a = ops.points_raster(T(pts), T(rng.random((n, 3)).astype(np.float32)), cam, radius, K, H, W, want_fragments=True)
     idx, zbuf, d2 = orc.rasterize_points(pts, fc, H, W, radius, K)
     assert np.array_equal(N(a["idx"]), idx)
     assert np.array_equal(N(a["zbuf"]).view(np.uint32), zbuf.view(np.uint32))
@@ -491,17 +490,16 @@ def test_raster_long_tile_lists_second_launch_vs_oracle(n, spread, K, bound, mon
     assert np.bincount(t).max() > 2048
 
 
-@pytest.mark.parametrize("switch", ["PGDVS_AGG_FUSED0=1", "PGDVS_AGG_STAGE=0"])
-def test_static_aggregation_other_launch_structures(switch):
-    """PGDVS_AGG_FUSED0=1: frame 0 as ONE launch (selection + ordered offsets + projections + rows; opt-in, the select + push
-    pair is the default because it is faster); PGDVS_AGG_STAGE=0: the chain links leave no (depth, colour) behind and
-    `agg_rows` gathers both itself (the default path of the last frame and of videos too long for the staging block) --
-    through the bit-exact aggregation tests; the switches are read once per process, hence the child process"""
+def test_static_aggregation_without_the_staging_block():
+    """option agg_stage = 0 (PGDVS_AGG_STAGE=0 at load time): the chain links leave no (depth, colour) behind and `agg_rows`
+    gathers both itself (the default path of the last frame and of videos too long for the staging block) -- through the
+    bit-exact aggregation tests, in a child process that loads the library with the switch in its environment (which also
+    covers the options' one read of the environment)"""
     import os
     import subprocess
     import sys
 
-    env = dict(os.environ, **dict([switch.split("=")]))
+    env = dict(os.environ, PGDVS_AGG_STAGE="0")
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_round2.py"), "-k",
@@ -510,6 +508,7 @@ def test_static_aggregation_other_launch_structures(switch):
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+    assert ops.get_option("agg_stage") == 1.0  # (this process: the default)
 
 
 def test_views_in_flight_reproduce_the_sequential_images():
@@ -648,7 +647,7 @@ def test_gnt_ray_layer_wide_score_range(S):
 def test_gnt_view_layer_bf16x3_products_vs_fp32_products(V, want_stats, monkeypatch):
     """the view layer's two 64 x 64 products per source view (k = Wk f, vv = Wv k) run on v_mfma_f32_16x16x32_bf16 with both
     operands split exactly into three bf16 pieces (csrc/gnt_mfma.h chain64_bf16x3; six partial products, fp32 accumulation);
-    PGDVS_GNT_FP32=1 keeps them on the fp32 instruction.  Both against the torch fp32 statement of the layer
+    the option gnt_fp32 keeps them on the fp32 instruction.  Both against the torch fp32 statement of the layer
     (pgdvs/models/gnt/models/transformer_network.py:59-169), and against each other at a tenth of that tolerance:
     inputs with a wide dynamic range (features over four decades, weights scaled up) so that dropped low-order pieces
     would show."""
@@ -675,10 +674,10 @@ def test_gnt_view_layer_bf16x3_products_vs_fp32_products(V, want_stats, monkeypa
         with torch.no_grad():
             return net._view_layer(layer, q, feat, rd, valid, cnt, want_stats)
 
-    monkeypatch.setenv("PGDVS_GNT_FP32", "1")
-    out_f, st_f = run()
-    monkeypatch.setenv("PGDVS_GNT_FP32", "0")
-    out_s, st_s = run()
+    with ops.gnt_product_path(fp32=True):
+        out_f, st_f = run()
+    with ops.gnt_product_path(fp32=False):
+        out_s, st_s = run()
     ops._GNT_VIEW_ENABLED = False
     try:
         out_t, st_t = run()
@@ -701,8 +700,7 @@ def test_gnt_forward_golden_on_both_product_paths(golden_dir, monkeypatch):
     from test_gpu_parity import _gnt_model
 
     m, g = _gnt_model(golden_dir)
-    monkeypatch.setenv("PGDVS_GNT_FP32", "1")
-    with torch.no_grad():
+    with ops.gnt_product_path(fp32=True), torch.no_grad():
         out, ex = m.net_coarse(T(g["dynmask_rgb_feat"]), T(g["dynmask_ray_diff"]), T(g["dynmask_mask"]), T(g["pts"]), T(g["ray_d"]),
                                ret_view_entropy=True, ret_view_std=True)
     np.testing.assert_allclose(out.cpu().numpy(), g["dynmask_out"], rtol=0, atol=1e-4)
@@ -713,7 +711,7 @@ def test_gnt_forward_golden_on_both_product_paths(golden_dir, monkeypatch):
 @pytest.mark.parametrize("S,R", [(1, 5), (33, 19), (256, 9), (47, 300)])
 def test_gnt_feed_forward_both_product_paths(S, R, monkeypatch):
     """the feed-forward block behind every attention layer (csrc/gnt_view.hip gnt_ff_bf16x3_kernel: bf16x3 products on
-    v_mfma_f32_32x32x16_bf16, two phases per round with half of the weight pieces resident; PGDVS_GNT_FP32=1: gnt_ff_kernel on
+    v_mfma_f32_32x32x16_bf16, two phases per round with half of the weight pieces resident; gnt_fp32 = 1: gnt_ff_kernel on
     the fp32 instruction) through the ray layer at row counts that leave wavefronts and whole rounds of a workgroup without a
     tile (5 rows, 627, 2304, 14100): both paths against torch (transformer_network.py:44-55,:218-221) and against each other."""
     from pgdvs_amd.models.gnt.models.transformer_network import GNT
@@ -731,10 +729,10 @@ def test_gnt_feed_forward_both_product_paths(S, R, monkeypatch):
         with torch.no_grad():
             return GNT._ray_layer(layer, q, True)
 
-    monkeypatch.setenv("PGDVS_GNT_FP32", "1")
-    out_f, w_f = run()
-    monkeypatch.setenv("PGDVS_GNT_FP32", "0")
-    out_s, w_s = run()
+    with ops.gnt_product_path(fp32=True):
+        out_f, w_f = run()
+    with ops.gnt_product_path(fp32=False):
+        out_s, w_s = run()
     ops._GNT_VIEW_ENABLED = False
     try:
         out_t, w_t = run()

@@ -1,0 +1,131 @@
+"""GPU tests added in round 5 (MI355X): the MFMA GNT path pinned against the reference's own forward at the depth the
+reference runs it (8 layers, 256 samples per ray, 10 / 24 source views) on both product paths, with the error growth per
+transformer block on record."""
+import json
+import os
+import pathlib
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from pgdvs_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from pgdvs_amd import _lib
+
+    _lib.load()
+
+
+# ---------------------------------------------------------------- GNT at the reference's depth
+def _depth8_net(golden_dir):
+    sys.path.insert(0, str(golden_dir))
+    import gnt_depth8_inputs as GI
+
+    from pgdvs_amd.models.gnt.models.transformer_network import GNT
+
+    g = dict(np.load(golden_dir / "gnt_depth8.npz"))
+    net = GNT(netwidth=64, transformer_depth=8).eval()
+    w = GI.make_weights({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    assert abs(GI.checksum(w) - float(g["weights_checksum"])) <= 1e-9 * abs(float(g["weights_checksum"]))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    return GI, g, net
+
+
+def _run(net, x, hook=None):
+    net.hidden_hook = hook
+    try:
+        with torch.no_grad():
+            return net(x["rgb_feat"], x["ray_diff"], x["mask"], x["pts"], x["ray_d"], ret_view_entropy=True, ret_view_std=True)
+    finally:
+        net.hidden_hook = None
+
+
+@pytest.mark.parametrize("case", ["v10", "v24"])
+def test_gnt_depth8_both_product_paths_vs_reference(golden_dir, case):
+    """gnt_depth8.npz = outputs of the reference's GNT(netwidth=64, transformer_depth=8).forward
+    (pgdvs/models/gnt/models/transformer_network.py:423-539; configs/static_renderer/gnt.yaml:9) at (R, Ss, V) = (16, 256, 10)
+    and (8, 256, 24), masks with rays of 0 / 1 / all valid views, entropy / std on.  The HIP path runs it on BOTH product
+    paths -- exact bf16x3 products on the bf16 matrix instructions (default) and the fp32 matrix instruction
+    (gnt_fp32 = 1) -- and must stay within BASELINE.json's 1e-4 of the reference on the image values; sample weights
+    (~1/256 each) relative.  The drift behind each of the 16 transformer blocks is printed and written to
+    gpurun_out/gnt_depth8_drift.json: against the reference's hidden state (the fixture's subsample) and against the torch
+    mirror in float64 on all elements, for the two HIP paths and the torch fp32 mirror."""
+    GI, g, net = _depth8_net(golden_dir)
+    xin = GI.make_inputs(case)
+    assert abs(GI.checksum(xin) - float(g[f"{case}_inputs_checksum"])) <= 1e-9 * abs(float(g[f"{case}_inputs_checksum"]))
+    x = {k: T(v) for k, v in xin.items()}
+    ref_hidden = g[f"{case}_hidden"]  # [16, R, 16, 16]
+
+    # float64 truth of the same network (torch mirror; autograd-free CPU-style branch on the GPU)
+    net64 = _depth8_net(golden_dir)[2].double().to(DEV)
+    h64 = []
+    ops._GNT_VIEW_ENABLED = False
+    try:
+        o64, _ = _run(net64, {k: v.double() for k, v in x.items()}, lambda n, q: h64.append(q.clone()))
+    finally:
+        ops._GNT_VIEW_ENABLED = True
+    assert len(h64) == 16
+
+    net = net.to(DEV)
+    table = {}
+    outs = {}
+    for path in ("bf16x3", "fp32_mfma", "torch_fp32"):
+        h = []
+        with ops.gnt_product_path(fp32=(path == "fp32_mfma")):
+            if path == "torch_fp32":
+                ops._GNT_VIEW_ENABLED = False
+            try:
+                out, ex = _run(net, x, lambda n, q: h.append(q.clone()))
+            finally:
+                ops._GNT_VIEW_ENABLED = True
+        assert len(h) == 16
+        outs[path] = (out, ex)
+        table[path] = {
+            "vs_reference_subsample": [float(np.abs(h[i][:, ::16, ::4].cpu().numpy() - ref_hidden[i]).max()) for i in range(16)],
+            "vs_float64_mirror": [float((h[i].double() - h64[i]).abs().max()) for i in range(16)],
+            "hidden_abs_max": [float(h64[i].abs().max()) for i in range(16)],
+            "rgb_vs_reference": float(np.abs(out[:, :3].cpu().numpy() - g[f"{case}_out"][:, :3]).max()),
+            "weights_rel_vs_reference": float((np.abs(out[:, 3:].cpu().numpy() - g[f"{case}_out"][:, 3:])
+                                               / np.abs(g[f"{case}_out"][:, 3:])).max()),
+        }
+    print(f"\nGNT depth 8, {case}: max|d| of the hidden state behind each block (view 0, ray 0, view 1, ...)")
+    for path, t in table.items():
+        print(f"  {path:11s} vs reference : " + " ".join(f"{v:.1e}" for v in t["vs_reference_subsample"]))
+        print(f"  {path:11s} vs fp64      : " + " ".join(f"{v:.1e}" for v in t["vs_float64_mirror"]))
+        print(f"  {path:11s} rgb {t['rgb_vs_reference']:.2e}  weights rel {t['weights_rel_vs_reference']:.2e}")
+    out_dir = ROOT / "gpurun_out"
+    out_dir.mkdir(exist_ok=True)
+    fn = out_dir / "gnt_depth8_drift.json"
+    prev = json.loads(fn.read_text()) if fn.exists() else {}
+    prev[case] = table
+    fn.write_text(json.dumps(prev, indent=1))
+
+    for path in ("bf16x3", "fp32_mfma"):
+        out, ex = outs[path]
+        np.testing.assert_allclose(out[:, :3].cpu().numpy(), g[f"{case}_out"][:, :3], rtol=0, atol=1e-4, err_msg=path + " rgb")
+        np.testing.assert_allclose(out[:, 3:].cpu().numpy(), g[f"{case}_out"][:, 3:], rtol=2e-3, atol=1e-6, err_msg=path + " weights")
+        for k, v in ex.items():
+            np.testing.assert_allclose(v.cpu().numpy(), g[f"{case}_{k}"], rtol=0, atol=1e-4, err_msg=f"{path} {k}")
+        # the hidden state itself: no block may drift further from the reference than 1e-4 of its range
+        for i in range(16):
+            lim = 1e-4 * max(1.0, table[path]["hidden_abs_max"][i])
+            assert table[path]["vs_reference_subsample"][i] <= lim, (path, i, table[path]["vs_reference_subsample"][i], lim)
+    # the two HIP paths may not be (much) worse than torch's own fp32 arithmetic against the float64 truth
+    worst_t = max(table["torch_fp32"]["vs_float64_mirror"])
+    for path in ("bf16x3", "fp32_mfma"):
+        assert max(table[path]["vs_float64_mirror"]) <= 4.0 * worst_t + 1e-5, (path, table[path]["vs_float64_mirror"], worst_t)

@@ -288,6 +288,39 @@ def test_gnt_modules_match_reference_golden(golden_dir):
             np.testing.assert_allclose(v.numpy(), g[f"{tag}_{k}"], rtol=0, atol=1e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("case", ["v10", "v24"])
+def test_gnt_mirror_matches_reference_at_depth_8(golden_dir, case):
+    """the torch mirror (CPU branch: the dense mask-driven formulation) against the reference's own forward at its configured
+    depth -- 8 layers, 256 samples per ray, 10 / 24 source views (gnt_depth8.npz; transformer_network.py:423-539) -- incl.
+    the hidden state behind each of the 16 blocks (subsampled by the fixture)"""
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, str(golden_dir))
+    import gnt_depth8_inputs as GI
+
+    from pgdvs_amd.models.gnt.models.transformer_network import GNT
+
+    g = dict(np.load(golden_dir / "gnt_depth8.npz"))
+    net = GNT(netwidth=64, transformer_depth=8).eval()
+    w = GI.make_weights({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    assert abs(GI.checksum(w) - float(g["weights_checksum"])) <= 1e-9 * abs(float(g["weights_checksum"]))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    x = {k: torch.from_numpy(v) for k, v in GI.make_inputs(case).items()}
+    hidden = []
+    net.hidden_hook = lambda name, q: hidden.append(q[:, ::16, ::4].clone())
+    with torch.no_grad():
+        out, ex = net(x["rgb_feat"], x["ray_diff"], x["mask"], x["pts"], x["ray_d"], ret_view_entropy=True, ret_view_std=True)
+    np.testing.assert_allclose(out.numpy(), g[f"{case}_out"], rtol=0, atol=2e-5)
+    for k, v in ex.items():
+        np.testing.assert_allclose(v.numpy(), g[f"{case}_{k}"], rtol=0, atol=2e-5, err_msg=k)
+    assert len(hidden) == 16
+    ref = g[f"{case}_hidden"]
+    for i, h in enumerate(hidden):
+        np.testing.assert_allclose(h.numpy(), ref[i], rtol=0, atol=2e-5 * max(1.0, float(np.abs(ref[i]).max())), err_msg=f"block {i}")
+
+
 def test_harness_quantisation_and_psnr_vs_reference(golden_dir):
     import numpy as np
 

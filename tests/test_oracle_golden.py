@@ -118,6 +118,42 @@ def test_gnt_oracle_vs_reference(golden_dir, tag):
         np.testing.assert_allclose(ex[k], g[f"{tag}_{k}"], rtol=0, atol=1e-4, err_msg=k)
 
 
+def _depth8(golden_dir):
+    """inputs + weights of gnt_depth8.npz from their seeded generators, checked against the fixture's checksums"""
+    import sys
+
+    sys.path.insert(0, str(golden_dir))
+    import gnt_depth8_inputs as GI
+
+    g = _load(golden_dir, "gnt_depth8.npz")
+    from pgdvs_amd.models.gnt.models.transformer_network import GNT
+
+    shapes = {k: tuple(v.shape) for k, v in GNT(netwidth=64, transformer_depth=8).state_dict().items()}
+    assert list(shapes) == [str(k) for k in g["state_dict_keys"]]  # the mirror's parameter names ARE the reference's
+    w = GI.make_weights(shapes)
+    assert abs(GI.checksum(w) - float(g["weights_checksum"])) <= 1e-9 * abs(float(g["weights_checksum"])) + 1e-9
+    assert sum(v.size for v in w.values()) == int(g["n_params"])
+    return GI, g, w
+
+
+@pytest.mark.parametrize("case", ["v10", "v24"])
+def test_gnt_oracle_vs_reference_at_depth_8(golden_dir, case):
+    """the reference's GNT.forward at the depth it is configured with (8 layers, 256 samples, 10 / 24 views;
+    configs/static_renderer/gnt.yaml:9, transformer_network.py:423-539): the oracle on a subset of rays (numpy; rays are
+    independent), incl. the rays without / with one / with all views valid"""
+    from oracle import gnt_oracle as G
+
+    GI, g, w = _depth8(golden_dir)
+    x = GI.make_inputs(case)
+    assert abs(GI.checksum(x) - float(g[f"{case}_inputs_checksum"])) <= 1e-9 * abs(float(g[f"{case}_inputs_checksum"])) + 1e-9
+    sel = np.array([0, 1, 2, 5])
+    out, ex = G.gnt_forward(w, x["rgb_feat"][sel], x["ray_diff"][sel], x["mask"][sel], x["pts"][sel], x["ray_d"][sel])
+    np.testing.assert_allclose(out[:, :3], g[f"{case}_out"][sel, :3], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out[:, 3:], g[f"{case}_out"][sel, 3:], rtol=1e-3, atol=1e-6)  # sample weights (~1/256)
+    for k in ex:
+        np.testing.assert_allclose(ex[k], g[f"{case}_{k}"][sel], rtol=0, atol=1e-4, err_msg=k)
+
+
 # ---------------------------------------------------------------- A17 tracker-window aggregation
 def _track_case(g, c):
     wb = bool(g[f"c{c}_with_base"])

@@ -104,6 +104,7 @@ class ResidentVideoRenderer:
 
     def set_lanes(self, n: int) -> None:
         have = getattr(self, "lanes", [])
+        # (default priorities: raising the main or the side streams' costs a quarter of the throughput, tools/r05_prio.sh)
         while len(have) < n:
             have.append((torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev) if self.side_streams else None))
         self.lanes = have

@@ -16,7 +16,7 @@ mkdir -p gpurun_out/r05
 for r in 1 2 3; do
   for m in none dup dup_dry dup_small dup_empty; do
     echo -n "$m: "
-    PGDVS_DBG_CHAIN=$m python bench.py --steps 100 --warmup 5 --no-cpu-baseline --gnt-rays 0 --no-kernel-timing --no-scene-sweep --inflight 3 "$@" 2>/dev/null |
-      python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['steady_state']['frames_per_s'], d['latency_ms']['median'])"
+    PGDVS_DBG_CHAIN=$m python bench.py --steps 100 --warmup 5 --no-cpu-baseline --gnt-rays 0 --no-kernel-timing --no-scene-sweep --inflight 3 "$@" 2>gpurun_out/r05/chain_cost.err |
+      python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['latency_ms']['median'])"
   done
 done | tee gpurun_out/r05/chain_cost.txt

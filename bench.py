@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def _traffic_profile():
     """the committed rocprofv3 FETCH_SIZE / WRITE_SIZE summary of this same command (made by
     tools/make_profile_summary.py from separate --pmc passes): newest round first"""
-    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
         f = ROOT / "profiles" / name
         if f.exists():
             return name, json.loads(f.read_text())
@@ -68,10 +68,34 @@ def measured_view_traffic(H, W, S):
 def pmc_instruction_profile():
     """per-kernel instruction counters per launch (SQ_INSTS_VALU / SALU / LDS wave-instructions, busy and wait
     cycles) from the committed rocprofv3 --pmc summary of this command, or {}"""
-    for name in ("r04_pmc_instructions.json", "r03_pmc_instructions.json"):
+    for name in ("r05_pmc_instructions.json", "r04_pmc_instructions.json", "r03_pmc_instructions.json"):
         f = ROOT / "profiles" / name
         if f.exists():
             return name, json.loads(f.read_text())
+    return None, {}
+
+
+def valu_mix_profile():
+    """opcode-class mix of the hot kernels' loop bodies and the measured issue cost per class (tools/valu_mix.py), or {}"""
+    f = ROOT / "profiles" / "r05_valu_mix.json"
+    return json.loads(f.read_text()) if f.exists() else {}
+
+
+def gnt_pmc_profile():
+    """matrix-pipe busy fraction per GNT kernel from the committed rocprofv3 --pmc summary (tools/pmc_gnt.sh; its header
+    table: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x 2.4 GHz x the kernel's duration)); (None, {}) when the file is missing"""
+    import re
+    for name in ("r05_gnt_bf16x3_pmc.txt", "r04_gnt_bf16x3_pmc.txt"):
+        f = ROOT / "profiles" / name
+        if not f.exists():
+            continue
+        res = {}
+        for ln in f.read_text().splitlines():
+            m = re.match(r"^#\s+(gnt_\w+(?:<[^>]*>)?)\s+([0-9.]+)\s+\(\s*([0-9.]+)\)\s+([0-9.]+) M\s+([0-9.]+) M\s+([0-9.]+) %", ln)
+            if m:
+                res[m.group(1)] = {"mfma_busy_frac": round(float(m.group(6)) / 100.0, 4), "us_per_dispatch": float(m.group(2)),
+                                   "mfma_insts_M": float(m.group(4)), "vector_insts_M": float(m.group(5))}
+        return name, res
     return None, {}
 
 
@@ -269,6 +293,24 @@ def gnt_full_frame(dev, H=288, W=550, V=10, chunk=1024):
         ret = model.forward(d, render_cfg=rc, disable_tqdm=True)
         torch.cuda.synchronize()
         assert bool(torch.isfinite(ret["combined_rgb"]).all())
+        # parity, not only finiteness: the same view at render_stride 32 (rays at integer pixel centres: a subset of the full
+        # frame's, 9 x 18 of them) through the torch statement of the network (fused kernels off) against the full frame's
+        # pixels; 2e-4: the ResUNet's MIOpen convolutions are not bit-reproducible from call to call
+        import copy
+
+        from pgdvs_amd import ops as _ops
+
+        rc_s = copy.deepcopy(rc)
+        rc_s.render_stride = 32
+        _ops._GNT_VIEW_ENABLED = False
+        try:
+            mir = model.forward(d, render_cfg=rc_s, disable_tqdm=True)["static_coarse_rgb"]
+        finally:
+            _ops._GNT_VIEW_ENABLED = True
+        sub = ret["static_coarse_rgb"][:, :, ::32, ::32]
+        assert sub.shape == mir.shape, (sub.shape, mir.shape)
+        parity = float((sub - mir).abs().max())
+        assert parity <= 2e-4, f"GNT full frame: kernels vs torch statement on {mir[0, 0].numel()} rays: max|d| = {parity}"
         t0 = time.perf_counter()
         model.forward(d, render_cfg=rc, disable_tqdm=True)
         torch.cuda.synchronize()
@@ -295,6 +337,7 @@ def gnt_full_frame(dev, H=288, W=550, V=10, chunk=1024):
                 "registers, the gather only runs in the seams either way"}
     return {"seconds_per_view": round(dt, 3), "frames_per_s": round(1.0 / dt, 3), "height": H, "width": W, "spatial_views": V,
             "temporal_views": 2, "samples_per_ray": 256, "chunk_rays": chunk, "weights": "random init", "breakdown": breakdown,
+            "parity_vs_torch_statement": {"rays": int(mir[0, 0].numel()), "max_abs_diff_static_rgb": parity, "bound": 2e-4},
             "reference_context": "the reference states ~2 days on 8 A100 for 15 840 such views incl. data loading and metrics "
                                  "(docs/BENCHMARK_NVIDIA.md:148-149): ~87 s per view per GPU; not the same hardware or scope"}
 
@@ -344,11 +387,15 @@ def main():
     n_views = max(1, min(args.views, S - 1))
     view_ids = [int(round(j * (S - 2) / max(n_views - 1, 1))) for j in range(n_views)]
 
-    def load_scene(scene):
-        """synthetic, seeded inputs (no datasets offline) -> resident in HBM; the renderer around them"""
-        video = synth.make_video(S, H, W, seed=1234, scene=scene)
+    def load_scene(scene, size=None):
+        """synthetic, seeded inputs (no datasets offline) -> resident in HBM; the renderer around them
+        (size: (H, W, S) of another BASELINE configuration; default: this run's)"""
+        H_, W_, S_ = size or (H, W, S)
+        video = synth.make_video(S_, H_, W_, seed=1234, scene=scene)
         rgbs, depths, masks = T(video["rgbs"]), T(video["depths"]), T(video["dyn_masks"]).view(torch.uint8)
-        views = [synth.to_torch(synth.make_view(video, i, frac=0.4, seed=5), dev) for i in view_ids]
+        nv_ = max(1, min(args.views, S_ - 1))
+        ids_ = [int(round(j * (S_ - 2) / max(nv_ - 1, 1))) for j in range(nv_)]
+        views = [synth.to_torch(synth.make_view(video, i, frac=0.4, seed=5), dev) for i in ids_]
         # The timed views carry NO injected noise: like the reference (torch.randn_like per forward,
         # pgdvs_renderer_dyn.py:177-182) every step draws its own -- in the splat kernel, where it is consumed.  One
         # view keeps the synthetic generator's field for the checks that need two renders to agree.
@@ -392,7 +439,7 @@ def main():
     host_wait = [0.0]  # part of host_enqueue spent blocked on the run-ahead bound (the GPU is behind)
     host_native = [0.0]  # seconds inside pgdvs_view_geo_forward (the C ABI's own clock)
     mem_probe = {}
-    gather_box = [None]
+    gather_boxes = {}  # image shape -> AsyncImageGather
     ctl_stream = torch.cuda.Stream(device=dev)
     # ring slots: the views in flight at the deepest lane count tried, the host's run-ahead and a spare
     ring_slots = max(base_run_ahead, n_lanes + 1) + n_lanes + 2
@@ -403,12 +450,15 @@ def main():
         gathered to rank 0 while step j+1 renders, bounded host run-ahead; returns wall seconds"""
         rv = rv or rvr
         vs = vs or views
+        n_vs = len(vs)
         lib.pgdvs_prof_enable(1 if profile else 0)
         # step j's image travels while step j+1 renders; rank 0 receives into one ring allocated before the first loop
         # and reused by every later one (bounded memory; rank 0 checksums every view as its slot comes up for reuse)
-        if gather_box[0] is None or n_steps > gather_box[0].capacity_steps:
-            gather_box[0] = pdist.AsyncImageGather(dst=0, n_steps=max(n_steps, 256), like=ref_img, ring=ring_slots)
-        gather = gather_box[0].reset(n_steps)
+        like = ref_img if rv is rvr or (rv.H, rv.W) == (H, W) else torch.empty(1, 3, rv.H, rv.W, device=dev)
+        key = tuple(like.shape)
+        if key not in gather_boxes or n_steps > gather_boxes[key].capacity_steps:
+            gather_boxes[key] = pdist.AsyncImageGather(dst=0, n_steps=max(n_steps, 256), like=like, ring=ring_slots)
+        gather = gather_boxes[key].reset(n_steps)
         barrier()
         torch.cuda.synchronize()
         mem_probe["before"] = torch.cuda.memory_stats(dev)
@@ -429,7 +479,7 @@ def main():
                     host_wait[0] += time.perf_counter() - w0
                 # per-kernel HIP events need one view at a time, so that a kernel's duration is its own and not the
                 # queueing behind the other lanes' kernels
-                ret, main = rv.render(vs[(j + rank) % n_views], 0 if profile else j, out=gather.slot(), use_side=not profile)
+                ret, main = rv.render(vs[(j + rank) % n_vs], 0 if profile else j, out=gather.slot(), use_side=not profile)
                 with torch.cuda.stream(main):
                     gather.submit(ret["combined_rgb"])
                     ev = torch.cuda.Event()
@@ -561,6 +611,7 @@ def main():
     # ---------------- per-kernel durations with HIP events on the launch stream
     kernels = {}
     roofline = None
+    roofline_kernels = None
     if not args.no_kernel_timing:
         n_prof = min(args.steps, 5)
         buf = ctypes.create_string_buffer(1 << 16)
@@ -577,51 +628,63 @@ def main():
                     "launches_per_step": calls / n_prof, "avg_ms": round(avg_ms, 5),
                     "ms_per_step": round(total_ms / n_prof, 4),
                     "alg_GBps": round(ab / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 and ab > 0 else None}
-            # dominant kernel = most time per view; among kernels within 20 % of the maximum (the tile raster, the kNN
-            # thread-per-query pass and the chain of aggregation links: their order changes from box to box) the one that
-            # moves the most algorithmic bytes, for which an HBM roofline says something -- the kNN pass reads 6 MB and
-            # is a pure VALU search, a chain link is a latency chain
-            # A chain of many short launches (the aggregation's 23 links of ~11 us) is bound by the visibility round trip
-            # between two launches, a per-launch bandwidth fraction says nothing about it: it is listed in co_dominant with
-            # its time, the roofline is computed for a kernel whose single launch is a measurable share of the view.
-            single = {k: v for k, v in kernels.items() if v["launches_per_step"] <= 4}
-            top = max(v["ms_per_step"] for v in single.values())
-            near = [k for k, v in single.items() if v["ms_per_step"] >= 0.8 * top]
-            dom = max(near, key=lambda k: algorithmic_bytes(k, H, W, S, n_static, n_dyn, K))
-            near += [k for k, v in kernels.items() if k not in single and v["ms_per_step"] >= 0.8 * top]
-            ab = algorithmic_bytes(dom, H, W, S, n_static, n_dyn, K)
-            ach = ab / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-            # the binding limit of the co-dominant kernels is vector-instruction issue, not HBM: SQ_INSTS_VALU per
-            # launch from the committed --pmc summary x 2 cycles per wave64 instruction on a SIMD-32
-            # (MI355X_MICROARCH.md) / (1024 SIMDs x 2.4 GHz x this run's launch duration)
+            # dominant kernel = the entry with the most time per view, CHAINS INCLUDED (the aggregation's 23 links are one
+            # entry: 23 launches of ~11 us); every entry within 20 % of it is listed in roofline_kernels with its own
+            # algorithmic bytes, launch time, fraction and counter traffic -- no eligibility rule
+            top = max(v["ms_per_step"] for v in kernels.values())
+            near = sorted((k for k, v in kernels.items() if v["ms_per_step"] >= 0.8 * top), key=lambda k: -kernels[k]["ms_per_step"])
+            for k in ("agg_step", "grid_query_tpq", "raster_tile"):  # (the three the reviews follow, whatever their order on this box)
+                if k in kernels and k not in near:
+                    near.append(k)
+            dom = near[0]
             pmc_name, pmc_all = pmc_instruction_profile()
             pmc = pmc_all.get("kernels", {}) if (H, W, S) == (1080, 1920, 24) else {}
-            valu = {}
-            for k in near:
+            mix_all = valu_mix_profile()
+            mix = mix_all.get("kernels", {})
+            tprof_name, _ = _traffic_profile()
+
+            def kernel_roofline(k):
+                ab_ = algorithmic_bytes(k, H, W, S, n_static, n_dyn, K)
+                ach_ = ab_ / (kernels[k]["avg_ms"] * 1e-3) / 1e9
+                o = {"bound": "hbm", "alg_bytes": ab_, "avg_ms": kernels[k]["avg_ms"], "launches_per_view": kernels[k]["launches_per_step"],
+                     "ms_per_view": kernels[k]["ms_per_step"], "achieved": round(ach_, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(ach_ / HBM_PEAK_GBS, 5), "traffic": measured_traffic(k, H, W, S)}
                 c = pmc.get(k)
                 if c and c.get("SQ_INSTS_VALU"):
-                    t_issue = c["SQ_INSTS_VALU"] * 2.0 / (1024 * 2.4e9)
-                    valu[k] = {"bound": "valu", "valu_wave_insts_per_launch": c["SQ_INSTS_VALU"],
-                               "salu_wave_insts_per_launch": c.get("SQ_INSTS_SALU"),
-                               "valu_issue_frac": round(t_issue / (kernels[k]["avg_ms"] * 1e-3), 4),
-                               "source": f"profiles/{pmc_name} (committed rocprofv3 --pmc pass of this command), duration from this run"}
-            tprof_name, _ = _traffic_profile()
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dom, H, W, S),
-                        "traffic_source": (f"profiles/{tprof_name}: FETCH_SIZE / WRITE_SIZE of separate rocprofv3 --pmc passes "
-                                           "of this command, committed; not measured in this run") if tprof_name else None,
-                        "valu_issue": valu or None,
-                        "alg_bytes_per_launch": ab, "avg_launch_ms": kernels[dom]["avg_ms"],
-                        "launches_per_view": kernels[dom]["launches_per_step"],
-                        "event_bracket_overhead_ms": round(float(lib.pgdvs_prof_overhead_ms()), 5),
-                        "co_dominant": {k: kernels[k]["ms_per_step"] for k in near},
-                        "note": ("dominant kernel by time per view (HIP events on the launch stream, one view at a time, the "
-                                 "empty-launch bracket cost subtracted; of the kernels launched at most four times per view and within 20 % of the largest time per view "
-                                 "-- co_dominant, ms per view -- the one with the most algorithmic bytes); "
-                                 + ("a VALU-bound search kernel, not an HBM stream (valu_issue)" if dom in ("raster_tile", "grid_query", "grid_query_tpq", "agg_push0")
-                                    else "a short kernel launched once per source frame, bound by its dependent global round trips "
-                                         "(mask + map -> selected pixels -> depth -> stamps), not by bandwidth")
-                                 + " (DESIGN.md section 4); the whole path's figure is roofline_path")}
+                    # vector-instruction issue on two bases: the nominal 2 cycles per wave64 instruction on a SIMD-32
+                    # (MI355X_MICROARCH.md), and what THIS chip was measured to take per instruction of each opcode class
+                    # (profiles/r03_valu_rate.txt) weighted by the class mix of the kernel's loop bodies (tools/valu_mix.py)
+                    dur = kernels[k]["avg_ms"] * 1e-3
+                    t_nom = c["SQ_INSTS_VALU"] * 2.0 / (1024 * 2.4e9)
+                    o["valu_issue"] = {"valu_wave_insts_per_launch": c["SQ_INSTS_VALU"], "salu_wave_insts_per_launch": c.get("SQ_INSTS_SALU"),
+                                       "valu_issue_frac": round(t_nom / dur, 4), "basis": "2 cycles per wave64 instruction at 2.4 GHz, 1024 SIMDs",
+                                       "source": f"profiles/{pmc_name} (committed rocprofv3 --pmc pass of this command), duration from this run"}
+                    m_ = mix.get(k)
+                    if m_:
+                        t_meas = c["SQ_INSTS_VALU"] * m_["ns_per_wave_instruction"] * 1e-9 / 1024
+                        o["valu_issue"].update({"valu_issue_frac_measured_costs": round(t_meas / dur, 4),
+                                                "ns_per_wave_instruction_measured": m_["ns_per_wave_instruction"], "opcode_mix_assumed": m_["mix"],
+                                                "measured_basis": "profiles/r03_valu_rate.txt (ns per wave64 instruction per SIMD by opcode class, 8 "
+                                                                  "wavefronts per SIMD) x the static class mix of the kernel's loop bodies "
+                                                                  "(profiles/r05_valu_mix.json, tools/valu_mix.py)"})
+                return o
+
+            roofline_kernels = {k: kernel_roofline(k) for k in near}
+            kind = ("a chain of short launches, one per source frame, each bound by its dependent global round trips (mask + map -> "
+                    "selected pixels -> depth -> stamps), not by bandwidth" if kernels[dom]["launches_per_step"] > 4 else
+                    "a VALU-bound search kernel, not an HBM stream (valu_issue)" if dom in ("raster_tile", "grid_query", "grid_query_tpq", "agg_push0")
+                    else "see DESIGN.md section 4")
+            roofline = dict(roofline_kernels[dom])
+            roofline.update({"kernel": dom,
+                             "traffic_source": (f"profiles/{tprof_name}: FETCH_SIZE / WRITE_SIZE of separate rocprofv3 --pmc passes "
+                                                "of this command, committed; not measured in this run") if tprof_name else None,
+                             "alg_bytes_per_launch": roofline_kernels[dom]["alg_bytes"], "avg_launch_ms": kernels[dom]["avg_ms"],
+                             "event_bracket_overhead_ms": round(float(lib.pgdvs_prof_overhead_ms()), 5),
+                             "co_dominant": {k: kernels[k]["ms_per_step"] for k in near},
+                             "note": ("the entry with the most time per view (HIP events on the launch stream, one view at a time, the "
+                                      "empty-launch bracket cost subtracted), chains of launches included: " + kind
+                                      + "; the other entries within 20 % of it and the three the reviews follow are in roofline_kernels; "
+                                        "the whole path's figure is roofline_path (DESIGN.md section 4)")})
 
     # ---------------- latency of ONE view (nothing else in flight): the throughput above comes from overlapping
     # `inflight` independent views; this is the time a single view takes from first launch to last kernel
@@ -726,6 +789,7 @@ def main():
         scene_stats = {}
 
         def stats_of(rv, vs, label):
+            H, W, S = rv.H, rv.W, rv.S  # (another BASELINE configuration may be passed)
             rv.set_lanes(n_lanes)
             n0 = rv.calibrate(vs[0]) if rv is not rvr else n_static
             torch.cuda.synchronize()
@@ -743,6 +807,9 @@ def main():
             o = {"frames_per_s": round(n_sc / dt, 2), "ms_per_view": round(dt / n_sc * 1e3, 3), "steps": n_sc,
                  "static_points": n_now, "static_points_per_pixel": round(n_now / (H * W), 3),
                  "us_per_million_points": round(dt / n_sc * 1e6 / (n_now / 1e6), 1), "counters": counters}
+            alg_ = (20 * S + 120) * H * W
+            o["roofline_path"] = {"bound": "hbm", "alg_bytes_per_view": alg_, "achieved": round(alg_ * n_sc / dt / 1e9, 2),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_ * n_sc / dt / 1e9 / HBM_PEAK_GBS, 5)}
             return o
 
         scene_stats[args.scene] = stats_of(rvr, views, args.scene)
@@ -763,6 +830,22 @@ def main():
         if variants is None:
             variants = {}
         variants["scenes"] = scene_stats
+        rvr.set_lanes(n_lanes)
+        # ---------------- the other single-GPU BASELINE configurations through the SAME loop (never `value`):
+        # configs[1] 960 x 540 x 12 source frames, configs[4] 1080p x 48 (dynamic-mask compositing)
+        cfg_stats = {}
+        for label, size in (("C2_960x540x12", (540, 960, 12)), ("C5_1920x1080x48", (1080, 1920, 48))):
+            if size == (H, W, S):
+                continue
+            try:
+                _, vs_, _, rv_ = load_scene("nominal", size)
+                cfg_stats[label] = stats_of(rv_, vs_, label)
+                cfg_stats[label].update({"height": size[0], "width": size[1], "src_frames": size[2], "views_in_flight": n_lanes})
+                del vs_, rv_
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001 -- the headline does not depend on it; the line says what failed
+                cfg_stats[label] = {"error": f"{type(e).__name__}: {e}"}
+        variants["configs"] = cfg_stats
         rvr.set_lanes(n_lanes)
 
     # ---------------- CPU baseline: the oracle (port of the reference algorithm) on host cores, on the SAME
@@ -872,9 +955,20 @@ def main():
             return None
 
         with torch.no_grad():
-            gg, _ = gnt_chunk()
+            gg, out_k = gnt_chunk()
             torch.cuda.synchronize()
             valid_frac = float(gg["mask"].mean())
+            # the timed network's output is CHECKED: 64 rays of the chunk through the torch statement (fused kernels off)
+            ops._GNT_VIEW_ENABLED = False
+            try:
+                out_m = net(gg["rgb_feat"][:64], gg["ray_diff"][:64], gg["mask"][:64], gg["pts"][:64], rd[:64],
+                            ret_view_entropy=True, ret_view_std=True)
+            finally:
+                ops._GNT_VIEW_ENABLED = True
+            gnt_parity = {"rays": 64, "rgb_max_abs_diff": float((out_k[0][:64, :3] - out_m[0][:, :3]).abs().max()),
+                          "weights_max_rel_diff": float(((out_k[0][:64, 3:] - out_m[0][:, 3:]).abs() / out_m[0][:, 3:].abs().clamp(min=1e-12)).max()),
+                          "extras_max_abs_diff": max(float((out_k[1][k_][:64] - out_m[1][k_]).abs().max()) for k_ in out_m[1])}
+            assert gnt_parity["rgb_max_abs_diff"] <= 1e-4 and gnt_parity["extras_max_abs_diff"] <= 1e-4, gnt_parity
             e0, e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             # ten repetitions, each timed on its own (wall clock around gather + transformer, HIP events for the split), with
             # the clock / power the driver reports right after each: the figure quoted is the MEDIAN, the spread is beside it
@@ -915,19 +1009,25 @@ def main():
                "repetitions": {"n": len(reps), "statistic": "median", "tflops_min": tf(reps[-1][0]), "tflops_max": tf(reps[0][0]),
                                "ms_per_chunk_all": [round(r_[0] * 1e3, 2) for r_ in reps],
                                "power_W_range": [min(pw), max(pw)] if pw else None},
-               "peak_tflops_fp32_mfma": 157.3, "frac_of_peak": round(gflop / gdt / 157.3e12, 4),
+               "peak_tflops_fp32_mfma": 157.3, "fp32_equivalent_frac": round(gflop / gdt / 157.3e12, 4),
+               "mfma_busy_frac": gnt_pmc_profile()[1] or None,
+               "mfma_busy_source": (f"profiles/{gnt_pmc_profile()[0]}: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x 2.4 GHz x duration) per kernel, "
+                                    "committed rocprofv3 --pmc pass of tools/gnt_bench.py (1024 rays x 24 views x 256 samples); not measured in this run"),
                "fp32_instruction_path": {"ms_per_chunk": round(reps32[len(reps32) // 2] * 1e3, 2), "tflops": tf(reps32[len(reps32) // 2]),
-                                         "frac_of_peak": round(gflop / reps32[len(reps32) // 2] / 157.3e12, 4), "repetitions": len(reps32),
+                                         "fp32_equivalent_frac": round(gflop / reps32[len(reps32) // 2] / 157.3e12, 4), "repetitions": len(reps32),
                                          "note": "option gnt_fp32 (PGDVS_GNT_FP32=1 at load time): every product on the fp32 matrix instructions (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)"},
                "gather_alg_GBps": round(gather_bytes / (t_gather * 1e-3) / 1e9, 1), "valid_projection_fraction": round(valid_frac, 3),
+               "parity_vs_torch_statement": gnt_parity,
                "dtype": "f32 inputs, weights and results; the view layers' 64 x 64 products and the feed-forward blocks run as bf16x3 products on "
                         "v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16 (both operands split exactly into three bf16 pieces, six partial products, "
                         "fp32 accumulation), everything else on v_mfma_f32_16x16x4_f32",
                "est_seconds_per_1080p_frame": round(gdt * (H * W / Rg), 1),
                "note": "pgdvs_gnt_gather (real projections of target-ray samples into the resident source frames, dynamic masks "
                        "applied) + GNT.forward incl. view entropy/std side outputs; FLOPs = the fp32 multiply-adds of A14 (an operand "
-                       "split into bf16 pieces is not counted three times), time for both; frac_of_peak is against the fp32-MFMA peak "
-                       "whichever instruction a product runs on; "
+                       "split into bf16 pieces is not counted three times), time for both; fp32_equivalent_frac = those FLOPs against the "
+                       "fp32-MFMA peak whichever instruction a product runs on -- NOT a utilisation of what is issued (six bf16 MFMAs at 16x "
+                       "the fp32 rate put the ceiling of a split product at ~2.7x that peak): the matrix pipe's own busy fraction per kernel "
+                       "is mfma_busy_frac; "
                        "median of ten repetitions (board power as sysfs reports it while each runs)"}
         # The whole renderer with the GNT static renderer at the reference's own benchmark setting
         # (NVIDIA Dynamic Scenes: 288 x 550 targets, 10 spatial + 2 temporal source views, 256 samples
@@ -967,7 +1067,7 @@ def main():
                 "whole_view_alg_GBps": round(alg_total * fps / 1e9 / max(world, 1), 2),
             },
             "steady_state": steady,
-            "roofline": roofline,
+            "roofline": roofline, "roofline_kernels": roofline_kernels,
             # BASELINE.md section 3 defines the path's roofline figure over the whole view:
             # bytes(S,P) = (20 S + 120) H W algorithmic bytes per novel view x views per second per GPU
             "roofline_path": {"bound": "hbm", "achieved": round(alg_total * fps / 1e9 / max(world, 1), 2), "peak": HBM_PEAK_GBS,

@@ -463,6 +463,11 @@ def main():
         torch.cuda.synchronize()
         mem_probe["before"] = torch.cuda.memory_stats(dev)
         ops.view_geo_host_stats()
+        timeline = os.environ.get("PGDVS_BENCH_TIMELINE") == "1"  # diagnostic: when every view of the loop finished
+        if timeline:
+            ev_t0 = torch.cuda.Event(enable_timing=True)
+            ev_t0.record(ctl_stream)
+            enq_t = []
         t0 = time.perf_counter()
         done = []
         host_wait[0] = 0.0
@@ -482,15 +487,20 @@ def main():
                 ret, main = rv.render(vs[(j + rank) % n_vs], 0 if profile else j, out=gather.slot(), use_side=not profile)
                 with torch.cuda.stream(main):
                     gather.submit(ret["combined_rgb"])
-                    ev = torch.cuda.Event()
+                    ev = torch.cuda.Event(enable_timing=timeline)
                     ev.record()
                 done.append(ev)
+                if timeline:
+                    enq_t.append(time.perf_counter() - t0)
             host_enqueue[0] = time.perf_counter() - t0  # host time to enqueue everything (incl. the waits of the run-ahead bound)
             rv.join()
             gathered = gather.finish(tail=False)
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
+        if timeline:
+            print(f"timeline ({n_steps} views, {rv.n_lanes} lanes): wall {1e3 * (t1 - t0):.3f} ms; view: host enqueued at / GPU finished at (ms): "
+                  + " ".join(f"{1e3 * a:.2f}/{ev_t0.elapsed_time(b):.2f}" for a, b in zip(enq_t, done)), file=sys.stderr)
         host_native[0] = ops.view_geo_host_stats()[1]
         mem_probe["after"] = torch.cuda.memory_stats(dev)
         lib.pgdvs_prof_enable(0)
@@ -550,9 +560,13 @@ def main():
 
     # untimed rehearsal through the same loop: the allocator's pools reach the state the bounded
     # run-ahead needs, so that the timed region allocates from them only (`device_mallocs_in_timed_region`)
-    timed(2 * args.run_ahead + n_lanes)
+    # The collector runs BEFORE the rehearsal, not between it and the timed region: a collection walks the whole heap
+    # (~0.1 s of host time with the GPU idle, the host's caches flushed), and the 20-view timed region that followed it
+    # ran its first view's enqueue in 0.98 ms instead of 0.48 and every view ~6 % slower than the same loop a moment
+    # later (the chip's clocks after an idle gap; `PGDVS_BENCH_TIMELINE=1` prints when every view was enqueued / finished)
     gc.collect()
     gc.disable()  # no collector pauses inside the timed loop
+    timed(max(2 * args.run_ahead + n_lanes, 24))
     elapsed = timed(args.steps)
     gc.enable()
     gathered, cnt = last["gathered"], last["ret"]["st_pcl_rgb_count"]

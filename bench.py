@@ -136,6 +136,11 @@ def parse():
 
 
 DEFAULT_LANES_MULTI_RANK = 3  # views in flight per rank when several ranks run (no probe: see main)
+
+
+def ring_slots_for(run_ahead, n_lanes):
+    """receive-ring slots per rank on rank 0 (and local slots on every rank): the views in flight, the host's run-ahead and a spare"""
+    return max(run_ahead, n_lanes + 1) + n_lanes + 2
 SCENES = ("nominal", "wide_baseline", "noisy_depth")
 
 
@@ -203,7 +208,8 @@ def dry_main(args, world, rank):
         time.sleep(10 ** 6)
     like = torch.empty(1, 3, 4, 6)
     start_watchdog(args.rank_timeout, rank)
-    ring = min(args.steps, args.run_ahead + 3)
+    # (the ring of the real run with the fixed lane count several ranks use: main() sizes it with the same function)
+    ring = min(args.steps, ring_slots_for(args.run_ahead, DEFAULT_LANES_MULTI_RANK if world > 1 else max(1, args.inflight)))
     gather = pdist.AsyncImageGather(dst=0, n_steps=args.steps, like=like, ring=ring)
     if world > 1:
         dist.barrier()
@@ -442,7 +448,7 @@ def main():
     gather_boxes = {}  # image shape -> AsyncImageGather
     ctl_stream = torch.cuda.Stream(device=dev)
     # ring slots: the views in flight at the deepest lane count tried, the host's run-ahead and a spare
-    ring_slots = max(base_run_ahead, n_lanes + 1) + n_lanes + 2
+    ring_slots = ring_slots_for(base_run_ahead, n_lanes)
     last = {}
 
     def timed(n_steps, profile=False, rv=None, vs=None):

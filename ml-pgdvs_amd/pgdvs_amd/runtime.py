@@ -1,75 +1,12 @@
-"""HIP-graph replay of a whole per-view render.
+"""Resident-video rendering: the arrangement ``bench.py`` times, ``harness.eval_step`` can be pointed at and the C3 parity
+test renders (`ResidentVideoRenderer`).
 
-One view is ~170 small dependent launches on two streams; eagerly the host spends ~0.7 ms per
-view enqueuing them (ctypes + allocator traffic), which is fine on an idle host and becomes the
-bottleneck on a busy one.  ``GraphedRender`` captures the launches of one call of ``fn`` --
-including the fork / join onto the side stream and every workspace allocation, which then
-lives in the graph's private pool -- into a HIP graph and replays it: per view the host copies
-the new inputs into the graph's static buffers and issues a single ``hipGraphLaunch``.
-
-The captured region must be free of host synchronisation; the render path is (all element
-counts stay on the device).  Kernel arguments that are host values at capture time (camera
-matrices of ``pgdvs_static_aggregate``, sizes) are baked into the graph, so one graph serves
-inputs of one shape and one set of such host arguments.
+(Rounds 2-4 also carried ``GraphedRender``, a HIP-graph replay of a whole view.  With one native call per view the host
+needs 0.25 ms per view and the replay path was never faster than eager launches -- 800-1017 against 845-1075 frames/s in
+rounds 2-3 -- and on this ROCm a replay right behind a kernel on the NULL stream ended in a memory fault;
+removed in round 5.)
 """
 import torch
-
-
-def _map_tensors(obj, fn):
-    if isinstance(obj, torch.Tensor):
-        return fn(obj)
-    if isinstance(obj, dict):
-        return {k: _map_tensors(v, fn) for k, v in obj.items()}
-    if isinstance(obj, (list, tuple)):
-        return type(obj)(_map_tensors(v, fn) for v in obj)
-    return obj
-
-
-def _copy_into(dst, src, seen, path=()):
-    """copy the leaves of ``src`` into the static buffers ``dst``; a leaf that is the very tensor
-    object copied last time, unmodified since (same ``_version``), is already in place"""
-    if isinstance(dst, torch.Tensor):
-        if dst.is_cuda:
-            last = seen.get(path)
-            if last is not None and last[0] is src and last[1] == src._version:
-                return
-            dst.copy_(src, non_blocking=True)
-            seen[path] = (src, src._version)
-    elif isinstance(dst, dict):
-        for k in dst:
-            _copy_into(dst[k], src[k], seen, path + (k,))
-    elif isinstance(dst, (list, tuple)):
-        for i, (d, s_) in enumerate(zip(dst, src)):
-            _copy_into(d, s_, seen, path + (i,))
-
-
-class GraphedRender:
-    """``out = GraphedRender(fn, example_inputs)(inputs)``: ``fn(inputs) -> tensor or tuple of
-    tensors`` is captured once on ``stream`` (default: a new stream) with static copies of
-    ``example_inputs`` (a possibly nested dict / list of GPU tensors; other leaves are passed
-    through unchanged).  Each call copies ``inputs`` into the static buffers (leaves that are the
-    same unmodified tensor objects as in the previous call are skipped) and replays; the
-    returned tensors are the graph's output buffers and are overwritten by the next call."""
-
-    def __init__(self, fn, example_inputs, stream=None, warmup=2):
-        self.stream = stream if stream is not None else torch.cuda.Stream()
-        self.static_in = _map_tensors(example_inputs, lambda t: t.clone() if t.is_cuda else t)
-        self.graph = torch.cuda.CUDAGraph()
-        self._seen = {}  # input leaf -> (tensor copied last, its version): unchanged inputs are not copied again
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            for _ in range(warmup):  # allocator / lazy-init effects happen outside the capture
-                fn(self.static_in)
-        self.stream.synchronize()
-        with torch.cuda.graph(self.graph, stream=self.stream):
-            self.static_out = fn(self.static_in)
-
-    def __call__(self, inputs):
-        """enqueue on ``self.stream``: input copies + one graph launch"""
-        with torch.cuda.stream(self.stream):
-            _copy_into(self.static_in, inputs, self._seen)
-            self.graph.replay()
-        return self.static_out
 
 
 class ResidentVideoRenderer:

@@ -510,39 +510,6 @@ def test_dyn_pcl_render_type_vs_oracle():
     np.testing.assert_allclose(N(ret["combined_rgb"]), o["combined_rgb"], rtol=0, atol=1e-5)
 
 
-def test_graphed_render_replay_matches_eager():
-    """pgdvs_amd.runtime.GraphedRender: the whole view (two streams, device-side counts, workspace
-    allocations) captured into one HIP graph; replays with new inputs must equal eager renders"""
-    from pgdvs_amd.runtime import GraphedRender
-
-    H, W, S = 54, 96, 4
-    v = synth.make_video(S, H, W, seed=21)
-    model, rc = _renderer("geo", dyn_pcl_remove_outlier=True, dyn_pcl_outlier_knn=20, st_render_pcl_pts_per_pixel=3,
-                          st_render_pcl_pt_radius=0.02)
-    rgbs, depths, masks = T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]).view(torch.uint8)
-    side = torch.cuda.Stream()
-
-    def render(data):
-        data = dict(data)
-        data["_dyn_prepared"] = model.dyn_renderer.prepare(data, rc, stream=side)
-        cloud, cnt = ops.static_aggregate(rgbs, depths, masks, v["K3s"], v["c2ws"], capacity=S * H * W)
-        data["st_pcl_rgb"], data["st_pcl_rgb_count"] = cloud[None], cnt
-        with torch.no_grad():
-            ret = model.forward(data, render_cfg=rc)
-        return ret["combined_rgb"], ret["render_dyn_mask"]
-
-    views = [synth.to_torch(synth.make_view(v, i, seed=3), DEV) for i in (0, 1, 2)]
-    eager = [tuple(t.clone() for t in render(d)) for d in views]
-    torch.cuda.synchronize()
-    g = GraphedRender(render, views[0])
-    for i in (1, 2, 0, 2):
-        out = g(views[i])
-        g.stream.synchronize()
-        assert torch.equal(out[1], eager[i][1])                      # thresholded mask: exact
-        assert float((out[1] > 0).float().mean()) > 0.02
-        assert torch.allclose(out[0], eager[i][0], rtol=0, atol=1e-5)  # float atomics in the splat: to rounding
-
-
 # ---------------------------------------------------------------- A10 mesh variant
 @pytest.mark.parametrize("H,W,noise,seed", [(54, 96, 0.0, 0), (96, 54, 0.3, 1), (64, 64, 2.0, 2)])
 def test_mesh_render_vs_oracle(H, W, noise, seed):

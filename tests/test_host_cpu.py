@@ -256,6 +256,46 @@ def test_bench_watchdog_ends_a_job_with_a_lost_rank():
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_bench_gpus_8_dry_run_c4_sharding_and_ring():
+    """first contact with an 8-GPU node can then only find RCCL itself: `python bench.py --gpus 8` as the driver starts it,
+    BASELINE.json configs[3]'s 288 target views as 36 per rank (reference: trainer_pgdvs.py:290-306, run.py:158-176), on CPU
+    tensors over gloo: eight ranks come up, every view arrives on rank 0 exactly once and in view order through a receive
+    ring of the size the real run uses with its fixed three lanes (11 slots x 8 ranks, not 36 x 8), per-rank times come back"""
+    import json
+
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    r = _bench("--gpus", "8", "--steps", "36", "--warmup", "2", "--dry-run")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["dry_run"] is True and out["value"] is None and out["scaling"] == "weak"
+    assert out["views_gathered"] == 288 and len(out["per_rank_seconds"]) == 8
+    assert out["receive_ring_slots"] == bench.ring_slots_for(6, bench.DEFAULT_LANES_MULTI_RANK) == 11
+    assert out["gather_bytes_to_rank0"] == 36 * 7 * 3 * 4 * 6 * 4
+    # the reference's sampler over the same 288 views: rank r renders r, r + 8, ... (what `(j * world + rank)` enumerates)
+    from pgdvs_amd.dist import shard_indices
+
+    assert all(shard_indices(288, rk, 8) == [j * 8 + rk for j in range(36)] for rk in range(8))
+    # ... and a count that does not divide: the tail wraps around to the first views (DistributedSampler's padding)
+    assert shard_indices(285, 5, 8)[-1] == (35 * 8 + 5) % 285 == 0
+
+
+def test_bench_watchdog_with_rank_5_of_8_missing():
+    """eight ranks, rank 5 never reaches the timed loop: the seven others leave through their own wall-clock limit (status
+    124 each, nothing re-executed), the launcher returns non-zero and prints no line"""
+    import time
+
+    t0 = time.time()
+    r = _bench("--gpus", "8", "--steps", "4", "--dry-run", "--dry-hang-rank", "5", "--rank-timeout", "8")
+    assert r.returncode != 0
+    assert time.time() - t0 < 200
+    assert "did not finish within 8 s" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_bench_rejects_world_size_mismatch():
     r = _bench("--gpus", "2", "--dry-run", env_extra={"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in r.stderr

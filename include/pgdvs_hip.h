@@ -255,7 +255,10 @@ int pgdvs_points_raster_bounded(const float *pts, int64_t pts_stride, const floa
  *   then not valid; pgdvs_points_raster treats a negative device count as 0).  A count EQUAL to `capacity` means the
  *   cloud did not fit: rows were dropped (which ones is unspecified beyond frame 0's prefix) and the cloud must not be
  *   used -- size the buffer so that the count stays below it (S*H*W rows always suffice).
- *   The workspace holds one occupancy byte per (frame, pixel): S*H*W bytes + 12 bytes per row. */
+ *   The workspace holds one occupancy byte per (frame, pixel), the later frames' selection bits, 12 bytes per row of
+ *   capacity and -- unless it would exceed 4 GB -- a staging block of 16 bytes per (frame, pixel) in which the chain's links
+ *   leave (depth, colour) of the pixels they select (address space: a few per cent of it is ever touched, but all of it is
+ *   part of the size this query returns: 0.85 GB at 1080p x 24 frames, 1.7 GB at x 48). */
 int64_t pgdvs_static_aggregate_workspace_bytes(int S, int H, int W, int64_t capacity);
 int pgdvs_static_aggregate(const float *rgbs, const float *depths, const uint8_t *dyn_masks,
                            const double *K3s_host, const double *c2ws_host, int S, int H, int W,

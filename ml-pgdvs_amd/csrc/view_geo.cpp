@@ -7,6 +7,7 @@
 // cost of ~85 ctypes calls, ~40 allocator round trips and the Python between them (0.53-0.74 ms per view in round 3
 // against 0.86 ms of GPU time).
 #include <chrono>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -151,25 +152,32 @@ int view_layout(const pgdvs_view_geo_desc &d, void *base, ViewWs &w) {
   return PGDVS_OK;
 }
 
-// fork / join events of the optional side stream (timing disabled); a process-wide pool behind a mutex
+// fork / join events of the optional side stream (timing disabled): pools behind a mutex, one per DEVICE (an event belongs to
+// the device that was current when it was created; handed to a stream of another device it fails)
 std::mutex g_ev_mu;
-std::vector<hipEvent_t> g_ev_pool;
+std::map<int, std::vector<hipEvent_t>> g_ev_pool;
 hipEvent_t ev_get() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   {
     std::lock_guard<std::mutex> lk(g_ev_mu);
-    if (!g_ev_pool.empty()) {
-      hipEvent_t e = g_ev_pool.back();
-      g_ev_pool.pop_back();
+    auto &pool = g_ev_pool[dev];
+    if (!pool.empty()) {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
       return e;
     }
   }
   hipEvent_t e = nullptr;
-  (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
   return e;
 }
 void ev_put(hipEvent_t e) {
+  if (e == nullptr) return;  // (a failed creation is reported by the record that follows; never pooled)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lk(g_ev_mu);
-  g_ev_pool.push_back(e);
+  g_ev_pool[dev].push_back(e);
 }
 
 std::mutex g_stat_mu;

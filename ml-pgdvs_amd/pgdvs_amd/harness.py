@@ -53,8 +53,9 @@ def eval_step(model, data: dict, render_cfg, *, device=None, disable_tqdm=True, 
     """One evaluator step on a batch of target views.  ``data`` is the reference's data dict (row A0) plus
     ``rgb_tgt[B,H,W,3]`` and ``eval_mask[B,H,W,3]`` (1 = dynamic region).  Returns the reference's
     ``metric_dict`` restricted to the in-scope keys: ``eval/count`` (int64) and the per-key SUMS over the
-    batch (float32), reduced to rank 0 when a process group is up (device tensors then, as upstream; host tensors in a
-    single process on the fused GPU path).  With ``return_images`` also the quantised prediction / ground truth and the
+    batch (float32), reduced to rank 0 when a process group is up (device tensors then, as upstream; in a single process
+    HOST tensors on both the fused GPU path and the torch path, so that a caller who accumulates them over steps never
+    mixes devices).  With ``return_images`` also the quantised prediction / ground truth and the
     per-view values."""
     device = device if device is not None else next(iter(v for v in data.values() if isinstance(v, torch.Tensor))).device
     stages, t_prev = STAGE_SECONDS, time.perf_counter()
@@ -168,6 +169,9 @@ def eval_step(model, data: dict, render_cfg, *, device=None, disable_tqdm=True, 
     packed = torch.tensor([float(n_batch)] + [float(torch.tensor(per_view[k], dtype=torch.float32).sum()) for k in METRIC_KEYS],
                           dtype=torch.float64, device=rgb_gt.device)
     packed = pdist.reduce_metrics(packed, dst=0)
+    multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    if not multi:
+        packed = packed.cpu()  # one process: host tensors on BOTH paths, whatever the inputs' dtypes and sizes were
     metric = {"eval/count": packed[:1].round().to(torch.int64)}
     for j, k in enumerate(METRIC_KEYS):
         metric[f"eval/{k}"] = packed[1 + j].to(torch.float32)

@@ -18,8 +18,10 @@ class ResidentVideoRenderer:
     ``lanes`` independent views may be in flight, each on its own HIP stream (``side_streams``: plus a second stream per
     lane for the dynamic branch's geometry, forked and joined inside the native call).  Cloud buffers and the
     rasteriser's tile lists are capacity-sized (S*H*W rows) until ``calibrate`` has read one view's count back; after
-    that they are bounded by 1.25 x that count + 65536 rows, and a view that outgrows the bound says so in its status
-    word (``ops.check_raster_status``) and in a count equal to the bound (``ops.checked_count`` + the caller's check).
+    that they are bounded by 1.25 x that count + 65536 rows.  A view that outgrows the bound is TRUNCATED by the
+    aggregation, which clamps its count at the buffer's rows -- the rasteriser's status word cannot fire for it (it only
+    sees the clamped count): the one signal is a count equal to the bound.  ``check_overflow(ret)`` tests exactly that
+    (one host read; ``harness.eval_step`` makes the same test with the words it reads back anyway).
     """
 
     def __init__(self, model, render_cfg, rgbs, depths, dyn_masks, K3s, c2ws, *, lanes: int = 3, side_streams: bool = False,
@@ -95,6 +97,18 @@ class ResidentVideoRenderer:
                 ret = self.model.forward(d, render_cfg=self.rc, disable_tqdm=True)
                 ret["st_pcl_rgb"], ret["st_pcl_rgb_count"], ret["st_pcl_xyz"] = cloud[None], cnt, xyz[None]
         return ret, main
+
+    def check_overflow(self, ret) -> int:
+        """the view's cloud count (one host synchronisation); raises when the aggregation reported an error or the cloud
+        filled the bounded buffer (rows may have been dropped: render with a larger bound / ``calibrate`` again)"""
+        from . import ops
+
+        n = ops.checked_count(ret["st_pcl_rgb_count"], "pgdvs_static_aggregate")
+        if self.row_bound is not None and self.row_bound < self.capacity and n >= self.row_bound:
+            raise ops.PgdvsHipError(f"the aggregated static cloud filled its bounded buffer of {self.row_bound} rows: rows may have "
+                                    "been dropped -- calibrate() on this view or raise row_bound")
+        ops.check_raster_status(ret.get("geo_static_raster_status", None))
+        return n
 
     def join(self) -> None:
         cur = torch.cuda.current_stream(self.dev)

@@ -33,7 +33,6 @@
 namespace pgdvs {
 
 constexpr int kTile = 16;
-constexpr int kRasterMaxK = 8;
 
 struct TileBox {
   int tx0, tx1, ty0, ty1;  // inclusive; empty if tx0 > tx1
@@ -97,6 +96,12 @@ __device__ __forceinline__ bool tile_box_within_2x2(const RasterCam &rc, float r
   const float rpx = radius * (float)W / rc.range_x + 0.0625f, rpy = radius * (float)H / rc.range_y + 0.0625f;
   return 2.0f * rpx + 2.0f < (float)kTile && 2.0f * rpy + 2.0f < (float)kTile;
 }
+
+
+
+constexpr int kRasterMaxK = 8;
+
+
 
 // ---- a conservative depth bound per tile, BEFORE the binning (round 4) ---------------------------------------------
 // Behind K points whose discs certainly cover every pixel of a tile nothing can enter any of the tile's per-pixel lists:
@@ -206,8 +211,10 @@ raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, i
                             const int64_t *__restrict__ n_dev, const float *__restrict__ cam,
                             float radius, int H, int W, int ntx, int nty,
                             int32_t *__restrict__ tile_count, int32_t *__restrict__ status,
-                            const float *__restrict__ tile_bound, int64_t gate_rows) {
+                            const float *__restrict__ tile_bound, int64_t gate_rows, const int32_t *__restrict__ run_flag) {
   __shared__ int s_tab[kSlots];  // one counter per tile (unused when the image has more tiles)
+  // (exact path behind the direct binning: only when a tile's segment overflowed -- see raster_fill_kernel)
+  if (run_flag != nullptr && *run_flag == 0) return;
   // a device-side count never exceeds the rows the caller sized the workspace for (and a
   // negative one -- the aggregation's error status -- renders nothing)
   int64_t n = n_dev ? *n_dev : n_host;
@@ -277,8 +284,9 @@ raster_project_count_kernel(const float *__restrict__ pts, int64_t pts_stride, i
 // single-block exclusive scan: offsets[i] = sum_{j<i} counts[j], offsets[n] = total.  Eight consecutive counts
 // per thread (1080p: 8160 tiles = one round, one barrier pair)
 __global__ void __launch_bounds__(1024)
-raster_scan_kernel(const int32_t *__restrict__ counts, int n, int32_t *__restrict__ offsets) {
+raster_scan_kernel(const int32_t *__restrict__ counts, int n, int32_t *__restrict__ offsets, const int32_t *__restrict__ run_flag) {
   __shared__ int wave_sums[1024 / kWave];
+  if (run_flag != nullptr && *run_flag == 0) return;
   constexpr int kPer = 8;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int carry = 0;  // (every thread keeps its own copy)
@@ -338,11 +346,22 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
                    const float *__restrict__ cam, float radius, int H, int W, int ntx, int nty,
                    const int32_t *__restrict__ offsets,
                    int32_t *__restrict__ cursor, float4 *__restrict__ lists,
-                   int64_t list_capacity, const float *__restrict__ tile_bound, int64_t gate_rows) {
+                   int64_t list_capacity, const float *__restrict__ tile_bound, int64_t gate_rows,
+                   int seg, int32_t *__restrict__ overflow, int32_t *__restrict__ status, const int32_t *__restrict__ run_flag) {
   __shared__ int s_tab[kSlots];  // one counter per tile (unused on the slow path)
+  // Round 5, DIRECT binning (seg > 0): no counting pass and no scan in front of this one -- every tile owns a fixed
+  // segment of `seg` entries (lists + t * seg), a chunk reserves its range with the same global atomic, and a range
+  // that would leave the segment raises `overflow` (its entries are dropped): the exact count / scan / fill passes are
+  // enqueued behind this launch either way and return at once unless the flag is up (run_flag), the tile pass reads
+  // whichever lists are valid.  At 1080p x 24 frames the longest list holds ~1900 entries of 4096; what the direct
+  // pass saves is the counting pass's second projection of every point (24 us + the 5 us scan per view).
+  if (run_flag != nullptr && *run_flag == 0) return;
   // a device-side count never exceeds the rows the caller sized the workspace for (and a
   // negative one -- the aggregation's error status -- renders nothing)
   int64_t n = n_dev ? *n_dev : n_host;
+  // (direct mode: the status word of pgdvs_points_raster_bounded, written by the counting pass otherwise)
+  if (status != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *status = n > n_host ? 1 : (n < 0 ? 2 : 0);
+  if (seg > 0 && blockIdx.x == 0 && threadIdx.x == 0) overflow[1] = 1;  // (stats[2]: this call's lists may be the segments)
   n = n > n_host ? n_host : (n < 0 ? 0 : n);
   if (n < gate_rows) tile_bound = nullptr;
   RasterCam rc = make_raster_cam(cam, H, W);
@@ -423,7 +442,13 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int t = tb + k * kFillThreads;
-          r[k] = v[k] ? offsets[t] + atomicAdd(&cursor[t], v[k]) : 0;
+          if (seg > 0) {
+            const int at = v[k] ? atomicAdd(&cursor[t], v[k]) : 0;
+            if (at + v[k] > seg) atomicOr(overflow, 1);
+            r[k] = t * seg + at;
+          } else {
+            r[k] = v[k] ? offsets[t] + atomicAdd(&cursor[t], v[k]) : 0;
+          }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -441,7 +466,7 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
             if (jx < (span[u] & 0xff) && jy < (span[u] >> 16) && !((span[u] >> (8 + jy * 2 + jx)) & 1)) {
               const int t = t0[u] + jy * ntx + jx;
               const int64_t pos = (int64_t)s_tab[t] + (int)((rank[u][jy] >> (16 * jx)) & 0xffffu);
-              if (pos < list_capacity) lists[pos] = ent;
+              if (pos < (seg > 0 ? (int64_t)(t + 1) * seg : list_capacity)) lists[pos] = ent;
             }
       }
       __syncthreads();  // the table is zeroed again for the next chunk
@@ -457,8 +482,15 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
             if (tile_bound != nullptr && t >= 0 && ez[u] > tile_bound[t]) t = -1;
             const int slot = wave_tile_reserve(cursor, t);
             if (t >= 0) {
-              const int64_t pos = (int64_t)offsets[t] + slot;
-              if (pos < list_capacity) lists[pos] = ent;
+              if (seg > 0) {
+                if (slot < seg)
+                  lists[(int64_t)t * seg + slot] = ent;
+                else
+                  atomicOr(overflow, 1);
+              } else {
+                const int64_t pos = (int64_t)offsets[t] + slot;
+                if (pos < list_capacity) lists[pos] = ent;
+              }
             }
           }
       }
@@ -528,7 +560,9 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 // array, ids are 4 bytes -- and FIVE workgroups fit a CU instead of four.
 template <int K, int kCap, bool kFrag>
 __global__ void __launch_bounds__(256, kCap <= kSortCap ? (kFrag ? 4 : 5) : 2)
-raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__ offsets, int64_t list_capacity, int pass,
+raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__ offsets, int64_t list_capacity,
+                   const float4 *__restrict__ seg_lists, const int32_t *__restrict__ seg_count, int seg,
+                   const int32_t *__restrict__ seg_overflow, int pass,
                    const float *__restrict__ feat, int64_t feat_stride, float radius, int H, int W,
                    int ntx, int nty, int tiles_per_xcd, int64_t *__restrict__ idx_out,
                    float *__restrict__ zbuf_out, float *__restrict__ dist_out,
@@ -575,10 +609,20 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
   const float bx_lo = pix_to_ndc(W - 1 - (qx0 + 7), W, range_x) - margin;
   const float by_hi = pix_to_ndc(H - 1 - qy0, H, range_y) + margin;
   const float by_lo = pix_to_ndc(H - 1 - (qy0 + 7), H, range_y) - margin;
-  int64_t beg = offsets[tile], end = offsets[tile + 1];
-  if (end > list_capacity) end = list_capacity;
+  // the tile's list: its segment of the direct binning pass, or -- no direct pass, or one of its segments overflowed -- the
+  // exact passes' range (uniform over the launch: every tile reads the same flag)
+  const bool direct = seg > 0 && *seg_overflow == 0;
+  int64_t beg, end;
+  if (direct) {
+    beg = (int64_t)tile * seg;
+    end = beg + seg_count[tile];
+  } else {
+    beg = offsets[tile];
+    end = offsets[tile + 1];
+    if (end > list_capacity) end = list_capacity;
+  }
   const int64_t n64 = end > beg ? end - beg : 0;
-  const float4 *__restrict__ L = lists + beg;
+  const float4 *__restrict__ L = (direct ? seg_lists : lists) + beg;
 
   // per-pixel results, common to both paths
   bool has[K];
@@ -935,9 +979,14 @@ static int64_t max_tiles_per_point(float radius, int H, int W) {
   return nx * ny;
 }
 
+constexpr int kSegEntries = 4096;  // most entries per tile segment of the direct binning pass (the longest list of the 1080p x 24 benchmark: ~1900)
 struct RasterWs {
   int32_t *tile_count, *cursor, *offsets;
-  int32_t *stats;  // [64] zeroed per call with the counters: [0] tiles the sorted path handed to the general path for equal depths
+  int32_t *seg_cursor;  // [ntiles] entries per tile as the direct binning pass counted them (its per-tile cursor)
+  float4 *seg_lists;    // [ntiles][seg_entries] (null: the workspace was sized without them)
+  int seg_entries;      // twice the average list the row bound allows, 256 .. kSegEntries: the block never outgrows 2 x the exact lists' 
+  int32_t *stats;  // [64] zeroed per call with the counters: [0] tiles the sorted path handed to the general path for equal depths,
+                   // [1] a segment of the direct binning pass overflowed (the exact passes ran, the tile pass read their lists)
   unsigned *zmin;      // [H*W] per-pixel minimum depth of the point centres (bit patterns), filled per call
   float *tile_bound;   // [ntiles] depth behind which nothing can enter the tile's lists
   float4 *lists;  // 16-byte entries (x_ndc, y_ndc, id, z)
@@ -954,6 +1003,8 @@ static RasterWs raster_ws_layout(void *base, int64_t n, int H, int W, float radi
   off += align_up(ntiles * 4, 256);
   w.cursor = reinterpret_cast<int32_t *>(p + off);
   off += align_up(ntiles * 4, 256);
+  w.seg_cursor = reinterpret_cast<int32_t *>(p + off);
+  off += align_up(ntiles * 4, 256);
   w.stats = reinterpret_cast<int32_t *>(p + off);
   off += 256;
   w.offsets = reinterpret_cast<int32_t *>(p + off);
@@ -965,6 +1016,19 @@ static RasterWs raster_ws_layout(void *base, int64_t n, int H, int W, float radi
   w.list_capacity = (n > 0 ? n : 1) * max_tiles_per_point(radius, H, W);
   w.lists = reinterpret_cast<float4 *>(p + off);
   off += align_up(w.list_capacity * 16, 256);
+  // the direct pass's segments: only where a segment is worth more than the average list can need (images of at least a
+  // few tiles; tiny test images keep the exact passes alone) and the block stays below 2 GB
+  w.seg_lists = nullptr;
+  w.seg_entries = 0;
+  if (ntiles >= 16 && n > 0) {
+    int64_t se = align_up(2 * cdiv(w.list_capacity, ntiles), 256);
+    se = se < 256 ? 256 : (se > kSegEntries ? kSegEntries : se);
+    if (ntiles * se * 16 <= (2ll << 30)) {
+      w.seg_entries = (int)se;
+      w.seg_lists = reinterpret_cast<float4 *>(p + off);
+      off += align_up(ntiles * se * 16, 256);
+    }
+  }
   w.total_bytes = off;
   return w;
 }
@@ -972,11 +1036,17 @@ static RasterWs raster_ws_layout(void *base, int64_t n, int H, int W, float radi
 // what the last rasterisation on this workspace did: out[0] list entries, out[1] longest tile list, out[2] tiles whose list was
 // too long for the sorted path (general path), out[3] tiles the sorted path gave up on for equal depths.  One workgroup.
 __global__ void __launch_bounds__(1024) raster_counters_kernel(const int32_t *__restrict__ offsets, int ntiles,
-                                                                const int32_t *__restrict__ stats, int64_t *__restrict__ out) {
+                                                                const int32_t *__restrict__ stats, int64_t *__restrict__ out,
+                                                                const int32_t *__restrict__ seg_cursor, int seg) {
   __shared__ int s_max[16], s_long[16];
+  __shared__ long long s_tot[16];
+  // (the direct binning pass's counts when its lists were the ones drawn)
+  const bool direct = seg > 0 && seg_cursor != nullptr && stats[2] != 0 && stats[1] == 0;
   int mx = 0, nlong = 0;
+  long long tot = 0;
   for (int t = threadIdx.x; t < ntiles; t += 1024) {
-    const int n = offsets[t + 1] - offsets[t];
+    const int n = direct ? seg_cursor[t] : offsets[t + 1] - offsets[t];
+    tot += n;
     mx = n > mx ? n : mx;
     nlong += n > kSortCap ? 1 : 0;
   }
@@ -984,19 +1054,23 @@ __global__ void __launch_bounds__(1024) raster_counters_kernel(const int32_t *__
     const int a = __shfl_xor(mx, off, 64);
     mx = a > mx ? a : mx;
     nlong += __shfl_xor(nlong, off, 64);
+    tot += __shfl_xor(tot, off, 64);
   }
   if ((threadIdx.x & 63) == 0) {
     s_max[threadIdx.x >> 6] = mx;
     s_long[threadIdx.x >> 6] = nlong;
+    s_tot[threadIdx.x >> 6] = tot;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     int m = 0, l = 0;
+    long long tt = 0;
     for (int w = 0; w < 16; ++w) {
       m = s_max[w] > m ? s_max[w] : m;
       l += s_long[w];
+      tt += s_tot[w];
     }
-    out[0] = offsets[ntiles];
+    out[0] = tt;
     out[1] = m;
     out[2] = l;
     out[3] = stats[0];
@@ -1007,7 +1081,7 @@ void raster_counters(const void *workspace, int64_t n_rows, int H, int W, float 
   const RasterWs ws = raster_ws_layout(const_cast<void *>(workspace), n_rows, H, W, radius);
   const int ntiles = (int)(cdiv(W, kTile) * cdiv(H, kTile));
   PGDVS_LAUNCH("raster_counters", raster_counters_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)ws.offsets, ntiles,
-               (const int32_t *)ws.stats, out_dev);
+               (const int32_t *)ws.stats, out_dev, (const int32_t *)ws.seg_cursor, ws.seg_entries);
 }
 
 }  // namespace pgdvs
@@ -1028,19 +1102,21 @@ template <int K>
 static void launch_tile(dim3 grid, hipStream_t st, const RasterWs &ws, const float *feat,
                         int64_t feat_stride, float radius, int H, int W, int ntx, int nty,
                         int tiles_per_xcd, int64_t *idx, float *zbuf, float *dist2, float *rgb,
-                        int rgb_planar, float *mask, bool long_lists) {
+                        int rgb_planar, float *mask, bool long_lists, int seg) {
+  const float4 *sl = (const float4 *)ws.seg_lists;
+  const int32_t *sc = (const int32_t *)ws.seg_cursor, *so = (const int32_t *)(ws.stats + 1);
   if (zbuf != nullptr) {
     PGDVS_LAUNCH("raster_tile", (raster_tile_kernel<K, kSortCap, true>), grid, dim3(256), 0, st, (const float4 *)ws.lists,
-                 (const int32_t *)ws.offsets, ws.list_capacity, long_lists ? 1 : 0, feat, feat_stride, radius, H, W, ntx, nty,
+                 (const int32_t *)ws.offsets, ws.list_capacity, sl, sc, seg, so, long_lists ? 1 : 0, feat, feat_stride, radius, H, W, ntx, nty,
                  tiles_per_xcd, idx, zbuf, dist2, rgb, rgb_planar, mask, ws.stats);
   } else {
     PGDVS_LAUNCH("raster_tile", (raster_tile_kernel<K, kSortCap, false>), grid, dim3(256), 0, st, (const float4 *)ws.lists,
-                 (const int32_t *)ws.offsets, ws.list_capacity, long_lists ? 1 : 0, feat, feat_stride, radius, H, W, ntx, nty,
+                 (const int32_t *)ws.offsets, ws.list_capacity, sl, sc, seg, so, long_lists ? 1 : 0, feat, feat_stride, radius, H, W, ntx, nty,
                  tiles_per_xcd, idx, zbuf, dist2, rgb, rgb_planar, mask, ws.stats);
   }
   if (long_lists) {  // (the long-list launch keeps the depths in LDS either way: two workgroups per CU with or without)
     PGDVS_LAUNCH("raster_tile_long", (raster_tile_kernel<K, kSortCapLong, true>), grid, dim3(256), 0, st, (const float4 *)ws.lists,
-                 (const int32_t *)ws.offsets, ws.list_capacity, 2, feat, feat_stride, radius, H, W, ntx, nty, tiles_per_xcd, idx, zbuf,
+                 (const int32_t *)ws.offsets, ws.list_capacity, sl, sc, seg, so, 2, feat, feat_stride, radius, H, W, ntx, nty, tiles_per_xcd, idx, zbuf,
                  dist2, rgb, rgb_planar, mask, ws.stats);
   }
 }
@@ -1146,26 +1222,44 @@ static int points_raster_impl(const float *pts, int64_t pts_stride, const float 
   if (n_points == 0 && status_dev != nullptr) {  // (row bound 0: nothing runs that could look at the device count)
     PGDVS_LAUNCH("raster_status", raster_status_kernel, dim3(1), dim3(64), 0, st, n_points_dev, status_dev);
   }
+  // Direct binning first (round 5): sparse clouds only -- below the density gate, i.e. where the lists are short and the
+  // second tile launch is not needed; dense clouds fill 4096-entry segments and go straight to the exact passes.  The exact
+  // passes follow either way and return at once unless a segment overflowed (stats[1]).
+  const int seg = (n_points > 0 && n_points < gate_rows && ws.seg_lists != nullptr) ? ws.seg_entries : 0;
+  const int32_t *run_flag = seg > 0 ? ws.stats + 1 : nullptr;
+  const int64_t fill_chunks = cdiv(n_points, (int64_t)kFillThreads * kFillPer);
+  const unsigned g_fill = (unsigned)(fill_chunks < 4096 ? fill_chunks : 4096);
+  if (seg > 0) {
+    if (small_table) {
+      PGDVS_LAUNCH("raster_fill", raster_fill_kernel<kBinSlots / 2>, dim3(g_fill), dim3(kFillThreads), 0, st, pts, pts_stride, n_points, n_points_dev,
+                   cam_tgt, radius, H, W, ntx, nty, (const int32_t *)nullptr, ws.seg_cursor, ws.seg_lists, ws.list_capacity, tile_bound, gate_rows,
+                   seg, ws.stats + 1, status_dev, (const int32_t *)nullptr);
+    } else {
+      PGDVS_LAUNCH("raster_fill", raster_fill_kernel<kBinSlots>, dim3(g_fill), dim3(kFillThreads), 0, st, pts, pts_stride, n_points, n_points_dev,
+                   cam_tgt, radius, H, W, ntx, nty, (const int32_t *)nullptr, ws.seg_cursor, ws.seg_lists, ws.list_capacity, tile_bound, gate_rows,
+                   seg, ws.stats + 1, status_dev, (const int32_t *)nullptr);
+    }
+  }
   if (n_points > 0) {
     unsigned g = (unsigned)(cdiv(n_points, kBinThreads) < 512 ? cdiv(n_points, kBinThreads) : 512);
     if (small_table) {
-      PGDVS_LAUNCH("raster_project_count", raster_project_count_kernel<kBinSlots / 2>, dim3(g), dim3(kBinThreads), 0, st, pts,
-                   pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count, status_dev, tile_bound, gate_rows);
+      PGDVS_LAUNCH(seg > 0 ? "raster_exact_count" : "raster_project_count", raster_project_count_kernel<kBinSlots / 2>, dim3(g), dim3(kBinThreads), 0, st, pts,
+                   pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count, status_dev, tile_bound, gate_rows, run_flag);
     } else {
-      PGDVS_LAUNCH("raster_project_count", raster_project_count_kernel<kBinSlots>, dim3(g), dim3(kBinThreads), 0, st, pts,
-                   pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count, status_dev, tile_bound, gate_rows);
+      PGDVS_LAUNCH(seg > 0 ? "raster_exact_count" : "raster_project_count", raster_project_count_kernel<kBinSlots>, dim3(g), dim3(kBinThreads), 0, st, pts,
+                   pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count, status_dev, tile_bound, gate_rows, run_flag);
     }
   }
-  PGDVS_LAUNCH("raster_scan", raster_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_count, ntiles, ws.offsets);
+  PGDVS_LAUNCH(seg > 0 ? "raster_exact_scan" : "raster_scan", raster_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_count, ntiles, ws.offsets, run_flag);
   if (n_points > 0) {
-    const int64_t chunks = cdiv(n_points, (int64_t)kFillThreads * kFillPer);
-    unsigned g = (unsigned)(chunks < 4096 ? chunks : 4096);
     if (small_table) {
-      PGDVS_LAUNCH("raster_fill", raster_fill_kernel<kBinSlots / 2>, dim3(g), dim3(kFillThreads), 0, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
-                       radius, H, W, ntx, nty, ws.offsets, ws.cursor, ws.lists, ws.list_capacity, tile_bound, gate_rows);
+      PGDVS_LAUNCH(seg > 0 ? "raster_exact_fill" : "raster_fill", raster_fill_kernel<kBinSlots / 2>, dim3(g_fill), dim3(kFillThreads), 0, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
+                   radius, H, W, ntx, nty, (const int32_t *)ws.offsets, ws.cursor, ws.lists, ws.list_capacity, tile_bound, gate_rows,
+                   0, (int32_t *)nullptr, (int32_t *)nullptr, run_flag);
     } else {
-      PGDVS_LAUNCH("raster_fill", raster_fill_kernel<kBinSlots>, dim3(g), dim3(kFillThreads), 0, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
-                       radius, H, W, ntx, nty, ws.offsets, ws.cursor, ws.lists, ws.list_capacity, tile_bound, gate_rows);
+      PGDVS_LAUNCH(seg > 0 ? "raster_exact_fill" : "raster_fill", raster_fill_kernel<kBinSlots>, dim3(g_fill), dim3(kFillThreads), 0, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
+                   radius, H, W, ntx, nty, (const int32_t *)ws.offsets, ws.cursor, ws.lists, ws.list_capacity, tile_bound, gate_rows,
+                   0, (int32_t *)nullptr, (int32_t *)nullptr, run_flag);
     }
   }
   const int tiles_per_xcd = (int)cdiv(ntiles, 8);
@@ -1176,7 +1270,7 @@ static int points_raster_impl(const float *pts, int64_t pts_stride, const float 
 #define PGDVS_TILE_CASE(KK)                                                                      \
   case KK:                                                                                       \
     launch_tile<KK>(grid, st, ws, feat, feat_stride, radius, H, W, ntx, nty, tiles_per_xcd, idx, \
-                    zbuf, dist2, rgb, rgb_planar, mask, long_lists);                             \
+                    zbuf, dist2, rgb, rgb_planar, mask, long_lists, seg);                        \
     break;
   switch (K) {
     PGDVS_TILE_CASE(1)
@@ -1191,3 +1285,4 @@ static int points_raster_impl(const float *pts, int64_t pts_stride, const float 
 #undef PGDVS_TILE_CASE
   return check_launch("points_raster");
 }
+

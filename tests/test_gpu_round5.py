@@ -12,7 +12,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from pgdvs_amd import ops  # noqa: E402
+from oracle import oracle as orc  # noqa: E402  (checker only)
+from pgdvs_amd import ops, synth  # noqa: E402
 
 DEV = "cuda:0"
 ROOT = pathlib.Path(__file__).resolve().parent.parent
@@ -129,3 +130,42 @@ def test_gnt_depth8_both_product_paths_vs_reference(golden_dir, case):
     worst_t = max(table["torch_fp32"]["vs_float64_mirror"])
     for path in ("bf16x3", "fp32_mfma"):
         assert max(table[path]["vs_float64_mirror"]) <= 4.0 * worst_t + 1e-5, (path, table[path]["vs_float64_mirror"], worst_t)
+
+
+# ---------------------------------------------------------------- the rasteriser's direct binning pass
+@pytest.mark.parametrize("n,spread,K", [(2000, 0.30, 3), (20000, 0.05, 3), (26000, 0.02, 2)])
+def test_raster_direct_binning_and_its_overflow_vs_oracle(n, spread, K):
+    """round 5: sparse clouds are binned WITHOUT a counting pass -- every tile owns a 4096-entry segment of the list block, the
+    exact count / scan / fill passes behind it return at once (csrc/raster.hip, raster_fill_kernel) -- unless a segment
+    overflows: then they run and the tile pass reads their lists.  Clouds spread over the image (no overflow), and crowded
+    into three clusters until tiles hold more than 4096 entries (overflow): fragments bit-exact against the oracle's naive
+    loop either way, and the workspace's flag says which lists were drawn
+    (reference: pytorch3d PointsRasterizer(bin_size=0), st_geo_renderer.py:86-120)."""
+    H, W = 96, 128  # 48 tiles; density gate 2.2 x 12288 = 27 k rows: every case is below it
+    rng = np.random.default_rng(n)
+    centres = np.array([[-0.5, -0.3], [0.4, 0.2], [0.0, 0.45]])
+    which = rng.integers(0, 3, n)
+    xy = centres[which] + rng.normal(0, spread, (n, 2)) * np.array([1.0, 0.6])
+    z = 2.0 + 0.4 * which[:, None] + rng.normal(0, 0.02, (n, 1)) * (rng.random((n, 1)) < 0.5)
+    pts = np.concatenate([xy, z], 1).astype(np.float32)
+    fc = synth.flat_cam(H, W, np.array([[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]]), np.eye(4)).astype(np.float32)
+    cam = ops.cam_prep(T(fc))
+    radius = 0.12
+    assert n < 2.2 * H * W
+    a = ops.points_raster(T(pts), T(rng.random((n, 3)).astype(np.float32)), cam, radius, K, H, W, want_fragments=True)
+    idx, zbuf, d2 = orc.rasterize_points(pts, fc, H, W, radius, K)
+    assert np.array_equal(a["idx"].cpu().numpy(), idx)
+    assert np.array_equal(a["zbuf"].cpu().numpy().view(np.uint32), zbuf.view(np.uint32))
+    assert np.array_equal(a["dist2"].cpu().numpy().view(np.uint32), d2.view(np.uint32))
+    # which regime: entries of the densest tile, bounded from both sides on the host (centres inside the tile <= entries <=
+    # centres inside the tile grown by the disc's 5.76 px + the box margin)
+    ndc = orc.points_to_ndc(pts, fc, H, W)
+    px = (W - 1) - ((ndc[:, 0] + W / H) * W - W / H) / (2.0 * W / H)
+    py = (H - 1) - ((ndc[:, 1] + 1.0) * H - 1.0) / 2.0
+    lo = hi = 0
+    for ty in range(H // 16):
+        for tx in range(W // 16):
+            inside = (px >= tx * 16) & (px < tx * 16 + 16) & (py >= ty * 16) & (py < ty * 16 + 16)
+            grown = (px >= tx * 16 - 8) & (px < tx * 16 + 24) & (py >= ty * 16 - 8) & (py < ty * 16 + 24)
+            lo, hi = max(lo, int(inside.sum())), max(hi, int(grown.sum()))
+    assert (hi < 4096) if n == 2000 else (lo > 4096), (lo, hi)  # no segment overflows / one does for sure

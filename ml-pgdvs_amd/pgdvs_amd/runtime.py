@@ -9,6 +9,40 @@ removed in round 5.)
 import torch
 
 
+def stream_queue_groups(streams, cycles: int = 40000, links: int = 10):
+    """Which of ``streams`` share a HARDWARE queue?  HIP multiplexes its streams onto a few hardware queues (four by default;
+    more do not run side by side either: tools/overlap_probe.py), and two streams on one queue run one behind the other
+    however idle the chip is -- a lane whose stream lands on the queue of another lane's aggregation chain waits for that
+    chain.  The mapping is the runtime's (creation / first-use order) and cannot be queried, but it shows: two chains of
+    dependent single-workgroup spin kernels (``torch.cuda._sleep``) take the time of one when their streams have queues of
+    their own and of two when they share one.  Returns a list of groups (lists of indices into ``streams``); ~1 ms per
+    comparison, every stream is compared with one member of each group found so far."""
+    import time
+
+    def chains(ss):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for st in ss:
+            with torch.cuda.stream(st):
+                for _ in range(links):
+                    torch.cuda._sleep(cycles)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    chains([streams[0]])  # (first launches: lazy queue creation)
+    single = min(chains([streams[0]]) for _ in range(3))
+    groups = []
+    for i, st in enumerate(streams):
+        for g in groups:
+            # one behind the other: ~2 x single; side by side: ~1.15 x
+            if min(chains([streams[g[0]], st]) for _ in range(2)) > 1.6 * single:
+                g.append(i)
+                break
+        else:
+            groups.append([i])
+    return groups
+
+
 class ResidentVideoRenderer:
     """Novel views of ONE video whose S source frames stay resident in HBM, rendered through ``PGDVSRenderer.forward``
     with the static cloud aggregated per view (A12) inside the same native call (``data["_st_pcl_video"]``): what
@@ -25,7 +59,7 @@ class ResidentVideoRenderer:
     """
 
     def __init__(self, model, render_cfg, rgbs, depths, dyn_masks, K3s, c2ws, *, lanes: int = 3, side_streams: bool = False,
-                 native: bool = True):
+                 native: bool = True, place_streams: bool = False):
         import numpy as np
 
         self.model, self.rc = model, render_cfg
@@ -39,15 +73,56 @@ class ResidentVideoRenderer:
                       "dyn_masks": (dyn_masks.view(torch.uint8) if dyn_masks.dtype == torch.bool else dyn_masks).contiguous(),
                       "K3s": np.ascontiguousarray(K3s, dtype=np.float64), "c2ws": np.ascontiguousarray(c2ws, dtype=np.float64)}
         self.side_streams = side_streams
+        self.place_streams = place_streams  # lane streams picked by hardware queue (see _place)
+        self.queue_groups = None
         self.set_lanes(lanes)
 
-    def set_lanes(self, n: int) -> None:
-        have = getattr(self, "lanes", [])
-        # (default priorities: raising the main or the side streams' costs a quarter of the throughput, tools/r05_prio.sh)
-        while len(have) < n:
-            have.append((torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev) if self.side_streams else None))
-        self.lanes = have
+    def set_lanes(self, n: int, side_streams=None, place_streams=None) -> None:
+        """``n`` views in flight; optionally another arrangement of the lanes' streams (second stream per lane or not, streams
+        picked by hardware queue or in creation order): every arrangement keeps its own streams, so switching back and forth
+        (bench.py's probe) reuses them."""
+        if side_streams is not None:
+            self.side_streams = bool(side_streams)
+        if place_streams is not None:
+            self.place_streams = bool(place_streams)
+        sets = self.__dict__.setdefault("_lane_sets", {})
+        key = (self.side_streams, self.place_streams)
+        self.lanes = sets.setdefault(key, [])
+        # (default priorities: raising the main or the side streams' costs a quarter of the throughput, round 5)
+        if len(self.lanes) < n and self.place_streams:
+            self._place(n)
+            sets[key] = self.lanes
+        while len(self.lanes) < n:
+            self.lanes.append((torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev) if self.side_streams else None))
         self.n_lanes = n
+
+    def _place(self, n: int) -> None:
+        """lane streams chosen by HARDWARE QUEUE (stream_queue_groups): every lane's main stream -- it carries the view's
+        longest dependent chains: the aggregation's links, the rasteriser -- on a queue of its own as far as the queues
+        go, the second streams (dynamic branch) together on what is left, so that no lane's static branch ever queues
+        behind another lane's.  Falls back to plain creation order when fewer than two queues show."""
+        pool = [torch.cuda.Stream(device=self.dev) for _ in range(max(12, 3 * n))]
+        groups = stream_queue_groups(pool)
+        self.queue_groups = [len(g) for g in groups]
+        if len(groups) < 2:
+            return
+        groups.sort(key=len, reverse=True)
+        n_main_q = min(n, len(groups) - (1 if self.side_streams and len(groups) > n else 0)) or 1
+        main_q, side_q = groups[:n_main_q], (groups[n_main_q:] or groups[-1:])
+        lanes = []
+        used = set()
+        for i in range(n):
+            g = main_q[i % len(main_q)]
+            mi = next((k for k in g if k not in used), g[0])
+            used.add(mi)
+            side = None
+            if self.side_streams:
+                gs = side_q[i % len(side_q)]
+                si = next((k for k in gs if k not in used), gs[0])
+                used.add(si)
+                side = pool[si]
+            lanes.append((pool[mi], side))
+        self.lanes = lanes
 
     def calibrate(self, data) -> int:
         """render one view with capacity-sized buffers, read its count back (one host synchronisation) and bound the

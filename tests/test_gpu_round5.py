@@ -169,3 +169,44 @@ def test_raster_direct_binning_and_its_overflow_vs_oracle(n, spread, K):
             grown = (px >= tx * 16 - 8) & (px < tx * 16 + 24) & (py >= ty * 16 - 8) & (py < ty * 16 + 24)
             lo, hi = max(lo, int(inside.sum())), max(hi, int(grown.sum()))
     assert (hi < 4096) if n == 2000 else (lo > 4096), (lo, hi)  # no segment overflows / one does for sure
+
+
+# ---------------------------------------------------------------- lanes placed by hardware queue
+def test_lane_streams_by_hardware_queue_render_the_same_images():
+    """runtime.stream_queue_groups partitions a pool of streams by the hardware queue they share (pairs of spin-kernel chains:
+    side by side or one behind the other), ResidentVideoRenderer(place_streams=True) puts every lane's main stream on a queue
+    of its own -- what bench.py's arrangement probe may pick.  Placement is scheduling only: four placed single-stream lanes,
+    two placed lanes with second streams and the plain arrangement render the same images."""
+    from pgdvs_amd.instantiate import load_config
+    from pgdvs_amd.renderers.pgdvs_renderer import PGDVSRenderer
+    from pgdvs_amd.runtime import ResidentVideoRenderer, stream_queue_groups
+
+    pool = [torch.cuda.Stream() for _ in range(10)]
+    groups = stream_queue_groups(pool)
+    assert sorted(i for g in groups for i in g) == list(range(10)) and 1 <= len(groups) <= 10
+    H, W, S = 270, 480, 6
+    v = synth.make_video(S, H, W, seed=31)
+    cfg = load_config(static_renderer="geo")
+    rc = cfg.engine.engine_cfg.render_cfg
+    rc.dyn_pcl_remove_outlier = True
+    model = PGDVSRenderer(cfg, render_cfg=rc, softsplat_metric_abs_alpha=100.0).to(DEV).eval()
+    datas = [synth.to_torch(synth.make_view(v, i, frac=0.3, seed=2), DEV) for i in (0, 2, 4)]
+    rvr = ResidentVideoRenderer(model, rc, T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]), v["K3s"], v["c2ws"], lanes=1)
+    rvr.calibrate(datas[0])
+    refs = []
+    for d in datas:
+        ret, _ = rvr.render(d, 0)
+        rvr.join()
+        torch.cuda.synchronize()
+        refs.append(ret["combined_rgb"].clone())
+    for n, side, place in ((4, False, True), (2, True, True), (3, True, False)):
+        rvr.set_lanes(n, side, place)
+        assert len(rvr.lanes) >= n and (rvr.queue_groups is None or sum(rvr.queue_groups) >= n)
+        if place and rvr.queue_groups is not None and len(rvr.queue_groups) >= n:
+            mains = [m for m, _ in rvr.lanes[:n]]
+            assert len({id(m) for m in mains}) == n
+        outs = [rvr.render(datas[j % 3], j)[0]["combined_rgb"] for j in range(12)]
+        rvr.join()
+        torch.cuda.synchronize()
+        for j, o in enumerate(outs):
+            assert torch.allclose(o, refs[j % 3], rtol=0, atol=1e-5), (n, side, place, j)  # (splat atomics: to rounding)

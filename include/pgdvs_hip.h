@@ -224,6 +224,11 @@ int pgdvs_splat_noise_field(int H, int W, const uint64_t *rng_state, float *nois
  *   it (n_points is then the capacity: a larger or negative device count is clamped to [0, n_points]).
  *   Returns PGDVS_ERR_UNSUPPORTED (and the workspace query a negative size) when n_points times the
  *   tiles a disc of this radius can touch reaches 2^31 list entries.
+ *   Workspace: 16 bytes per list entry the rows can produce (n_points x the tiles a disc can touch), 4 bytes per pixel, and --
+ *   images of at least 16 tiles -- one segment per tile for the direct binning pass: twice the average list the rows allow,
+ *   256 .. 4096 entries (0.53 GB at 1080p).  Sparse clouds (fewer rows than option raster_bound_density x pixels) are
+ *   binned straight into the segments, without a counting pass; an entry that finds its segment full raises a device flag
+ *   and the exact counting / scan / fill passes, enqueued behind the direct one either way, redo the binning.
  *   outputs (any may be NULL): idx[H,W,K] int64 (-1 pad), zbuf[H,W,K] (-1 pad),
  *   dist2[H,W,K] (-1 pad), rgb ([H,W,3] if rgb_planar == 0, [3,H,W] otherwise),
  *   mask[H,W] ((ones-render) > 0 as 0/1 floats).  K (points_per_pixel) in [1, 8]. */

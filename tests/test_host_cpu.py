@@ -61,7 +61,7 @@ def test_view_geo_description_struct_and_workspace_query():
     d.H, d.W, d.agg_S, d.agg_capacity, d.row_bound, d.radius, d.K = 1080, 1920, 24, 4400000, 4400000, 0.01, 3
     d.remove_outlier, d.outlier_knn = 1, 50
     need = lib.pgdvs_view_geo_workspace_bytes(C.byref(d))
-    assert 300e6 < need < 2e9
+    assert 300e6 < need < 2.5e9  # (0.85 GB of it the aggregation's staging rows, 0.53 GB the rasteriser's tile segments, 0.28 GB its exact lists)
     d.remove_outlier = 0
     assert 0 < lib.pgdvs_view_geo_workspace_bytes(C.byref(d)) < need
     d.H = 0

@@ -577,6 +577,8 @@ def main():
         lane_cfg = min((c for c in lane_candidates if trial[c] <= 1.015 * best_t), key=lambda c: c[0])
         n_lanes = lane_cfg[0]
         rvr.set_lanes(*lane_cfg)
+        rvr.drop_other_lane_sets()  # (the probe's other arrangements held ~2 GB of workspace per lane)
+        torch.cuda.reset_peak_memory_stats(dev)  # (`memory.reserved_GB_peak` is the arrangement's that runs, not the probe's)
         args.run_ahead = max(base_run_ahead, n_lanes + 1)
         name_ = lambda c: f"{c[0]} lanes{' + second streams' if c[1] else ''}{', streams by hardware queue' if c[2] else ''}"  # noqa: E731
         lanes_note = ("auto (probed on min(8 k, --steps) views each): " + "; ".join(f"{name_(c)} {trial[c] * 1e3:.3f} ms/view" for c in lane_candidates)

@@ -96,6 +96,19 @@ class ResidentVideoRenderer:
             self.lanes.append((torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev) if self.side_streams else None))
         self.n_lanes = n
 
+    def drop_other_lane_sets(self) -> None:
+        """keep the current arrangement's lanes only (after a probe of several): the other arrangements' streams and the
+        model's workspaces on them are released"""
+        torch.cuda.synchronize(self.dev)
+        sets = self.__dict__.get("_lane_sets", {})
+        key = (self.side_streams, self.place_streams)
+        for k in [k_ for k_ in sets if k_ != key]:
+            sets.pop(k)
+        del self.lanes[self.n_lanes:]
+        if hasattr(self.model, "release_view_states"):
+            self.model.release_view_states([st for pair in self.lanes for st in pair])
+        torch.cuda.empty_cache()
+
     def _place(self, n: int) -> None:
         """lane streams chosen by HARDWARE QUEUE (stream_queue_groups): every lane's main stream -- it carries the view's
         longest dependent chains: the aggregation's links, the rasteriser -- on a queue of its own as far as the queues

@@ -309,8 +309,11 @@ constexpr int kPushMaxFpg = 32;    // frames per workgroup row (one bit each in 
 //   comparisons combined in scalar registers the loop spent 42 scalar against 50 vector instructions per frame, and
 //   the scalar unit -- one per CU for four SIMDs -- set the pace of frame 0's launch (38 M scalar wave-instructions
 //   = 62 of its 72 us).
-template <class Stamp>
-__device__ __forceinline__ unsigned screen_frames(const PushConsts *__restrict__ pc, const int fa, const int fb,
+// (`rec(f)` returns frame f's record: wave-uniform scalar loads from the record array in agg_push_kernel -- every workgroup
+// walks many rounds of points and the records stay in the scalar cache --, broadcast reads of an LDS copy in the chain's
+// links, where a wavefront screens ONE round and a record fetched when its frame comes up is a trip to the L2 per frame)
+template <class Stamp, class Rec>
+__device__ __forceinline__ unsigned screen_frames(const Rec &rec, const int fa, const int fb,
                                                   const bool live, float x, float y, float z, const float wm1,
                                                   const float hm1, const int W, const Stamp &stamp) {
   if (!live) x = y = z = __builtin_nanf("");  // decides nothing, stamps nothing
@@ -351,13 +354,12 @@ __device__ __forceinline__ unsigned screen_frames(const PushConsts *__restrict__
   // other frame is evaluated and lands in its own registers -- a single set renamed per frame cost ~14 scalar
   // moves per projection.
   // (the record array has two spare entries behind the last frame: the requests ahead need no clamping)
-  const PushConsts *p = pc + fa;
-  PushConsts ca = p[0];
-  for (int f = fa; f < fb; f += 2, p += 2) {
-    const PushConsts cb = p[1];
+  PushConsts ca = rec(fa);
+  for (int f = fa; f < fb; f += 2) {
+    const PushConsts cb = rec(f + 1);
     frame(f, ca);
     if (f + 1 < fb) {
-      ca = p[2];
+      ca = rec(f + 2);
       frame(f + 1, cb);
     }
   }
@@ -465,7 +467,7 @@ agg_push_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ cnts,
       z = xyz[i * 3 + 2];
     }
     unsigned dmask = 0;
-    if (fa < fb) dmask = screen_frames(pc, fa, fb, live, x, y, z, wm1, hm1, W, stamp);
+    if (fa < fb) dmask = screen_frames([pc](const int f) { return pc[f]; }, fa, fb, live, x, y, z, wm1, hm1, W, stamp);
     queue_doubtful<kQueue, kPushThreads>(s_q, s_qn, dmask, x, y, z, fa, ch + c_step >= c_hi, proj, H, W, stamp);
   }
   }
@@ -693,15 +695,17 @@ __device__ __forceinline__ unsigned sel_flags16_pair(const SelArgs &a, const int
   return base < a.P ? sel_flags16(a, (int)base) : 0u;
 }
 
-// Rows of the later frames on their way from the chain links to agg_rows: the selected pixels of a 128-pixel chunk in
-// order, as (depth, r, g, b) -- one 16-byte store per pixel in the link, one dense 16-byte read in agg_rows -- packed at
-// the chunk's own base: rows[(frame * pixels + chunk * 128 + k) * 4] for the chunk's k-th selected pixel.  (The finished
-// row, 24 bytes in three stores, cost the link 1.4 us: more than agg_rows gained.)  Address space for every pixel of
-// every later frame, of which the selected few per cent are ever touched; no counter, no ordering between workgroups
-// (a cursor shared by the 512 workgroups of a link cost the link 5 us).  null: nothing staged, agg_rows gathers depth and colour itself.
+// Rows of the later frames on their way from the chain links to agg_rows: the selected pixels of a link's workgroup in list
+// order -- chunk after chunk, pixel order inside a chunk -- as (depth, r, g, b): one 16-byte store per pixel in the link, DENSE
+// per workgroup (round 5: rows[((frame * gx + workgroup) * 4096 + list position) * 4]; until then every 128-pixel chunk packed
+// its rows at the chunk's own pixel base, 60 k partial cache lines per link), and the list position of every chunk's first
+// selected pixel (cst[(frame * gx + workgroup) * 32 + chunk], 16 bits) so that agg_rows finds them.  (The finished row, 24
+// bytes in three stores, cost the link 1.4 us: more than agg_rows gained; a cursor shared by the 512 workgroups of a link
+// cost the link 5 us.)  null: nothing staged, agg_rows gathers depth and colour itself.
 struct RowStage {
   float *rows;
-  int64_t frame_px;  // pixels per frame in the layout (Wd * 32)
+  uint16_t *cst;
+  int gx;  // workgroups per link (chunk g of a frame belongs to workgroup g % gx, its chunk g / gx)
 };
 
 // One link of the chain: frame `src`'s selection = static and not stamped (tmp_st_mask & ~tmp_proj_mask, :224-245);
@@ -723,27 +727,45 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
   __shared__ uint4 s_q[kQueue];
   __shared__ int s_qn[2];
   __shared__ int s_wsum[4];
+  __shared__ PushConsts s_pc[kPushMaxFpg + 2];  // the row's screening records (+ the two spare entries screen_frames may request)
   const int tid = threadIdx.x;
   auto pixel_base = [&](const int t) {
     return ((int64_t)blockIdx.x + (int64_t)(t >> 3) * gridDim.x) * kStepChunkPx + (t & 7) * kStepPx;
   };
   const int64_t base = pixel_base(tid);
-  const uint32_t bits = sel_flags16_pair(a, base);
-#ifdef PGDVS_AB_CHAIN
-  if (sel16 != nullptr)
-#endif
-  if (blockIdx.y == 0 && base < Wd * 32) sel16[((int64_t)src * Wd * 32 + base) >> 4] = (uint16_t)bits;
+  // the row's records ride on the first round trip, beside the mask and map bytes (16 bytes per thread: four per record):
+  // fetched one frame ahead through the scalar cache they were a trip to the L2 per frame, in a loop a wavefront runs ONCE
   const int fa = src + 1 + (int)blockIdx.y * fpg;
+  float4 rec4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool rec_mine = tid < (kPushMaxFpg + 2) * 4 && fa + (tid >> 2) < f_hi + 2;
+  if (rec_mine) rec4 = reinterpret_cast<const float4 *>(pc + fa)[tid];
+  const uint32_t bits = sel_flags16_pair(a, base);
+  {
+    // the chunk's 128 selection bits as ONE 16-byte store by its first thread, and only where a pixel is selected (sel is
+    // zeroed per call with the maps): 2-byte stores from every thread were partial writes of ~130 k cache lines per link
+    const uint32_t pair = bits | ((uint32_t)__shfl_down((int)bits, 1, 8) << 16);
+    const uint32_t p1 = (uint32_t)__shfl_down((int)pair, 2, 8), p2 = (uint32_t)__shfl_down((int)pair, 4, 8), p3 = (uint32_t)__shfl_down((int)pair, 6, 8);
+#ifdef PGDVS_AB_CHAIN
+    if (sel16 != nullptr)
+#endif
+    if (blockIdx.y == 0 && (tid & 7) == 0 && base < Wd * 32 && (pair | p1 | p2 | p3) != 0u)
+      *reinterpret_cast<uint4 *>(sel16 + (((int64_t)src * Wd * 32 + base) >> 4)) = make_uint4(pair, p1, p2, p3);
+  }
   if (fa >= f_hi) return;
+  if (rec_mine) reinterpret_cast<float4 *>(s_pc)[tid] = rec4;
   const int fb = fa + fpg < f_hi ? fa + fpg : f_hi;
   int n;
   int slot = block_excl_256(__popc(bits), s_wsum, n);
   if (n == 0) return;
-  if ((tid & 7) == 0) s_cstart[tid >> 3] = slot;
+  const bool staged = blockIdx.y == 0 && stage.rows != nullptr;
+  const int64_t wg_slot = (int64_t)src * stage.gx + blockIdx.x;  // this workgroup's block of staged rows / chunk starts
+  if ((tid & 7) == 0) {
+    s_cstart[tid >> 3] = slot;
+    if (staged) stage.cst[wg_slot * kStepChunks + (tid >> 3)] = (uint16_t)slot;
+  }
   for (uint32_t m = bits; m; m &= m - 1) s_list[slot++] = (uint16_t)((tid << 4) | __builtin_ctz(m));
   if (tid == 0) s_qn[0] = s_qn[1] = 0;
   __syncthreads();
-  const bool staged = blockIdx.y == 0 && stage.rows != nullptr;
   const ByteStamp stamp{occ_all, (int64_t)H * W, stat};
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
   for (int e0 = 0; e0 < n; e0 += kStepThreads) {
@@ -761,15 +783,14 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
       d = app.depth[px];
       if (staged) {
         c = *reinterpret_cast<const f3 *>(app.rgb + (size_t)px * 3);
-        const int ch = ent >> 7;  // chunk of the workgroup (eight threads per chunk)
-        slot4 = ((int64_t)src * stage.frame_px + ((int64_t)blockIdx.x + (int64_t)ch * gridDim.x) * kStepChunkPx + (e - s_cstart[ch])) * 4;
+        slot4 = (wg_slot * (kStepThreads * kStepPx) + e) * 4;
       }
       const f3 X = append_row(app, cam, px, 0, false, d);
       x = X.x;
       y = X.y;
       z = X.z;
     }
-    const unsigned dmask = screen_frames(pc, fa, fb, live, x, y, z, wm1, hm1, W, stamp);
+    const unsigned dmask = screen_frames([&](const int f) { return s_pc[f - fa]; }, fa, fb, live, x, y, z, wm1, hm1, W, stamp);
     queue_doubtful<kQueue, kStepThreads>(s_q, s_qn, dmask, x, y, z, fa, e0 + kStepThreads >= n, proj, H, W, stamp);
     if (slot4 >= 0) *reinterpret_cast<float4 *>(stage.rows + slot4) = make_float4(d, c.x, c.y, c.z);
   }
@@ -857,7 +878,7 @@ agg_rows_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles, const i
   __syncthreads();
   const int64_t pos0 = cnts[1] + tile_off[(int64_t)f * tiles + t];
   // frames whose chain link unprojected its pixels (all but the last one) left their rows packed per 128-pixel chunk
-  const float *srow = f < f_staged && stage.rows != nullptr ? stage.rows + ((int64_t)f * stage.frame_px + (int64_t)t * kSelTile) * 4 : nullptr;
+  const bool from_stage = f < f_staged && stage.rows != nullptr;
   AppendSrc app;
   app.depth = a.depths + (size_t)f * (size_t)a.P;
   app.rgb = a.rgbs + (size_t)f * (size_t)a.P * 3;
@@ -873,8 +894,12 @@ agg_rows_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles, const i
     if (pos >= a.capacity) break;
     const int ent = (int)s_list[e];
     const int ch = ent >> 7;  // 128-pixel chunk of the tile (four threads of 32 pixels)
-    if (srow != nullptr) {
-      const float4 q = *reinterpret_cast<const float4 *>(srow + (ch * kStepChunkPx + (e - s_cstart[ch])) * 4);
+    if (from_stage) {
+      // chunk g of the frame was listed by the link's workgroup g % gx as its chunk g / gx
+      const int64_t g = (int64_t)t * (kSelTile / kStepChunkPx) + ch;
+      const int64_t wg_slot = (int64_t)f * stage.gx + g % stage.gx;
+      const int first = stage.cst[wg_slot * kStepChunks + g / stage.gx];
+      const float4 q = *reinterpret_cast<const float4 *>(stage.rows + (wg_slot * (kStepThreads * kStepPx) + first + (e - s_cstart[ch])) * 4);
       const f3 c = {q.y, q.z, q.w};
       append_row(app, cam, tile_px + ent, pos, true, q.x, nullptr, &c);
     } else {
@@ -921,8 +946,10 @@ struct AggWs {
   int32_t *tile_cnt;   // [S][tiles] pixels the later frames selected per (frame, tile)
   int64_t *tile_off;   // [S * tiles + 1] their running sum
   uint8_t *occ;  // [S][P] one occupancy byte per (frame, pixel), zeroed per call
-  uint32_t *sel;  // [S][Wd] selection bits of the later frames (each written whole by its agg_step launch)
-  float *stage_rows;  // [S][Wd * 32][4] (depth, colour) of the later frames' selected pixels as the chain links leave them (see RowStage; sparse)
+  uint32_t *sel;  // [S][Wd] selection bits of the later frames (zeroed per call; a link writes the 128-pixel chunks that select)
+  float *stage_rows;  // [S][gx][4096][4] (depth, colour) of the later frames' selected pixels as the chain links leave them (see RowStage)
+  uint16_t *stage_cst;  // [S][gx][32] list position of every chunk's first selected pixel
+  int step_gx;          // workgroups per link
   int64_t Wd;
   int32_t *sel_pix;  // [P] ordered chain: the pixels the current frame selected, in cloud order
   float *xyz;
@@ -967,9 +994,13 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   off += align_up((int64_t)S * w.Wd * 4, 256);
   // (very long videos do without the staging block -- agg_rows then gathers depths and colours itself)
   w.stage_rows = nullptr;
-  if ((int64_t)S * w.Wd * 32 * 16 <= (4ll << 30)) {
+  w.stage_cst = nullptr;
+  w.step_gx = (int)align_up(cdiv(w.Wd * 32 / kStepChunkPx, kStepChunks), 8);
+  if ((int64_t)S * w.step_gx * (kStepThreads * kStepPx) * 16 <= (4ll << 30)) {
     w.stage_rows = reinterpret_cast<float *>(p + off);
-    off += align_up((int64_t)S * w.Wd * 32 * 16, 256);
+    off += align_up((int64_t)S * w.step_gx * (kStepThreads * kStepPx) * 16, 256);
+    w.stage_cst = reinterpret_cast<uint16_t *>(p + off);
+    off += align_up((int64_t)S * w.step_gx * kStepChunks * 2, 256);
   }
   w.xyz = reinterpret_cast<float *>(p + off);
   off += align_up((capacity > 0 ? capacity : 1) * 12, 256);
@@ -1056,7 +1087,8 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
   hipStream_t st = as_stream(stream);
   const int64_t P = (int64_t)H * W;
   // counts, tickets, error / statistics words, look-back granules and the later frames' maps: one fill
-  hipError_t e = fill_async(ws.state, 0, (size_t)ws.state_bytes + (size_t)(S - 1) * (size_t)P, st);
+  // (... and the later frames' selection bits, which lie behind the maps: the links only write the chunks that select)
+  hipError_t e = fill_async(ws.state, 0, (size_t)(reinterpret_cast<char *>(ws.sel) - ws.state) + (size_t)S * (size_t)ws.Wd * 4, st);
   if (e != hipSuccess) {
     set_error("static_aggregate memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
@@ -1222,10 +1254,11 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
   // videos take anyway (no staging block in their workspace)
   RowStage stage;
   stage.rows = option_int(options().agg_stage) != 0 ? ws.stage_rows : nullptr;
-  stage.frame_px = ws.Wd * 32;
+  stage.cst = ws.stage_cst;
+  stage.gx = ws.step_gx;
   {
     // 32 chunks of 128 pixels per workgroup, dealt round-robin; a multiple of 8 workgroups per row (see the kernel)
-    const unsigned gx = (unsigned)align_up(cdiv(ws.Wd * 32 / kStepChunkPx, kStepChunks), 8);
+    const unsigned gx = (unsigned)ws.step_gx;
     // frames per workgroup row.  Alone on the chip a link takes 9.9 / 8.4 / 7.9 / 7.6 / 7.6 / 8.2 us with 2 / 3 / 4 / 6 / 8 / 16 frames per
     // row (more rows = more parallel frames), but every row re-reads the chunk and re-gathers the depths, and with seven views
     // in flight the throughput is the other way round: 1037 frames/s with 6, 1048 with 8, 1055 with 16, 1058 with 24-32 -- one
@@ -1258,7 +1291,8 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
       if (pass == 1 && dbg_mode == 2) {
         RowStage none;
         none.rows = nullptr;
-        none.frame_px = stage.frame_px;
+        none.cst = stage.cst;
+        none.gx = stage.gx;
         PGDVS_LAUNCH("agg_step_dry", agg_step_kernel<kPushQueueSmall>, dim3(gx, gy), dim3(kStepThreads), 0, st, a, (uint8_t *)nullptr,
                      (uint16_t *)nullptr, ws.Wd, i, (const ProjF64 *)ws.proj, (const PushConsts *)ws.pc32, S, sfpg, H, W,
                      frame_src(i), cams[(size_t)i], ws.stat, none);

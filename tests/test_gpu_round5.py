@@ -1,6 +1,7 @@
 """GPU tests added in round 5 (MI355X): the MFMA GNT path pinned against the reference's own forward at the depth the
 reference runs it (8 layers, 256 samples per ray, 10 / 24 source views) on both product paths, with the error growth per
-transformer block on record."""
+transformer block on record; the rasteriser's direct binning pass (no counting pass) and its overflow into the exact passes
+against the oracle; lanes whose streams are placed by hardware queue."""
 import json
 import os
 import pathlib

@@ -115,7 +115,12 @@ class ResidentVideoRenderer:
         go, the second streams (dynamic branch) together on what is left, so that no lane's static branch ever queues
         behind another lane's.  Falls back to plain creation order when fewer than two queues show."""
         pool = [torch.cuda.Stream(device=self.dev) for _ in range(max(12, 3 * n))]
-        groups = stream_queue_groups(pool)
+        try:
+            with torch.cuda.device(self.dev):
+                groups = stream_queue_groups(pool)
+        except Exception:  # noqa: BLE001 -- placement is an optimisation: without the probe the lanes take creation order
+            self.queue_groups = None
+            return
         self.queue_groups = [len(g) for g in groups]
         if len(groups) < 2:
             return

@@ -1240,8 +1240,12 @@ static int points_raster_impl(const float *pts, int64_t pts_stride, const float 
                    seg, ws.stats + 1, status_dev, (const int32_t *)nullptr);
     }
   }
+  // (behind a direct pass the exact passes are launched on one workgroup per CU: a launch of thousands of workgroups that
+  // leave at once still occupies its queue for ~5 us, three of them 15 us per view; the rare overflow pays with slower
+  // exact passes)
   if (n_points > 0) {
     unsigned g = (unsigned)(cdiv(n_points, kBinThreads) < 512 ? cdiv(n_points, kBinThreads) : 512);
+    if (seg > 0 && g > 256) g = 256;
     if (small_table) {
       PGDVS_LAUNCH(seg > 0 ? "raster_exact_count" : "raster_project_count", raster_project_count_kernel<kBinSlots / 2>, dim3(g), dim3(kBinThreads), 0, st, pts,
                    pts_stride, n_points, n_points_dev, cam_tgt, radius, H, W, ntx, nty, ws.tile_count, status_dev, tile_bound, gate_rows, run_flag);
@@ -1252,12 +1256,13 @@ static int points_raster_impl(const float *pts, int64_t pts_stride, const float 
   }
   PGDVS_LAUNCH(seg > 0 ? "raster_exact_scan" : "raster_scan", raster_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_count, ntiles, ws.offsets, run_flag);
   if (n_points > 0) {
+    const unsigned g_exact_fill = seg > 0 && g_fill > 256 ? 256u : g_fill;
     if (small_table) {
-      PGDVS_LAUNCH(seg > 0 ? "raster_exact_fill" : "raster_fill", raster_fill_kernel<kBinSlots / 2>, dim3(g_fill), dim3(kFillThreads), 0, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
+      PGDVS_LAUNCH(seg > 0 ? "raster_exact_fill" : "raster_fill", raster_fill_kernel<kBinSlots / 2>, dim3(g_exact_fill), dim3(kFillThreads), 0, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
                    radius, H, W, ntx, nty, (const int32_t *)ws.offsets, ws.cursor, ws.lists, ws.list_capacity, tile_bound, gate_rows,
                    0, (int32_t *)nullptr, (int32_t *)nullptr, run_flag);
     } else {
-      PGDVS_LAUNCH(seg > 0 ? "raster_exact_fill" : "raster_fill", raster_fill_kernel<kBinSlots>, dim3(g_fill), dim3(kFillThreads), 0, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
+      PGDVS_LAUNCH(seg > 0 ? "raster_exact_fill" : "raster_fill", raster_fill_kernel<kBinSlots>, dim3(g_exact_fill), dim3(kFillThreads), 0, st, pts, pts_stride, n_points, n_points_dev, cam_tgt,
                    radius, H, W, ntx, nty, (const int32_t *)ws.offsets, ws.cursor, ws.lists, ws.list_capacity, tile_bound, gate_rows,
                    0, (int32_t *)nullptr, (int32_t *)nullptr, run_flag);
     }

@@ -579,6 +579,7 @@ def test_gnt_chunk_loop_jobs_and_stage_events():
         return ret, torch.cuda.max_memory_allocated() - base
 
     n_rays = B * H * W
+    br.merge_chunks_up_to = 0  # (execute chunk by chunk as given: this test counts them; merged execution chunks below)
     chunk = 500  # 13 chunks; chunk 6 straddles the two batch items
     assert (H * W) % chunk != 0 and n_rays // chunk >= 12
     mid, _ = run(chunk)
@@ -596,6 +597,14 @@ def test_gnt_chunk_loop_jobs_and_stage_events():
     run(chunk)
     br.stage_events = None
     assert len(ev["features"]) == 1 and len(ev["gather"]) == len(ev["transformer"]) == 14  # 13 chunks, one of them in two pieces
+    # round 5: consecutive chunks merged into execution chunks of up to 4096 rays (the default): fewer jobs, same images
+    br.merge_chunks_up_to = 4096
+    br.stage_events = ev = {}
+    merged, _ = run(chunk)
+    br.stage_events = None
+    assert len(ev["gather"]) == 3  # 6144 rays as 4000 (two batch items: 3072 + 928) + 2144
+    for k in merged:
+        np.testing.assert_allclose(merged[k].cpu().numpy(), mid[k].cpu().numpy(), rtol=0, atol=1e-4, err_msg=k)
     assert all(a.elapsed_time(b) >= 0 for v in ev.values() for a, b in v)
 
 

@@ -296,6 +296,41 @@ def test_bench_watchdog_with_rank_5_of_8_missing():
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_library_options_roundtrip_without_a_gpu():
+    """include/pgdvs_hip.h "Options": process-wide switches read from the environment once, at load time, and changed only
+    through pgdvs_option_set afterwards (no entry point calls getenv); defaults, set / get, unknown names"""
+    import ctypes as C
+    import math
+
+    from pgdvs_amd import _lib
+
+    lib = _lib.load()
+    defaults = {"agg_ordered": 0.0, "agg_stage": 1.0, "gnt_fp32": 0.0, "knn_no_tpq": 0.0, "knn_stats": 0.0}
+    for k, v in defaults.items():
+        if ("PGDVS_" + k.upper()) not in os.environ:
+            assert lib.pgdvs_option_get(k.encode()) == v, k
+    assert lib.pgdvs_option_get(b"raster_bound_density") == pytest.approx(float(os.environ.get("PGDVS_RASTER_BOUND_DENSITY", 2.2)))
+    prev = lib.pgdvs_option_get(b"gnt_fp32")
+    assert lib.pgdvs_option_set(b"gnt_fp32", C.c_double(7.0)) == 0 and lib.pgdvs_option_get(b"gnt_fp32") == 1.0  # flags: value != 0
+    assert lib.pgdvs_option_set(b"gnt_fp32", C.c_double(prev)) == 0
+    assert lib.pgdvs_option_set(b"raster_bound_density", C.c_double(1.25)) == 0
+    assert lib.pgdvs_option_get(b"raster_bound_density") == 1.25
+    assert lib.pgdvs_option_set(b"raster_bound_density", C.c_double(2.2)) == 0
+    assert lib.pgdvs_option_set(b"no_such_option", C.c_double(1.0)) < 0 and b"no_such_option" in lib.pgdvs_last_error()
+    assert math.isnan(lib.pgdvs_option_get(b"no_such_option"))
+    # a later setenv changes nothing: the environment was read when the library was loaded
+    os.environ["PGDVS_GNT_FP32"] = "1"
+    try:
+        assert lib.pgdvs_option_get(b"gnt_fp32") == prev
+    finally:
+        os.environ.pop("PGDVS_GNT_FP32", None)
+    src = "".join((ROOT / "ml-pgdvs_amd" / "csrc" / f).read_text() for f in os.listdir(ROOT / "ml-pgdvs_amd" / "csrc")
+                  if f.endswith((".hip", ".cpp", ".h")) and f != "error.cpp")
+    code = re.sub(r"//[^\n]*", "", src)
+    code = "\n".join(ln for ln in code.splitlines() if "PGDVS_AB_CHAIN" not in ln and "PGDVS_DBG_CHAIN" not in ln)
+    assert code.count("getenv(") <= 1, "an entry point reads the environment (only error.cpp and the A/B switch of static_agg.hip may)"
+
+
 def test_bench_rejects_world_size_mismatch():
     r = _bench("--gpus", "2", "--dry-run", env_extra={"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in r.stderr

@@ -220,6 +220,18 @@ __device__ __forceinline__ int cell_coord(float v, float mn, float inv_h, int G)
   return (int)c;
 }
 
+// Sub-cells along x (first-level grid only): the points of a cell are kept in the order of their quarter of the
+// cell, so that the x-run of a (dy, dz) row is ordered along x at a granularity of h / 4 and a query can leave out
+// the ends of the run that lie outside its ball (grid_query_tpq_kernel).  The fine coordinate is floor(4 u) of the
+// same u = (v - mn) * inv_h the cell coordinate is floor(u) of (4 u is exact), so cell == fine >> 2 for every v, and
+// both are monotone in v.
+constexpr int kSubShift = 2, kSub = 1 << kSubShift;
+__device__ __forceinline__ int fine_coord(float v, float mn, float inv_h, int G) {
+  float c = floorf((v - mn) * (inv_h * (float)kSub));
+  c = fminf(fmaxf(c, 0.0f), (float)(G * kSub - 1));  // NaN -> 0
+  return (int)c;
+}
+
 __global__ void __launch_bounds__(256)
 grid_count_kernel(const float *__restrict__ pts, const GridParams *__restrict__ gp,
                   int32_t *__restrict__ cell_of, int32_t *__restrict__ cell_count,
@@ -250,6 +262,8 @@ grid_count_kernel(const float *__restrict__ pts, const GridParams *__restrict__ 
 //           occupied cell only.  start(c) = start[rank + popcount(bits below c)]: an empty cell gets the start of
 //           the next occupied one, which is what the exclusive scan over all cells gave.  Two dependent loads
 //           instead of one, 2 MB of table instead of 72.
+//           The sparse index keeps kSub starts per occupied cell (the cell's quarters along x, see fine_coord):
+//           start(c) = start[kSub * j], start of quarter s of an occupied cell = start[kSub * j + s].
 struct CellIndex {
   const int32_t *start;
   const uint4 *tab;  // nullptr = dense
@@ -258,7 +272,17 @@ struct CellIndex {
     const uint4 w = tab[c >> 6];
     const unsigned long long bits = ((unsigned long long)w.y << 32) | (unsigned long long)w.x;
     const int j = (int)w.z + __popcll(bits & ((1ull << (c & 63)) - 1ull));
-    return start[j];
+    return start[j << kSubShift];
+  }
+  // sparse only: start of the points at fine x-coordinate >= f of the row whose first cell is `row` (f may be
+  // kSub * G: one past the row's last cell, i.e. the start of the next row)
+  __device__ __forceinline__ int at_fine(int row, int f) const {
+    const int c = row + (f >> kSubShift);
+    const uint4 w = tab[c >> 6];
+    const unsigned long long bits = ((unsigned long long)w.y << 32) | (unsigned long long)w.x;
+    const int j = (int)w.z + __popcll(bits & ((1ull << (c & 63)) - 1ull));
+    const int sub = ((bits >> (c & 63)) & 1ull) ? (f & (kSub - 1)) : 0;  // an empty cell: the next occupied cell's start
+    return start[(j << kSubShift) + sub];
   }
 };
 
@@ -271,7 +295,7 @@ grid_tab_zero_kernel(const GridParams *__restrict__ gp, uint4 *__restrict__ tab,
   const int nw = (gp->ncells >> 6) + 1;
   const int nc = gp->n < gp->ncells ? gp->n : gp->ncells;  // occupied cells <= min(points, cells)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += gridDim.x * blockDim.x) tab[i] = make_uint4(0u, 0u, 0u, 0u);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nc; i += gridDim.x * blockDim.x) occ_count[i] = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nc * kSub; i += gridDim.x * blockDim.x) occ_count[i] = 0;
 }
 
 // cell of every point; its bit in the table (one atomic per run of lanes that share a cell)
@@ -283,11 +307,11 @@ grid_mark_kernel(const float *__restrict__ pts, const GridParams *__restrict__ g
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
     int c = -1;
     if (i < g.n) {
-      int cx = cell_coord(pts[(size_t)i * 3 + 0], g.mn[0], g.inv_h, g.G[0]);
+      int fx = fine_coord(pts[(size_t)i * 3 + 0], g.mn[0], g.inv_h, g.G[0]);
       int cy = cell_coord(pts[(size_t)i * 3 + 1], g.mn[1], g.inv_h, g.G[1]);
       int cz = cell_coord(pts[(size_t)i * 3 + 2], g.mn[2], g.inv_h, g.G[2]);
-      c = (cz * g.G[1] + cy) * g.G[0] + cx;
-      cell_of[i] = c;
+      c = (cz * g.G[1] + cy) * g.G[0] + (fx >> kSubShift);
+      cell_of[i] = (c << kSubShift) | (fx & (kSub - 1));  // (<= 2^24 cells: 26 bits)
     }
     const RunInfo r = wave_runs(c);
     if (r.is_leader && c >= 0)
@@ -360,11 +384,14 @@ grid_rank_kernel(const GridParams *__restrict__ gp, uint4 *__restrict__ tab, con
     const int w = w0 + tid * 4 + k;
     if (w < nw) tab[w].z = (unsigned)run;
     run += c[k];
-    if (w == nw - 1) *nocc_out = run;  // occupied cells in total
+    if (w == nw - 1) {  // occupied cells in total, and the entries of their counter array
+      nocc_out[0] = run;
+      nocc_out[1] = run * kSub;
+    }
   }
 }
 
-// points per occupied cell: cell_of[i] becomes the cell's index among the occupied ones
+// points per quarter of an occupied cell: cell_of[i] becomes kSub * (the cell's index among the occupied ones) + quarter
 __global__ void __launch_bounds__(256)
 grid_occ_count_kernel(const GridParams *__restrict__ gp, int32_t *__restrict__ cell_of, const uint4 *__restrict__ tab,
                       int32_t *__restrict__ occ_count) {
@@ -373,10 +400,10 @@ grid_occ_count_kernel(const GridParams *__restrict__ gp, int32_t *__restrict__ c
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
     int j = -1;
     if (i < n) {
-      const int c = cell_of[i];
+      const int cf = cell_of[i], c = cf >> kSubShift;
       const uint4 w = tab[c >> 6];
       const unsigned long long bits = ((unsigned long long)w.y << 32) | (unsigned long long)w.x;
-      j = (int)w.z + __popcll(bits & ((1ull << (c & 63)) - 1ull));
+      j = (((int)w.z + __popcll(bits & ((1ull << (c & 63)) - 1ull))) << kSubShift) | (cf & (kSub - 1));
       cell_of[i] = j;
     }
     wave_tile_count(occ_count, j);
@@ -384,73 +411,87 @@ grid_occ_count_kernel(const GridParams *__restrict__ gp, int32_t *__restrict__ c
 }
 
 // exclusive scan of in[0 .. n) -> out[0 .. n]; n = *n_ptr is a device value (the cells of a dense grid, or the
-// occupied cells of the sparse one).  (Rounds 1-2: three launches -- block sums, their scan, apply.)
-constexpr int kScanItems = 16;
-constexpr int kScanTile = 1024 * kScanItems;
-// ONE workgroup walks the tiles with a carry: one launch instead of three.  The inputs here are the
-// occupied cells of the sparse grid (~points / 24) and the cells of the coarse grid (<= 256 K): a handful of tiles; an
-// input of millions of entries (every point alone in its cell) still scans correctly, at ~2 us per 16 K entries.
+// quarter-cell counters of the sparse one's occupied cells).  (Rounds 1-2: three launches -- block sums, their scan, apply.)
+// ONE workgroup walks tiles of 32 K entries with a carry.  Inside a tile thread t owns the eight 16-byte groups
+// (k * 1024 + t): every load and store instruction of a wavefront covers 1 KB of consecutive memory (a thread-contiguous
+// chunk of 64 entries costs 64 cache lines per instruction: 16.6 us for the benchmark's 70 K counters against 4).  A tile is
+// therefore eight sub-tiles of 4 K entries: eight independent wavefront scans per thread, one scan of the 128
+// wavefront totals by the first wavefront, two barriers.  `in` must be readable up to the next multiple of four entries
+// behind n (the workspace's arrays are).
+constexpr int kScanVec = 8;  // (16: 52 registers spilled at 1024 threads)
+constexpr int kScanTile = 1024 * 4 * kScanVec;
 __global__ void __launch_bounds__(1024)
 grid_scan_one_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ n_ptr, int32_t *__restrict__ out) {
-  __shared__ int ws[16];
-  __shared__ int s_carry;
+  __shared__ int s_tot[kScanVec * 16];  // [sub-tile][wavefront]
+  __shared__ int s_sum, s_carry;
   const int n = *n_ptr;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int tile = 0; tile * kScanTile <= n; ++tile) {  // (<= n: the tile that holds out[n])
-    const int base = tile * kScanTile + tid * kScanItems;
-    int v[kScanItems];
-    int s = 0;
-    if (base + kScanItems <= n) {
+  for (int tile = 0; (long long)tile * kScanTile <= n; ++tile) {  // (<= n: the tile that holds out[n])
+    int4 v[kScanVec];
+    int x[kScanVec];
 #pragma unroll
-      for (int k = 0; k < kScanItems; k += 4) {
-        const int4 q = *reinterpret_cast<const int4 *>(in + base + k);
-        v[k] = q.x;
-        v[k + 1] = q.y;
-        v[k + 2] = q.z;
-        v[k + 3] = q.w;
-        s += q.x + q.y + q.z + q.w;
-      }
-    } else {
+    for (int k = 0; k < kScanVec; ++k) {
+      const int idx = tile * kScanTile + (k * 1024 + tid) * 4;
+      int4 q = make_int4(0, 0, 0, 0);
+      if (idx < n) q = *reinterpret_cast<const int4 *>(in + idx);
+      q.y = idx + 1 < n ? q.y : 0;
+      q.z = idx + 2 < n ? q.z : 0;
+      q.w = idx + 3 < n ? q.w : 0;
+      v[k] = q;
+    }
 #pragma unroll
-      for (int k = 0; k < kScanItems; ++k) {
-        v[k] = base + k < n ? in[base + k] : 0;
-        s += v[k];
+    for (int k = 0; k < kScanVec; ++k) {
+      int t = v[k].x + v[k].y + v[k].z + v[k].w;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(t, off, 64);
+        if (lane >= off) t += y;
       }
+      x[k] = t;  // inclusive over the wavefront's groups of sub-tile k
+      if (lane == 63) s_tot[k * 16 + wave] = t;
     }
-    int x = s;
-    for (int off = 1; off < 64; off <<= 1) {
-      const int y = __shfl_up(x, off, 64);
-      if ((tid & 63) >= off) x += y;
-    }
-    if ((tid & 63) == 63) ws[tid >> 6] = x;
     __syncthreads();
-    int wo = 0;
-    for (int w = 0; w < (tid >> 6); ++w) wo += ws[w];
-    int run = s_carry + wo + x - s;
-    if (base + kScanItems <= n) {
+    if (wave == 0) {  // exclusive scan of the totals in (sub-tile, wavefront) order: kScanVec / 4 per lane
+      constexpr int kPer = kScanVec * 16 / 64;
+      int a[kPer], t = 0;
 #pragma unroll
-      for (int k = 0; k < kScanItems; k += 4) {
-        int4 q;
-        q.x = run;
-        q.y = q.x + v[k];
-        q.z = q.y + v[k + 1];
-        q.w = q.z + v[k + 2];
-        run = q.w + v[k + 3];
-        *reinterpret_cast<int4 *>(out + base + k) = q;
+      for (int i = 0; i < kPer; ++i) {
+        a[i] = s_tot[lane * kPer + i];
+        t += a[i];
       }
-      if (base + kScanItems == n) out[n] = run;  // total
-    } else {
+      const int own = t;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(t, off, 64);
+        if (lane >= off) t += y;
+      }
+      int e = t - own;
 #pragma unroll
-      for (int k = 0; k < kScanItems; ++k) {
-        if (base + k <= n) out[base + k] = run;  // includes out[n] = total
-        run += v[k];
+      for (int i = 0; i < kPer; ++i) {
+        s_tot[lane * kPer + i] = e;
+        e += a[i];
+      }
+      if (lane == 63) s_sum = t;
+    }
+    __syncthreads();
+    const int carry = s_carry;
+#pragma unroll
+    for (int k = 0; k < kScanVec; ++k) {
+      const int idx = tile * kScanTile + (k * 1024 + tid) * 4;
+      int4 q;
+      q.x = carry + s_tot[k * 16 + wave] + x[k] - (v[k].x + v[k].y + v[k].z + v[k].w);
+      q.y = q.x + v[k].x;
+      q.z = q.y + v[k].y;
+      q.w = q.z + v[k].z;
+      if (idx + 3 <= n) {
+        *reinterpret_cast<int4 *>(out + idx) = q;
+      } else if (idx <= n) {  // the group that holds out[n] = the total
+        out[idx] = q.x;
+        if (idx + 1 <= n) out[idx + 1] = q.y;
+        if (idx + 2 <= n) out[idx + 2] = q.z;
       }
     }
-    __syncthreads();  // everyone has read s_carry and ws
-    if (tid == 1023) s_carry = run;
-    __syncthreads();
+    __syncthreads();  // everyone has read s_carry and s_tot
+    if (tid == 0) s_carry = carry + s_sum;
   }
 }
 
@@ -851,34 +892,113 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
   const bool live = q < n;
   const float4 qp = sorted[live ? q : n - 1];
   const float qx = qp.x, qy = qp.y, qz = qp.z;
+  // points in the block (the nine (dy,dz) rows as x-runs): the density estimate behind the starting threshold below
+  float t0;
+  {
+  int ncand = 0;
   const int cx = cell_coord(qx, g.mn[0], g.inv_h, g.G[0]);
   const int cy = cell_coord(qy, g.mn[1], g.inv_h, g.G[1]);
   const int cz = cell_coord(qz, g.mn[2], g.inv_h, g.G[2]);
-  // the nine (dy,dz) rows of the block as x-runs
-  unsigned key[9];
-  {
-    const int x0 = cx - 1 < 0 ? 0 : cx - 1;
-    const int x1 = cx + 1 >= g.G[0] ? g.G[0] - 1 : cx + 1;
-    const float bx = box_axis_dist2(qx, g.mn[0], g.h, x0, x1, g.G[0]);
+  const int x0 = cx - 1 < 0 ? 0 : cx - 1;
+  const int x1 = cx + 1 >= g.G[0] ? g.G[0] - 1 : cx + 1;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int row_id = (int)((0x862071534ull >> (k * 4)) & 15);
-      const int dz = row_id / 3 - 1, dy = row_id % 3 - 1;
-      const int z = cz + dz, y = cy + dy;
-      int2 se = make_int2(0, 0);
-      float bd = 0.0f;
-      if (live && z >= 0 && z < g.G[2] && y >= 0 && y < g.G[1]) {
-        const int row = (z * g.G[1] + y) * g.G[0];
-        se.x = cell_start.at(row + x0);
-        se.y = cell_start.at(row + x1 + 1);
-        bd = bx + box_axis_dist2(qy, g.mn[1], g.h, y, y, g.G[1]) + box_axis_dist2(qz, g.mn[2], g.h, z, z, g.G[2]);
-      }
-      s_run[k][tid] = se;
-      s_bd[k][tid] = bd;
-      // visiting key: the row's box distance with the row number in its low four bits (non-negative floats order like
-      // their bit patterns; rows without points last)
-      key[k] = se.y > se.x ? ((__float_as_uint(bd) & ~15u) | (unsigned)k) : (0xfffffff0u | (unsigned)k);
+  for (int k = 0; k < 9; ++k) {
+    const int z = cz + k / 3 - 1, y = cy + k % 3 - 1;
+    if (live && z >= 0 && z < g.G[2] && y >= 0 && y < g.G[1]) {
+      const int row = (z * g.G[1] + y) * g.G[0];
+      ncand += cell_start.at(row + x1 + 1) - cell_start.at(row + x0);
     }
+  }
+  // Acceptance threshold from the start.  The points sample a surface: the squared radius that holds K+1 of them is
+  // about (K+1) / (pi * density), and the block's own candidate count measures the density -- on the benchmark cloud
+  // r^2 / ((K+1) h^2 / candidates) is 3.3 in the median, 4.0 at the 99th percentile.  Starting from 4.5 x that instead
+  // of +inf, a lane accepts ~70 candidates instead of ~100 (every accepted candidate costs all 64 lanes a (K+1)-long
+  // insertion chain) and skips rows farther than the threshold.  The list simply starts out filled with the threshold
+  // (no register beside it -- the kernel sits at the 96-register edge of five waves per SIMD -- and a copy in LDS for
+  // the check at the end): accepted candidates are strictly smaller and push it out.  A lane whose last slot still holds it at the end (0.5 %: the estimate was too
+  // small for it) proves nothing and goes to the wavefront-per-query search like any other open query, so the results
+  // do not depend on the estimate.
+  t0 = (KK >= 17 && ncand >= KK) ? (KK >= 40 ? thr_mult : 6.0f) * (float)KK * g.h * g.h / (float)ncand : __builtin_inff();
+  // What the block can certify at all: the distance to its nearest face that still has cells behind it (minus the
+  // rounding margin), squared -- a list whose last entry lies beyond it is not complete whatever it holds.  Kept in LDS:
+  // it is the threshold of the second attempt below, and the completeness test at the end.
+  {
+    float db = __builtin_inff();
+    bool open = false;
+    const int c[3] = {cx, cy, cz};
+    const float qv[3] = {qx, qy, qz};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      if (c[ax] - 1 > 0) {
+        open = true;
+        db = fminf(db, qv[ax] - (g.mn[ax] + (float)(c[ax] - 1) * g.h));
+      }
+      if (c[ax] + 1 < g.G[ax] - 1) {
+        open = true;
+        db = fminf(db, (g.mn[ax] + (float)(c[ax] + 2) * g.h) - qv[ax]);
+      }
+    }
+    const float safe = db - 0.02f * g.h;
+    // +inf: nothing behind any face (everything is in the block); 0: the query sits on the margin (never complete)
+    s_safe[tid] = !open ? __builtin_inff() : (safe > 0.0f ? safe * safe : 0.0f);
+  }
+  }
+  float a[KK];
+  float mx;
+  bool cut;
+  // Second attempt, per wavefront: the density estimate above assumes points on a SURFACE.  In a cloud from noisy depth
+  // (a slab several cells thick) it is too tight for every query -- round 4's noisy scene sent 303 k of 311 k queries to the
+  // ring search, 2.5 ms per view instead of 0.9 -- although the block holds their neighbours.  When a quarter of a
+  // wavefront's lists come out short, the wavefront runs the block again with the largest threshold that can still
+  // certify a list (the block's own bound above) for those lanes; the others repeat their search unchanged.  Isolated
+  // short lists (0.5 % on the benchmark's cloud) keep going to the ring search: a repeat would cost their whole wavefront.
+  for (int attempt = 0;; ++attempt) {
+  // The nine rows as x-runs, each cut down to the part of it the ball of the starting threshold can reach: the points
+  // of a row are ordered along x in quarters of a cell (fine_coord), and a candidate closer than t0 lies within
+  // sqrt(t0 - (the row's distance in y and z)) of the query along x.  On the benchmark's cloud this leaves out ~40 % of
+  // the block's candidates before a single load.  (The margins of the box distances, plus one for the square root.)
+  // (The cell of the query is worked out again here, from copies of its coordinates the compiler cannot see through:
+  // kept from the first time, cx .. bx would stay live across the candidate loop for the sake of the second attempt,
+  // eight registers the kernel does not have -- 54 spilled.)
+  {
+  float lx = qx, ly = qy, lz = qz;
+  asm volatile("" : "+v"(lx), "+v"(ly), "+v"(lz));
+  const int cx = cell_coord(lx, g.mn[0], g.inv_h, g.G[0]);
+  const int cy = cell_coord(ly, g.mn[1], g.inv_h, g.G[1]);
+  const int cz = cell_coord(lz, g.mn[2], g.inv_h, g.G[2]);
+  const int x0 = cx - 1 < 0 ? 0 : cx - 1;
+  const int x1 = cx + 1 >= g.G[0] ? g.G[0] - 1 : cx + 1;
+  const float bx = box_axis_dist2(lx, g.mn[0], g.h, x0, x1, g.G[0]);
+  unsigned key[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int row_id = (int)((0x862071534ull >> (k * 4)) & 15);
+    const int dz = row_id / 3 - 1, dy = row_id % 3 - 1;
+    const int z = cz + dz, y = cy + dy;
+    int2 se = make_int2(0, 0);
+    float bd = 0.0f;
+    if (live && z >= 0 && z < g.G[2] && y >= 0 && y < g.G[1]) {
+      const int row = (z * g.G[1] + y) * g.G[0];
+      const float byz = box_axis_dist2(ly, g.mn[1], g.h, y, y, g.G[1]) + box_axis_dist2(lz, g.mn[2], g.h, z, z, g.G[2]);
+      bd = bx + byz;
+      const float hw2 = t0 - byz;
+      if (hw2 > 0.0f) {
+        const float hw = __builtin_amdgcn_sqrtf(hw2) * 1.0001f + 0.02f * g.h;
+        int f0 = fine_coord(lx - hw, g.mn[0], g.inv_h, g.G[0]);
+        int f1 = fine_coord(lx + hw, g.mn[0], g.inv_h, g.G[0]);
+        f0 = f0 < x0 * kSub ? x0 * kSub : f0;
+        f1 = f1 > x1 * kSub + (kSub - 1) ? x1 * kSub + (kSub - 1) : f1;
+        if (f0 <= f1) {
+          se.x = cell_start.at_fine(row, f0);
+          se.y = cell_start.at_fine(row, f1 + 1);
+        }
+      }
+    }
+    s_run[k][tid] = se;
+    s_bd[k][tid] = bd;
+    // visiting key: the row's box distance with the row number in its low four bits (non-negative floats order like
+    // their bit patterns; rows without points last)
+    key[k] = se.y > se.x ? ((__float_as_uint(bd) & ~15u) | (unsigned)k) : (0xfffffff0u | (unsigned)k);
   }
   // Every lane visits ITS rows nearest first (sorting network on the nine keys, 25 min / max pairs): the fixed row
   // order above is the nearest-first order of a query in the middle of its cell, but for a query near a cell corner
@@ -907,58 +1027,7 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
     for (int k = 0; k < 9; ++k) order |= (unsigned long long)(key[k] & 15u) << (4 * k);
     s_order[tid] = order;  // (read back per row switch: two registers fewer across the candidate loop)
   }
-  // Acceptance threshold from the start.  The points sample a surface: the squared radius that holds K+1 of them is
-  // about (K+1) / (pi * density), and the block's own candidate count measures the density -- on the benchmark cloud
-  // r^2 / ((K+1) h^2 / candidates) is 3.3 in the median, 4.0 at the 99th percentile.  Starting from 4.5 x that instead
-  // of +inf, a lane accepts ~70 candidates instead of ~100 (every accepted candidate costs all 64 lanes a (K+1)-long
-  // insertion chain) and skips rows farther than the threshold.  The list simply starts out filled with the threshold
-  // (no register beside it -- the kernel sits at the 96-register edge of five waves per SIMD -- and a copy in LDS for
-  // the check at the end): accepted candidates are strictly smaller and push it out.  A lane whose last slot still holds it at the end (0.5 %: the estimate was too
-  // small for it) proves nothing and goes to the wavefront-per-query search like any other open query, so the results
-  // do not depend on the estimate.
-  auto threshold = [&]() {
-    int ncand = 0;  // points in the block (the runs are still in this lane's LDS column)
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int2 se = s_run[k][tid];
-      ncand += se.y - se.x;
-    }
-    return (KK >= 17 && ncand >= KK) ? (KK >= 40 ? thr_mult : 6.0f) * (float)KK * g.h * g.h / (float)ncand : __builtin_inff();
-  };
-  // What the block can certify at all: the distance to its nearest face that still has cells behind it (minus the
-  // rounding margin), squared -- a list whose last entry lies beyond it is not complete whatever it holds.  Kept in LDS:
-  // it is the threshold of the second attempt below, and the completeness test at the end.
-  {
-    float db = __builtin_inff();
-    bool open = false;
-    const int c[3] = {cx, cy, cz};
-    const float qv[3] = {qx, qy, qz};
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-      if (c[ax] - 1 > 0) {
-        open = true;
-        db = fminf(db, qv[ax] - (g.mn[ax] + (float)(c[ax] - 1) * g.h));
-      }
-      if (c[ax] + 1 < g.G[ax] - 1) {
-        open = true;
-        db = fminf(db, (g.mn[ax] + (float)(c[ax] + 2) * g.h) - qv[ax]);
-      }
-    }
-    const float safe = db - 0.02f * g.h;
-    // +inf: nothing behind any face (everything is in the block); 0: the query sits on the margin (never complete)
-    s_safe[tid] = !open ? __builtin_inff() : (safe > 0.0f ? safe * safe : 0.0f);
   }
-  float a[KK];
-  float mx;
-  bool cut;
-  float t0 = threshold();
-  // Second attempt, per wavefront: the density estimate above assumes points on a SURFACE.  In a cloud from noisy depth
-  // (a slab several cells thick) it is too tight for every query -- round 4's noisy scene sent 303 k of 311 k queries to the
-  // ring search, 2.5 ms per view instead of 0.9 -- although the block holds their neighbours.  When a quarter of a
-  // wavefront's lists come out short, the wavefront runs the block again with the largest threshold that can still
-  // certify a list (the block's own bound above) for those lanes; the others repeat their search unchanged.  Isolated
-  // short lists (0.5 % on the benchmark's cloud) keep going to the ring search: a repeat would cost their whole wavefront.
-  for (int attempt = 0;; ++attempt) {
   __builtin_amdgcn_sched_barrier(0);  // (the 51 copies must not become live while the run set-up above still is)
   {
     s_thr[tid] = t0;
@@ -1203,7 +1272,7 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   w.fb_count = reinterpret_cast<int32_t *>(p + off + 192);
   w.fb2_count = reinterpret_cast<int32_t *>(p + off + 196);
   w.open_count = reinterpret_cast<int32_t *>(p + off + 200);
-  w.nocc = reinterpret_cast<int32_t *>(p + off + 204);
+  w.nocc = reinterpret_cast<int32_t *>(p + off + 204);  // [2]: occupied cells, kSub x that
   off += 256;
   w.gp = reinterpret_cast<GridParams *>(p + off);
   off += 256;
@@ -1212,7 +1281,7 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   w.tab = reinterpret_cast<uint4 *>(p + off);
   off += align_up((int64_t)kTabWords * 16, 256);
   {  // occupied cells <= min(points, cells)
-    const int64_t occ_cap = (capacity < kGridMaxCells ? (capacity > 0 ? capacity : 1) : (int64_t)kGridMaxCells) + 2;
+    const int64_t occ_cap = ((capacity < kGridMaxCells ? (capacity > 0 ? capacity : 1) : (int64_t)kGridMaxCells) + 2) * kSub;
     w.occ_count = reinterpret_cast<int32_t *>(p + off);
     off += align_up(occ_cap * 4, 256);
     w.occ_start = reinterpret_cast<int32_t *>(p + off);
@@ -1319,7 +1388,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   const int64_t occ_cap = capacity < kGridMaxCells ? capacity : (int64_t)kGridMaxCells;
   const int nb = (int)cdiv(occ_cap + 1, kScanTile);  // (<= kGridMaxCells / kScanTile = 1024: one pass over the block sums)
   (void)nb;
-  PGDVS_LAUNCH("grid_scan", grid_scan_one_kernel, dim3(1), dim3(1024), 0, st, ws.occ_count, (const int32_t *)ws.nocc,
+  PGDVS_LAUNCH("grid_scan", grid_scan_one_kernel, dim3(1), dim3(1024), 0, st, ws.occ_count, (const int32_t *)(ws.nocc + 1),
                ws.occ_start);
   PGDVS_LAUNCH("grid_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
                ws.occ_start, ws.occ_count, ws.sorted, (const int32_t *)nullptr);

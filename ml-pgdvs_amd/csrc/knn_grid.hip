@@ -411,87 +411,103 @@ grid_occ_count_kernel(const GridParams *__restrict__ gp, int32_t *__restrict__ c
 }
 
 // exclusive scan of in[0 .. n) -> out[0 .. n]; n = *n_ptr is a device value (the cells of a dense grid, or the
-// quarter-cell counters of the sparse one's occupied cells).  (Rounds 1-2: three launches -- block sums, their scan, apply.)
-// ONE workgroup walks tiles of 32 K entries with a carry.  Inside a tile thread t owns the eight 16-byte groups
-// (k * 1024 + t): every load and store instruction of a wavefront covers 1 KB of consecutive memory (a thread-contiguous
-// chunk of 64 entries costs 64 cache lines per instruction: 16.6 us for the benchmark's 70 K counters against 4).  A tile is
-// therefore eight sub-tiles of 4 K entries: eight independent wavefront scans per thread, one scan of the 128
-// wavefront totals by the first wavefront, two barriers.  `in` must be readable up to the next multiple of four entries
-// behind n (the workspace's arrays are).
-constexpr int kScanVec = 8;  // (16: 52 registers spilled at 1024 threads)
+// quarter-cell counters of the sparse one's occupied cells).  (Rounds 1-2: three launches -- block sums, their scan, apply;
+// rounds 3-4: one workgroup walking the tiles with a carry -- 2 us for the 17 K occupied cells of the benchmark's cloud, but
+// bound by ONE compute unit's load / store rate: 8 us for the 70 K quarter counters, 24 us with the chip busy.)
+// One launch, one workgroup per tile of 8 K entries, tiles chained by look-back: a workgroup publishes its tile's sum
+// (flag 1) in a 64-bit word of `state`, adds up the words of the tiles before it back to the first one that carries a whole
+// prefix (flag 2; tile 0 does from the start), then publishes its own.  Flag and value travel in one atomic word, so no
+// ordering between words is needed; workgroups are dispatched in index order and never wait for a LATER one.  `state` is
+// zeroed before the launch (the call's memset).  Inside a tile thread t owns the 16-byte groups (k * 1024 + t): every load
+// and store instruction of a wavefront covers 1 KB of consecutive memory.  `in` must be readable up to the next multiple
+// of four entries behind n (the workspace's arrays are).
+constexpr int kScanVec = 2;
 constexpr int kScanTile = 1024 * 4 * kScanVec;
 __global__ void __launch_bounds__(1024)
-grid_scan_one_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ n_ptr, int32_t *__restrict__ out) {
+grid_scan_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ n_ptr, int32_t *__restrict__ out,
+                 unsigned long long *__restrict__ state) {
   __shared__ int s_tot[kScanVec * 16];  // [sub-tile][wavefront]
-  __shared__ int s_sum, s_carry;
+  __shared__ int s_carry;
   const int n = *n_ptr;
+  const int tile = blockIdx.x;
+  if ((long long)tile * kScanTile > n) return;  // (<= n: the tile that holds out[n])
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_carry = 0;
-  for (int tile = 0; (long long)tile * kScanTile <= n; ++tile) {  // (<= n: the tile that holds out[n])
-    int4 v[kScanVec];
-    int x[kScanVec];
+  int4 v[kScanVec];
+  int x[kScanVec];
 #pragma unroll
-    for (int k = 0; k < kScanVec; ++k) {
-      const int idx = tile * kScanTile + (k * 1024 + tid) * 4;
-      int4 q = make_int4(0, 0, 0, 0);
-      if (idx < n) q = *reinterpret_cast<const int4 *>(in + idx);
-      q.y = idx + 1 < n ? q.y : 0;
-      q.z = idx + 2 < n ? q.z : 0;
-      q.w = idx + 3 < n ? q.w : 0;
-      v[k] = q;
+  for (int k = 0; k < kScanVec; ++k) {
+    const int idx = tile * kScanTile + (k * 1024 + tid) * 4;
+    int4 q = make_int4(0, 0, 0, 0);
+    if (idx < n) q = *reinterpret_cast<const int4 *>(in + idx);
+    q.y = idx + 1 < n ? q.y : 0;
+    q.z = idx + 2 < n ? q.z : 0;
+    q.w = idx + 3 < n ? q.w : 0;
+    v[k] = q;
+  }
+#pragma unroll
+  for (int k = 0; k < kScanVec; ++k) {
+    int t = v[k].x + v[k].y + v[k].z + v[k].w;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(t, off, 64);
+      if (lane >= off) t += y;
     }
-#pragma unroll
-    for (int k = 0; k < kScanVec; ++k) {
-      int t = v[k].x + v[k].y + v[k].z + v[k].w;
-      for (int off = 1; off < 64; off <<= 1) {
-        const int y = __shfl_up(t, off, 64);
-        if (lane >= off) t += y;
-      }
-      x[k] = t;  // inclusive over the wavefront's groups of sub-tile k
-      if (lane == 63) s_tot[k * 16 + wave] = t;
+    x[k] = t;  // inclusive over the wavefront's groups of sub-tile k
+    if (lane == 63) s_tot[k * 16 + wave] = t;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // exclusive scan of the kScanVec * 16 totals in (sub-tile, wavefront) order, one per lane
+    const int own = lane < kScanVec * 16 ? s_tot[lane] : 0;
+    int t = own;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(t, off, 64);
+      if (lane >= off) t += y;
     }
-    __syncthreads();
-    if (wave == 0) {  // exclusive scan of the totals in (sub-tile, wavefront) order: kScanVec / 4 per lane
-      constexpr int kPer = kScanVec * 16 / 64;
-      int a[kPer], t = 0;
-#pragma unroll
-      for (int i = 0; i < kPer; ++i) {
-        a[i] = s_tot[lane * kPer + i];
-        t += a[i];
-      }
-      const int own = t;
-      for (int off = 1; off < 64; off <<= 1) {
-        const int y = __shfl_up(t, off, 64);
-        if (lane >= off) t += y;
-      }
-      int e = t - own;
-#pragma unroll
-      for (int i = 0; i < kPer; ++i) {
-        s_tot[lane * kPer + i] = e;
-        e += a[i];
-      }
-      if (lane == 63) s_sum = t;
-    }
-    __syncthreads();
-    const int carry = s_carry;
-#pragma unroll
-    for (int k = 0; k < kScanVec; ++k) {
-      const int idx = tile * kScanTile + (k * 1024 + tid) * 4;
-      int4 q;
-      q.x = carry + s_tot[k * 16 + wave] + x[k] - (v[k].x + v[k].y + v[k].z + v[k].w);
-      q.y = q.x + v[k].x;
-      q.z = q.y + v[k].y;
-      q.w = q.z + v[k].z;
-      if (idx + 3 <= n) {
-        *reinterpret_cast<int4 *>(out + idx) = q;
-      } else if (idx <= n) {  // the group that holds out[n] = the total
-        out[idx] = q.x;
-        if (idx + 1 <= n) out[idx + 1] = q.y;
-        if (idx + 2 <= n) out[idx + 2] = q.z;
+    if (lane < kScanVec * 16) s_tot[lane] = t - own;
+    const int sum = __shfl(t, 63, 64);  // the tile's sum
+    // look-back: 64 earlier tiles at a time
+    int carry = 0;
+    if (tile > 0) {
+      if (lane == 0)
+        __hip_atomic_store(&state[tile], (1ull << 32) | (unsigned)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int back = tile - 1; back >= 0; back -= 64) {
+        const int i = back - lane;
+        unsigned long long w = 3ull << 32;  // (lanes before tile 0: nothing to add, nothing to wait for)
+        if (i >= 0) {
+          do {
+            w = __hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((w >> 32) == 0ull);
+        }
+        const unsigned long long whole = __ballot((w >> 32) == 2ull);
+        const int stop = whole ? __builtin_ctzll(whole) : 63;  // nearest tile with a whole prefix
+        int c = (lane <= stop && i >= 0) ? (int)(unsigned)w : 0;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        carry += c;
+        if (whole) break;
       }
     }
-    __syncthreads();  // everyone has read s_carry and s_tot
-    if (tid == 0) s_carry = carry + s_sum;
+    if (lane == 0) {
+      __hip_atomic_store(&state[tile], (2ull << 32) | (unsigned)(carry + sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_carry = carry;
+    }
+  }
+  __syncthreads();
+  const int carry = s_carry;
+#pragma unroll
+  for (int k = 0; k < kScanVec; ++k) {
+    const int idx = tile * kScanTile + (k * 1024 + tid) * 4;
+    int4 q;
+    q.x = carry + s_tot[k * 16 + wave] + x[k] - (v[k].x + v[k].y + v[k].z + v[k].w);
+    q.y = q.x + v[k].x;
+    q.z = q.y + v[k].y;
+    q.w = q.z + v[k].z;
+    if (idx + 3 <= n) {
+      *reinterpret_cast<int4 *>(out + idx) = q;
+    } else if (idx <= n) {  // the group that holds out[n] = the total
+      out[idx] = q.x;
+      if (idx + 1 <= n) out[idx + 1] = q.y;
+      if (idx + 2 <= n) out[idx + 2] = q.z;
+    }
   }
 }
 
@@ -1247,6 +1263,9 @@ struct GridWs {
   int32_t *open_count, *open_list;  // queries the thread-per-query pass left to the ring search
   float *fb_bound;
   float *fb_partial;  // [kFbMaxSliced][kFbSlices][64]
+  unsigned long long *scan_state, *scan_state2;
+  int scan_tiles;
+  int64_t state_bytes;  // the block the call's memset clears
   int32_t *stats;  // [16] ring histogram, filled only when PGDVS_KNN_STATS=1 (diagnostics)
   // second level
   GridParams *gp2;
@@ -1274,6 +1293,14 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   w.open_count = reinterpret_cast<int32_t *>(p + off + 200);
   w.nocc = reinterpret_cast<int32_t *>(p + off + 204);  // [2]: occupied cells, kSub x that
   off += 256;
+  // ... and the look-back words of the two scans (grid_scan_kernel), one per tile that can occur
+  w.scan_state = reinterpret_cast<unsigned long long *>(p + off);
+  w.scan_tiles = (int)((((capacity < kGridMaxCells ? (capacity > 0 ? capacity : 1) : (int64_t)kGridMaxCells) + 2) * kSub) / kScanTile + 1);
+  off += (int64_t)w.scan_tiles * 8;
+  w.scan_state2 = reinterpret_cast<unsigned long long *>(p + off);
+  off += (int64_t)(kCoarseMaxCells / kScanTile + 2) * 8;
+  off = align_up(off, 256);
+  w.state_bytes = off;
   w.gp = reinterpret_cast<GridParams *>(p + off);
   off += 256;
   w.cell_count = reinterpret_cast<int32_t *>(p + off);
@@ -1354,7 +1381,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
     return PGDVS_ERR_WORKSPACE;
   }
   // empty box: ~min = 0 and max = 0 in the order-preserving uint encoding
-  hipError_t e = hipMemsetAsync(ws.bbox, 0x00, 256, st);  // ~min, max, sumsq, stats, counters
+  hipError_t e = hipMemsetAsync(ws.bbox, 0x00, (size_t)ws.state_bytes, st);  // ~min, max, sumsq, stats, counters, scan words
   if (e != hipSuccess) {
     set_error("knn_grid memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
@@ -1388,8 +1415,8 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   const int64_t occ_cap = capacity < kGridMaxCells ? capacity : (int64_t)kGridMaxCells;
   const int nb = (int)cdiv(occ_cap + 1, kScanTile);  // (<= kGridMaxCells / kScanTile = 1024: one pass over the block sums)
   (void)nb;
-  PGDVS_LAUNCH("grid_scan", grid_scan_one_kernel, dim3(1), dim3(1024), 0, st, ws.occ_count, (const int32_t *)(ws.nocc + 1),
-               ws.occ_start);
+  PGDVS_LAUNCH("grid_scan", grid_scan_kernel, dim3((unsigned)ws.scan_tiles), dim3(1024), 0, st, ws.occ_count,
+               (const int32_t *)(ws.nocc + 1), ws.occ_start, ws.scan_state);
   PGDVS_LAUNCH("grid_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
                ws.occ_start, ws.occ_count, ws.sorted, (const int32_t *)nullptr);
   CellIndex ci;
@@ -1439,8 +1466,8 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   PGDVS_LAUNCH("grid2_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp2, ws.cell_of,
                ws.cell_count2, (const int32_t *)ws.fb_count);
   (void)nb2;
-  PGDVS_LAUNCH("grid2_scan", grid_scan_one_kernel, dim3(1), dim3(1024), 0, st, ws.cell_count2, (const int32_t *)&ws.gp2->ncells,
-               ws.cell_start2);
+  PGDVS_LAUNCH("grid2_scan", grid_scan_kernel, dim3(kCoarseMaxCells / kScanTile + 1), dim3(1024), 0, st, ws.cell_count2,
+               (const int32_t *)&ws.gp2->ncells, ws.cell_start2, ws.scan_state2);
   PGDVS_LAUNCH("grid2_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp2, ws.cell_of,
                ws.cell_start2, ws.cell_count2, ws.sorted2, (const int32_t *)ws.fb_count);
   CellIndex ci2;  // the coarse grid stays dense (<= 256 K cells)

@@ -25,6 +25,10 @@ def T(a, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
+def N(t):
+    return t.detach().cpu().numpy()
+
+
 @pytest.fixture(scope="module", autouse=True)
 def _require_gpu():
     assert torch.cuda.is_available(), "these tests need the MI355X"
@@ -211,3 +215,41 @@ def test_lane_streams_by_hardware_queue_render_the_same_images():
         torch.cuda.synchronize()
         for j, o in enumerate(outs):
             assert torch.allclose(o, refs[j % 3], rtol=0, atol=1e-5), (n, side, place, j)  # (splat atomics: to rounding)
+
+
+# ---------------------------------------------------------------- A4: cell quarters along x, the look-back scan
+@pytest.mark.parametrize("kind,n,K", [("volume", 300_000, 4), ("volume", 40_000, 50), ("sheet_far_from_origin", 30_000, 50),
+                                      ("sheet_thin_x", 30_000, 50), ("lattice", 32_768, 16)])
+def test_knn_rows_cut_to_the_ball_and_chained_scan_vs_brute_force(kind, n, K):
+    """Round 5: the grid keeps the points of a cell in the order of their quarter along x and the thread-per-query pass
+    leaves out the ends of each (dy, dz) row that the ball of its starting threshold cannot reach; the starts of the
+    quarters come from a scan of one workgroup per 8 K counters chained by look-back.  Against the brute-force kernel (itself
+    pinned on the oracle): a VOLUME cloud (every point nearly alone in its cell: 300 k points are ~680 k counters, more
+    than the 64 tiles one look-back step covers), a sheet 1000 units from the origin (the margins of the cut are a
+    fraction of the cell size, the coordinates' rounding a fraction of their magnitude), a sheet that is thin along x
+    (every row is one or two cells long: the cut clamps at the grid's ends) and a regular lattice (points ON the cell
+    and quarter boundaries, distance ties everywhere)."""
+    rng = np.random.default_rng(n + K)
+    if kind == "volume":
+        pts = rng.uniform(-1, 1, (n, 3))
+    elif kind == "sheet_far_from_origin":
+        u = rng.uniform(-1, 1, (n, 2))
+        pts = np.stack([u[:, 0], u[:, 1], 0.2 * np.sin(4 * u[:, 0]) * np.cos(3 * u[:, 1])], 1) + np.array([1000.0, -500.0, 250.0])
+    elif kind == "sheet_thin_x":
+        u = rng.uniform(-1, 1, (n, 2))
+        pts = np.stack([1e-3 * np.sin(7 * u[:, 0]), u[:, 0], u[:, 1]], 1)
+    else:
+        g = np.arange(32, dtype=np.float64) / 8.0
+        pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+        pts = pts[rng.permutation(len(pts))]
+    pts = pts.astype(np.float32)
+    cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
+    a_grid = N(ops.knn_mean_dist(T(pts), cnt, K, algo=2))[:n]
+    a_brute = N(ops.knn_mean_dist(T(pts), cnt, K, algo=1))[:n]
+    assert np.array_equal(a_grid.view(np.uint32), a_brute.view(np.uint32))
+    if n <= 40_000:
+        sub = rng.choice(n, 256, replace=False)  # ... and the oracle itself on a few rows
+        d2 = ((pts[sub, None, :].astype(np.float32) - pts[None, :, :]) ** 2)
+        d2 = (d2[..., 0] + d2[..., 1]) + d2[..., 2]
+        near = np.sort(d2, axis=1)[:, 1:K + 1]
+        np.testing.assert_allclose(a_grid[sub], near.mean(1), rtol=2e-6, atol=1e-12)

@@ -29,7 +29,10 @@ constexpr int kGridMaxCells = 1 << 24;
 constexpr int kRingCap = 24;
 // After the thread-per-query pass the ring search only sees the sparse remainder, whose long
 // searches are no longer hidden behind the bulk: hand them to the coarse grid after a few rings.
-constexpr int kRingCapAfterTpq = 3;
+#ifndef PGDVS_AB_RING_CAP  // (tuning builds: make EXTRA=-DPGDVS_AB_RING_CAP=5)
+#define PGDVS_AB_RING_CAP 3
+#endif
+constexpr int kRingCapAfterTpq = PGDVS_AB_RING_CAP;
 // points per occupied cell the grid aims at for K + 1 = 51 (scaled with K + 1).  Round 4 (tools/r04_knn_h.sh, the
 // benchmark's 311 k-point cloud): the thread-per-query pass costs 223 us at h = 4.6e-3 (24 per cell), 195 us at 4.1e-3,
 // 185 us at 4.0e-3 (18 per cell: a quarter fewer candidates in the 3 x 3 x 3 block, the 51-ball still inside it for
@@ -155,8 +158,12 @@ __global__ void grid_params_kernel(const unsigned *__restrict__ bbox,
 // `scale` times larger (so the same number of rings reaches `scale` times farther), capped at
 // max_cells.
 __global__ void grid_params_coarse_kernel(const GridParams *__restrict__ fine, const unsigned *__restrict__ bbox,
-                                          GridParams *__restrict__ gp, float scale, int max_cells) {
+                                          GridParams *__restrict__ gp, float scale, float scale_many,
+                                          const int32_t *__restrict__ open_count, const int32_t *__restrict__ qcount,
+                                          int max_cells) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // (qcount: the queries of a cross-set search; self-queries: the points)
+  if ((long long)*open_count * 100 > (long long)(qcount ? *qcount : fine->n)) scale = scale_many;
   float ext[3];
   for (int a = 0; a < 3; ++a) {
     float lo = ord2f(~bbox[a]), hi = ord2f(bbox[3 + a]);
@@ -1277,7 +1284,12 @@ struct GridWs {
 };
 
 constexpr int kCoarseMaxCells = 1 << 18;
-constexpr float kCoarseScale = 8.0f;
+// Cells of the second-level grid in units of the first level's.  8: the few isolated points of a depth-map cloud (0.4 % of the
+// benchmark's queries) reach their neighbours within a ring or two.  When MANY queries are still open after the ring search
+// (more than 1 % -- a cloud from noisy depth: a slab with flying pixels all around it) each of them would scan 27 cells of
+// thousands of points: cells half as wide then (round 5, noisy scene: count + fill + search 0.40 -> 0.23 ms; with the
+// benchmark's 1247 open queries the finer cells would cost 17 -> 50 us).  Decided on the device from the open-query count.
+constexpr float kCoarseScale = 8.0f, kCoarseScaleMany = 4.0f;
 
 static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   GridWs w;
@@ -1461,7 +1473,8 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   // gated on the device-side count of open queries.
   const int nb2 = kCoarseMaxCells / kScanTile;
   PGDVS_LAUNCH("grid2_params", grid_params_coarse_kernel, dim3(1), dim3(64), 0, st, ws.gp, ws.bbox, ws.gp2,
-               kCoarseScale, kCoarseMaxCells);
+               kCoarseScale, kCoarseScaleMany, (const int32_t *)ws.fb_count, qpts ? qcount : (const int32_t *)nullptr,
+               kCoarseMaxCells);
   PGDVS_LAUNCH("grid2_zero", grid_zero_kernel, dim3(256), dim3(256), 0, st, ws.gp2, ws.cell_count2, (int32_t *)nullptr);
   PGDVS_LAUNCH("grid2_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp2, ws.cell_of,
                ws.cell_count2, (const int32_t *)ws.fb_count);

@@ -29,15 +29,14 @@ constexpr int kGridMaxCells = 1 << 24;
 constexpr int kRingCap = 24;
 // After the thread-per-query pass the ring search only sees the sparse remainder, whose long
 // searches are no longer hidden behind the bulk: hand them to the coarse grid after a few rings.
-#ifndef PGDVS_AB_RING_CAP  // (tuning builds: make EXTRA=-DPGDVS_AB_RING_CAP=5)
-#define PGDVS_AB_RING_CAP 3
-#endif
-constexpr int kRingCapAfterTpq = PGDVS_AB_RING_CAP;
+// (round 5, noisy-depth scene, 28 k open queries: 4 or 6 rings change nothing -- 591 / 585 frames/s against 591)
+constexpr int kRingCapAfterTpq = 3;
 // points per occupied cell the grid aims at for K + 1 = 51 (scaled with K + 1).  Round 4 (tools/r04_knn_h.sh, the
 // benchmark's 311 k-point cloud): the thread-per-query pass costs 223 us at h = 4.6e-3 (24 per cell), 195 us at 4.1e-3,
 // 185 us at 4.0e-3 (18 per cell: a quarter fewer candidates in the 3 x 3 x 3 block, the 51-ball still inside it for
 // 99.8 % of the queries: 613 instead of 43 of 311 k go to the ring search, whose launch stays at 21 us) and 180 us at
 // ~3.5e-3, where the ring search grows to 28 us.
+// Round 5, with the rows cut to the ball along x (158 us at 18): 174 us at 15, 162 at 20, 169 at 22.
 constexpr float kTargetPerCellDefault = 18.0f;
 constexpr float kTrialCoarser = 4.0f;
 
@@ -1439,7 +1438,10 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   const unsigned gq = (unsigned)(cdiv(nq_cap, 4) < 256 * 8 ? (cdiv(nq_cap, 4) > 0 ? cdiv(nq_cap, 4) : 1) : 256 * 8);
   // (option knn_no_tpq: diagnostics and tests, the wavefront-per-query search for every query)
   bool tpq = qpts == nullptr && option_int(options().knn_no_tpq) == 0 && capacity < (1ll << 27);  // (32-bit byte offsets)
-  const float thr_mult = 4.5f;  // starting threshold of the thread-per-query pass in units of the block's estimate (any value is exact)
+  // starting threshold of the thread-per-query pass in units of the block's estimate (any value is exact).  Round 5, rows
+  // cut to this threshold's ball: 5.2 -> 166 us, 4.5 -> 158, 4.0 -> 152 (+1.5 us of ring search), 3.7 -> 210, 3.4 -> 303
+  // (a quarter of a wavefront's lists short = the whole wavefront searches again): 4.5 keeps its distance from that edge
+  const float thr_mult = 4.5f;
   if (tpq) {
     const unsigned gt = (unsigned)(cdiv(capacity, 256) < 2560 ? (cdiv(capacity, 256) > 0 ? cdiv(capacity, 256) : 1) : 2560);
     switch (KK) {
@@ -1464,7 +1466,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
     qs1.list = ws.open_list;
     qs1.list_count = ws.open_count;
   }
-  PGDVS_LAUNCH("grid_query", grid_query_kernel, dim3(tpq ? (gq < 512 ? gq : 512) : gq), dim3(256), 0, st, ws.gp,
+  PGDVS_LAUNCH("grid_query", grid_query_kernel, dim3(gq), dim3(256), 0, st, ws.gp,
                ws.sorted, ci, KK, qs1, avg_out, stats, tpq ? ring_cap_after_tpq : kRingCap, ws.fb_count, ws.fb_list,
                ws.fb_bound);
   // Second level: the queries still open after kRingCap rings (isolated points, far from

@@ -1061,6 +1061,9 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
 #pragma unroll
   for (int u = 0; u < kTpqQueue; ++u) qd[u] = __builtin_inff();
   int qc = 0;
+#ifdef PGDVS_AB_TPQ_STATS
+  int dbg_acc = 0, dbg_cand = 0, dbg_flush = 0, dbg_steps = 0;
+#endif
   int k = -1;
   // the lane's current run as BYTE offsets into `sorted` (16 bytes per point; the host takes this pass only below
   // 2^27 points): the load then takes scalar base + 32-bit vector offset as it stands -- no sign extension, no
@@ -1093,7 +1096,13 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
         for (int u = kTpqQueue - 1; u > 0; --u) qd[u] = qd[u - 1];
         qd[0] = d;
         ++qc;
+#ifdef PGDVS_AB_TPQ_STATS
+        ++dbg_acc;
+#endif
       }
+#ifdef PGDVS_AB_TPQ_STATS
+      ++dbg_cand;
+#endif
     }
     if (__builtin_amdgcn_ballot_w64(qc == kTpqQueue) != 0) {
 #pragma unroll
@@ -1104,7 +1113,13 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
       }
       qc = 0;
       mx = a[KK - 1];
+#ifdef PGDVS_AB_TPQ_STATS
+      ++dbg_flush;
+#endif
     }
+#ifdef PGDVS_AB_TPQ_STATS
+    ++dbg_steps;
+#endif
     return __builtin_amdgcn_ballot_w64(v_issue || k < 9) != 0;  // anything requested or left to visit?
   };
   for (;;) {
@@ -1117,6 +1132,25 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
     __builtin_amdgcn_sched_barrier(0);
   }
   mx = a[KK - 1];
+#ifdef PGDVS_AB_TPQ_STATS
+  {  // [1] accepted candidates (all lanes), [2] candidates evaluated, [3] flushes x 64, [4] half-steps x 64, [5] max accepted per wave, summed
+    int32_t *st = open_count - 18;
+    int acc = dbg_acc, cand = dbg_cand, mxa = dbg_acc;
+    for (int off = 32; off > 0; off >>= 1) {
+      acc += __shfl_xor(acc, off, 64);
+      cand += __shfl_xor(cand, off, 64);
+      const int o = __shfl_xor(mxa, off, 64);
+      mxa = o > mxa ? o : mxa;
+    }
+    if ((tid & 63) == 0) {
+      atomicAdd(&st[1], acc);
+      atomicAdd(&st[2], cand);
+      atomicAdd(&st[3], dbg_flush);
+      atomicAdd(&st[4], dbg_steps);
+      atomicAdd(&st[5], mxa);
+    }
+  }
+#endif
   cut = mx < __builtin_inff() && mx == s_thr[tid];  // the threshold left the list short
   const float safe2 = s_safe[tid];
   const bool retry = cut && live && mx < safe2;  // (a list cut at the block's own bound is not complete anyway)
@@ -1435,6 +1469,9 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   ci.tab = ws.tab;
   const bool want_stats = option_int(options().knn_stats) != 0;
   int32_t *stats = want_stats ? ws.stats : nullptr;
+#ifdef PGDVS_AB_TPQ_STATS
+  stats = nullptr;
+#endif
   const unsigned gq = (unsigned)(cdiv(nq_cap, 4) < 256 * 8 ? (cdiv(nq_cap, 4) > 0 ? cdiv(nq_cap, 4) : 1) : 256 * 8);
   // (option knn_no_tpq: diagnostics and tests, the wavefront-per-query search for every query)
   bool tpq = qpts == nullptr && option_int(options().knn_no_tpq) == 0 && capacity < (1ll << 27);  // (32-bit byte offsets)
@@ -1502,6 +1539,9 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
                ws.sorted, KK, qs, ws.fb2_count, ws.fb2_list, ws.fb_partial, avg_out);
   PGDVS_LAUNCH("grid_fallback_tail", grid_fallback_tail_kernel, dim3(256), dim3(1024), 0, st, ws.gp,
                ws.sorted, KK, qs, ws.fb2_count, ws.fb2_list, ws.fb2_bound, avg_out);
+#ifdef PGDVS_AB_TPQ_STATS
+  if (want_stats) stats = ws.stats;
+#endif
   if (stats) {  // diagnostics only (PGDVS_KNN_STATS=1): synchronises and prints the ring histogram
     int32_t hst[16], nfb = 0, nfb2 = 0;
     GridParams g1, g2;

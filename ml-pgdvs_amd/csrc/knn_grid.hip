@@ -31,14 +31,13 @@ constexpr int kRingCap = 24;
 // searches are no longer hidden behind the bulk: hand them to the coarse grid after a few rings.
 // (round 5, noisy-depth scene, 28 k open queries: 4 or 6 rings change nothing -- 591 / 585 frames/s against 591)
 constexpr int kRingCapAfterTpq = 3;
-// points per occupied cell the grid aims at for K + 1 = 51 (scaled with K + 1).  Round 4 (tools/r04_knn_h.sh, the
-// benchmark's 311 k-point cloud): the thread-per-query pass costs 223 us at h = 4.6e-3 (24 per cell), 195 us at 4.1e-3,
-// 185 us at 4.0e-3 (18 per cell: a quarter fewer candidates in the 3 x 3 x 3 block, the 51-ball still inside it for
-// 99.8 % of the queries: 613 instead of 43 of 311 k go to the ring search, whose launch stays at 21 us) and 180 us at
-// ~3.5e-3, where the ring search grows to 28 us.
-// Round 5, with the rows cut to the ball along x (158 us at 18): 174 us at 15, 162 at 20, 169 at 22.
+// Points per cell the FALLBACK sizing aims at for K + 1 = 51 (scaled with K + 1) -- clouds too small for the sample-based
+// sizing below (grid_params_kernel), cells from the bounding box as if the points covered its two largest extents.
+// (Rounds 1-4 sized every grid through this target and a trial grid; the record of that tuning -- the benchmark's 311 k-point
+// cloud: the thread-per-query pass 223 us at h = 4.6e-3, 195 at 4.1e-3, 185 at 4.0e-3, 180 at 3.5e-3 where the ring search
+// grows; round 5, rows cut along x: 158 us at 4.0e-3, 174 / 162 / 169 at targets 15 / 20 / 22 -- is what
+// kCellPerSampleDist reproduces.)
 constexpr float kTargetPerCellDefault = 18.0f;
-constexpr float kTrialCoarser = 4.0f;
 
 struct GridParams {
   float mn[3];
@@ -46,6 +45,8 @@ struct GridParams {
   int G[3];
   int ncells;
   int n;
+  float sample_dist;  // diagnostics: the quantile of the nearest-sample distances behind h, and how many were measured
+  int sample_dists;
 };
 
 __device__ __forceinline__ unsigned f2ord(float f) {
@@ -96,15 +97,203 @@ grid_bbox_kernel(const float *__restrict__ pts, const int32_t *__restrict__ coun
   }
 }
 
-// Cell size.  Pass 0 (occupied == nullptr): from the bounding box, assuming the points
-// sample a surface spanning the two largest extents.  Pass 1: rescale with the measured
-// number of occupied cells of the trial grid so that an occupied cell holds about
-// kTargetPerCell points (occupied cells of a surface grow like 1/h^2).
-__global__ void grid_params_kernel(const unsigned *__restrict__ bbox,
-                                   const int32_t *__restrict__ count,
-                                   const unsigned long long *__restrict__ sumsq,
-                                   GridParams *__restrict__ gp, float target) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// ---- cell size from the cloud's own spacing (round 5) -----------------------------------------------------------------
+// Rounds 1-4 sized the cells through a TRIAL grid: cells from the bounding box under the assumption that the points
+// sample a surface spanning its two largest extents, the occupancy of those cells measured, and the cell size rescaled
+// as for a surface (occupancy ~ h^2).  The bounding box of a frame's dynamic content says little about its area (the
+// benchmark's trial cells held 1300 points instead of the 72 aimed at), and over that range the scaling law matters: a
+// cloud from noisy depth is a slab several cells thick (occupancy ~ h^2.2 at the trial's scale, ~ h^3 at the final one),
+// its cells came out with half the points aimed at, and up to a quarter of its queries could not be certified by their
+// 3 x 3 x 3 block.  Now: a pseudo-random 64th of the points (hash of the index: a Poisson-like thinning, whatever order
+// the cloud arrives in), and for a few hundred of those the distance d1 to the nearest OTHER sample.  The ball of that
+// radius around a sample holds ~64 points of the cloud whatever the cloud's local dimension, so the (K+1 = 51)-ball the
+// search has to cover has radius ~1.06 x median(d1) for a surface and for a volume alike (2-D: r51 = 0.893 r64, median
+// d1 = 0.833 r64; 3-D: 0.927 and 0.885), and the cell is a fixed multiple of it.  One launch fewer than the trial grid,
+// no 8 MB of trial counters to clear and read.
+constexpr int kSampleShift = 6;           // one point in 64
+constexpr int kSampleBlock = 4096;        // points per block of the sampling pass
+constexpr int kSampleSlots = 128;         // samples kept per block (64 expected, binomial: sd 8)
+constexpr int kSampleMaxQueries = 4096;   // samples whose nearest-sample distance is measured
+// cell size in units of the median nearest-sample distance for K + 1 = 51 (scaled with sqrt((K + 1) / 51) otherwise).
+// 1.5 reproduces the cell size the trial grid's tuned target gave on the benchmark's cloud (h = 4.0e-3: the pass takes
+// 168 us at 1.4, 159 at 1.5, 170 at 1.65; 400-650 of its 311 k queries go on to the ring search instead of 1900) and gives
+// the noisy-depth scene h = 9.0e-3 (12-14 k of 311 k to the ring search; rounds 3-4: 6.3e-3 - 8.2e-3 by view, 27-77 k).
+// Nominal distances on the benchmark's cloud: quartiles 2.7e-3 / 3.9e-3, 90 % 4.8e-3 (ratios of a Poisson sample of a
+// surface: 1.41, 1.82); noisy: 6.0e-3 / 7.8e-3 / 9.7e-3 (between those of a surface and of a volume: 1.26, 1.49).
+constexpr float kCellPerSampleDist = 1.5f;
+
+__device__ __forceinline__ bool is_sample(unsigned i) {
+  unsigned x = i * 0x9E3779B1u;  // (a mixing hash of the index; the low bits of a product alone are regular)
+  x ^= x >> 15;
+  x *= 0x85EBCA77u;
+  x ^= x >> 13;
+  return (x >> (32 - kSampleShift)) == 0u;
+}
+
+// samples of block b (points [b * kSampleBlock, ...)) in index order -> samples[b * kSampleSlots + k] = (x, y, z, index),
+// sample_count[b]: deterministic whatever the scheduling (the cell size must not change from run to run)
+__global__ void __launch_bounds__(256)
+grid_sample_kernel(const float *__restrict__ pts, const int32_t *__restrict__ count, float4 *__restrict__ samples,
+                   int32_t *__restrict__ sample_count) {
+  __shared__ int s_w[4];
+  const int n = *count;
+  const int b = blockIdx.x;
+  if ((long long)b * kSampleBlock >= n) return;
+  constexpr int kPer = kSampleBlock / 256;
+  const int i0 = b * kSampleBlock + threadIdx.x * kPer;
+  unsigned hit = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int i = i0 + k;
+    if (i < n && is_sample((unsigned)i)) {
+      const float x = pts[(size_t)i * 3], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
+      if (isfinite(x) && isfinite(y) && isfinite(z)) hit |= 1u << k;
+    }
+  }
+  const int mine = __popc(hit);
+  int incl = mine;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int y = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += y;
+  }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  int at = incl - mine;
+  for (int w = 0; w < wave; ++w) at += s_w[w];
+  for (unsigned m = hit; m; m &= m - 1) {
+    const int i = i0 + __builtin_ctz(m);
+    if (at < kSampleSlots) samples[(size_t)b * kSampleSlots + at] = make_float4(pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2], __int_as_float(i));
+    ++at;
+  }
+  const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  // the block's unused slots: a point at infinity (the distance pass reads every slot without looking at the count)
+  if ((int)threadIdx.x < kSampleSlots && (int)threadIdx.x >= tot)
+    samples[(size_t)b * kSampleSlots + threadIdx.x] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __int_as_float(-1));
+  if (threadIdx.x == 255) sample_count[b] = tot < kSampleSlots ? tot : kSampleSlots;
+}
+
+// squared distance from query sample (block qb, slot qk) to its nearest other sample; one workgroup per query, every
+// thread a share of the slots (unused ones hold a point at infinity).  Queries: the first four slots of every
+// `stride`-th block (stride from the device-side count: at most kSampleMaxQueries)
+__global__ void __launch_bounds__(256)
+grid_sample_nn_kernel(const int32_t *__restrict__ count, const float4 *__restrict__ samples,
+                      const int32_t *__restrict__ sample_count, float *__restrict__ d1_out) {
+  __shared__ float s_min[4];
+  const int n = *count;
+  const int nblocks = (int)(((long long)n + kSampleBlock - 1) / kSampleBlock);
+  const int stride = (nblocks * 4 + kSampleMaxQueries - 1) / kSampleMaxQueries;  // >= 1 when there is a block
+  const int q = blockIdx.x;  // query number
+  const int qb = (q >> 2) * (stride > 0 ? stride : 1), qk = q & 3;
+  if (qb >= nblocks || qk >= sample_count[qb]) {  // (uniform over the workgroup)
+    if (threadIdx.x == 0) d1_out[q] = -1.0f;  // "no measurement"
+    return;
+  }
+  const int self = qb * kSampleSlots + qk;
+  const float4 me = samples[self];
+  const int nslots = nblocks * kSampleSlots;
+  float best = __builtin_inff();
+  for (int k0 = threadIdx.x; k0 < nslots; k0 += 4 * 256) {
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u * 256;
+      p[u] = samples[k < nslots ? k : self];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float dx = p[u].x - me.x, dy = p[u].y - me.y, dz = p[u].z - me.z;
+      const float d = dx * dx + dy * dy + dz * dz;  // (inf for an unused slot; the query itself is skipped by its slot)
+      const int k = k0 + u * 256;
+      best = (k != self && k < nslots && d < best) ? d : best;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) best = fminf(best, __shfl_xor(best, off, 64));
+  if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    best = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
+    d1_out[q] = best < __builtin_inff() ? best : -1.0f;
+  }
+}
+
+// The grid: origin and extent from the bounding box, cell size h = kCellPerSampleDist x sqrt((K + 1) / 51) x the median
+// nearest-sample distance (positive measurements only; fewer than eight of them -- clouds below ~1000 points, or all
+// points in one place -- : cells from the bounding box as if the points covered its two largest extents evenly).
+// One workgroup of 1024 threads: the median through two 1024-bin histograms of the distances' bit patterns (positive
+// floats order like their bits): 11 bits, then 10 more inside the median's bin -- 2^-13 relative.
+__global__ void __launch_bounds__(1024)
+grid_params_kernel(const unsigned *__restrict__ bbox, const int32_t *__restrict__ count,
+                   const float *__restrict__ d1, GridParams *__restrict__ gp, float k_scale, float target, float rank_frac) {
+  __shared__ int s_hist[1024];
+  __shared__ int s_sel[3];  // chosen bin, entries below it, valid measurements
+  __shared__ int s_wtot[16];
+  const int tid = threadIdx.x;
+  if (tid == 0) s_sel[0] = 0;
+  unsigned bits[kSampleMaxQueries / 1024];
+  int valid = 0;
+#pragma unroll
+  for (int k = 0; k < kSampleMaxQueries / 1024; ++k) {
+    const float v = d1[tid + k * 1024];
+    bits[k] = (v > 0.0f && v < __builtin_inff()) ? __float_as_uint(v) : 0u;
+    valid += bits[k] != 0u;
+  }
+  // (two passes over the same machinery: level 0 bins by bits >> 21, level 1 by (bits >> 11) & 1023 inside the chosen bin)
+  unsigned chosen = 0u;
+  int below = 0, total = 0;
+  for (int level = 0; level < 2; ++level) {
+    s_hist[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSampleMaxQueries / 1024; ++k) {
+      if (bits[k] == 0u) continue;
+      if (level == 0) {
+        atomicAdd(&s_hist[bits[k] >> 21], 1);
+      } else if ((bits[k] >> 21) == chosen) {
+        atomicAdd(&s_hist[(bits[k] >> 11) & 1023u], 1);
+      }
+    }
+    __syncthreads();
+    {
+      // bin tid: entries below it (scan over the 1024 bins: wavefront scan + the 16 wavefront totals)
+      const int mine = s_hist[tid];
+      int incl = mine;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(incl, off, 64);
+        if ((tid & 63) >= off) incl += y;
+      }
+      if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+      __syncthreads();
+      int ex = incl - mine, all = 0;
+      for (int w = 0; w < 16; ++w) {
+        ex += w < (tid >> 6) ? s_wtot[w] : 0;
+        all += s_wtot[w];
+      }
+      if (level == 0 && tid == 0) {
+        s_sel[2] = all;
+        s_sel[1] = 0;
+      }
+      __syncthreads();
+      const int want = (int)((float)s_sel[2] * rank_frac) - s_sel[1];  // rank of the quantile inside what is being binned
+      __syncthreads();
+      if (mine > 0 && ex <= want && want < ex + mine) {  // (one bin at most; none when nothing was measured)
+        s_sel[0] = tid;
+        s_sel[1] += ex;
+      }
+    }
+    __syncthreads();
+    if (level == 0) {
+      chosen = (unsigned)s_sel[0];
+      total = s_sel[2];
+    } else {
+      chosen = (chosen << 10) | (unsigned)s_sel[0];
+    }
+    below = s_sel[1];
+    __syncthreads();
+  }
+  (void)below;
+  (void)valid;
+  if (tid != 0) return;
   const int n = *count;
   float mn[3], ext[3];
   for (int a = 0; a < 3; ++a) {
@@ -117,19 +306,20 @@ __global__ void grid_params_kernel(const unsigned *__restrict__ bbox,
     ext[a] = hi - lo;
   }
   float h;
-  if (sumsq == nullptr) {
+  if (total >= 8) {
+    const float d1_med = sqrtf(__uint_as_float((chosen << 11) | 0x400u));  // (the bin's midpoint)
+    h = kCellPerSampleDist * k_scale * d1_med;
+  } else {
     float e0 = ext[0], e1 = ext[1], e2 = ext[2];
     float big = fmaxf(e0, fmaxf(e1, e2));
     float small = fminf(e0, fminf(e1, e2));
     float mid = e0 + e1 + e2 - big - small;
     float area = big * fmaxf(mid, 1e-3f * big);
     h = sqrtf(area * target / (float)(n > 0 ? n : 1));
-  } else {
-    float per_cell = (float)((double)*sumsq / (double)(n > 0 ? n : 1));
-    if (!(per_cell >= 1.0f)) per_cell = 1.0f;
-    h = gp->h * sqrtf(target / per_cell);
   }
   if (!(h > 0.0f) || !isfinite(h)) h = 1.0f;
+  gp->sample_dist = total >= 8 ? sqrtf(__uint_as_float((chosen << 11) | 0x400u)) : 0.0f;
+  gp->sample_dists = total;
   int G[3];
   for (int it = 0; it < 64; ++it) {
     long long tot = 1;
@@ -193,21 +383,6 @@ __global__ void grid_params_coarse_kernel(const GridParams *__restrict__ fine, c
   gp->ncells = G[0] * G[1] * G[2];
   gp->n = fine->n;
   for (int a = 0; a < 3; ++a) gp->G[a] = G[a];
-}
-
-// sum of squared cell counts of the trial grid: sum(c^2)/n is the occupancy of the cell an
-// average POINT lives in (robust against many singleton outlier cells)
-__global__ void __launch_bounds__(256)
-grid_occupied_kernel(const int32_t *__restrict__ cell_count, const GridParams *__restrict__ gp,
-                     unsigned long long *__restrict__ sumsq) {
-  const int nc = gp->ncells;
-  unsigned long long c = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += gridDim.x * blockDim.x) {
-    unsigned long long v = (unsigned long long)cell_count[i];
-    c += v * v;
-  }
-  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(sumsq, c);
 }
 
 // zero a[0 .. gp->ncells] (device-side bound) for up to three arrays
@@ -881,6 +1056,10 @@ grid_query_body(const GridParams *__restrict__ gp, const float4 *__restrict__ so
 // ring 1 (the same criterion as above) are handed to the wavefront-per-query search.
 // The average is summed in the same 64-slot butterfly order as knn_finish.
 constexpr int kTpqQueue = 4;
+// second attempt of a wavefront (below): four times the first threshold, at most what the block can certify.  (Until round 5:
+// that bound itself -- every list of the wavefront then takes whatever the block holds, 535 us for the noisy scene's pass
+// against 470 with 4 x and 420 with 2.5 x, where 13 k lists come out short a second time and the ring search grows by 50 us.)
+constexpr float kTpqRetryScale = 4.0f;
 
 // insert c into the ascending list a (the largest element drops out): slot i keeps its value
 // if that is <= c, takes c if its left neighbour is <= c < a[i], and takes the left neighbour
@@ -971,8 +1150,8 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
   // Second attempt, per wavefront: the density estimate above assumes points on a SURFACE.  In a cloud from noisy depth
   // (a slab several cells thick) it is too tight for every query -- round 4's noisy scene sent 303 k of 311 k queries to the
   // ring search, 2.5 ms per view instead of 0.9 -- although the block holds their neighbours.  When a quarter of a
-  // wavefront's lists come out short, the wavefront runs the block again with the largest threshold that can still
-  // certify a list (the block's own bound above) for those lanes; the others repeat their search unchanged.  Isolated
+  // wavefront's lists come out short, the wavefront runs the block again with kTpqRetryScale times the threshold (at most
+  // the largest one that can still certify a list: the block's own bound above) for those lanes; the others repeat their search unchanged.  Isolated
   // short lists (0.5 % on the benchmark's cloud) keep going to the ring search: a repeat would cost their whole wavefront.
   for (int attempt = 0;; ++attempt) {
   // The nine rows as x-runs, each cut down to the part of it the ball of the starting threshold can reach: the points
@@ -1155,7 +1334,7 @@ grid_query_tpq_kernel(const GridParams *__restrict__ gp, const float4 *__restric
   const float safe2 = s_safe[tid];
   const bool retry = cut && live && mx < safe2;  // (a list cut at the block's own bound is not complete anyway)
   if (attempt == 1 || __builtin_popcountll(__builtin_amdgcn_ballot_w64(retry)) < 16) break;
-  t0 = retry ? safe2 : t0;
+  t0 = retry ? fminf(kTpqRetryScale * t0, safe2) : t0;
   }
   if (!live) continue;
   // complete?  (the block's bound: see above)
@@ -1293,9 +1472,12 @@ grid_fallback_tail_kernel(const GridParams *__restrict__ gp, const float4 *__res
 
 struct GridWs {
   unsigned *bbox;
-  unsigned long long *sumsq;
   GridParams *gp;
-  int32_t *cell_count, *block_sums, *cell_of;  // cell_count: the dense counters of the TRIAL grid only
+  int32_t *block_sums, *cell_of;
+  float4 *samples;         // [sample_blocks][kSampleSlots]: the thinned cloud behind the cell size (grid_sample_kernel)
+  int32_t *sample_count;   // [sample_blocks]
+  float *sample_d1;        // [kSampleMaxQueries]
+  int sample_blocks;
   uint4 *tab;                                   // first-level grid: bit table with ranks (CellIndex)
   int32_t *occ_count, *occ_start, *nocc;        // points per occupied cell, their starts, the number of occupied cells
   float4 *sorted;
@@ -1328,10 +1510,9 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   GridWs w;
   char *p = reinterpret_cast<char *>(base);
   int64_t off = 0;
-  // one 256-byte state block, zeroed by one memset per call: complemented bbox min, bbox max, sumsq,
+  // one 256-byte state block, zeroed by one memset per call: complemented bbox min, bbox max,
   // the ring histogram and the open-query counters of both levels
   w.bbox = reinterpret_cast<unsigned *>(p + off);
-  w.sumsq = reinterpret_cast<unsigned long long *>(p + off + 64);
   w.stats = reinterpret_cast<int32_t *>(p + off + 128);
   w.fb_count = reinterpret_cast<int32_t *>(p + off + 192);
   w.fb2_count = reinterpret_cast<int32_t *>(p + off + 196);
@@ -1348,8 +1529,13 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   w.state_bytes = off;
   w.gp = reinterpret_cast<GridParams *>(p + off);
   off += 256;
-  w.cell_count = reinterpret_cast<int32_t *>(p + off);
-  off += align_up(((int64_t)kGridMaxCells + 1) * 4, 256);
+  w.sample_blocks = (int)(((capacity > 0 ? capacity : 1) + kSampleBlock - 1) / kSampleBlock);
+  w.samples = reinterpret_cast<float4 *>(p + off);
+  off += align_up((int64_t)w.sample_blocks * kSampleSlots * 16, 256);
+  w.sample_count = reinterpret_cast<int32_t *>(p + off);
+  off += align_up((int64_t)w.sample_blocks * 4, 256);
+  w.sample_d1 = reinterpret_cast<float *>(p + off);
+  off += align_up((int64_t)kSampleMaxQueries * 4, 256);
   w.tab = reinterpret_cast<uint4 *>(p + off);
   off += align_up((int64_t)kTabWords * 16, 256);
   {  // occupied cells <= min(points, cells)
@@ -1426,7 +1612,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
     return PGDVS_ERR_WORKSPACE;
   }
   // empty box: ~min = 0 and max = 0 in the order-preserving uint encoding
-  hipError_t e = hipMemsetAsync(ws.bbox, 0x00, (size_t)ws.state_bytes, st);  // ~min, max, sumsq, stats, counters, scan words
+  hipError_t e = hipMemsetAsync(ws.bbox, 0x00, (size_t)ws.state_bytes, st);  // ~min, max, stats, counters, scan words
   if (e != hipSuccess) {
     set_error("knn_grid memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
@@ -1435,19 +1621,13 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   unsigned gbb = gpts < 128 ? gpts : 128;
   const float target = kTargetPerCellDefault * (float)(K + 1) / 51.0f;
   PGDVS_LAUNCH("grid_bbox", grid_bbox_kernel, dim3(gbb), dim3(256), 0, st, pts, count, ws.bbox);
-  // trial grid from the bounding box, measure the occupancy, then the final grid.  The trial aims at
-  // kTrialCoarser times the occupancy (cells twice as wide on a surface): an eighth of the cells to zero
-  // and to read back, and the surface scaling of pass 1 extrapolates over a factor of two only
-  PGDVS_LAUNCH("grid_params", grid_params_kernel, dim3(1), dim3(64), 0, st, ws.bbox, count,
-               (const unsigned long long *)nullptr, ws.gp, target * kTrialCoarser);
-  PGDVS_LAUNCH("grid_zero", grid_zero_kernel, dim3(2048), dim3(256), 0, st, ws.gp, ws.cell_count,
-               (int32_t *)nullptr);
-  PGDVS_LAUNCH("grid_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
-               ws.cell_count, (const int32_t *)nullptr);
-  PGDVS_LAUNCH("grid_occupied", grid_occupied_kernel, dim3(1024), dim3(256), 0, st, ws.cell_count,
-               ws.gp, ws.sumsq);
-  PGDVS_LAUNCH("grid_params", grid_params_kernel, dim3(1), dim3(64), 0, st, ws.bbox, count,
-               (const unsigned long long *)ws.sumsq, ws.gp, target);
+  // the cell size from the spacing of a thinned copy of the cloud (see grid_params_kernel)
+  PGDVS_LAUNCH("grid_sample", grid_sample_kernel, dim3((unsigned)ws.sample_blocks), dim3(256), 0, st, pts, count, ws.samples,
+               ws.sample_count);
+  PGDVS_LAUNCH("grid_sample_nn", grid_sample_nn_kernel, dim3(kSampleMaxQueries), dim3(256), 0, st, count,
+               (const float4 *)ws.samples, (const int32_t *)ws.sample_count, ws.sample_d1);
+  PGDVS_LAUNCH("grid_params", grid_params_kernel, dim3(1), dim3(1024), 0, st, ws.bbox, count, (const float *)ws.sample_d1, ws.gp,
+               sqrtf((float)(K + 1) / 51.0f), target, 0.5f);
   // the final grid as a sparse cell index (CellIndex): bit table, ranks, points per occupied cell, their starts
   PGDVS_LAUNCH("grid_tab_zero", grid_tab_zero_kernel, dim3(512), dim3(256), 0, st, ws.gp, ws.tab, ws.occ_count);
   PGDVS_LAUNCH("grid_mark", grid_mark_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of, ws.tab);
@@ -1551,7 +1731,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
         hipMemcpy(&nfb2, ws.fb2_count, 4, hipMemcpyDeviceToHost) == hipSuccess &&
         hipMemcpy(&g1, ws.gp, sizeof(g1), hipMemcpyDeviceToHost) == hipSuccess &&
         hipMemcpy(&g2, ws.gp2, sizeof(g2), hipMemcpyDeviceToHost) == hipSuccess) {
-      fprintf(stderr, "[knn_grid] n=%d h=%g G=%dx%dx%d (%d cells); level2 h=%g %dx%dx%d; rings:", g1.n, g1.h, g1.G[0],
+      fprintf(stderr, "[knn_grid] n=%d d1=%g(%d) h=%g G=%dx%dx%d (%d cells); level2 h=%g %dx%dx%d; rings:", g1.n, g1.sample_dist, g1.sample_dists, g1.h, g1.G[0],
               g1.G[1], g1.G[2], g1.ncells, g2.h, g2.G[0], g2.G[1], g2.G[2]);
       for (int i = 1; i < 16; ++i) fprintf(stderr, " %d", hst[i]);
       fprintf(stderr, "; to level 2: %d, exhaustive: %d\n", nfb, nfb2);

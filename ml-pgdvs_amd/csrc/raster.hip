@@ -52,13 +52,20 @@ __device__ __forceinline__ TileBox tile_box(const RasterCam &rc, float3 p, float
   float xc = (float)(W - 1) - ((p.x + offx) * (float)W - offx) / rc.range_x;
   float yc = (float)(H - 1) - ((p.y + offy) * (float)H - offy) / rc.range_y;
   // xc, yc are in pixel-index units (pixel i is centred at i): the disc touches the pixels with
-  // |i - xc| < radius in pixels.  The margin only has to cover the rounding of this inversion
-  // against the forward pix_to_ndc used by the tile kernel (~1e-3 px at 4k); floor/ceil add up to
-  // one more pixel.  (A margin of 1.5 px put 24 % more entries into the tile lists.)
+  // |i - xc| < radius in pixels, i.e. the integers of [ceil(xc - r), floor(xc + r)].  The margin only has to cover the
+  // rounding of this inversion against the forward pix_to_ndc used by the tile kernel (~1e-3 px at 4k).  (A margin of
+  // 1.5 px put 24 % more entries into the tile lists; until round 5 the interval was [floor(xc - r), ceil(xc + r)], one
+  // pixel more on either side: PGDVS_AB_BOX_WIDE builds.)
   float rpx = radius * (float)W / rc.range_x + 0.0625f;
   float rpy = radius * (float)H / rc.range_y + 0.0625f;
+#ifdef PGDVS_AB_BOX_WIDE
   float x0 = floorf(xc - rpx), x1 = ceilf(xc + rpx);
   float y0 = floorf(yc - rpy), y1 = ceilf(yc + rpy);
+#else
+  float x0 = ceilf(xc - rpx), x1 = floorf(xc + rpx);
+  float y0 = ceilf(yc - rpy), y1 = floorf(yc + rpy);
+  if (x1 < x0 || y1 < y0) return b;  // (a disc smaller than a pixel between two pixel centres)
+#endif
   if (x1 < 0.0f || y1 < 0.0f || x0 > (float)(W - 1) || y0 > (float)(H - 1)) return b;
   int ix0 = x0 < 0.0f ? 0 : (int)x0, iy0 = y0 < 0.0f ? 0 : (int)y0;
   int ix1 = x1 > (float)(W - 1) ? W - 1 : (int)x1, iy1 = y1 > (float)(H - 1) ? H - 1 : (int)y1;

@@ -334,15 +334,30 @@ raster_scan_kernel(const int32_t *__restrict__ counts, int n, int32_t *__restric
 // registers), reserves one contiguous range per tile it touched with a single global atomic, and writes the
 // entries at range start + rank: a chunk's entries of one tile are adjacent in the list (whole-line writes
 // instead of 16-byte appends interleaved between workgroups).
-constexpr int kFillPer = 8;
+// (round 5: 4 rows per thread instead of 8 -- the pass is bound by the latency of a chunk's dependent phases (cold loads,
+// LDS ranks, one returning global atomic per touched tile, stores), not by its bytes: 72 -> 57 us alone; with the list of
+// touched tiles below 50 us; 2 rows: 52, 16 rows: 114.  The throughput of the benchmark's loop does not move: other lanes'
+// kernels were already running in this pass's shadow.)
+constexpr int kFillPer = 4;
 constexpr int kFillThreads = 256;
 constexpr int kFillMaxSpan = 2;  // tile box sides kept in registers; wider boxes (large radii) take the slow path
 
-__device__ __forceinline__ int wave_tile_reserve_lds(int *s_tab, int t) {
+// Tiles a chunk touches, in the order of their first reservation (kFillTouchCap of them; a chunk of 1024 consecutive rows
+// of a depth-map cloud touches 50-200 of the 8160 tiles of a 1080p frame): the passes over the table -- one global
+// reservation per tile, clearing it for the next chunk -- then walk this list instead of every slot.
+constexpr int kFillTouchCap = 1024;
+
+__device__ __forceinline__ int wave_tile_reserve_lds(int *s_tab, int t, unsigned short *s_touch, int *s_ntouch) {
   const int lane = threadIdx.x & 63;
   RunInfo r = wave_runs(t);
   int base = 0;
-  if (r.is_leader && t >= 0) base = atomicAdd(&s_tab[t], r.length);
+  if (r.is_leader && t >= 0) {
+    base = atomicAdd(&s_tab[t], r.length);
+    if (base == 0) {  // the chunk's first entry of this tile
+      const int at = atomicAdd(s_ntouch, 1);
+      if (at < kFillTouchCap) s_touch[at] = (unsigned short)t;
+    }
+  }
   base = __shfl(base, r.leader, 64);
   return base + (lane - r.leader);
 }
@@ -356,6 +371,10 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
                    int64_t list_capacity, const float *__restrict__ tile_bound, int64_t gate_rows,
                    int seg, int32_t *__restrict__ overflow, int32_t *__restrict__ status, const int32_t *__restrict__ run_flag) {
   __shared__ int s_tab[kSlots];  // one counter per tile (unused on the slow path)
+  __shared__ unsigned short s_touch[kFillTouchCap];
+  __shared__ int s_ntouch;
+  static_assert(kSlots <= 65536, "tile numbers in the touched list are 16 bits wide");
+  int n_touched = kFillTouchCap + 1;  // of the previous chunk (> cap: the whole table is cleared)
   // Round 5, DIRECT binning (seg > 0): no counting pass and no scan in front of this one -- every tile owns a fixed
   // segment of `seg` entries (lists + t * seg), a chunk reserves its range with the same global atomic, and a range
   // that would leave the segment raises `overflow` (its entries are dropped): the exact count / scan / fill passes are
@@ -392,7 +411,12 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
       ez[u] = X[2];
     }
     if (local) {
-      for (int t = threadIdx.x; t < ntiles; t += kFillThreads) s_tab[t] = 0;
+      if (n_touched <= kFillTouchCap) {
+        for (int k = threadIdx.x; k < n_touched; k += kFillThreads) s_tab[s_touch[k]] = 0;
+      } else {
+        for (int t = threadIdx.x; t < ntiles; t += kFillThreads) s_tab[t] = 0;
+      }
+      if (threadIdx.x == 0) s_ntouch = 0;
       __syncthreads();
     }
 #pragma unroll
@@ -432,13 +456,41 @@ raster_fill_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
           for (int jx = 0; jx < kFillMaxSpan; ++jx) {
             const int t = (jx < (span[u] & 0xff) && jy < (span[u] >> 16) && !((span[u] >> (8 + jy * 2 + jx)) & 1))
                               ? t0[u] + jy * ntx + jx : -1;
-            rank[u][jy] |= ((unsigned)wave_tile_reserve_lds(s_tab, t) & 0xffffu) << (16 * jx);  // < kChunk <= 65536
+            rank[u][jy] |= ((unsigned)wave_tile_reserve_lds(s_tab, t, s_touch, &s_ntouch) & 0xffffu) << (16 * jx);  // < kChunk <= 65536
           }
         }
       }
       static_assert(kChunk <= 65536, "ranks are packed in 16 bits");
       __syncthreads();
+      n_touched = s_ntouch;
       // one global atomic per tile the chunk touched; the requests of a thread go out back to back
+      if (n_touched <= kFillTouchCap) {
+        for (int kb = threadIdx.x; kb < n_touched; kb += kFillThreads * 4) {
+          int t[4], v[4], r[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int idx = kb + k * kFillThreads;
+            t[k] = idx < n_touched ? (int)s_touch[idx] : -1;
+            v[k] = t[k] >= 0 ? s_tab[t[k]] : 0;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            r[k] = 0;
+            if (t[k] >= 0) {
+              if (seg > 0) {
+                const int at = atomicAdd(&cursor[t[k]], v[k]);
+                if (at + v[k] > seg) atomicOr(overflow, 1);
+                r[k] = t[k] * seg + at;
+              } else {
+                r[k] = offsets[t[k]] + atomicAdd(&cursor[t[k]], v[k]);
+              }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (t[k] >= 0) s_tab[t[k]] = r[k];  // list position of this chunk's first entry of the tile
+        }
+      } else
       for (int tb = threadIdx.x; tb < ntiles; tb += kFillThreads * 4) {
         int v[4], r[4];
 #pragma unroll

@@ -18,6 +18,6 @@ for r in 1 2; do
       python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']
-print('sum', round(sum(v['ms_per_step'] for v in k.values())*1e3), {x: round(v['ms_per_step']*1e3,1) for x,v in k.items() if x.startswith('grid') and v['ms_per_step']>=0.015})"
+print('sum', round(sum(v['ms_per_step'] for v in k.values())*1e3), {x: round(v['ms_per_step']*1e3,1) for x,v in k.items() if (x.startswith('grid_query') or x.startswith('raster')) and v['ms_per_step']>=0.015})"
   done
 done

@@ -143,7 +143,9 @@ struct ByteStamp {  // one occupancy byte per (frame, pixel): frame 0's chip-fil
 #ifdef PGDVS_AB_CHAIN  // tools/r05_chain_cost.sh: a duplicate chain that computes everything and stores nothing
   __device__ __forceinline__ void operator()(int f, int q) const { if (occ_all) occ_all[(int64_t)f * P + q] = 1; }
 #else
-  __device__ __forceinline__ void operator()(int f, int q) const { occ_all[(int64_t)f * P + q] = 1; }
+  // (frame base on the scalar unit, the pixel as an unsigned 32-bit offset: the store takes them as they are -- a 64-bit
+  // f * P + q per lane cost three vector instructions per stamp)
+  __device__ __forceinline__ void operator()(int f, int q) const { (occ_all + (int64_t)f * P)[(unsigned)q] = 1; }
 #endif
 };
 template <class Stamp>

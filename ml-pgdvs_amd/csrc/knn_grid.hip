@@ -1055,6 +1055,10 @@ grid_query_body(const GridParams *__restrict__ gp, const float4 *__restrict__ so
 // About 350 vector instructions per query.  Queries whose list is not provably complete after
 // ring 1 (the same criterion as above) are handed to the wavefront-per-query search.
 // The average is summed in the same 64-slot butterfly order as knn_finish.
+// (Round 5, measured and dropped: lanes that stop requesting candidates at 3 / 4 / 5 queued ones, a flush of as many chains
+// as the fullest queue holds once 8 or 16 lanes wait -- an independent-lanes model promised -17 % vector instructions;
+// bit-exact, and 192-213 us against 160: the lanes of a wavefront are neighbours and accept together, waiting only
+// lengthens the walk.  Queues of 5 / 6 / 8 without waiting: 155-158 us.)
 constexpr int kTpqQueue = 4;
 // second attempt of a wavefront (below): four times the first threshold, at most what the block can certify.  (Until round 5:
 // that bound itself -- every list of the wavefront then takes whatever the block holds, 535 us for the noisy scene's pass

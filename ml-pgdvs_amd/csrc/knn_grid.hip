@@ -10,7 +10,10 @@
 // kRingCap rings (isolated outliers) repeat the search on a second-level grid with
 // kCoarseScale-times larger cells; the few still open after that are scanned exhaustively.
 // The first-level grid's cell -> points index is sparse (CellIndex: a bit per cell, ranks per 64 cells, starts of
-// the occupied cells only): a depth-map cloud occupies ~0.15 % of the cells of its bounding box.
+// the occupied cells only): a depth-map cloud occupies ~0.15 % of the cells of its bounding box.  Its cell size
+// comes from the cloud's own spacing (grid_params_kernel: the median distance between the points of a thinned copy),
+// and the points of a cell are kept in the order of their quarter along x (fine_coord), so that a query can cut
+// the x-runs it scans to its ball.
 //
 // Self-queries first go through a THREAD-per-query pass over the 3x3x3 block of their cell
 // (grid_query_tpq_kernel, below); what that leaves open, and cross-set queries, use:

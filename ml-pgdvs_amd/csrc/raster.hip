@@ -645,8 +645,13 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
   __shared__ int s_flag;
   // XCD-aware mapping: blocks b, b+8, ... share an XCD -> give them a contiguous tile band
   const int ntiles = ntx * nty;
-  int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= tiles_per_xcd || tile >= ntiles) return;
+  // Tiles in launch order: neighbouring tiles land on different XCDs (workgroup b runs on XCD b mod 8).  Until round 5 every
+  // XCD drew one contiguous band of the image (tiles_per_xcd: b -> (b & 7) * band + (b >> 3)) for the locality of the
+  // epilogue's feature gathers -- but the bands' work differs (longer lists where the scene is near) and the launch lasted
+  // as long as its slowest XCD: 177 -> 167 us with the plain order, +1.9 % throughput (A/B, three pairs).
+  (void)tiles_per_xcd;
+  const int tile = blockIdx.x;
+  if (tile >= ntiles) return;
   const int ty = tile / ntx, tx = tile - ty * ntx;
   // a wavefront owns one 8x8 quadrant of the tile so that it can cull the list against its own
   // (radius-expanded) bounds before the per-pixel tests
@@ -1326,8 +1331,8 @@ static int points_raster_impl(const float *pts, int64_t pts_stride, const float 
                    0, (int32_t *)nullptr, (int32_t *)nullptr, run_flag);
     }
   }
-  const int tiles_per_xcd = (int)cdiv(ntiles, 8);
-  dim3 grid(8 * tiles_per_xcd);
+  const int tiles_per_xcd = (int)cdiv(ntiles, 8);  // (unused by the kernel since round 5: see raster_tile_kernel)
+  dim3 grid((unsigned)ntiles);
   // dense clouds (the same density from which the depth bound is computed): a second tile launch with a 4096-entry sorted
   // path takes the lists the first one cannot hold
   const bool long_lists = n_points > 0 && n_points >= gate_rows;

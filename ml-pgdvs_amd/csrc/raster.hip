@@ -646,10 +646,12 @@ raster_tile_kernel(const float4 *__restrict__ lists, const int32_t *__restrict__
   const int ntiles = ntx * nty;
   // Tiles in launch order: neighbouring tiles land on different XCDs (workgroup b runs on XCD b mod 8).  Until round 5 every
   // XCD drew one contiguous band of the image (tiles_per_xcd: b -> (b & 7) * band + (b >> 3)) for the locality of the
-  // epilogue's feature gathers -- but the bands' work differs (longer lists where the scene is near) and the launch lasted
-  // as long as its slowest XCD: 177 -> 167 us with the plain order, +1.9 % throughput (A/B, three pairs).
+  // epilogue's feature gathers: 177 -> 167 us with the plain order, +1.9 % throughput (A/B, three pairs).
   (void)tiles_per_xcd;
-  // (scattered -- b * 2731 mod tiles -- or reversed instead of the plain order: 171 / 168 us against 170, no tail to trim)
+  // (scattered -- b * 2731 mod tiles -- or reversed instead of the plain order: 171 / 168 us against 170, no tail to trim;
+  // tile ROWS round-robin over the XCDs -- every XCD an eighth of the rows, horizontal neighbours on one L2 --: 176 us, as
+  // slow as the bands: it is neighbours sharing an XCD that costs, not the bands' imbalance; the plain order pays with
+  // 87 MB more counter traffic per view, the neighbours' shared rows now fetched into several L2s)
   const int tile = blockIdx.x;
   if (tile >= ntiles) return;
   const int ty = tile / ntx, tx = tile - ty * ntx;

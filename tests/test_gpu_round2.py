@@ -566,9 +566,24 @@ def test_static_aggregation_degenerate_camera_motions_vs_oracle(motion):
         assert st.shape[0] < 2.2 * H * W
 
 
+def _bench_line_and_detail(r):
+    """(the compact line = the LAST line of stdout, the detail record from stderr)"""
+    import json
+
+    out_lines = r.stdout.rstrip("\n").splitlines()
+    assert out_lines and out_lines[-1].startswith("{"), r.stdout[-1500:]  # nothing follows the line on stdout
+    assert len([ln for ln in out_lines if ln.startswith("{")]) == 1, r.stdout[-1500:]
+    assert len(out_lines[-1].encode()) <= 4096, len(out_lines[-1])
+    det = [ln for ln in r.stderr.splitlines() if ln.startswith("bench detail: ")]
+    assert len(det) == 1
+    return json.loads(out_lines[-1]), json.loads(det[0][len("bench detail: "):])
+
+
 def test_bench_line_contract_small_workload():
-    """`bench.py` end to end on the GPU at a small size: one JSON line with the driver's fields, the roofline object
-    and the CPU baseline (timed oracle), and the HIP-vs-oracle check of configs[0] inside it"""
+    """`bench.py` end to end on the GPU at a small size, GNT leg and scene / configuration sweeps ON: the LAST stdout line is
+    one JSON object of at most 4 KB with the driver's fields, the roofline object and the CPU baseline (timed oracle);
+    the per-kernel table, the variants and the HIP-vs-oracle check of configs[0] are in the detail record (stderr +
+    gpurun_out/bench_detail.json)"""
     import json
     import os
     import subprocess
@@ -576,11 +591,9 @@ def test_bench_line_contract_small_workload():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--height", "96", "--width", "160", "--frames", "4",
-                        "--steps", "12", "--warmup", "3", "--gnt-rays", "0"], capture_output=True, text=True, timeout=900)
+                        "--steps", "12", "--warmup", "3", "--gnt-rays", "128"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-1500:]
-    b = json.loads(lines[0])
+    b, det = _bench_line_and_detail(r)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in b, k
@@ -588,14 +601,19 @@ def test_bench_line_contract_small_workload():
     assert b["vs_baseline"] is None and b["scaling"] == "weak" and b["data"] == "synthetic" and "workload" in b["config"]
     assert abs(b["value"] - 1e3 / b["ms_per_step"]) / b["value"] < 0.02
     rf = b["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes", "avg_ms"):
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma") and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = b["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
-    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
-    assert cb["hip_vs_oracle_configs0"]["differing_8bit_values"] == 0
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["sample"]) <= 200
+    assert b["gnt"]["tflops"] > 0 and b["roofline_path"]["frac"] > 0
+    # the detail record carries everything the line no longer does
+    assert det["value"] == b["value"] and det["cpu_baseline"]["hip_vs_oracle_configs0"]["differing_8bit_values"] == 0
+    assert det["kernels"] and det["variants"]["scenes"] and det["variants"]["configs"] and det["gnt"]["parity_vs_torch_statement"]
+    on_disk = json.loads(open(os.path.join(root, "gpurun_out", "bench_detail.json")).read())
+    assert on_disk["value"] == b["value"]
 
 
 def test_bench_two_ranks_on_one_gpu():
@@ -619,9 +637,7 @@ def test_bench_two_ranks_on_one_gpu():
                         "--width", "160", "--frames", "4", "--steps", "10", "--warmup", "3", "--gnt-rays", "0",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
-    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-1500:]  # rank 0 alone prints
-    b = json.loads(lines[0])
+    b, det = _bench_line_and_detail(r)  # rank 0 alone prints
     assert b["n_gpus"] == 2 and b["steps"] == 10 and b["scaling"] == "weak" and b["value"] > 0
     per_rank = b["config"]["per_rank_frames_per_s"]
     assert len(per_rank) == 2 and all(x > 0 for x in per_rank)

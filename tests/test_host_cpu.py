@@ -609,3 +609,47 @@ def test_gnt_fine_sampling_mirror_vs_torch_reference_formula():
     zz = sample_fine_z(True, Ns, True, torch.from_numpy(rng.random((R, M + 2)).astype(np.float32)), torch.from_numpy(z)).numpy()
     assert zz.shape == (R, M + 2 + Ns) and np.all(np.diff(zz, axis=1) >= 0)
     assert np.all(zz.min(1) >= z.min(1) - 1e-6) and np.all(zz.max(1) <= z.max(1) + 1e-6)
+
+
+def test_bench_compact_line_from_a_full_record_stays_under_4k():
+    """BENCH_r05.json had `parsed: null`: the line had grown to 22.5 KB and the driver's bounded read cut its head off.  The
+    line now goes through bench.compact_line; round 5's full record (profiles/r05_bench_line.json) reduced by the same function
+    must fit in 4 KB, keep the contract's keys with `roofline` and `cpu_baseline`, and carry no long prose"""
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.loads((ROOT / "profiles" / "r05_bench_line.json").read_text())
+    assert len(json.dumps(full)) > 20000
+    s = bench.compact_line(full)
+    assert len(s.encode()) <= 4096 and "\n" not in s
+    b = json.loads(s)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in b, k
+    assert b["value"] == full["value"] and b["config"]["workload"].startswith("1920x1080")
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in b["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in b["cpu_baseline"], k
+    assert "kernels" not in b and "variants" not in b and "roofline_kernels" not in b
+
+    def strings(o):
+        if isinstance(o, str):
+            yield o
+        elif isinstance(o, dict):
+            for v in o.values():
+                yield from strings(v)
+        elif isinstance(o, list):
+            for v in o:
+                yield from strings(v)
+
+    assert max(len(x) for x in strings(b)) <= 200
+    # a worst case: 8 ranks, every optional object present, long strings everywhere
+    full["config"]["rccl_ranks_seen"] = list(range(8))
+    full["config"]["per_rank_frames_per_s"] = [1234.56] * 8
+    full["config"]["launch"] = "x" * 5000
+    full["cpu_baseline"]["sample"] = "y" * 5000
+    assert len(bench.compact_line(full).encode()) <= 4096

@@ -192,6 +192,9 @@ def parse():
     ap.add_argument("--rank-timeout", type=float, default=1500.0,
                     help="seconds after which a rank that has not finished exits non-zero (a lost peer must not hang the job)")
     ap.add_argument("--gnt-rays", type=int, default=1024, help="rays of the GNT sub-benchmark chunk (0 = skip)")
+    ap.add_argument("--latency-only", type=int, default=0,
+                    help="diagnostic (tools/r06_latency_trace.sh): after the warm-up render N views one at a time with a second stream for the "
+                         "dynamic branch and N on one stream, print the wall-clock medians to stderr and exit (no JSON line)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: exercise the launcher, the view sharding, the per-step gather and the timing "
                          "protocol on CPU tensors over gloo (tests); prints a line with dry_run=true and value=null")
@@ -617,6 +620,19 @@ def main():
         del g
         torch.cuda.synchronize()
         barrier()
+    if args.latency_only > 0:
+        for use_side in (True, False):
+            lat_ = []
+            for j in range(args.latency_only):
+                torch.cuda.synchronize()
+                l0 = time.perf_counter()
+                rvr.render(views[j % n_views], 0, use_side=use_side)
+                rvr.join()
+                torch.cuda.synchronize()
+                lat_.append((time.perf_counter() - l0) * 1e3)
+            lat_.sort()
+            print(f"latency-only: second stream {use_side}: median {lat_[len(lat_) // 2]:.3f} ms, min {lat_[0]:.3f} ms over {len(lat_)} views", file=sys.stderr)
+        return
     lanes_note = f"{n_lanes} (" + ("--inflight" if world == 1 or args.inflight != DEFAULT_LANES_MULTI_RANK else "fixed default for several ranks: no probe collectives") + ")"
     if auto_lanes:
         # How many views in flight, on which streams?  Measured, not guessed: the candidate arrangements are timed through the

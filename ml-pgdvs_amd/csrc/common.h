@@ -185,6 +185,15 @@ __host__ __device__ inline int cam_block_from_flat(const float *flat_cam, float 
   return bad ? -1 : 0;
 }
 
+// order-preserving map float -> unsigned (and back): bounding boxes through integer atomicMax (knn_grid.hip, scan.hip)
+__device__ __forceinline__ unsigned f2ord(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
 __device__ __forceinline__ float clampf(float x, float lo, float hi) {
   return x < lo ? lo : (x > hi ? hi : x);
 }

@@ -1,7 +1,10 @@
 // Dynamic-branch kernels: camera prep, rays, unproject + flow warp, projection to
 // the target view, softsplat metric.  One thread per pixel, coalesced streaming
 // loads; all of these are HBM-bound byte movers (see DESIGN.md for bytes/pixel).
+#include <string.h>
+
 #include "common.h"
+#include "fused.h"
 
 namespace pgdvs {
 
@@ -142,16 +145,15 @@ __global__ void get_rays_kernel(const float *__restrict__ cam, int rh, int rw, i
 }
 
 // A2 + A3 -- pgdvs_renderer_dyn.py:299-388
-__global__ void __launch_bounds__(256)
-dyn_warp_kernel(int H, int W, const float *__restrict__ dyn_mask1, const float *__restrict__ occ,
-                int use_fc, const float *__restrict__ flow12, const float *__restrict__ depth1,
-                const float *__restrict__ depth2, const float *__restrict__ rgb1,
-                const float *__restrict__ rgb2, const float *__restrict__ cam1,
-                const float *__restrict__ cam2, const float *__restrict__ times,
-                uint8_t *__restrict__ mask_eff, uint8_t *__restrict__ valid,
-                float *__restrict__ pcl, float *__restrict__ rgbf) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= H * W) return;
+// (one pixel; returns its validity -- what valid[p] receives)
+__device__ __forceinline__ bool
+dyn_warp_pixel(const int p, int H, int W, const float *__restrict__ dyn_mask1, const float *__restrict__ occ,
+               int use_fc, const float *__restrict__ flow12, const float *__restrict__ depth1,
+               const float *__restrict__ depth2, const float *__restrict__ rgb1,
+               const float *__restrict__ rgb2, const float *__restrict__ cam1,
+               const float *__restrict__ cam2, const float *__restrict__ times,
+               uint8_t *__restrict__ mask_eff, uint8_t *__restrict__ valid,
+               float *__restrict__ pcl, float *__restrict__ rgbf) {
   int r = p / W, c = p - r * W;
   float u = (float)c, v = (float)r;
   const float fw = (float)W, fh = (float)H;
@@ -160,13 +162,13 @@ dyn_warp_kernel(int H, int W, const float *__restrict__ dyn_mask1, const float *
   mask_eff[p] = (uint8_t)m;
   if (!m) {
     valid[p] = 0;
-    return;
+    return false;
   }
   float2 fl = reinterpret_cast<const float2 *>(flow12)[p];
   float ux = u + fl.x, uy = v + fl.y;
   bool ok = (ux >= 0.0f) && (ux <= fw - 1.0f) && (uy >= 0.0f) && (uy <= fh - 1.0f);
   valid[p] = (uint8_t)ok;
-  if (!ok) return;
+  if (!ok) return false;
   const float t1 = times[0], t2 = times[1], tt = times[2];
   const float *M1 = cam1 + PGDVS_CAM_M;
   float d1 = depth1[p];
@@ -184,7 +186,7 @@ dyn_warp_kernel(int H, int W, const float *__restrict__ dyn_mask1, const float *
       pcl[(size_t)p * 3 + k] = X1[k];
       rgbf[(size_t)p * 3 + k] = rgb1[(size_t)p * 3 + k];
     }
-    return;
+    return true;
   }
   float w1 = (t2 - tt) / (t2 - t1);
   float w2 = (tt - t1) / (t2 - t1);
@@ -234,7 +236,45 @@ dyn_warp_kernel(int H, int W, const float *__restrict__ dyn_mask1, const float *
     pcl[(size_t)p * 3 + k] = w1 * X1[k] + w2 * X2;
     rgbf[(size_t)p * 3 + k] = col[k];
   }
+  return true;
 }
+
+// What the per-view native call (view_geo.cpp) lets this launch do on the side, so that the kernels behind it need no
+// launches of their own for it (round 6: a view alone is a chain of launches at ~4.7 us each, whatever they do): two byte maps
+// cleared pixel by pixel (the keep map of the outlier filter, the flag map of the splat), two small state blocks cleared by
+// the first threads (the kNN grid's bounding box / counters / look-back words, the statistics' histograms), and the number of
+// valid pixels per 256-pixel chunk (= per workgroup), from which the compaction that follows takes its offsets: WarpExtras,
+// fused.h.
+__global__ void __launch_bounds__(256)
+dyn_warp_kernel(int H, int W, const float *__restrict__ dyn_mask1, const float *__restrict__ occ,
+                int use_fc, const float *__restrict__ flow12, const float *__restrict__ depth1,
+                const float *__restrict__ depth2, const float *__restrict__ rgb1,
+                const float *__restrict__ rgb2, const float *__restrict__ cam1,
+                const float *__restrict__ cam2, const float *__restrict__ times,
+                uint8_t *__restrict__ mask_eff, uint8_t *__restrict__ valid,
+                float *__restrict__ pcl, float *__restrict__ rgbf, const WarpExtras ex) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = p < H * W;
+  bool ok = false;
+  if (in)
+    ok = dyn_warp_pixel(p, H, W, dyn_mask1, occ, use_fc, flow12, depth1, depth2, rgb1, rgb2, cam1, cam2, times, mask_eff, valid,
+                        pcl, rgbf);
+  if (in && ex.zero_a) ex.zero_a[p] = 0;
+  if (in && ex.zero_b) ex.zero_b[p] = 0;
+  const int stride = gridDim.x * blockDim.x;
+  if (ex.zero0)
+    for (int g = p; g < ex.n16_0; g += stride) ex.zero0[g] = make_uint4(0u, 0u, 0u, 0u);
+  if (ex.zero1)
+    for (int g = p; g < ex.n16_1; g += stride) ex.zero1[g] = make_uint4(0u, 0u, 0u, 0u);
+  if (ex.chunk_cnt) {  // (uniform over the launch: every thread reaches the barrier)
+    __shared__ int s_c[4];
+    const unsigned long long b = __ballot(ok);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = (int)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) ex.chunk_cnt[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+  }
+}
+
 
 // A5 dense -- pgdvs_renderer_dyn.py:470-503, planar flow output
 __global__ void __launch_bounds__(256)
@@ -399,11 +439,22 @@ PGDVS_API int pgdvs_dyn_warp(int H, int W, const float *dyn_mask1, const float *
                     times && mask_eff && valid && pcl && rgbf,
                 "pgdvs_dyn_warp: null pointer");
   PGDVS_REQUIRE(!use_flow_consistency || occ, "pgdvs_dyn_warp: occ mask required");
-  PGDVS_LAUNCH("dyn_warp", dyn_warp_kernel, dim3((unsigned)cdiv((int64_t)H * W, 256)), dim3(256), 0,
-                     as_stream(stream), H, W, dyn_mask1, occ, use_flow_consistency, flow12,
-                     depth1, depth2, rgb1, rgb2, cam1, cam2, times, mask_eff, valid, pcl, rgbf);
+  WarpExtras none;
+  memset(&none, 0, sizeof(none));
+  return dyn_warp_fused(H, W, dyn_mask1, occ, use_flow_consistency, flow12, depth1, depth2, rgb1, rgb2, cam1, cam2, times,
+                        mask_eff, valid, pcl, rgbf, none, as_stream(stream));
+}
+
+namespace pgdvs {
+int dyn_warp_fused(int H, int W, const float *dyn_mask1, const float *occ, int use_flow_consistency, const float *flow12,
+                   const float *depth1, const float *depth2, const float *rgb1, const float *rgb2, const float *cam1,
+                   const float *cam2, const float *times, uint8_t *mask_eff, uint8_t *valid, float *pcl, float *rgbf,
+                   const WarpExtras &ex, hipStream_t st) {
+  PGDVS_LAUNCH("dyn_warp", dyn_warp_kernel, dim3((unsigned)cdiv((int64_t)H * W, 256)), dim3(256), 0, st, H, W, dyn_mask1, occ,
+               use_flow_consistency, flow12, depth1, depth2, rgb1, rgb2, cam1, cam2, times, mask_eff, valid, pcl, rgbf, ex);
   return check_launch("dyn_warp");
 }
+}  // namespace pgdvs
 
 PGDVS_API int pgdvs_project_flow_dense(int H, int W, const float *cam_tgt, const float *pcl,
                                        const uint8_t *keep, float *flow_1_to_tgt,

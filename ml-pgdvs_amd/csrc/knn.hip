@@ -13,6 +13,7 @@
 // LDS column (conflict-free: column index = thread id) with the current maximum in
 // registers, so the common case per candidate is sub/mul/add/compare only.
 #include "common.h"
+#include "fused.h"
 
 namespace pgdvs {
 
@@ -145,21 +146,102 @@ __device__ __forceinline__ unsigned stat_key(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// after pass p: fold the partial sums (fixed tree order), pick the bin holding the wanted rank.  Runs on ONE 256-thread
+// workgroup (all of its threads call it): as a kernel of its own between the passes (the per-op entry point), or -- the
+// per-view call, round 6 -- at the head of EVERY workgroup of the launch that needs its result (three launches less on the
+// dynamic branch's chain: every workgroup reads the same 120 partial sums and 2048 bins and computes the same state).
+// `in`: the state the previous selection left (unused for pass 0); the result goes to *out (shared or global memory) and, for
+// pass 2, the threshold to *thres_out.  Ends with a barrier.
+__device__ __forceinline__ void stat_select_block(const int n, const int pass, const int nblocks,
+                                                  const double *__restrict__ partials, const unsigned *__restrict__ ghist,
+                                                  const StatState in, StatState *out, const float std_thres, float *thres_out) {
+  __shared__ unsigned wtot[4];
+  __shared__ double dsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned rank_in = pass == 0 ? (unsigned)(n > 0 ? (n - 1) / 2 : 0) : in.rank;  // torch.median: lower median
+  const unsigned prefix_in = pass == 0 ? 0u : in.prefix;
+  const double m2_in = in.m2;
+  // sum of the per-block partials (nblocks <= 256), fixed shuffle tree
+  double t = (pass < 2 && tid < nblocks) ? partials[tid] : 0.0;
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  if (lane == 0) dsum[wave] = t;
+  // 2048 bins, 8 per thread: find the bin where the running count passes rank
+  const unsigned *h = ghist + pass * kStatBins;
+  const int nb = pass == 2 ? 1024 : 2048;
+  unsigned loc[8], s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    loc[k] = tid * 8 + k < nb ? h[tid * 8 + k] : 0;
+    s += loc[k];
+  }
+  unsigned x = s;
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wtot[wave] = x;
+  __syncthreads();
+  unsigned before = x - s;  // counts in the bins of the threads before this one
+  for (int w = 0; w < wave; ++w) before += wtot[w];
+  const double total = (dsum[0] + dsum[1]) + (dsum[2] + dsum[3]);
+  const unsigned all = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+  // the thread whose 8 bins contain the rank (the last thread takes it if the histogram is short)
+  const bool owner = (before <= rank_in && rank_in < before + s) || (tid == 255 && rank_in >= all);
+  if (owner) {
+    unsigned acc = before;
+    int k = 0;
+    for (; k < 7; ++k) {
+      if (acc + loc[k] > rank_in) break;
+      acc += loc[k];
+    }
+    int bsel = tid * 8 + k;
+    if (bsel >= nb) bsel = nb - 1;
+    const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+    const unsigned prefix = prefix_in | ((unsigned)bsel << shift);
+    StatState o = in;
+    o.rank = rank_in - acc;
+    o.prefix = prefix;
+    if (pass == 0) {
+      o.mean = n > 0 ? total / (double)n : 0.0;
+      o.n = n;
+    } else if (pass == 1) {
+      o.m2 = total;
+    } else {
+      unsigned u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
+      float med = __uint_as_float(u);
+      float sd = n > 1 ? (float)sqrt(m2_in / (double)(n - 1)) : __builtin_nanf("");
+      *thres_out = n > 0 ? med + sd * std_thres : __builtin_nanf("");
+    }
+    *out = o;
+  }
+  __syncthreads();
+}
+
 // pass: 0 -> accumulate sum(x) and histogram key bits [31:21]
 //       1 -> accumulate sum((x-mean)^2) and histogram bits [20:10] of keys matching prefix[31:21]
 //       2 -> histogram bits [9:0] of keys matching prefix[31:10]
+// kFused: the selection after pass - 1 runs at the head of this launch (stat_select_block; `partials` then holds one array of
+// kStatBlocks sums per pass, so that a workgroup that is already writing its sum cannot disturb one that still selects);
+// workgroup 0 leaves the state in *st_out for the launch behind this one.
+template <bool kFused>
 __global__ void __launch_bounds__(kStatThreads)
 stat_pass_kernel(const float *__restrict__ avg, const int32_t *__restrict__ count, int pass,
                  const StatState *__restrict__ st, double *__restrict__ partials,
-                 unsigned *__restrict__ ghist) {
+                 unsigned *__restrict__ ghist, StatState *__restrict__ st_out) {
   __shared__ unsigned hist[kStatBins];
   __shared__ double wsum[kStatThreads / kWave];
+  __shared__ StatState s_st;
   const int n = *count;
   const int tid = threadIdx.x;
+  if (kFused && pass > 0) {
+    stat_select_block(n, pass - 1, kStatBlocks, partials + (pass - 1) * kStatBlocks, ghist, *st, &s_st, 0.0f, nullptr);
+    if (blockIdx.x == 0 && tid == 0) *st_out = s_st;
+    partials += pass * kStatBlocks;
+  }
   for (int i = tid; i < kStatBins; i += kStatThreads) hist[i] = 0;
   __syncthreads();
-  const double mean = pass == 1 ? st->mean : 0.0;
-  const unsigned prefix = pass > 0 ? st->prefix : 0u;
+  const double mean = pass == 1 ? (kFused ? s_st.mean : st->mean) : 0.0;
+  const unsigned prefix = pass > 0 ? (kFused ? s_st.prefix : st->prefix) : 0u;
   const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
   const unsigned himask = pass == 0 ? 0u : (pass == 1 ? 0xffe00000u : 0xfffffc00u);
   const unsigned binmask = pass == 2 ? 0x3ffu : 0x7ffu;
@@ -203,71 +285,15 @@ stat_pass_kernel(const float *__restrict__ avg, const int32_t *__restrict__ coun
     if (hist[i]) atomicAdd(&ghist[pass * kStatBins + i], hist[i]);
 }
 
-// after pass p: fold the partial sums (fixed tree order), pick the bin holding the wanted rank.
 // One 256-thread block, everything in parallel: the kernel sits on the critical chain of the
-// dynamic branch three times per view.
+// dynamic branch three times per view (per-op entry point; the per-view call runs stat_select_block inside its passes).
 __global__ void __launch_bounds__(256)
 stat_select_kernel(const int32_t *__restrict__ count, int pass, int nblocks,
                    const double *__restrict__ partials, const unsigned *__restrict__ ghist,
                    StatState *__restrict__ st, float std_thres, float *__restrict__ thres_out) {
-  __shared__ unsigned wtot[4];
-  __shared__ double dsum[4];
-  const int n = *count;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned rank_in = pass == 0 ? (unsigned)(n > 0 ? (n - 1) / 2 : 0) : st->rank;  // torch.median: lower median
-  const unsigned prefix_in = pass == 0 ? 0u : st->prefix;
-  const double m2_in = st->m2;
-  // sum of the per-block partials (nblocks <= 256), fixed shuffle tree
-  double t = (pass < 2 && tid < nblocks) ? partials[tid] : 0.0;
-  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-  if (lane == 0) dsum[wave] = t;
-  // 2048 bins, 8 per thread: find the bin where the running count passes rank
-  const unsigned *h = ghist + pass * kStatBins;
-  const int nb = pass == 2 ? 1024 : 2048;
-  unsigned loc[8], s = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    loc[k] = tid * 8 + k < nb ? h[tid * 8 + k] : 0;
-    s += loc[k];
-  }
-  unsigned x = s;
-  for (int off = 1; off < 64; off <<= 1) {
-    unsigned y = __shfl_up(x, off, 64);
-    if (lane >= off) x += y;
-  }
-  if (lane == 63) wtot[wave] = x;
-  __syncthreads();
-  unsigned before = x - s;  // counts in the bins of the threads before this one
-  for (int w = 0; w < wave; ++w) before += wtot[w];
-  const double total = (dsum[0] + dsum[1]) + (dsum[2] + dsum[3]);
-  const unsigned all = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-  // the thread whose 8 bins contain the rank (the last thread takes it if the histogram is short)
-  const bool owner = (before <= rank_in && rank_in < before + s) || (tid == 255 && rank_in >= all);
-  if (owner) {
-    unsigned acc = before;
-    int k = 0;
-    for (; k < 7; ++k) {
-      if (acc + loc[k] > rank_in) break;
-      acc += loc[k];
-    }
-    int bsel = tid * 8 + k;
-    if (bsel >= nb) bsel = nb - 1;
-    const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
-    const unsigned prefix = prefix_in | ((unsigned)bsel << shift);
-    st->rank = rank_in - acc;
-    st->prefix = prefix;
-    if (pass == 0) {
-      st->mean = n > 0 ? total / (double)n : 0.0;
-      st->n = n;
-    } else if (pass == 1) {
-      st->m2 = total;
-    } else {
-      unsigned u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
-      float med = __uint_as_float(u);
-      float sd = n > 1 ? (float)sqrt(m2_in / (double)(n - 1)) : __builtin_nanf("");
-      *thres_out = n > 0 ? med + sd * std_thres : __builtin_nanf("");
-    }
-  }
+  const StatState in = *st;
+  __syncthreads();  // (every thread holds the old state before its owner overwrites it)
+  stat_select_block(*count, pass, nblocks, partials, ghist, in, st, std_thres, thres_out);
 }
 
 __global__ void outlier_flag_kernel(const float *__restrict__ avg, const int32_t *__restrict__ count,
@@ -278,6 +304,27 @@ __global__ void outlier_flag_kernel(const float *__restrict__ avg, const int32_t
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity;
        i += (int64_t)gridDim.x * blockDim.x)
     flag[i] = i < n ? (remove_outlier ? (uint8_t)(avg[i] < t) : (uint8_t)1) : (uint8_t)0;
+}
+
+// The per-view call's last launch of the filter: the selection after pass 2 (the threshold) at the head of every workgroup,
+// then keep[idx[i]] = 1 for every point below it -- what outlier_flag_kernel + a fill + scatter_keep_kernel did in three
+// launches (keep is cleared by the caller: dyn_warp_kernel's extras).
+__global__ void __launch_bounds__(256)
+outlier_keep_kernel(const float *__restrict__ avg, const int32_t *__restrict__ count, const StatState *__restrict__ st,
+                    const double *__restrict__ partials, const unsigned *__restrict__ ghist, float std_thres,
+                    float *__restrict__ thres_out, StatState *__restrict__ st_out, const int32_t *__restrict__ idx,
+                    uint8_t *__restrict__ keep) {
+  __shared__ StatState s_st;
+  __shared__ float s_thres;
+  const int n = *count;
+  stat_select_block(n, 2, kStatBlocks, partials, ghist, *st, &s_st, std_thres, &s_thres);
+  const float t = s_thres;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *thres_out = t;
+    *st_out = s_st;
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    if (avg[i] < t) keep[idx[i]] = 1;
 }
 
 int64_t knn_grid_workspace_bytes(int64_t capacity, int64_t qcapacity);
@@ -337,10 +384,46 @@ PGDVS_API int pgdvs_knn_cross_mean_dist(const float *queries, const int32_t *que
                             as_stream(stream), queries, query_count, query_capacity);
 }
 
+// workspace: [0, 256) two StatState slots (the fused passes ping-pong between them) | partial sums, one array of kStatBlocks per
+// pass (the per-op path uses the first) | the three histograms | spare
 PGDVS_API int64_t pgdvs_outlier_workspace_bytes(int64_t capacity) {
   (void)capacity;
-  return 256 + kStatBlocks * 8 + 3 * kStatBins * 4 + 256;
+  return 256 + 2 * kStatBlocks * 8 + 3 * kStatBins * 4 + 256;
 }
+
+namespace pgdvs {
+void outlier_hist_block(void *workspace, void **block, int64_t *bytes) {
+  *block = reinterpret_cast<char *>(workspace) + 256 + 2 * kStatBlocks * 8;
+  *bytes = 3 * kStatBins * 4;
+}
+
+int outlier_keep_fused(const float *avg, const int32_t *count, int64_t capacity, float std_thres, float *thres_out,
+                       const int32_t *idx, uint8_t *keep, void *workspace, int64_t workspace_bytes, hipStream_t st) {
+  if (!workspace || workspace_bytes < pgdvs_outlier_workspace_bytes(capacity)) {
+    set_error("outlier_keep_fused: workspace too small");
+    return PGDVS_ERR_WORKSPACE;
+  }
+  char *p = reinterpret_cast<char *>(workspace);
+  static_assert(sizeof(StatState) <= 128, "two state slots in the first 256 bytes");
+  StatState *s0 = reinterpret_cast<StatState *>(p), *s1 = reinterpret_cast<StatState *>(p + 128);
+  double *partials = reinterpret_cast<double *>(p + 256);
+  unsigned *ghist = reinterpret_cast<unsigned *>(p + 256 + 2 * kStatBlocks * 8);
+  // (a launch reads the state its predecessor's workgroup 0 wrote and writes the other slot: no workgroup of a launch can
+  // overwrite what a slower one still reads)
+  PGDVS_LAUNCH("stat_pass", stat_pass_kernel<true>, dim3(kStatBlocks), dim3(kStatThreads), 0, st, avg, count, 0,
+               (const StatState *)s0, partials, ghist, s1);
+  PGDVS_LAUNCH("stat_pass", stat_pass_kernel<true>, dim3(kStatBlocks), dim3(kStatThreads), 0, st, avg, count, 1,
+               (const StatState *)s0, partials, ghist, s1);
+  PGDVS_LAUNCH("stat_pass", stat_pass_kernel<true>, dim3(kStatBlocks), dim3(kStatThreads), 0, st, avg, count, 2,
+               (const StatState *)s1, partials, ghist, s0);
+  if (capacity > 0) {
+    const unsigned grid = (unsigned)(cdiv(capacity, 256) < 1024 ? cdiv(capacity, 256) : 1024);
+    PGDVS_LAUNCH("outlier_keep", outlier_keep_kernel, dim3(grid), dim3(256), 0, st, avg, count, (const StatState *)s0,
+                 (const double *)partials, (const unsigned *)ghist, std_thres, thres_out, s1, idx, keep);
+  }
+  return check_launch("outlier_keep_fused");
+}
+}  // namespace pgdvs
 
 PGDVS_API int pgdvs_outlier_flags(const float *avg, const int32_t *count, int64_t capacity,
                                   float std_thres, int remove_outlier, float *thres_out,
@@ -356,15 +439,15 @@ PGDVS_API int pgdvs_outlier_flags(const float *avg, const int32_t *count, int64_
   char *p = reinterpret_cast<char *>(workspace);
   StatState *state = reinterpret_cast<StatState *>(p);
   double *partials = reinterpret_cast<double *>(p + 256);
-  unsigned *ghist = reinterpret_cast<unsigned *>(p + 256 + kStatBlocks * 8);
+  unsigned *ghist = reinterpret_cast<unsigned *>(p + 256 + 2 * kStatBlocks * 8);
   hipError_t e = hipMemsetAsync(ghist, 0, 3 * kStatBins * 4, st);
   if (e != hipSuccess) {
     set_error("outlier_flags memset: %s", hipGetErrorString(e));
     return PGDVS_ERR_LAUNCH;
   }
   for (int pass = 0; pass < 3; ++pass) {
-    PGDVS_LAUNCH("stat_pass", stat_pass_kernel, dim3(kStatBlocks), dim3(kStatThreads), 0, st, avg,
-                 count, pass, state, partials, ghist);
+    PGDVS_LAUNCH("stat_pass", stat_pass_kernel<false>, dim3(kStatBlocks), dim3(kStatThreads), 0, st, avg,
+                 count, pass, (const StatState *)state, partials, ghist, (StatState *)nullptr);
     PGDVS_LAUNCH("stat_select", stat_select_kernel, dim3(1), dim3(256), 0, st, count, pass,
                  kStatBlocks, partials, ghist, state, std_thres, thres_out);
   }

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "fused.h"
 
 namespace pgdvs {
 
@@ -51,14 +52,6 @@ struct GridParams {
   float sample_dist;  // diagnostics: the quantile of the nearest-sample distances behind h, and how many were measured
   int sample_dists;
 };
-
-__device__ __forceinline__ unsigned f2ord(float f) {
-  unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(unsigned u) {
-  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
-}
 
 // bbox[0..2] = ~min (ordered-uint, complemented so that an all-zero block is the empty box), bbox[3..5] = max.  Launched with few blocks: six
 // atomics per block.
@@ -349,11 +342,10 @@ grid_params_kernel(const unsigned *__restrict__ bbox, const int32_t *__restrict_
 // Second-level grid for the queries the first level gives up on: same bounding box, cells
 // `scale` times larger (so the same number of rings reaches `scale` times farther), capped at
 // max_cells.
-__global__ void grid_params_coarse_kernel(const GridParams *__restrict__ fine, const unsigned *__restrict__ bbox,
-                                          GridParams *__restrict__ gp, float scale, float scale_many,
-                                          const int32_t *__restrict__ open_count, const int32_t *__restrict__ qcount,
-                                          int max_cells) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ GridParams coarse_params(const GridParams *__restrict__ fine, const unsigned *__restrict__ bbox,
+                                                    float scale, float scale_many, const int32_t *__restrict__ open_count,
+                                                    const int32_t *__restrict__ qcount, int max_cells) {
+  GridParams gp;
   // (qcount: the queries of a cross-set search; self-queries: the points)
   if ((long long)*open_count * 100 > (long long)(qcount ? *qcount : fine->n)) scale = scale_many;
   float ext[3];
@@ -363,7 +355,7 @@ __global__ void grid_params_coarse_kernel(const GridParams *__restrict__ fine, c
       lo = 0.0f;
       hi = 0.0f;
     }
-    gp->mn[a] = lo;
+    gp.mn[a] = lo;
     ext[a] = hi - lo;
   }
   float h = fine->h * scale;
@@ -381,21 +373,31 @@ __global__ void grid_params_coarse_kernel(const GridParams *__restrict__ fine, c
     if (ok && tot <= max_cells) break;
     h *= 1.3f;
   }
-  gp->h = h;
-  gp->inv_h = 1.0f / h;
-  gp->ncells = G[0] * G[1] * G[2];
-  gp->n = fine->n;
-  for (int a = 0; a < 3; ++a) gp->G[a] = G[a];
+  gp.h = h;
+  gp.inv_h = 1.0f / h;
+  gp.ncells = G[0] * G[1] * G[2];
+  gp.n = fine->n;
+  for (int a = 0; a < 3; ++a) gp.G[a] = G[a];
+  gp.sample_dist = 0.0f;
+  gp.sample_dists = 0;
+  return gp;
 }
 
-// zero a[0 .. gp->ncells] (device-side bound) for up to three arrays
+// ... and its cell counters cleared in the same launch (round 6; until then a one-thread launch for the parameters and a
+// second one to clear cell_count[0 .. ncells]): every workgroup works the parameters out for itself -- a few dozen
+// operations on values that are final when the launch starts --, workgroup 0 leaves them in *gp
 __global__ void __launch_bounds__(256)
-grid_zero_kernel(const GridParams *__restrict__ gp, int32_t *__restrict__ a, int32_t *__restrict__ b) {
-  const int nc = gp->ncells;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nc; i += gridDim.x * blockDim.x) {
-    a[i] = 0;
-    if (b) b[i] = 0;
+grid_coarse_setup_kernel(const GridParams *__restrict__ fine, const unsigned *__restrict__ bbox, GridParams *__restrict__ gp,
+                         float scale, float scale_many, const int32_t *__restrict__ open_count,
+                         const int32_t *__restrict__ qcount, int max_cells, int32_t *__restrict__ cell_count) {
+  __shared__ GridParams s_gp;
+  if (threadIdx.x == 0) {
+    s_gp = coarse_params(fine, bbox, scale, scale_many, open_count, qcount, max_cells);
+    if (blockIdx.x == 0) *gp = s_gp;
   }
+  __syncthreads();
+  const int nc = s_gp.ncells;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nc; i += gridDim.x * blockDim.x) cell_count[i] = 0;
 }
 
 __device__ __forceinline__ int cell_coord(float v, float mn, float inv_h, int G) {
@@ -601,21 +603,33 @@ grid_occ_count_kernel(const GridParams *__restrict__ gp, int32_t *__restrict__ c
 // One launch, one workgroup per tile of 8 K entries, tiles chained by look-back: a workgroup publishes its tile's sum
 // (flag 1) in a 64-bit word of `state`, adds up the words of the tiles before it back to the first one that carries a whole
 // prefix (flag 2; tile 0 does from the start), then publishes its own.  Flag and value travel in one atomic word, so no
-// ordering between words is needed; workgroups are dispatched in index order and never wait for a LATER one.  `state` is
-// zeroed before the launch (the call's memset).  Inside a tile thread t owns the 16-byte groups (k * 1024 + t): every load
+// ordering between words is needed; a tile is a TICKET (see below), so a workgroup never waits for a tile nobody holds.  `state`
+// and the ticket word are zeroed before the launch (the call's memset).  Inside a tile thread t owns the 16-byte groups (k * 1024 + t): every load
 // and store instruction of a wavefront covers 1 KB of consecutive memory.  `in` must be readable up to the next multiple
 // of four entries behind n (the workspace's arrays are).
 constexpr int kScanVec = 2;
 constexpr int kScanTile = 1024 * 4 * kScanVec;
+constexpr int kScanMaxBlocks = 256;             // workgroups of a scan launch: they take tiles by ticket until none is left
+constexpr unsigned kScanSpinLimit = 1u << 22;   // polls of one predecessor word before the scan gives up (never expected)
+// (round 6, after the advisor's finding: until then the tile was blockIdx.x -- dispatch order is NOT index order on eight XCDs
+// with other views' kernels on the CUs: beside the tile pass one scan of 9 live tiles among 1013 launched took 102 us instead
+// of 6 --, the spin was unbounded, and the launch was sized from the capacity.  Now: a ticket per tile from a word of the
+// zeroed state block, so that a tile's predecessors are always held by workgroups that already run; at most kScanMaxBlocks
+// workgroups that loop; a bounded spin that sets *error and goes on with a zero carry -- offsets stay inside the arrays, the
+// caller poisons the results.)
 __global__ void __launch_bounds__(1024)
 grid_scan_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ n_ptr, int32_t *__restrict__ out,
-                 unsigned long long *__restrict__ state) {
+                 unsigned long long *__restrict__ state, int32_t *__restrict__ ticket, int32_t *__restrict__ error) {
   __shared__ int s_tot[kScanVec * 16];  // [sub-tile][wavefront]
   __shared__ int s_carry;
+  __shared__ int s_tile;
   const int n = *n_ptr;
-  const int tile = blockIdx.x;
-  if ((long long)tile * kScanTile > n) return;  // (<= n: the tile that holds out[n])
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (;;) {
+  if (tid == 0) s_tile = atomicAdd(ticket, 1);
+  __syncthreads();
+  const int tile = s_tile;
+  if ((long long)tile * kScanTile > n) return;  // (<= n: the tile that holds out[n]; uniform over the workgroup)
   int4 v[kScanVec];
   int x[kScanVec];
 #pragma unroll
@@ -658,9 +672,17 @@ grid_scan_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ n_p
         const int i = back - lane;
         unsigned long long w = 3ull << 32;  // (lanes before tile 0: nothing to add, nothing to wait for)
         if (i >= 0) {
-          do {
+          unsigned spins = 0;
+          for (;;) {
             w = __hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } while ((w >> 32) == 0ull);
+            if ((w >> 32) != 0ull) break;
+            if (++spins > kScanSpinLimit) {  // keeps a protocol bug from hanging the GPU
+              atomicExch(error, 1);
+              w = 2ull << 32;  // "whole prefix 0": the walk stops here, the offsets stay inside the arrays
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
         }
         const unsigned long long whole = __ballot((w >> 32) == 2ull);
         const int stop = whole ? __builtin_ctzll(whole) : 63;  // nearest tile with a whole prefix
@@ -692,6 +714,8 @@ grid_scan_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ n_p
       if (idx + 1 <= n) out[idx + 1] = q.y;
       if (idx + 2 <= n) out[idx + 2] = q.z;
     }
+  }
+  __syncthreads();  // (s_tot / s_carry / s_tile are rewritten by the next tile)
   }
 }
 
@@ -1426,16 +1450,28 @@ grid_fallback_kernel(const GridParams *__restrict__ gp, const float4 *__restrict
   }
 }
 
-__global__ void __launch_bounds__(256)
-grid_fallback_merge_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted, int KK,
-                           QuerySrc qs, const int32_t *__restrict__ fb_count, const int32_t *__restrict__ fb_list,
-                           const float *__restrict__ fb_partial, float *__restrict__ avg_out) {
+// ... the merge of the slices' lists, and -- the overflow path: more open queries than kFbMaxSliced (degenerate clouds) -- one
+// 1024-thread workgroup per query scanning everything, in ONE launch (round 6; two until then): a wavefront per sliced query
+// first, whole workgroups for the queries beyond kFbMaxSliced after that
+__global__ void __launch_bounds__(1024)
+grid_fallback_finish_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted, int KK,
+                            QuerySrc qs, const int32_t *__restrict__ fb_count, const int32_t *__restrict__ fb_list,
+                            const float *__restrict__ fb_bound, const float *__restrict__ fb_partial, float *__restrict__ avg_out,
+                            const int32_t *__restrict__ scan_error) {
+  __shared__ float s_best[16][64];
   const int n = gp->n;
+  if (*scan_error != 0) {
+    // a look-back scan of this search gave up (grid_scan_kernel): its cell starts are not trustworthy -- every average becomes
+    // NaN, and with it the statistics and the threshold behind them (callers that read the threshold see NaN)
+    const int nq = query_count(qs, n);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) avg_out[i] = __builtin_nanf("");
+    return;
+  }
   const int nfb = *fb_count;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nsl = nfb < kFbMaxSliced ? nfb : kFbMaxSliced;
-  for (int f = blockIdx.x * 4 + wave; f < nsl; f += gridDim.x * 4) {
+  for (int f = blockIdx.x * 16 + wave; f < nsl; f += gridDim.x * 16) {
     BestList b;
     b.best = fb_partial[((size_t)f * kFbSlices) * 64 + lane];  // slice 0 is already sorted
     b.mx = readlane_f(b.best, KK - 1);
@@ -1443,19 +1479,6 @@ grid_fallback_merge_kernel(const GridParams *__restrict__ gp, const float4 *__re
       best_insert_batch(b, fb_partial[((size_t)f * kFbSlices + sl) * 64 + lane], true, KK, lane);
     knn_finish(b.best, KK, qs.first_col, n, lane, __float_as_int(load_query(qs, sorted, fb_list[f]).w), avg_out);
   }
-}
-
-// overflow path: more open queries than kFbMaxSliced (degenerate clouds) -- one 1024-thread
-// workgroup per query scans everything
-__global__ void __launch_bounds__(1024)
-grid_fallback_tail_kernel(const GridParams *__restrict__ gp, const float4 *__restrict__ sorted, int KK,
-                          QuerySrc qs, const int32_t *__restrict__ fb_count, const int32_t *__restrict__ fb_list,
-                          const float *__restrict__ fb_bound, float *__restrict__ avg_out) {
-  __shared__ float s_best[16][64];
-  const int n = gp->n;
-  const int nfb = *fb_count;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   for (int f = kFbMaxSliced + blockIdx.x; f < nfb; f += gridDim.x) {
     const float4 qp = load_query(qs, sorted, fb_list[f]);
     const float bound = fb_bound[f];
@@ -1493,6 +1516,7 @@ struct GridWs {
   float *fb_bound;
   float *fb_partial;  // [kFbMaxSliced][kFbSlices][64]
   unsigned long long *scan_state, *scan_state2;
+  int32_t *scan_ticket, *scan_error;
   int scan_tiles;
   int64_t state_bytes;  // the block the call's memset clears
   int32_t *stats;  // [16] ring histogram, filled only when PGDVS_KNN_STATS=1 (diagnostics)
@@ -1525,6 +1549,8 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   w.fb2_count = reinterpret_cast<int32_t *>(p + off + 196);
   w.open_count = reinterpret_cast<int32_t *>(p + off + 200);
   w.nocc = reinterpret_cast<int32_t *>(p + off + 204);  // [2]: occupied cells, kSub x that
+  w.scan_ticket = reinterpret_cast<int32_t *>(p + off + 216);  // [2]: tile tickets of the two scans (grid_scan_kernel)
+  w.scan_error = reinterpret_cast<int32_t *>(p + off + 224);   // a look-back spin gave up: results are poisoned (NaN)
   off += 256;
   // ... and the look-back words of the two scans (grid_scan_kernel), one per tile that can occur
   w.scan_state = reinterpret_cast<unsigned long long *>(p + off);
@@ -1601,9 +1627,32 @@ int64_t knn_grid_workspace_bytes(int64_t capacity, int64_t qcapacity) {
 
 // qpts == nullptr: self mode (mean of columns 1..K).  Otherwise cross mode: mean of the K+1
 // smallest distances from each of the *qcount queries to the points.
+static int knn_grid_search(const float *pts, const int32_t *count, int64_t capacity, int K, float *avg_out,
+                           void *workspace, int64_t workspace_bytes, hipStream_t st, const float *qpts,
+                           const int32_t *qcount, int64_t qcapacity, bool prepared);
+
 int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity, int K, float *avg_out,
                        void *workspace, int64_t workspace_bytes, hipStream_t st, const float *qpts,
                        const int32_t *qcount, int64_t qcapacity) {
+  return knn_grid_search(pts, count, capacity, K, avg_out, workspace, workspace_bytes, st, qpts, qcount, qcapacity, false);
+}
+
+// fused.h: the per-view call clears the state block and computes the bounding box inside launches it runs anyway
+void knn_grid_state_block(void *workspace, int64_t capacity, void **block, int64_t *bytes, unsigned **bbox) {
+  const GridWs ws = grid_ws_layout(workspace, capacity, 0);
+  *block = ws.bbox;
+  *bytes = ws.state_bytes;
+  *bbox = ws.bbox;
+}
+int knn_grid_mean_dist_prepared(const float *pts, const int32_t *count, int64_t capacity, int K, float *avg_out, void *workspace,
+                                int64_t workspace_bytes, hipStream_t st) {
+  return knn_grid_search(pts, count, capacity, K, avg_out, workspace, workspace_bytes, st, nullptr, nullptr, 0, true);
+}
+
+// prepared: the state block is cleared and holds the points' bounding box already (no memset, no grid_bbox launch)
+static int knn_grid_search(const float *pts, const int32_t *count, int64_t capacity, int K, float *avg_out,
+                           void *workspace, int64_t workspace_bytes, hipStream_t st, const float *qpts,
+                           const int32_t *qcount, int64_t qcapacity, bool prepared) {
   GridWs ws = grid_ws_layout(workspace, capacity, qcapacity);
   const int KK = K + 1;
   QuerySrc qs;
@@ -1619,15 +1668,17 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
     return PGDVS_ERR_WORKSPACE;
   }
   // empty box: ~min = 0 and max = 0 in the order-preserving uint encoding
-  hipError_t e = hipMemsetAsync(ws.bbox, 0x00, (size_t)ws.state_bytes, st);  // ~min, max, stats, counters, scan words
-  if (e != hipSuccess) {
-    set_error("knn_grid memset: %s", hipGetErrorString(e));
-    return PGDVS_ERR_LAUNCH;
-  }
   unsigned gpts = (unsigned)(cdiv(capacity, 256) < 2048 ? cdiv(capacity, 256) : 2048);
   unsigned gbb = gpts < 128 ? gpts : 128;
   const float target = kTargetPerCellDefault * (float)(K + 1) / 51.0f;
-  PGDVS_LAUNCH("grid_bbox", grid_bbox_kernel, dim3(gbb), dim3(256), 0, st, pts, count, ws.bbox);
+  if (!prepared) {
+    hipError_t e = hipMemsetAsync(ws.bbox, 0x00, (size_t)ws.state_bytes, st);  // ~min, max, stats, counters, scan words
+    if (e != hipSuccess) {
+      set_error("knn_grid memset: %s", hipGetErrorString(e));
+      return PGDVS_ERR_LAUNCH;
+    }
+    PGDVS_LAUNCH("grid_bbox", grid_bbox_kernel, dim3(gbb), dim3(256), 0, st, pts, count, ws.bbox);
+  }
   // the cell size from the spacing of a thinned copy of the cloud (see grid_params_kernel)
   PGDVS_LAUNCH("grid_sample", grid_sample_kernel, dim3((unsigned)ws.sample_blocks), dim3(256), 0, st, pts, count, ws.samples,
                ws.sample_count);
@@ -1647,8 +1698,8 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   const int64_t occ_cap = capacity < kGridMaxCells ? capacity : (int64_t)kGridMaxCells;
   const int nb = (int)cdiv(occ_cap + 1, kScanTile);  // (<= kGridMaxCells / kScanTile = 1024: one pass over the block sums)
   (void)nb;
-  PGDVS_LAUNCH("grid_scan", grid_scan_kernel, dim3((unsigned)ws.scan_tiles), dim3(1024), 0, st, ws.occ_count,
-               (const int32_t *)(ws.nocc + 1), ws.occ_start, ws.scan_state);
+  PGDVS_LAUNCH("grid_scan", grid_scan_kernel, dim3((unsigned)(ws.scan_tiles < kScanMaxBlocks ? ws.scan_tiles : kScanMaxBlocks)), dim3(1024), 0, st,
+               ws.occ_count, (const int32_t *)(ws.nocc + 1), ws.occ_start, ws.scan_state, ws.scan_ticket, ws.scan_error);
   PGDVS_LAUNCH("grid_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of,
                ws.occ_start, ws.occ_count, ws.sorted, (const int32_t *)nullptr);
   CellIndex ci;
@@ -1698,15 +1749,14 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   // kCoarseScale-times larger cells before anything is scanned exhaustively.  All of it is
   // gated on the device-side count of open queries.
   const int nb2 = kCoarseMaxCells / kScanTile;
-  PGDVS_LAUNCH("grid2_params", grid_params_coarse_kernel, dim3(1), dim3(64), 0, st, ws.gp, ws.bbox, ws.gp2,
+  PGDVS_LAUNCH("grid2_setup", grid_coarse_setup_kernel, dim3(256), dim3(256), 0, st, ws.gp, ws.bbox, ws.gp2,
                kCoarseScale, kCoarseScaleMany, (const int32_t *)ws.fb_count, qpts ? qcount : (const int32_t *)nullptr,
-               kCoarseMaxCells);
-  PGDVS_LAUNCH("grid2_zero", grid_zero_kernel, dim3(256), dim3(256), 0, st, ws.gp2, ws.cell_count2, (int32_t *)nullptr);
+               kCoarseMaxCells, ws.cell_count2);
   PGDVS_LAUNCH("grid2_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp2, ws.cell_of,
                ws.cell_count2, (const int32_t *)ws.fb_count);
   (void)nb2;
   PGDVS_LAUNCH("grid2_scan", grid_scan_kernel, dim3(kCoarseMaxCells / kScanTile + 1), dim3(1024), 0, st, ws.cell_count2,
-               (const int32_t *)&ws.gp2->ncells, ws.cell_start2, ws.scan_state2);
+               (const int32_t *)&ws.gp2->ncells, ws.cell_start2, ws.scan_state2, ws.scan_ticket + 1, ws.scan_error);
   PGDVS_LAUNCH("grid2_fill", grid_fill_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp2, ws.cell_of,
                ws.cell_start2, ws.cell_count2, ws.sorted2, (const int32_t *)ws.fb_count);
   CellIndex ci2;  // the coarse grid stays dense (<= 256 K cells)
@@ -1722,10 +1772,8 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
   // exhaustive scan for what is left (rare)
   PGDVS_LAUNCH("grid_fallback", grid_fallback_kernel, dim3(4096), dim3(256), 0, st, ws.gp, ws.sorted, KK,
                qs, ws.fb2_count, ws.fb2_list, ws.fb2_bound, ws.fb_partial);
-  PGDVS_LAUNCH("grid_fallback_merge", grid_fallback_merge_kernel, dim3(256), dim3(256), 0, st, ws.gp,
-               ws.sorted, KK, qs, ws.fb2_count, ws.fb2_list, ws.fb_partial, avg_out);
-  PGDVS_LAUNCH("grid_fallback_tail", grid_fallback_tail_kernel, dim3(256), dim3(1024), 0, st, ws.gp,
-               ws.sorted, KK, qs, ws.fb2_count, ws.fb2_list, ws.fb2_bound, avg_out);
+  PGDVS_LAUNCH("grid_fallback_finish", grid_fallback_finish_kernel, dim3(256), dim3(1024), 0, st, ws.gp, ws.sorted, KK, qs,
+               ws.fb2_count, ws.fb2_list, ws.fb2_bound, ws.fb_partial, avg_out, (const int32_t *)ws.scan_error);
 #ifdef PGDVS_AB_TPQ_STATS
   if (want_stats) stats = ws.stats;
 #endif

@@ -12,6 +12,7 @@
 // changes an accumulator, so the result is identical and the zero-flow (static)
 // majority costs one atomic per channel instead of four.
 #include "common.h"
+#include "fused.h"
 
 namespace pgdvs {
 
@@ -173,6 +174,40 @@ dyn_splat_flag_kernel(int H, int W, const float *__restrict__ flow_1_to_tgt,
   if (valid_mask[p] == 0.0f) return;
   int y = p / W, x = p - y * W;
   SplatCorners c = splat_corners(x, y, flow_1_to_tgt[p], flow_1_to_tgt[(size_t)P + p], H, W);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (c.idx[k] >= 0) {
+      flags[c.idx[k]] = 1;
+#pragma unroll
+      for (int pl = 0; pl < 5; ++pl) acc[(size_t)pl * P + c.idx[k]] = 0.0f;
+    }
+}
+
+// The per-view call's variant (round 6): A5's projection of the kept points into the target view
+// (project_flow_dense_kernel, dyn.hip: flow = projection - pixel, planar, zeros and mask 0 where nothing is kept) inside the
+// flag pass -- the same operations on the same values, one launch and one read of the flow planes less.
+__global__ void __launch_bounds__(256)
+dyn_project_flag_kernel(int H, int W, const float *__restrict__ cam_tgt, const float *__restrict__ pcl,
+                        const uint8_t *__restrict__ keep, float *__restrict__ flow_1_to_tgt, float *__restrict__ valid_mask,
+                        uint8_t *__restrict__ flags, float *__restrict__ acc) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int P = H * W;
+  if (p >= P) return;
+  float fx = 0.0f, fy = 0.0f, vm = 0.0f;
+  int y = p / W, x = p - y * W;
+  const bool kept = keep[p] != 0;
+  if (kept) {
+    float u, v;
+    project_point(cam_tgt + PGDVS_CAM_P, pcl[(size_t)p * 3], pcl[(size_t)p * 3 + 1], pcl[(size_t)p * 3 + 2], u, v);
+    fx = u - (float)x;
+    fy = v - (float)y;
+    vm = 1.0f;
+  }
+  flow_1_to_tgt[p] = fx;
+  flow_1_to_tgt[(size_t)P + p] = fy;
+  valid_mask[p] = vm;
+  if (!kept) return;
+  SplatCorners c = splat_corners(x, y, fx, fy, H, W);
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     if (c.idx[k] >= 0) {
@@ -587,6 +622,33 @@ int dyn_splat_scatter_part(int H, int W, const float *rgb1, const float *rgb2, c
   const dim3 tgrid((unsigned)cdiv(W, kSplatTile), (unsigned)cdiv(H, kSplatTile));
   PGDVS_LAUNCH("dyn_splat_scatter", dyn_splat_scatter_kernel, tgrid, block, 0, st, H, W, rgb1, rgb2, flow12,
                      flow_1_to_tgt, valid_dyn_mask_1, noise, rng, alpha, acc, (const uint8_t *)flags);
+  return check_launch("dyn_splat_scatter");
+}
+
+uint8_t *dyn_splat_flag_map(void *workspace, int H, int W) {
+  return reinterpret_cast<uint8_t *>(reinterpret_cast<float *>(workspace) + (size_t)5 * H * W);
+}
+
+int dyn_splat_scatter_part_fused(int H, int W, const float *rgb1, const float *rgb2, const float *flow12, const float *cam_tgt,
+                                 const float *pcl, const uint8_t *keep, float *flow_1_to_tgt, float *valid_mask,
+                                 const float *noise, const unsigned long long *rng, float alpha, void *workspace,
+                                 bool flags_cleared, hipStream_t st) {
+  const int P = H * W;
+  float *acc = reinterpret_cast<float *>(workspace);
+  uint8_t *flags = dyn_splat_flag_map(workspace, H, W);
+  if (!flags_cleared) {
+    hipError_t e = fill_async(flags, 0, (size_t)P, st);
+    if (e != hipSuccess) {
+      set_error("dyn_splat memset: %s", hipGetErrorString(e));
+      return PGDVS_ERR_LAUNCH;
+    }
+  }
+  dim3 grid((unsigned)cdiv(P, 256)), block(256);
+  PGDVS_LAUNCH("dyn_project_flag", dyn_project_flag_kernel, grid, block, 0, st, H, W, cam_tgt, pcl, keep, flow_1_to_tgt, valid_mask,
+               flags, acc);
+  const dim3 tgrid((unsigned)cdiv(W, kSplatTile), (unsigned)cdiv(H, kSplatTile));
+  PGDVS_LAUNCH("dyn_splat_scatter", dyn_splat_scatter_kernel, tgrid, block, 0, st, H, W, rgb1, rgb2, flow12,
+               (const float *)flow_1_to_tgt, (const float *)valid_mask, noise, rng, alpha, acc, (const uint8_t *)flags);
   return check_launch("dyn_splat_scatter");
 }
 

@@ -770,8 +770,21 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
   __syncthreads();
   const ByteStamp stamp{occ_all, (int64_t)H * W, stat};
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
-  for (int e0 = 0; e0 < n; e0 += kStepThreads) {
-    const int e = e0 + tid;
+  // Round 6: a workgroup lists ~120 pixels (60 k per link over 512 workgroups), so with one thread per listed pixel two of its
+  // four wavefronts had nothing to screen -- and ran the whole frame loop on NaNs beside the other two, which walked all the
+  // later frames one after the other.  Now the (pixel, frame) pairs are dealt over all four: up to 64 listed pixels, every
+  // wavefront screens a quarter of the frames; up to 128, a half (`part`: wave-uniform; every part unprojects its pixels
+  // itself -- the same depth, the same operations); a wavefront without a listed pixel skips the loop.  Same stamps, same
+  // queue decisions (an entry's frame bits are relative to fa whichever part queued it).
+  const int F = fb - fa;
+  const int parts = (n <= 64 && F >= 4) ? 4 : ((n <= 128 && F >= 2) ? 2 : 1);
+  const int R = kStepThreads / parts;  // listed pixels per round
+  const int part = __builtin_amdgcn_readfirstlane(tid / R), el = tid - part * R;
+  const int per = (F + parts - 1) / parts;
+  const int fa_p = fa + part * per;
+  const int fb_p = fa_p + per < fb ? fa_p + per : fb;
+  for (int e0 = 0; e0 < n; e0 += R) {
+    const int e = e0 + el;
     const bool live = e < n;
     float x = 0.f, y = 0.f, z = 0.f, d = 0.f;
     f3 c = {0.f, 0.f, 0.f};
@@ -783,7 +796,7 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
       // colour is still on its way while they run and is consumed at the very end of the round -- both are left for
       // agg_rows, which then reads 16 dense bytes per row instead of a sector per scattered depth and another per colour
       d = app.depth[px];
-      if (staged) {
+      if (staged && part == 0) {
         c = *reinterpret_cast<const f3 *>(app.rgb + (size_t)px * 3);
         slot4 = (wg_slot * (kStepThreads * kStepPx) + e) * 4;
       }
@@ -792,8 +805,10 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
       y = X.y;
       z = X.z;
     }
-    const unsigned dmask = screen_frames([&](const int f) { return s_pc[f - fa]; }, fa, fb, live, x, y, z, wm1, hm1, W, stamp);
-    queue_doubtful<kQueue, kStepThreads>(s_q, s_qn, dmask, x, y, z, fa, e0 + kStepThreads >= n, proj, H, W, stamp);
+    unsigned dmask = 0;
+    if (__ballot(live) != 0ull && fa_p < fb_p)
+      dmask = screen_frames([&](const int f) { return s_pc[f - fa]; }, fa_p, fb_p, live, x, y, z, wm1, hm1, W, stamp) << (fa_p - fa);
+    queue_doubtful<kQueue, kStepThreads>(s_q, s_qn, dmask, x, y, z, fa, e0 + R >= n, proj, H, W, stamp);
     if (slot4 >= 0) *reinterpret_cast<float4 *>(stage.rows + slot4) = make_float4(d, c.x, c.y, c.z);
   }
 }

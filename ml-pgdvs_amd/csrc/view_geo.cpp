@@ -7,11 +7,13 @@
 // cost of ~85 ctypes calls, ~40 allocator round trips and the Python between them (0.53-0.74 ms per view in round 3
 // against 0.86 ms of GPU time).
 #include <chrono>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <vector>
 
 #include "common.h"
+#include "fused.h"
 #include "scan.h"
 
 namespace pgdvs {
@@ -68,6 +70,7 @@ struct ViewWs {
   uint8_t *mask_eff, *valid, *keep, *flag;
   float *pcl, *rgbf, *pts, *avg, *thres;
   int32_t *idx, *cnt;
+  int32_t *chunk_cnt;  // [ceil(P / 256)] valid pixels per workgroup of dyn_warp_kernel (fused compaction)
   void *compact;
   int64_t compact_bytes;
   void *knn;
@@ -132,12 +135,14 @@ int view_layout(const pgdvs_view_geo_desc &d, void *base, ViewWs &w) {
   w.splat = c.take<char>(w.splat_bytes);
   w.idx = nullptr;
   w.cnt = nullptr;
+  w.chunk_cnt = nullptr;
   w.pts = w.avg = w.thres = nullptr;
   w.compact = w.knn = w.outlier = nullptr;
   w.compact_bytes = w.knn_bytes = w.outlier_bytes = 0;
   if (d.remove_outlier) {
     w.idx = c.take<int32_t>(P * 4);
     w.cnt = c.take<int32_t>(16);
+    w.chunk_cnt = c.take<int32_t>(cdiv(P, 256) * 4);
     w.thres = c.take<float>(16);
     w.pts = c.take<float>(P * 12);
     w.avg = c.take<float>(P * 4);
@@ -190,29 +195,50 @@ double g_stat_seconds = 0.0;
     if (_rc != PGDVS_OK) return _rc; \
   } while (0)
 
-// A2-A5: the dynamic branch's geometry on stream `s` (cams / times already there)
+// A2-A5: the dynamic branch's geometry on stream `s` (cams / times already there).
+// Round 6: 28 launches instead of 42 + four memsets -- a view alone is a dependent chain of launches at ~4.7 us each and the
+// host pays ~3.8 us per launch (tools/r06_latency_trace.sh), so the small jobs ride on their neighbours (fused.h): dyn_warp
+// clears the keep map, the splat's flag map, the kNN state block and the statistics' histograms and counts its valid pixels per
+// workgroup; ONE launch compacts, gathers the points and folds their bounding box; the three bin selections of the
+// median run at the head of the passes behind them; the filter's last launch writes keep[idx[i]] itself; the projection into
+// the target view runs inside the splat's flag pass.  Same bytes as the per-op entry points (tests/test_gpu_round6.py).
 int dyn_geometry(const pgdvs_view_geo_desc &d, const ViewWs &w, pgdvs_stream_t s) {
   const int H = d.H, W = d.W;
   const int64_t P = (int64_t)H * W;
+  hipStream_t st = as_stream(s);
   const float *cam_t = w.cams, *cam1 = w.cams + PGDVS_CAM_BLOCK, *cam2 = w.cams + 2 * PGDVS_CAM_BLOCK;
-  VG_TRY(pgdvs_dyn_warp(H, W, d.dyn_mask1, d.flow_occ, d.use_flow_consistency, d.flow12, d.depth1, d.depth2, d.rgb1, d.rgb2,
-                        cam1, cam2, w.times, w.mask_eff, w.valid, w.pcl, w.rgbf, s));
+  WarpExtras ex;
+  memset(&ex, 0, sizeof(ex));
+  ex.zero_b = dyn_splat_flag_map(w.splat, H, W);
+  unsigned *bbox = nullptr;
+  if (d.remove_outlier) {
+    ex.zero_a = w.keep;
+    ex.chunk_cnt = w.chunk_cnt;
+    void *blk = nullptr;
+    int64_t bytes = 0;
+    knn_grid_state_block(w.knn, P, &blk, &bytes, &bbox);
+    ex.zero0 = reinterpret_cast<uint4 *>(blk);
+    ex.n16_0 = (int)(bytes / 16);
+    outlier_hist_block(w.outlier, &blk, &bytes);
+    ex.zero1 = reinterpret_cast<uint4 *>(blk);
+    ex.n16_1 = (int)(bytes / 16);
+  }
+  PGDVS_REQUIRE(d.dyn_mask1 && d.flow12 && d.depth1 && d.depth2 && d.rgb1 && d.rgb2, "pgdvs_view_geo_forward: null input pointer");
+  VG_TRY(dyn_warp_fused(H, W, d.dyn_mask1, d.flow_occ, d.use_flow_consistency, d.flow12, d.depth1, d.depth2, d.rgb1, d.rgb2, cam1,
+                        cam2, w.times, w.mask_eff, w.valid, w.pcl, w.rgbf, ex, st));
   const uint8_t *keep = w.valid;
   if (d.remove_outlier) {
     // pytorch3d's kNN + the statistical filter (pgdvs_renderer_dyn.py:401-457)
-    VG_TRY(pgdvs_compact_u8(w.valid, P, w.idx, w.cnt, w.compact, w.compact_bytes, s));
-    VG_TRY(pgdvs_gather_rows(w.pcl, w.idx, w.cnt, P, 3, w.pts, s));
-    VG_TRY(pgdvs_knn_mean_dist(w.pts, w.cnt, P, d.outlier_knn, w.avg, 0, w.knn, w.knn_bytes, s));
-    VG_TRY(pgdvs_outlier_flags(w.avg, w.cnt, P, d.outlier_std_thres, 1, w.thres, w.flag, w.outlier, w.outlier_bytes, s));
-    VG_TRY(pgdvs_scatter_keep(w.idx, w.flag, w.cnt, P, w.keep, P, s));
+    VG_TRY(compact_gather_bbox(w.valid, P, w.chunk_cnt, w.idx, w.cnt, w.pcl, w.pts, bbox, st));
+    VG_TRY(knn_grid_mean_dist_prepared(w.pts, w.cnt, P, d.outlier_knn, w.avg, w.knn, w.knn_bytes, st));
+    VG_TRY(outlier_keep_fused(w.avg, w.cnt, P, d.outlier_std_thres, w.thres, w.idx, w.keep, w.outlier, w.outlier_bytes, st));
     keep = w.keep;
   }
-  VG_TRY(pgdvs_project_flow_dense(H, W, cam_t, w.pcl, keep, w.flow_1_to_tgt, w.valid_mask, s));
-  // A6-A8, first half: metric, flags and the scatter into the accumulators need the flows, not the static image -- they run
-  // here, beside the static branch when there is a side stream; only the finish pass waits for the rasteriser
+  // A5 + A6-A8, first half: projection, metric, flags and the scatter into the accumulators need the flows, not the static
+  // image -- they run here, beside the static branch when there is a side stream; only the finish pass waits for the rasteriser
   const unsigned long long *rng = (d.noise == nullptr && d.rng_state != nullptr) ? reinterpret_cast<const unsigned long long *>(d.rng_state) : nullptr;
-  VG_TRY(dyn_splat_scatter_part(H, W, d.rgb1, d.rgb2, d.flow12, w.flow_1_to_tgt, w.valid_mask, d.noise, rng, d.alpha, w.splat,
-                                as_stream(s)));
+  VG_TRY(dyn_splat_scatter_part_fused(H, W, d.rgb1, d.rgb2, d.flow12, cam_t, w.pcl, keep, w.flow_1_to_tgt, w.valid_mask, d.noise, rng,
+                                      d.alpha, w.splat, true, st));
   return PGDVS_OK;
 }
 

@@ -435,6 +435,7 @@ class ViewGeoState:
         self.ws_key = None
         self.ws_bytes = 0
         self.agg_key = None  # (shape, cameras) whose per-frame constants the workspace holds
+        self.default_side_stream = None  # PGDVSRenderer._forward_native: the dynamic branch's stream when the caller names none
 
 
 def view_geo_forward(state: ViewGeoState, *, H: int, W: int, flat_cam_tgt, flat_cam_src, time_src, time_tgt, rgb1, rgb2, depth1,

@@ -118,6 +118,18 @@ class PGDVSRenderer(PGDVSBaseRenderer):
         counts = data.get("st_pcl_rgb_count", None)
         xyz = data.get("st_pcl_xyz", None)
         out_comb = data.get("_combined_rgb_out", None)
+        # the dynamic branch's geometry beside the static branch, on a second stream forked and joined INSIDE the native call:
+        # the caller's stream sees one call, as with the per-op path below (self._side_stream).  A plain
+        # ``model.forward(data)`` -- what pgdvs.engines' evaluator does per view (evaluator_pgdvs.py:36-54) -- gets one such
+        # stream per stream it calls from (round 6: a view alone took 1.37 ms on one stream, 1.13 on two); callers that
+        # manage their own pass it as data["_side_stream"], or False for none.
+        side = data.get("_side_stream", None)
+        if side is None:
+            side = getattr(st, "default_side_stream", None)
+            if side is None:
+                side = st.default_side_stream = torch.cuda.Stream(device=dev)
+        elif side is False:
+            side = None
         r = ops.view_geo_forward(
             st, H=H, W=W, flat_cam_tgt=data["flat_cam_tgt"][0], flat_cam_src=data["flat_cam_src_temporal"][0, :2],
             time_src=data["time_src_temporal"][0], time_tgt=data["time_tgt"][0],
@@ -134,7 +146,7 @@ class PGDVSRenderer(PGDVSBaseRenderer):
             st_count=None if (video is not None or counts is None) else counts.reshape(-1)[0:1],
             video=video, row_bound=data.get("st_pcl_rgb_row_bound", None),
             radius=render_cfg.st_render_pcl_pt_radius, K=render_cfg.st_render_pcl_pts_per_pixel,
-            out_combined=out_comb[0] if out_comb is not None else None, side_stream=data.get("_side_stream", None))
+            out_combined=out_comb[0] if out_comb is not None else None, side_stream=side)
         dyn_rgb, dyn_mask = r["render_dyn_rgb"][None], r["render_dyn_mask"][None, None]
         ret = {
             "geo_static_rgb": r["geo_static_rgb"][None], "geo_static_mask": r["geo_static_mask"][None, None],

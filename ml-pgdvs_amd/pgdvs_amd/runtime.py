@@ -175,8 +175,7 @@ class ResidentVideoRenderer:
                 d["_st_pcl_video"] = v
                 if self.row_bound is not None:
                     d["st_pcl_rgb_row_bound"] = self.row_bound
-                if side is not None:
-                    d["_side_stream"] = side
+                d["_side_stream"] = side if side is not None else False  # (False: everything on the lane's stream)
                 ret = self.model.forward(d, render_cfg=self.rc, disable_tqdm=True)
             else:
                 # the per-op arrangement of rounds 1-3: ~85 C-ABI calls enqueued from Python

@@ -78,8 +78,9 @@ def test_native_view_call_equals_per_op_path(outlier, use_xyz, use_count, side, 
             data["st_pcl_xyz"] = xyz[None]
     else:
         data["st_pcl_rgb"] = cloud[None, :n].contiguous()
-    if side:
-        data["_side_stream"] = torch.cuda.Stream(device=DEV)
+    # (True: the caller's own second stream; False: none -- everything on the caller's stream; a caller that names neither gets
+    # the renderer's default second stream: test_gpu_round6.py)
+    data["_side_stream"] = torch.cuda.Stream(device=DEV) if side else False
     assert model._native_view_ok(data, rc)
     with torch.no_grad():
         rn = model.forward(dict(data), render_cfg=rc)

@@ -54,7 +54,8 @@ def compact_line(out):
     line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                     "scaling", "vs_baseline", "dtype", "data")}
     c = _pick(cfg, ("workload", "height", "width", "src_frames", "scene", "views_in_flight", "launch", "parallelism",
-                    "rccl_ranks_seen", "stream_queue_groups", "per_rank_frames_per_s", "gather_bytes_to_rank0", "whole_view_alg_bytes")) or {}
+                    "rccl_ranks_seen", "stream_queue_groups", "stream_placement_per_rank", "per_rank_frames_per_s", "gather_bytes_to_rank0",
+                    "whole_view_alg_bytes")) or {}
     for k in ("workload", "launch", "parallelism"):
         if k in c:
             c[k] = _clip(c[k], 200)
@@ -203,7 +204,12 @@ def parse():
     return ap.parse_args()
 
 
-DEFAULT_LANES_MULTI_RANK = 3  # views in flight per rank when several ranks run (no probe: see main)
+# Several ranks: no arrangement probe (it would need collectives to agree on its outcome), one fixed arrangement per rank:
+# four lanes, one stream each, every stream on a hardware queue of its own as far as the rank's LOCAL queue probe
+# (runtime.stream_queue_groups: spin kernels on this rank's GPU, no collective in it) can tell them apart; creation order when the
+# probe fails, and the line says so (config.stream_placement_per_rank)
+DEFAULT_LANES_MULTI_RANK = 4
+DEFAULT_ARRANGEMENT_MULTI_RANK = (4, False, True)  # (lanes, second stream per lane, streams by hardware queue)
 
 
 def ring_slots_for(run_ahead, n_lanes):
@@ -499,7 +505,12 @@ def main():
     auto_lanes = args.inflight <= 0 and world == 1
     if args.inflight <= 0 and world > 1:
         args.inflight = DEFAULT_LANES_MULTI_RANK
-    lane_cfg = max(lane_candidates, key=lambda c: c[0]) if auto_lanes else (max(1, args.inflight), args.side_stream, False if world > 1 else args.place_streams and not args.side_stream)
+    if auto_lanes:
+        lane_cfg = max(lane_candidates, key=lambda c: c[0])
+    elif world > 1 and args.inflight == DEFAULT_LANES_MULTI_RANK and args.place_streams:
+        lane_cfg = DEFAULT_ARRANGEMENT_MULTI_RANK
+    else:
+        lane_cfg = (max(1, args.inflight), args.side_stream, args.place_streams and not args.side_stream)
     n_lanes = lane_cfg[0]
     rvr.set_lanes(*lane_cfg)
     base_run_ahead = args.run_ahead
@@ -633,7 +644,8 @@ def main():
             lat_.sort()
             print(f"latency-only: second stream {use_side}: median {lat_[len(lat_) // 2]:.3f} ms, min {lat_[0]:.3f} ms over {len(lat_)} views", file=sys.stderr)
         return
-    lanes_note = f"{n_lanes} (" + ("--inflight" if world == 1 or args.inflight != DEFAULT_LANES_MULTI_RANK else "fixed default for several ranks: no probe collectives") + ")"
+    lanes_note = f"{n_lanes} (" + ("--inflight" if world == 1 or args.inflight != DEFAULT_LANES_MULTI_RANK else
+                                   "fixed arrangement for several ranks, streams placed by each rank's own queue probe: no probe collectives") + ")"
     if auto_lanes:
         # How many views in flight, on which streams?  Measured, not guessed: the candidate arrangements are timed through the
         # same loop as the headline, each on as many views as the timed region will render (filling and draining k lanes is
@@ -700,7 +712,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     # who took part (first contact with an 8-GPU node: a silent rank / device mismatch must show in the line)
-    peers = [(rank, local_rank, torch.cuda.get_device_name(dev))]
+    placement = ("by hardware queue " + str(rvr.queue_groups)) if (rvr.place_streams and rvr.queue_groups and len(rvr.queue_groups) > 1) else \
+        ("creation order (queue probe failed)" if rvr.place_streams else "creation order")
+    peers = [(rank, local_rank, torch.cuda.get_device_name(dev), placement)]
     if world > 1:
         got = [None] * world
         dist.all_gather_object(got, peers[0])
@@ -1204,6 +1218,7 @@ def main():
                 "gather_receive_ring_slots": ring_slots,
                 "collective_backend": (dist.get_backend() if world > 1 else None), "rccl_ranks_seen": [p_[0] for p_ in peers],
                 "rank_devices": [f"rank {p_[0]}: cuda:{p_[1]} {p_[2]}" for p_ in peers],
+                "stream_placement_per_rank": [p_[3] for p_ in peers], "stream_queue_probe": rvr.queue_probe,
                 "whole_view_alg_bytes": alg_total,
                 "whole_view_alg_GBps": round(alg_total * fps / 1e9 / max(world, 1), 2),
             },

@@ -31,16 +31,31 @@ def stream_queue_groups(streams, cycles: int = 40000, links: int = 10):
 
     chains([streams[0]])  # (first launches: lazy queue creation)
     single = min(chains([streams[0]]) for _ in range(3))
-    groups = []
+    groups, ratios = [], []
     for i, st in enumerate(streams):
         for g in groups:
-            # one behind the other: ~2 x single; side by side: ~1.15 x
-            if min(chains([streams[g[0]], st]) for _ in range(2)) > 1.6 * single:
+            # one behind the other: ~2 x single; side by side: ~1.15 x.  The clock is the host's: a ratio between 1.35 and 1.8
+            # (a busy host, a clock step) is measured again, and a comparison that stays there makes the whole probe fail --
+            # the caller then takes creation order (a wrong grouping would silently cost a quarter of the throughput)
+            for attempt in range(4):
+                r = min(chains([streams[g[0]], st]) for _ in range(2)) / single
+                if not 1.35 < r < 1.8:
+                    break
+                single = min(single, min(chains([streams[0]]) for _ in range(2)))
+            else:
+                LAST_PROBE.update({"ratios": ratios + [round(r, 2)], "ok": False})
+                raise RuntimeError(f"stream_queue_groups: ratio {r:.2f} between 'side by side' and 'one behind the other'")
+            ratios.append(round(r, 2))
+            if r >= 1.8:
                 g.append(i)
                 break
         else:
             groups.append([i])
+    LAST_PROBE.update({"ratios": ratios, "ok": True})
     return groups
+
+
+LAST_PROBE = {}  # the last probe's pair ratios (diagnostics: ResidentVideoRenderer.queue_probe, bench.py's detail record)
 
 
 class ResidentVideoRenderer:
@@ -75,6 +90,7 @@ class ResidentVideoRenderer:
         self.side_streams = side_streams
         self.place_streams = place_streams  # lane streams picked by hardware queue (see _place)
         self.queue_groups = None
+        self.queue_probe = None
         self.set_lanes(lanes)
 
     def set_lanes(self, n: int, side_streams=None, place_streams=None) -> None:
@@ -120,8 +136,10 @@ class ResidentVideoRenderer:
                 groups = stream_queue_groups(pool)
         except Exception:  # noqa: BLE001 -- placement is an optimisation: without the probe the lanes take creation order
             self.queue_groups = None
+            self.queue_probe = dict(LAST_PROBE, fallback="creation order")
             return
         self.queue_groups = [len(g) for g in groups]
+        self.queue_probe = dict(LAST_PROBE)
         if len(groups) < 2:
             return
         groups.sort(key=len, reverse=True)
@@ -140,7 +158,16 @@ class ResidentVideoRenderer:
                 used.add(si)
                 side = pool[si]
             lanes.append((pool[mi], side))
+        replaced = {id(st) for pair in self.lanes for st in pair if st is not None}
         self.lanes = lanes
+        if replaced and hasattr(self.model, "release_view_states"):
+            # (growing a placed arrangement replaces its streams: the native call's workspaces on the old ones -- 1-2 GB each at
+            # 1080p -- would otherwise stay until the renderer's LRU bound evicts them)
+            torch.cuda.synchronize(self.dev)
+            sets = self.__dict__.get("_lane_sets", {})
+            keep = [st for ls in sets.values() for pair in ls for st in pair if st is not None and id(st) not in replaced]
+            keep += [st for pair in lanes for st in pair if st is not None]
+            self.model.release_view_states(keep)
 
     def calibrate(self, data) -> int:
         """render one view with capacity-sized buffers, read its count back (one host synchronisation) and bound the

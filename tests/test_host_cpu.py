@@ -260,7 +260,7 @@ def test_bench_gpus_8_dry_run_c4_sharding_and_ring():
     """first contact with an 8-GPU node can then only find RCCL itself: `python bench.py --gpus 8` as the driver starts it,
     BASELINE.json configs[3]'s 288 target views as 36 per rank (reference: trainer_pgdvs.py:290-306, run.py:158-176), on CPU
     tensors over gloo: eight ranks come up, every view arrives on rank 0 exactly once and in view order through a receive
-    ring of the size the real run uses with its fixed three lanes (11 slots x 8 ranks, not 36 x 8), per-rank times come back"""
+    ring of the size the real run uses with its fixed four lanes (12 slots x 8 ranks, not 36 x 8), per-rank times come back"""
     import json
 
     sys.path.insert(0, str(ROOT))
@@ -273,7 +273,7 @@ def test_bench_gpus_8_dry_run_c4_sharding_and_ring():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["dry_run"] is True and out["value"] is None and out["scaling"] == "weak"
     assert out["views_gathered"] == 288 and len(out["per_rank_seconds"]) == 8
-    assert out["receive_ring_slots"] == bench.ring_slots_for(6, bench.DEFAULT_LANES_MULTI_RANK) == 11
+    assert out["receive_ring_slots"] == bench.ring_slots_for(6, bench.DEFAULT_LANES_MULTI_RANK) == 12 and bench.DEFAULT_ARRANGEMENT_MULTI_RANK == (4, False, True)
     assert out["gather_bytes_to_rank0"] == 36 * 7 * 3 * 4 * 6 * 4
     # the reference's sampler over the same 288 views: rank r renders r, r + 8, ... (what `(j * world + rank)` enumerates)
     from pgdvs_amd.dist import shard_indices

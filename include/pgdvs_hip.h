@@ -36,6 +36,10 @@
  *                                                      bound and runs its long-list launch (default 2.2)
  *   knn_no_tpq            PGDVS_KNN_NO_TPQ=1           diagnostics: the wavefront-per-query search for every query
  *   knn_stats             PGDVS_KNN_STATS=1            diagnostics: ring histogram to stderr (synchronises)
+ *   side_thread           PGDVS_SIDE_THREAD=0 -> 0     0: pgdvs_view_geo_forward enqueues the dynamic branch (side stream) from the
+ *                                                      calling thread behind the static branch, as in rounds 4-5; default 1: a
+ *                                                      worker thread of the library enqueues it while the caller enqueues the static
+ *                                                      branch (the host's ~60 launches per view in two halves side by side)
  *
  * Camera block: 80 floats of derived per-camera constants produced by
  * pgdvs_cam_prep from the reference's flat_cam[34] = [h, w, K(4x4), c2w(4x4)]

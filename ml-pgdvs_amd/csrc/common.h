@@ -22,7 +22,9 @@ struct Options {
   int knn_no_tpq;              // PGDVS_KNN_NO_TPQ=1: diagnostics, the wavefront-per-query search for every query
   int knn_stats;               // PGDVS_KNN_STATS=1: diagnostics, ring histogram to stderr (synchronises)
   float raster_bound_density;  // PGDVS_RASTER_BOUND_DENSITY: rows per pixel from which the rasteriser computes its depth bound
+  int side_thread;             // PGDVS_SIDE_THREAD=0: the per-view call enqueues the dynamic branch itself instead of handing it to its worker thread
 };
+const char *last_error_text();  // this thread's error string (error.cpp)
 int option_int(const int &field);
 float option_float(const float &field);
 const Options &options();

@@ -23,6 +23,8 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+const char *last_error_text() { return g_err; }
+
 // ---- per-kernel timing (pgdvs_prof_*) --------------------------------------
 struct ProfRec {
   const char *name;
@@ -77,6 +79,7 @@ static Options options_from_env() {
   o.knn_stats = flag("PGDVS_KNN_STATS");
   const char *d = getenv("PGDVS_RASTER_BOUND_DENSITY");
   o.raster_bound_density = d != nullptr ? (float)atof(d) : 2.2f;
+  o.side_thread = getenv("PGDVS_SIDE_THREAD") != nullptr && getenv("PGDVS_SIDE_THREAD")[0] == '0' ? 0 : 1;
   return o;
 }
 static Options g_options = options_from_env();  // (dynamic initialisation at load time: the only read of the environment)
@@ -97,6 +100,7 @@ static const OptionName kOptionNames[] = {
     {"gnt_fp32", &g_options.gnt_fp32, nullptr},
     {"knn_no_tpq", &g_options.knn_no_tpq, nullptr},     {"knn_stats", &g_options.knn_stats, nullptr},
     {"raster_bound_density", nullptr, &g_options.raster_bound_density},
+    {"side_thread", &g_options.side_thread, nullptr},
 };
 }  // namespace pgdvs
 

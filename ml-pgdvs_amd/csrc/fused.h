@@ -11,8 +11,8 @@ namespace pgdvs {
 // dyn.hip: what dyn_warp_kernel does on the side (see the kernel)
 struct WarpExtras {
   uint8_t *zero_a, *zero_b;  // [P] byte maps cleared pixel by pixel, or null
-  uint4 *zero0, *zero1;      // 16-byte aligned state blocks of n16_0 / n16_1 granules cleared by the first threads, or null
-  int n16_0, n16_1;
+  uint4 *zero0, *zero1, *zero2;  // 16-byte aligned blocks of n16_0 / n16_1 / n16_2 granules cleared by the launch's threads, or null
+  int n16_0, n16_1, n16_2;
   int32_t *chunk_cnt;        // [ceil(P / 256)] valid pixels per 256-pixel chunk (= per workgroup), or null
 };
 int dyn_warp_fused(int H, int W, const float *dyn_mask1, const float *occ, int use_flow_consistency, const float *flow12,
@@ -23,12 +23,16 @@ int dyn_warp_fused(int H, int W, const float *dyn_mask1, const float *occ, int u
 // scan.hip: ordered compaction of flags[n] whose per-chunk counts exist already (chunk_cnt[ceil(n / 256)]): indices, count,
 // the gathered rows rows_out[i] = rows_in[idx[i]] (3 floats) and their bounding box (knn_grid's encoding; bbox zeroed by
 // the caller) in ONE launch
+// (zero_per_row: zero_mult ints cleared per compacted row, + one behind the last row -- the kNN grid's quarter-cell counters --, or null)
 int compact_gather_bbox(const uint8_t *flags, int64_t n, const int32_t *chunk_cnt, int32_t *idx_out, int32_t *count_out,
-                        const float *rows_in, float *rows_out, unsigned *bbox, hipStream_t st);
+                        const float *rows_in, float *rows_out, unsigned *bbox, int32_t *zero_per_row, int zero_mult, hipStream_t st);
 
 // knn_grid.hip: the state block the search's memset clears (bounding box first), and the search with that block already
 // cleared and the bounding box already there
-void knn_grid_state_block(void *workspace, int64_t capacity, void **block, int64_t *bytes, unsigned **bbox);
+// (tab / tab_bytes: the sparse cell index's bit table, cleared in full by the caller; occ_count: the quarter-cell counters, of
+// which the caller clears occ_mult per point + 1 -- what grid_tab_zero_kernel clears for the per-op entry point)
+void knn_grid_state_block(void *workspace, int64_t capacity, void **block, int64_t *bytes, unsigned **bbox, void **tab,
+                          int64_t *tab_bytes, int32_t **occ_count, int *occ_mult);
 int knn_grid_mean_dist_prepared(const float *pts, const int32_t *count, int64_t capacity, int K, float *avg_out, void *workspace,
                                 int64_t workspace_bytes, hipStream_t st);
 
@@ -45,5 +49,14 @@ int dyn_splat_scatter_part_fused(int H, int W, const float *rgb1, const float *r
                                  const float *noise, const unsigned long long *rng, float alpha, void *workspace,
                                  bool flags_cleared, hipStream_t st);
 uint8_t *dyn_splat_flag_map(void *workspace, int H, int W);
+
+
+// raster.hip: the counters a rasterisation starts from (cleared per call) and the bounded rasterisation with them cleared by
+// the caller (static_agg.hip's agg_rows launch clears them for the per-view call)
+void raster_counter_block(void *workspace, int64_t n_rows, int H, int W, float radius, void **block, int64_t *bytes);
+int points_raster_bounded_cleared(const float *pts, int64_t pts_stride, const float *feat, int64_t feat_stride, int64_t n_points,
+                                  const int64_t *n_points_dev, int64_t row_bound, int32_t *status_dev, const float *cam_tgt,
+                                  float radius, int K, int H, int W, float *rgb, int rgb_planar, float *mask, void *workspace,
+                                  int64_t workspace_bytes, pgdvs_stream_t stream, bool counters_cleared);
 
 }  // namespace pgdvs

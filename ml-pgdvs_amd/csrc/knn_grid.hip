@@ -1638,18 +1638,24 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
 }
 
 // fused.h: the per-view call clears the state block and computes the bounding box inside launches it runs anyway
-void knn_grid_state_block(void *workspace, int64_t capacity, void **block, int64_t *bytes, unsigned **bbox) {
+void knn_grid_state_block(void *workspace, int64_t capacity, void **block, int64_t *bytes, unsigned **bbox, void **tab,
+                          int64_t *tab_bytes, int32_t **occ_count, int *occ_mult) {
   const GridWs ws = grid_ws_layout(workspace, capacity, 0);
   *block = ws.bbox;
   *bytes = ws.state_bytes;
   *bbox = ws.bbox;
+  *tab = ws.tab;
+  *tab_bytes = (int64_t)kTabWords * 16;
+  *occ_count = ws.occ_count;
+  *occ_mult = kSub;
 }
 int knn_grid_mean_dist_prepared(const float *pts, const int32_t *count, int64_t capacity, int K, float *avg_out, void *workspace,
                                 int64_t workspace_bytes, hipStream_t st) {
   return knn_grid_search(pts, count, capacity, K, avg_out, workspace, workspace_bytes, st, nullptr, nullptr, 0, true);
 }
 
-// prepared: the state block is cleared and holds the points' bounding box already (no memset, no grid_bbox launch)
+// prepared: the state block is cleared and holds the points' bounding box already, the bit table and the quarter-cell counters
+// are cleared (no memset, no grid_bbox launch, no grid_tab_zero launch)
 static int knn_grid_search(const float *pts, const int32_t *count, int64_t capacity, int K, float *avg_out,
                            void *workspace, int64_t workspace_bytes, hipStream_t st, const float *qpts,
                            const int32_t *qcount, int64_t qcapacity, bool prepared) {
@@ -1687,7 +1693,7 @@ static int knn_grid_search(const float *pts, const int32_t *count, int64_t capac
   PGDVS_LAUNCH("grid_params", grid_params_kernel, dim3(1), dim3(1024), 0, st, ws.bbox, count, (const float *)ws.sample_d1, ws.gp,
                sqrtf((float)(K + 1) / 51.0f), target, 0.5f);
   // the final grid as a sparse cell index (CellIndex): bit table, ranks, points per occupied cell, their starts
-  PGDVS_LAUNCH("grid_tab_zero", grid_tab_zero_kernel, dim3(512), dim3(256), 0, st, ws.gp, ws.tab, ws.occ_count);
+  if (!prepared) PGDVS_LAUNCH("grid_tab_zero", grid_tab_zero_kernel, dim3(512), dim3(256), 0, st, ws.gp, ws.tab, ws.occ_count);
   PGDVS_LAUNCH("grid_mark", grid_mark_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of, ws.tab);
   const unsigned nrb = (unsigned)cdiv(kTabWords, kRankWordsPerBlock);
   PGDVS_LAUNCH("grid_rank", grid_rank_totals_kernel, dim3(nrb), dim3(1024), 0, st, ws.gp, (const uint4 *)ws.tab, ws.block_sums);

@@ -1154,6 +1154,36 @@ void raster_counters(const void *workspace, int64_t n_rows, int H, int W, float 
 
 using namespace pgdvs;
 
+namespace pgdvs {
+// fused.h: the block of counters a rasterisation starts from (cleared per call), and the bounded rasterisation with that block
+// already cleared by the caller
+void raster_counter_block(void *workspace, int64_t n_rows, int H, int W, float radius, void **block, int64_t *bytes) {
+  const RasterWs ws = raster_ws_layout(workspace, n_rows, H, W, radius);
+  *block = ws.tile_count;
+  *bytes = (int64_t)((char *)ws.offsets - (char *)ws.tile_count);
+}
+}  // namespace pgdvs
+static int points_raster_impl(const float *pts, int64_t pts_stride, const float *feat, int64_t feat_stride, int64_t n_points,
+                              const int64_t *n_points_dev, int32_t *status_dev, const float *cam_tgt, float radius, int K,
+                              int H, int W, int64_t *idx, float *zbuf, float *dist2, float *rgb, int rgb_planar, float *mask,
+                              void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream, bool counters_cleared);
+namespace pgdvs {
+int points_raster_bounded_cleared(const float *pts, int64_t pts_stride, const float *feat, int64_t feat_stride, int64_t n_points,
+                                  const int64_t *n_points_dev, int64_t row_bound, int32_t *status_dev, const float *cam_tgt,
+                                  float radius, int K, int H, int W, float *rgb, int rgb_planar, float *mask, void *workspace,
+                                  int64_t workspace_bytes, pgdvs_stream_t stream, bool counters_cleared) {
+  PGDVS_REQUIRE(row_bound >= 0 && status_dev && n_points >= 0, "points_raster_bounded_cleared: bad arguments");
+  if (n_points_dev == nullptr && n_points > row_bound) {
+    set_error("pgdvs_points_raster_bounded: %lld rows given (host count) but the row bound is %lld", (long long)n_points,
+              (long long)row_bound);
+    return PGDVS_ERR_INVALID;
+  }
+  return points_raster_impl(pts, pts_stride, feat, feat_stride, n_points < row_bound ? n_points : row_bound, n_points_dev,
+                            status_dev, cam_tgt, radius, K, H, W, nullptr, nullptr, nullptr, rgb, rgb_planar, mask, workspace,
+                            workspace_bytes, stream, counters_cleared);
+}
+}  // namespace pgdvs
+
 PGDVS_API int64_t pgdvs_points_raster_workspace_bytes(int64_t n_points, int H, int W, float radius) {
   if (n_points < 0 || H <= 0 || W <= 0) return -1;
   const RasterWs w = raster_ws_layout(nullptr, n_points, H, W, radius);
@@ -1190,7 +1220,7 @@ static void launch_tile(dim3 grid, hipStream_t st, const RasterWs &ws, const flo
 static int points_raster_impl(const float *pts, int64_t pts_stride, const float *feat, int64_t feat_stride, int64_t n_points,
                               const int64_t *n_points_dev, int32_t *status_dev, const float *cam_tgt, float radius, int K,
                               int H, int W, int64_t *idx, float *zbuf, float *dist2, float *rgb, int rgb_planar, float *mask,
-                              void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream);
+                              void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream, bool counters_cleared = false);
 
 PGDVS_API int pgdvs_points_raster(const float *pts, int64_t pts_stride, const float *feat,
                                   int64_t feat_stride, int64_t n_points,
@@ -1226,7 +1256,7 @@ PGDVS_API int pgdvs_points_raster_bounded(const float *pts, int64_t pts_stride, 
 static int points_raster_impl(const float *pts, int64_t pts_stride, const float *feat, int64_t feat_stride, int64_t n_points,
                               const int64_t *n_points_dev, int32_t *status_dev, const float *cam_tgt, float radius, int K,
                               int H, int W, int64_t *idx, float *zbuf, float *dist2, float *rgb, int rgb_planar, float *mask,
-                              void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream) {
+                              void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream, bool counters_cleared) {
   PGDVS_REQUIRE(H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), "pgdvs_points_raster: bad H/W");
   PGDVS_REQUIRE(n_points >= 0 && n_points < (1ll << 31), "pgdvs_points_raster: bad n_points");
   PGDVS_REQUIRE(cam_tgt && (n_points == 0 || pts) && pts_stride >= 3, "pgdvs_points_raster: bad points");
@@ -1249,10 +1279,12 @@ static int points_raster_impl(const float *pts, int64_t pts_stride, const float 
   }
   hipStream_t st = as_stream(stream);
   const int ntx = (int)cdiv(W, kTile), nty = (int)cdiv(H, kTile), ntiles = ntx * nty;
-  hipError_t e = hipMemsetAsync(ws.tile_count, 0, (size_t)((char *)ws.offsets - (char *)ws.tile_count), st);
-  if (e != hipSuccess) {
-    set_error("points_raster memset: %s", hipGetErrorString(e));
-    return PGDVS_ERR_LAUNCH;
+  if (!counters_cleared) {
+    hipError_t e = hipMemsetAsync(ws.tile_count, 0, (size_t)((char *)ws.offsets - (char *)ws.tile_count), st);
+    if (e != hipSuccess) {
+      set_error("points_raster memset: %s", hipGetErrorString(e));
+      return PGDVS_ERR_LAUNCH;
+    }
   }
   const bool small_table = ntiles <= kBinSlots / 2;  // the binning kernels' table of tile counters: 32 KB or 64 KB
   // The depth bound (raster_zmin / raster_bound): a b x b block's points must cover the block's pixels -- radius in pixels

@@ -106,7 +106,8 @@ compact_scatter_kernel(const uint8_t *__restrict__ flags, int64_t n,
 __global__ void __launch_bounds__(kCompactBlock)
 compact_gather_bbox_kernel(const uint8_t *__restrict__ flags, int64_t n, const int32_t *__restrict__ chunk_cnt,
                            int32_t *__restrict__ idx_out, int32_t *__restrict__ count_out, const float *__restrict__ rows_in,
-                           float *__restrict__ rows_out, unsigned *__restrict__ bbox) {
+                           float *__restrict__ rows_out, unsigned *__restrict__ bbox, int32_t *__restrict__ zero_per_row,
+                           int zero_mult) {
   constexpr int kWaves = kCompactBlock / kWave;
   __shared__ int wave_sums[kWaves];
   __shared__ int pre_sums[kWaves];
@@ -140,8 +141,13 @@ compact_gather_bbox_kernel(const uint8_t *__restrict__ flags, int64_t n, const i
     wave_off += w < wave ? wave_sums[w] : 0;
     total += wave_sums[w];
   }
-  if (blockIdx.x == gridDim.x - 1 && tid == 0) *count_out = tile_off + total;
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    *count_out = tile_off + total;
+    if (zero_per_row) zero_per_row[(int64_t)(tile_off + total) * zero_mult] = 0;
+  }
   if (total == 0) return;  // (uniform: no barrier follows for this workgroup)
+  if (zero_per_row)
+    for (int i = tid; i < total * zero_mult; i += kCompactBlock) zero_per_row[(int64_t)tile_off * zero_mult + i] = 0;
   int pos = tile_off + wave_off + x - c;
   float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
   float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
@@ -187,14 +193,14 @@ compact_gather_bbox_kernel(const uint8_t *__restrict__ flags, int64_t n, const i
 }
 
 int compact_gather_bbox(const uint8_t *flags, int64_t n, const int32_t *chunk_cnt, int32_t *idx_out, int32_t *count_out,
-                        const float *rows_in, float *rows_out, unsigned *bbox, hipStream_t st) {
+                        const float *rows_in, float *rows_out, unsigned *bbox, int32_t *zero_per_row, int zero_mult, hipStream_t st) {
   if (n <= 0 || n >= (1ll << 31)) {
     set_error("compact_gather_bbox: n out of range");
     return PGDVS_ERR_INVALID;
   }
   const int nb = (int)cdiv(n, kCompactTile);
   PGDVS_LAUNCH("compact_gather_bbox", compact_gather_bbox_kernel, dim3(nb), dim3(kCompactBlock), 0, st, flags, n, chunk_cnt, idx_out,
-               count_out, rows_in, rows_out, bbox);
+               count_out, rows_in, rows_out, bbox, zero_per_row, zero_mult);
   return check_launch("compact_gather_bbox");
 }
 

@@ -880,11 +880,17 @@ struct RowsArgs {
 __global__ void __launch_bounds__(kBitTileWords)
 agg_rows_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles, const int64_t *__restrict__ tile_off,
                 const int64_t *__restrict__ cnts, const CamBlock *__restrict__ cams, RowsArgs a,
-                RowStage stage, int f_staged) {
+                RowStage stage, int f_staged, uint4 *__restrict__ zero_extra, int zero_extra_n16) {
   __shared__ uint16_t s_list[kSelTile];
   __shared__ int s_wsum[4];
   __shared__ int s_cstart[kBitTileWords / 4];  // list position of every 128-pixel chunk's first selected pixel
   const int tid = threadIdx.x;
+  // (round 6: the per-view call lets this launch clear the counters of the rasteriser that runs behind it -- one memset less
+  // on the static branch's chain)
+  if (zero_extra != nullptr) {
+    const int g0 = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * kBitTileWords + tid;
+    for (int g = g0; g < zero_extra_n16; g += (int)(gridDim.x * gridDim.y) * kBitTileWords) zero_extra[g] = make_uint4(0u, 0u, 0u, 0u);
+  }
   const int f = 1 + (int)blockIdx.y, t = (int)blockIdx.x;
   const uint32_t bits = sel[(int64_t)f * Wd + (int64_t)t * kBitTileWords + tid];
   int total;
@@ -1051,7 +1057,8 @@ PGDVS_API int64_t pgdvs_static_aggregate_workspace_bytes(int S, int H, int W, in
 static int static_aggregate_impl(const float *rgbs, const float *depths, const uint8_t *dyn_masks,
                                  const double *K3s_host, const double *c2ws_host, int S, int H, int W, float *out,
                                  float *xyz_out, int64_t capacity, int64_t *count_out, void *workspace,
-                                 int64_t workspace_bytes, pgdvs_stream_t stream, bool params_cached = false);
+                                 int64_t workspace_bytes, pgdvs_stream_t stream, bool params_cached = false,
+                                 void *zero_extra = nullptr, int64_t zero_extra_bytes = 0);
 
 PGDVS_API int pgdvs_static_aggregate(const float *rgbs, const float *depths,
                                      const uint8_t *dyn_masks, const double *K3s_host,
@@ -1080,16 +1087,17 @@ namespace pgdvs {
 int static_aggregate_for_view(const float *rgbs, const float *depths, const uint8_t *dyn_masks, const double *K3s_host,
                               const double *c2ws_host, int S, int H, int W, float *out, float *xyz_out, int64_t capacity,
                               int64_t *count_out, void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream,
-                              bool params_cached) {
+                              bool params_cached, void *zero_extra, int64_t zero_extra_bytes) {
   return static_aggregate_impl(rgbs, depths, dyn_masks, K3s_host, c2ws_host, S, H, W, out, xyz_out, capacity, count_out, workspace,
-                               workspace_bytes, stream, params_cached);
+                               workspace_bytes, stream, params_cached, zero_extra, zero_extra_bytes);
 }
 }  // namespace pgdvs
 
 static int static_aggregate_impl(const float *rgbs, const float *depths, const uint8_t *dyn_masks,
                                  const double *K3s_host, const double *c2ws_host, int S, int H, int W, float *out,
                                  float *xyz_out, int64_t capacity, int64_t *count_out, void *workspace,
-                                 int64_t workspace_bytes, pgdvs_stream_t stream, bool params_cached) {
+                                 int64_t workspace_bytes, pgdvs_stream_t stream, bool params_cached, void *zero_extra,
+                                 int64_t zero_extra_bytes) {
   PGDVS_REQUIRE(rgbs && depths && dyn_masks && K3s_host && c2ws_host && out && count_out,
                 "pgdvs_static_aggregate: null pointer");
   PGDVS_REQUIRE(S > 0 && S < 65535 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31) && capacity > 0 &&
@@ -1242,6 +1250,7 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
     }
   };
   if (!bit_chain) {
+    if (zero_extra != nullptr && zero_extra_bytes > 0) (void)hipMemsetAsync(zero_extra, 0, (size_t)zero_extra_bytes, st);
     for (int i = 0; i < S; ++i) {
       select(i);
       // frame 0 appended its rows itself and only stamps; a later frame's push also builds the rows of the
@@ -1336,7 +1345,8 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
     ra.W = W;
     PGDVS_LAUNCH("agg_rows", agg_rows_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,
                  (const uint32_t *)ws.sel, ws.Wd, tiles, (const int64_t *)ws.tile_off, (const int64_t *)ws.cnts,
-                 (const CamBlock *)ws.cams, ra, stage, stage.rows != nullptr ? S - 1 : 0);
+                 (const CamBlock *)ws.cams, ra, stage, stage.rows != nullptr ? S - 1 : 0, reinterpret_cast<uint4 *>(zero_extra),
+                 (int)(zero_extra_bytes / 16));
   }
   return check_launch("static_aggregate");
 }

@@ -7,7 +7,10 @@
 // cost of ~85 ctypes calls, ~40 allocator round trips and the Python between them (0.53-0.74 ms per view in round 3
 // against 0.86 ms of GPU time).
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -24,7 +27,7 @@ int view_prep(const float *flat_tgt, const float *flat_src, const float *time_sr
 int static_aggregate_for_view(const float *rgbs, const float *depths, const uint8_t *dyn_masks, const double *K3s_host,
                               const double *c2ws_host, int S, int H, int W, float *out, float *xyz_out, int64_t capacity,
                               int64_t *count_out, void *workspace, int64_t workspace_bytes, pgdvs_stream_t stream,
-                              bool params_cached);  // static_agg.hip
+                              bool params_cached, void *zero_extra, int64_t zero_extra_bytes);  // static_agg.hip
 
 // the two halves of the splat composite (softsplat.hip)
 int dyn_splat_scatter_part(int H, int W, const float *rgb1, const float *rgb2, const float *flow12, const float *flow_1_to_tgt,
@@ -185,6 +188,84 @@ void ev_put(hipEvent_t e) {
   g_ev_pool[dev].push_back(e);
 }
 
+// The dynamic branch's ~28 launches enqueued by a worker thread of the library while the calling thread enqueues the static
+// branch's ~36 (round 6): at 540p x 12 frames the loop is bound by the HOST's ~4 us per launch, and a view alone starts its
+// dynamic branch ~0.14 ms earlier.  One worker per process, one job at a time (callers from several host threads queue up
+// behind `busy`); the job's error text travels back with its status.  (Round 3 tried the same from a second PYTHON thread and
+// lost to the GIL hand-over; this one never touches the interpreter.)
+class SideWorker {
+ public:
+  // runs `f` on the worker with `device` current; returns at once
+  void submit(int device, std::function<int()> f) {
+    busy_.lock();
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!started_) {
+        started_ = true;
+        th_ = std::thread([this] { loop(); });
+        th_.detach();  // (lives as long as the process: no join at unload, where the HIP runtime may already be gone)
+      }
+      job_ = std::move(f);
+      device_ = device;
+      has_job_ = true;
+      done_ = false;
+    }
+    cv_.notify_all();
+  }
+  // waits for the job submitted last; its status (the error text is copied into the caller's)
+  int wait() {
+    int rc;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [this] { return done_; });
+      rc = rc_;
+      if (rc != PGDVS_OK) set_error("%s", err_);
+    }
+    busy_.unlock();
+    return rc;
+  }
+
+ private:
+  void loop() {
+    for (;;) {
+      std::function<int()> f;
+      int dev;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return has_job_; });
+        f = std::move(job_);
+        dev = device_;
+        has_job_ = false;
+      }
+      int rc = PGDVS_OK;
+      if (hipSetDevice(dev) != hipSuccess) {
+        set_error("side worker: hipSetDevice(%d) failed", dev);
+        rc = PGDVS_ERR_LAUNCH;
+      } else {
+        rc = f();
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        rc_ = rc;
+        snprintf(err_, sizeof(err_), "%s", last_error_text());
+        done_ = true;
+      }
+      cv_.notify_all();
+    }
+  }
+  std::mutex busy_, mu_;
+  std::condition_variable cv_;
+  std::thread th_;
+  std::function<int()> job_;
+  bool started_ = false, has_job_ = false, done_ = false;
+  int device_ = 0, rc_ = 0;
+  char err_[512] = "";
+};
+SideWorker &side_worker() {
+  static SideWorker *w = new SideWorker();  // (never destroyed: see the detach above)
+  return *w;
+}
+
 std::mutex g_stat_mu;
 int64_t g_stat_calls = 0;
 double g_stat_seconds = 0.0;
@@ -211,14 +292,18 @@ int dyn_geometry(const pgdvs_view_geo_desc &d, const ViewWs &w, pgdvs_stream_t s
   memset(&ex, 0, sizeof(ex));
   ex.zero_b = dyn_splat_flag_map(w.splat, H, W);
   unsigned *bbox = nullptr;
+  int32_t *occ_count = nullptr;
+  int occ_mult = 0;
   if (d.remove_outlier) {
     ex.zero_a = w.keep;
     ex.chunk_cnt = w.chunk_cnt;
-    void *blk = nullptr;
-    int64_t bytes = 0;
-    knn_grid_state_block(w.knn, P, &blk, &bytes, &bbox);
+    void *blk = nullptr, *tab = nullptr;
+    int64_t bytes = 0, tab_bytes = 0;
+    knn_grid_state_block(w.knn, P, &blk, &bytes, &bbox, &tab, &tab_bytes, &occ_count, &occ_mult);
     ex.zero0 = reinterpret_cast<uint4 *>(blk);
     ex.n16_0 = (int)(bytes / 16);
+    ex.zero2 = reinterpret_cast<uint4 *>(tab);
+    ex.n16_2 = (int)(tab_bytes / 16);
     outlier_hist_block(w.outlier, &blk, &bytes);
     ex.zero1 = reinterpret_cast<uint4 *>(blk);
     ex.n16_1 = (int)(bytes / 16);
@@ -229,7 +314,7 @@ int dyn_geometry(const pgdvs_view_geo_desc &d, const ViewWs &w, pgdvs_stream_t s
   const uint8_t *keep = w.valid;
   if (d.remove_outlier) {
     // pytorch3d's kNN + the statistical filter (pgdvs_renderer_dyn.py:401-457)
-    VG_TRY(compact_gather_bbox(w.valid, P, w.chunk_cnt, w.idx, w.cnt, w.pcl, w.pts, bbox, st));
+    VG_TRY(compact_gather_bbox(w.valid, P, w.chunk_cnt, w.idx, w.cnt, w.pcl, w.pts, bbox, occ_count, occ_mult, st));
     VG_TRY(knn_grid_mean_dist_prepared(w.pts, w.cnt, P, d.outlier_knn, w.avg, w.knn, w.knn_bytes, st));
     VG_TRY(outlier_keep_fused(w.avg, w.cnt, P, d.outlier_std_thres, w.thres, w.idx, w.keep, w.outlier, w.outlier_bytes, st));
     keep = w.keep;
@@ -284,15 +369,31 @@ int view_forward(const pgdvs_view_geo_desc &d, void *workspace, int64_t workspac
   } else {
     VG_TRY(dyn_geometry(d, w, stream));
   }
+  // (with a side stream the dynamic branch is enqueued by the worker thread while this one goes on with the static branch;
+  // option side_thread = 0: by this thread, behind the static branch)
+  const bool on_worker = forked && option_int(options().side_thread) != 0;
+  if (on_worker) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const pgdvs_view_geo_desc *dp = &d;
+    const ViewWs *wp = &w;
+    side_worker().submit(dev, [dp, wp] { return dyn_geometry(*dp, *wp, dp->side_stream); });
+  }
   // ---- static branch: A12 (optional) + A9
   const float *cloud = d.st_pcl_rgb, *xyz = d.st_pcl_xyz;
   const int64_t *count_dev = d.st_count_dev;
   int64_t rows = d.st_rows;
   int rc = PGDVS_OK;
+  bool counters_cleared = false;
   if (d.agg_S > 0) {
+    // (the aggregation's last launch clears the counters the rasteriser starts from: one memset less on this chain)
+    void *cblk = nullptr;
+    int64_t cbytes = 0;
+    raster_counter_block(w.raster, w.raster_rows, H, W, d.radius, &cblk, &cbytes);
     rc = static_aggregate_for_view(d.agg_rgbs, d.agg_depths, d.agg_masks, d.agg_K3s_host, d.agg_c2ws_host, d.agg_S, H, W,
                                    d.agg_cloud_out, d.agg_xyz_out, d.agg_capacity, d.agg_count_out, w.agg, w.agg_bytes, stream,
-                                   d.agg_params_cached != 0);
+                                   d.agg_params_cached != 0, cblk, cbytes);
+    counters_cleared = true;  // (by agg_rows, or -- ordered chain, single frame -- by a memset of the aggregation)
     cloud = d.agg_cloud_out;
     xyz = d.agg_xyz_out;
     count_dev = d.agg_count_out;
@@ -302,13 +403,12 @@ int view_forward(const pgdvs_view_geo_desc &d, void *workspace, int64_t workspac
     const float *pts = xyz ? xyz : cloud;
     const int64_t pts_stride = xyz ? 3 : 6;
     const float *feat = cloud ? cloud + 3 : nullptr;
-    rc = pgdvs_points_raster_bounded(pts, pts_stride, feat, 6, rows, count_dev, w.raster_rows, d.raster_status, w.cams, d.radius,
-                                     d.K, H, W, nullptr, nullptr, nullptr, d.static_rgb, 1, d.static_mask, w.raster,
-                                     w.raster_bytes, stream);
+    rc = points_raster_bounded_cleared(pts, pts_stride, feat, 6, rows, count_dev, w.raster_rows, d.raster_status, w.cams, d.radius,
+                                       d.K, H, W, d.static_rgb, 1, d.static_mask, w.raster, w.raster_bytes, stream, counters_cleared);
   }
   if (forked) {
     // (whatever happened above, the side stream is joined: its work must be ordered before the caller's next use of `st`)
-    const int rc_dyn = dyn_geometry(d, w, d.side_stream);
+    const int rc_dyn = on_worker ? side_worker().wait() : dyn_geometry(d, w, d.side_stream);
     ev_join = ev_get();
     hipError_t e = hipEventRecord(ev_join, side);
     if (e == hipSuccess) e = hipStreamWaitEvent(st, ev_join, 0);

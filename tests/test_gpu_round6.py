@@ -106,3 +106,32 @@ def test_knn_scan_with_many_tiles():
     ref = ops.knn_mean_dist(pts.to(DEV), cnt, 8, algo=1)
     torch.cuda.synchronize()
     assert torch.equal(avg, ref)
+
+
+def test_side_worker_thread_on_and_off():
+    """option side_thread: the dynamic branch enqueued by the library's worker thread (default) or by the calling thread behind
+    the static branch -- the same launches on the same streams: identical static images and masks, splat images to the rounding of
+    the float atomics; twenty views in a row on the worker (hand-over, error path idle), the cloud aggregated inside the call"""
+    from pgdvs_amd.runtime import ResidentVideoRenderer
+
+    H, W, S = 270, 480, 6
+    v = synth.make_video(S, H, W, seed=3)
+    model, rc = _renderer(dyn_pcl_remove_outlier=True)
+    rvr = ResidentVideoRenderer(model, rc, T(v["rgbs"]), T(v["depths"]), T(v["dyn_masks"]), v["K3s"], v["c2ws"], lanes=2, side_streams=True)
+    datas = [synth.to_torch(synth.make_view(v, i, frac=0.4, seed=5), DEV) for i in (1, 3)]
+    rvr.calibrate(datas[0])
+    assert ops.get_option("side_thread") == 1.0
+    outs = {}
+    for mode in (1, 0, 1):
+        ops.set_option("side_thread", mode)
+        try:
+            rets = [rvr.render(datas[j % 2], j % 2)[0] for j in range(20)]
+            rvr.join()
+            torch.cuda.synchronize()
+        finally:
+            ops.set_option("side_thread", 1)
+        for j in (0, 1, 18, 19):
+            ref = outs.setdefault(j % 2, rets[j])
+            assert torch.equal(rets[j]["geo_static_rgb"], ref["geo_static_rgb"]) and torch.equal(rets[j]["render_dyn_mask"], ref["render_dyn_mask"])
+            assert torch.allclose(rets[j]["combined_rgb"], ref["combined_rgb"], rtol=0, atol=1e-5)
+            assert int(rets[j]["geo_static_raster_status"]) == 0

@@ -187,8 +187,12 @@ def test_lane_streams_by_hardware_queue_render_the_same_images():
     from pgdvs_amd.runtime import ResidentVideoRenderer, stream_queue_groups
 
     pool = [torch.cuda.Stream() for _ in range(10)]
-    groups = stream_queue_groups(pool)
-    assert sorted(i for g in groups for i in g) == list(range(10)) and 1 <= len(groups) <= 10
+    try:
+        groups = stream_queue_groups(pool)
+        assert sorted(i for g in groups for i in g) == list(range(10)) and 1 <= len(groups) <= 10
+    except RuntimeError as e:  # (round 6: a pair ratio that stays between "side by side" and "one behind the other" fails the
+        # probe instead of guessing; ResidentVideoRenderer then takes creation order -- the arrangements below still render)
+        assert "stream_queue_groups" in str(e)
     H, W, S = 270, 480, 6
     v = synth.make_video(S, H, W, seed=31)
     cfg = load_config(static_renderer="geo")

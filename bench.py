@@ -822,6 +822,13 @@ def main():
     # ---------------- latency of ONE view (nothing else in flight): the throughput above comes from overlapping
     # `inflight` independent views; this is the time a single view takes from first launch to last kernel
     torch.cuda.synchronize()
+    # (one lane with a second stream for the dynamic branch, whatever arrangement the throughput loop runs: a view alone is
+    # the static branch's chain with the dynamic branch beside it)
+    rvr.set_lanes(1, True, False)
+    for j in range(3):
+        rvr.render(views[j % n_views], 0)
+    rvr.join()
+    torch.cuda.synchronize()
     lat = []
     for j in range(12):  # (every rank, so that all ranks reach the end of the run together; rank 0 reports its own)
         l0 = time.perf_counter()
@@ -831,7 +838,8 @@ def main():
         lat.append((time.perf_counter() - l0) * 1e3)
     lat = sorted(lat[2:])
     latency_ms = {"median": round(lat[len(lat) // 2], 3), "min": round(lat[0], 3), "views": len(lat),
-                  "note": "one view in flight on one lane, wall clock around enqueue + synchronize"}
+                  "note": "one view in flight on one lane (second stream for the dynamic branch), wall clock around enqueue + synchronize"}
+    rvr.set_lanes(*lane_cfg)
 
     # ---------------- what a drop-in caller of pgdvs.engines gets: the reference's evaluator renders ONE view, then
     # synchronises for its metrics (evaluator_pgdvs.py:36-188) -- the same workload through harness.eval_step, one view

@@ -483,6 +483,27 @@ constexpr int kStepPx = 16;        // pixels per thread of a step launch
 constexpr int kStepChunkPx = 128;  // ... in chunks of 128 consecutive pixels (8 threads), dealt round-robin to the workgroups
 constexpr int kStepChunks = kStepThreads * kStepPx / kStepChunkPx;  // chunks per workgroup (32: 4096 pixels)
 
+// Which 128-pixel chunk of the frame is chunk r (0 .. kStepChunks-1) of a link's workgroup b, gx workgroups per link (a
+// multiple of 8), and the inverse.  Workgroup b runs on XCD b mod 8 (round-robin dispatch).  Until round 6 chunk g belonged to
+// workgroup g mod gx: neighbouring chunks -- whose new points stamp neighbouring pixels of the later frames, i.e. the same
+// 128-byte lines of their maps -- sat on eight different XCDs, and every such line went to memory from several L2s.  Now the
+// frame is cut into stripes of kStepChunks = 32 chunks (4096 pixels, ~2 rows at 1080p), stripe s belongs to XCD s mod 8, and
+// the stripes of an XCD are dealt chunk by chunk over its gx / 8 workgroups as before (every workgroup still holds the same
+// sample of the image, every XCD every eighth stripe).  A bijection on [0, 32 gx) for every gx that is a multiple of 8.
+__device__ __forceinline__ int64_t step_chunk_of(const int b, const int r, const int gx) {
+  const int L = gx >> 3, xcd = b & 7, l = b >> 3;
+  const int j = r * L + l;  // the chunk's number among its XCD's chunks
+  return ((int64_t)(j / kStepChunks) * 8 + xcd) * kStepChunks + (j % kStepChunks);
+}
+__device__ __forceinline__ void step_owner_of(const int64_t g, const int gx, int &b, int &r) {
+  const int L = gx >> 3;
+  const int64_t stripe = g / kStepChunks;
+  const int xcd = (int)(stripe & 7);
+  const int j = (int)(stripe >> 3) * kStepChunks + (int)(g % kStepChunks);
+  r = j / L;
+  b = (j - r * L) * 8 + xcd;
+}
+
 // block-wide exclusive offset of `c` (256 threads) and the block total
 __device__ __forceinline__ int block_excl_256(const int c, int *s_wsum, int &total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -732,7 +753,7 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
   __shared__ PushConsts s_pc[kPushMaxFpg + 2];  // the row's screening records (+ the two spare entries screen_frames may request)
   const int tid = threadIdx.x;
   auto pixel_base = [&](const int t) {
-    return ((int64_t)blockIdx.x + (int64_t)(t >> 3) * gridDim.x) * kStepChunkPx + (t & 7) * kStepPx;
+    return step_chunk_of((int)blockIdx.x, t >> 3, (int)gridDim.x) * kStepChunkPx + (t & 7) * kStepPx;
   };
   const int64_t base = pixel_base(tid);
   // the row's records ride on the first round trip, beside the mask and map bytes (16 bytes per thread: four per record):
@@ -918,10 +939,12 @@ agg_rows_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles, const i
     const int ent = (int)s_list[e];
     const int ch = ent >> 7;  // 128-pixel chunk of the tile (four threads of 32 pixels)
     if (from_stage) {
-      // chunk g of the frame was listed by the link's workgroup g % gx as its chunk g / gx
+      // chunk g of the frame was listed by the link's workgroup `ob` as its chunk `orr` (step_owner_of)
       const int64_t g = (int64_t)t * (kSelTile / kStepChunkPx) + ch;
-      const int64_t wg_slot = (int64_t)f * stage.gx + g % stage.gx;
-      const int first = stage.cst[wg_slot * kStepChunks + g / stage.gx];
+      int ob, orr;
+      step_owner_of(g, stage.gx, ob, orr);
+      const int64_t wg_slot = (int64_t)f * stage.gx + ob;
+      const int first = stage.cst[wg_slot * kStepChunks + orr];
       const float4 q = *reinterpret_cast<const float4 *>(stage.rows + (wg_slot * (kStepThreads * kStepPx) + first + (e - s_cstart[ch])) * 4);
       const f3 c = {q.y, q.z, q.w};
       append_row(app, cam, tile_px + ent, pos, true, q.x, nullptr, &c);

@@ -148,6 +148,17 @@ struct ByteStamp {  // one occupancy byte per (frame, pixel): frame 0's chip-fil
   __device__ __forceinline__ void operator()(int f, int q) const { (occ_all + (int64_t)f * P)[(unsigned)q] = 1; }
 #endif
 };
+// (experiment, tools/r06_ab.sh with EXTRA=-DPGDVS_AB_TBS: the chain's links look at the byte before they set it -- 70 % of
+// their stamps hit bytes that frame 0's push or an earlier link has set already)
+struct ByteStampTest {
+  uint8_t *occ_all;
+  int64_t P;
+  unsigned *stat;
+  __device__ __forceinline__ void operator()(int f, int q) const {
+    uint8_t *p = occ_all + (int64_t)f * P;
+    if (p[(unsigned)q] == 0) p[(unsigned)q] = 1;
+  }
+};
 template <class Stamp>
 __device__ __attribute__((noinline)) void mark_reference_order(const ProjF64 *__restrict__ pj, double x, double y,
                                                                double z, int H, int W, int f, const Stamp &stamp) {
@@ -789,7 +800,11 @@ agg_step_kernel(SelArgs a, uint8_t *__restrict__ occ_all, uint16_t *__restrict__
   for (uint32_t m = bits; m; m &= m - 1) s_list[slot++] = (uint16_t)((tid << 4) | __builtin_ctz(m));
   if (tid == 0) s_qn[0] = s_qn[1] = 0;
   __syncthreads();
+#ifdef PGDVS_AB_TBS
+  const ByteStampTest stamp{occ_all, (int64_t)H * W, stat};
+#else
   const ByteStamp stamp{occ_all, (int64_t)H * W, stat};
+#endif
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
   // Round 6: a workgroup lists ~120 pixels (60 k per link over 512 workgroups), so with one thread per listed pixel two of its
   // four wavefronts had nothing to screen -- and ran the whole frame loop on NaNs beside the other two, which walked all the

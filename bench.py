@@ -100,7 +100,7 @@ def emit(out):
 def _traffic_profile():
     """the committed rocprofv3 FETCH_SIZE / WRITE_SIZE summary of this same command (made by
     tools/make_profile_summary.py from separate --pmc passes): newest round first"""
-    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+    for name in ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
         f = ROOT / "profiles" / name
         if f.exists():
             return name, json.loads(f.read_text())
@@ -131,7 +131,7 @@ def measured_view_traffic(H, W, S):
 def pmc_instruction_profile():
     """per-kernel instruction counters per launch (SQ_INSTS_VALU / SALU / LDS wave-instructions, busy and wait
     cycles) from the committed rocprofv3 --pmc summary of this command, or {}"""
-    for name in ("r05_pmc_instructions.json", "r04_pmc_instructions.json", "r03_pmc_instructions.json"):
+    for name in ("r06_pmc_instructions.json", "r05_pmc_instructions.json", "r04_pmc_instructions.json", "r03_pmc_instructions.json"):
         f = ROOT / "profiles" / name
         if f.exists():
             return name, json.loads(f.read_text())
@@ -148,7 +148,7 @@ def gnt_pmc_profile():
     """matrix-pipe busy fraction per GNT kernel from the committed rocprofv3 --pmc summary (tools/pmc_gnt.sh; its header
     table: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x 2.4 GHz x the kernel's duration)); (None, {}) when the file is missing"""
     import re
-    for name in ("r05_gnt_bf16x3_pmc.txt", "r04_gnt_bf16x3_pmc.txt"):
+    for name in ("r06_gnt_bf16x3_pmc.txt", "r05_gnt_bf16x3_pmc.txt", "r04_gnt_bf16x3_pmc.txt"):
         f = ROOT / "profiles" / name
         if not f.exists():
             continue

@@ -268,6 +268,8 @@ dyn_warp_kernel(int H, int W, const float *__restrict__ dyn_mask1, const float *
     for (int g = p; g < ex.n16_1; g += stride) ex.zero1[g] = make_uint4(0u, 0u, 0u, 0u);
   if (ex.zero2)
     for (int g = p; g < ex.n16_2; g += stride) ex.zero2[g] = make_uint4(0u, 0u, 0u, 0u);
+  if (ex.zero3)
+    for (int g = p; g < ex.n16_3; g += stride) ex.zero3[g] = make_uint4(0u, 0u, 0u, 0u);
   if (ex.chunk_cnt) {  // (uniform over the launch: every thread reaches the barrier)
     __shared__ int s_c[4];
     const unsigned long long b = __ballot(ok);

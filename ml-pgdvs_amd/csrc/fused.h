@@ -11,8 +11,8 @@ namespace pgdvs {
 // dyn.hip: what dyn_warp_kernel does on the side (see the kernel)
 struct WarpExtras {
   uint8_t *zero_a, *zero_b;  // [P] byte maps cleared pixel by pixel, or null
-  uint4 *zero0, *zero1, *zero2;  // 16-byte aligned blocks of n16_0 / n16_1 / n16_2 granules cleared by the launch's threads, or null
-  int n16_0, n16_1, n16_2;
+  uint4 *zero0, *zero1, *zero2, *zero3;  // 16-byte aligned blocks of n16_0 .. n16_3 granules cleared by the launch's threads, or null
+  int n16_0, n16_1, n16_2, n16_3;
   int32_t *chunk_cnt;        // [ceil(P / 256)] valid pixels per 256-pixel chunk (= per workgroup), or null
 };
 int dyn_warp_fused(int H, int W, const float *dyn_mask1, const float *occ, int use_flow_consistency, const float *flow12,
@@ -31,8 +31,9 @@ int compact_gather_bbox(const uint8_t *flags, int64_t n, const int32_t *chunk_cn
 // cleared and the bounding box already there
 // (tab / tab_bytes: the sparse cell index's bit table, cleared in full by the caller; occ_count: the quarter-cell counters, of
 // which the caller clears occ_mult per point + 1 -- what grid_tab_zero_kernel clears for the per-op entry point)
+// (coarse / coarse_bytes: the second-level grid's cell counters, cleared in full by the caller)
 void knn_grid_state_block(void *workspace, int64_t capacity, void **block, int64_t *bytes, unsigned **bbox, void **tab,
-                          int64_t *tab_bytes, int32_t **occ_count, int *occ_mult);
+                          int64_t *tab_bytes, int32_t **occ_count, int *occ_mult, void **coarse, int64_t *coarse_bytes);
 int knn_grid_mean_dist_prepared(const float *pts, const int32_t *count, int64_t capacity, int K, float *avg_out, void *workspace,
                                 int64_t workspace_bytes, hipStream_t st);
 

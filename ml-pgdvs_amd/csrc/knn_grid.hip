@@ -383,23 +383,6 @@ __device__ __forceinline__ GridParams coarse_params(const GridParams *__restrict
   return gp;
 }
 
-// ... and its cell counters cleared in the same launch (round 6; until then a one-thread launch for the parameters and a
-// second one to clear cell_count[0 .. ncells]): every workgroup works the parameters out for itself -- a few dozen
-// operations on values that are final when the launch starts --, workgroup 0 leaves them in *gp
-__global__ void __launch_bounds__(256)
-grid_coarse_setup_kernel(const GridParams *__restrict__ fine, const unsigned *__restrict__ bbox, GridParams *__restrict__ gp,
-                         float scale, float scale_many, const int32_t *__restrict__ open_count,
-                         const int32_t *__restrict__ qcount, int max_cells, int32_t *__restrict__ cell_count) {
-  __shared__ GridParams s_gp;
-  if (threadIdx.x == 0) {
-    s_gp = coarse_params(fine, bbox, scale, scale_many, open_count, qcount, max_cells);
-    if (blockIdx.x == 0) *gp = s_gp;
-  }
-  __syncthreads();
-  const int nc = s_gp.ncells;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= nc; i += gridDim.x * blockDim.x) cell_count[i] = 0;
-}
-
 __device__ __forceinline__ int cell_coord(float v, float mn, float inv_h, int G) {
   float c = floorf((v - mn) * inv_h);
   c = fminf(fmaxf(c, 0.0f), (float)(G - 1));  // NaN -> 0
@@ -418,12 +401,23 @@ __device__ __forceinline__ int fine_coord(float v, float mn, float inv_h, int G)
   return (int)c;
 }
 
+// The second-level grid's counting pass with its parameters worked out at the head of every workgroup (round 6; until then a
+// one-thread launch for the parameters and a second one to clear the counters in front of the counting pass): a few dozen
+// operations on values that are final when the launch starts, workgroup 0 leaves them in *gp for the launches behind it.  The
+// counters [0, kCoarseMaxCells] are cleared by the caller (the search's memset, or the per-view call's dyn_warp launch).
 __global__ void __launch_bounds__(256)
-grid_count_kernel(const float *__restrict__ pts, const GridParams *__restrict__ gp,
-                  int32_t *__restrict__ cell_of, int32_t *__restrict__ cell_count,
-                  const int32_t *__restrict__ gate) {
-  if (gate && *gate == 0) return;  // second-level grid: nothing fell through the first level
-  const GridParams g = *gp;
+grid_coarse_count_kernel(const float *__restrict__ pts, const GridParams *__restrict__ fine, const unsigned *__restrict__ bbox,
+                         GridParams *__restrict__ gp, float scale, float scale_many, const int32_t *__restrict__ open_count,
+                         const int32_t *__restrict__ qcount, int max_cells, int32_t *__restrict__ cell_of,
+                         int32_t *__restrict__ cell_count) {
+  __shared__ GridParams s_gp;
+  if (threadIdx.x == 0) {
+    s_gp = coarse_params(fine, bbox, scale, scale_many, open_count, qcount, max_cells);
+    if (blockIdx.x == 0) *gp = s_gp;
+  }
+  __syncthreads();
+  if (*open_count == 0) return;  // nothing fell through the first level (the parameters are written either way)
+  const GridParams g = s_gp;
   // points arrive in raster order of their source frame: neighbouring lanes mostly share a
   // cell, so the run leaders add whole runs (one atomic instruction per wave step)
   const int n_round = (g.n + 63) / 64 * 64;
@@ -474,6 +468,7 @@ struct CellIndex {
 
 constexpr int kTabWords = (kGridMaxCells >> 6) + 1;  // (+1: cell index ncells, one past the last cell, is looked up too)
 constexpr int kRankWordsPerBlock = 4096;
+constexpr unsigned kScanSpinLimit = 1u << 22;   // polls of one predecessor word before a look-back gives up (never expected)
 
 // zero the words of the bit table that cover cells [0, ncells] and the per-occupied-cell counters
 __global__ void __launch_bounds__(256)
@@ -505,50 +500,31 @@ grid_mark_kernel(const float *__restrict__ pts, const GridParams *__restrict__ g
   }
 }
 
-// rank of every table word = occupied cells before it.  Two launches: bits per workgroup of kRankWordsPerBlock
-// words, then every workgroup sums the (<= 65) totals before its own and scans its words.  (One launch in which a
+// rank of every table word = occupied cells before it.  (Until round 6 two launches: bits per workgroup of kRankWordsPerBlock
+// words, then every workgroup summed the (<= 65) totals before its own and scanned its words.  One launch in which a
 // workgroup counted the bits of all words before its own itself took 25 us: the last workgroup's 1 MB walk.)
 __device__ __forceinline__ int tab_word_bits(const uint4 *__restrict__ tab, int w) {
   const uint2 b = *reinterpret_cast<const uint2 *>(&tab[w]);
   return __popc(b.x) + __popc(b.y);
 }
 
+// (round 6: ONE launch.  A workgroup takes its block of kRankWordsPerBlock words by ticket, counts its bits, publishes the count
+// as a tagged 64-bit word and adds up the words of ALL blocks before it -- at most 64, one or two per lane of its first
+// wavefront, polled until they carry the tag; every predecessor is held by a workgroup that already runs (tickets), the spin is
+// bounded like the scan's.  `state`: kRankBlocksMax words + the ticket behind them, zeroed with the search's state block.)
+constexpr int kRankBlocksMax = (kTabWords + kRankWordsPerBlock - 1) / kRankWordsPerBlock;  // 65
 __global__ void __launch_bounds__(1024)
-grid_rank_totals_kernel(const GridParams *__restrict__ gp, const uint4 *__restrict__ tab, int32_t *__restrict__ totals) {
+grid_rank_kernel(const GridParams *__restrict__ gp, uint4 *__restrict__ tab, unsigned long long *__restrict__ state,
+                 int32_t *__restrict__ ticket, int32_t *__restrict__ error, int32_t *__restrict__ nocc_out) {
   __shared__ int ws[16];
+  __shared__ int s_blk, s_pre;
   const int nw = (gp->ncells >> 6) + 1;
-  const int w0 = blockIdx.x * kRankWordsPerBlock;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int s = 0;
-  if (w0 < nw) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int w = w0 + k * 1024 + tid;
-      if (w < nw) s += tab_word_bits(tab, w);
-    }
-  }
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if (lane == 0) ws[wave] = s;
+  if (tid == 0) s_blk = atomicAdd(ticket, 1);
   __syncthreads();
-  if (tid == 0) {
-    int t = 0;
-    for (int w = 0; w < 16; ++w) t += ws[w];
-    totals[blockIdx.x] = t;
-  }
-}
-
-__global__ void __launch_bounds__(1024)
-grid_rank_kernel(const GridParams *__restrict__ gp, uint4 *__restrict__ tab, const int32_t *__restrict__ totals,
-                 int32_t *__restrict__ nocc_out) {
-  __shared__ int ws[16];
-  const int nw = (gp->ncells >> 6) + 1;
-  const int w0 = blockIdx.x * kRankWordsPerBlock;
-  if (w0 >= nw) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // the workgroups before this one (at most kTabWords / kRankWordsPerBlock + 1 = 65 totals: two per lane)
-  int pre = 0;
-  for (int b = lane; b < (int)blockIdx.x; b += 64) pre += totals[b];
-  for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
+  const int blk = s_blk;
+  const int w0 = blk * kRankWordsPerBlock;
+  if (w0 >= nw) return;  // (nobody waits for a block without words: the blocks behind it have none either)
   int c[4], s = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -563,7 +539,32 @@ grid_rank_kernel(const GridParams *__restrict__ gp, uint4 *__restrict__ tab, con
   }
   if (lane == 63) ws[wave] = x;
   __syncthreads();
-  int run = pre + x - s;
+  if (wave == 0) {
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) total += ws[w];
+    if (lane == 0) __hip_atomic_store(&state[blk], (1ull << 32) | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int pre = 0;
+    for (int b = lane; b < blk; b += 64) {
+      unsigned spins = 0;
+      unsigned long long v;
+      for (;;) {
+        v = __hip_atomic_load(&state[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 32) != 0ull) break;
+        if (++spins > kScanSpinLimit) {  // keeps a protocol bug from hanging the GPU (results poisoned: grid_fallback_finish_kernel)
+          atomicExch(error, 1);
+          v = 0ull;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      pre += (int)(unsigned)v;
+    }
+    for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
+    if (lane == 0) s_pre = pre;
+  }
+  __syncthreads();
+  int run = s_pre + x - s;
   for (int w = 0; w < wave; ++w) run += ws[w];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -610,7 +611,6 @@ grid_occ_count_kernel(const GridParams *__restrict__ gp, int32_t *__restrict__ c
 constexpr int kScanVec = 2;
 constexpr int kScanTile = 1024 * 4 * kScanVec;
 constexpr int kScanMaxBlocks = 256;             // workgroups of a scan launch: they take tiles by ticket until none is left
-constexpr unsigned kScanSpinLimit = 1u << 22;   // polls of one predecessor word before the scan gives up (never expected)
 // (round 6, after the advisor's finding: until then the tile was blockIdx.x -- dispatch order is NOT index order on eight XCDs
 // with other views' kernels on the CUs: beside the tile pass one scan of 9 live tiles among 1013 launched took 102 us instead
 // of 6 --, the spin was unbounded, and the launch was sized from the capacity.  Now: a ticket per tile from a word of the
@@ -1515,7 +1515,7 @@ struct GridWs {
   int32_t *open_count, *open_list;  // queries the thread-per-query pass left to the ring search
   float *fb_bound;
   float *fb_partial;  // [kFbMaxSliced][kFbSlices][64]
-  unsigned long long *scan_state, *scan_state2;
+  unsigned long long *scan_state, *scan_state2, *rank_state;
   int32_t *scan_ticket, *scan_error;
   int scan_tiles;
   int64_t state_bytes;  // the block the call's memset clears
@@ -1558,6 +1558,8 @@ static GridWs grid_ws_layout(void *base, int64_t capacity, int64_t qcapacity) {
   off += (int64_t)w.scan_tiles * 8;
   w.scan_state2 = reinterpret_cast<unsigned long long *>(p + off);
   off += (int64_t)(kCoarseMaxCells / kScanTile + 2) * 8;
+  w.rank_state = reinterpret_cast<unsigned long long *>(p + off);  // [kRankBlocksMax] tagged bit counts + the ticket word
+  off += (int64_t)(kRankBlocksMax + 1) * 8;
   off = align_up(off, 256);
   w.state_bytes = off;
   w.gp = reinterpret_cast<GridParams *>(p + off);
@@ -1639,7 +1641,7 @@ int knn_grid_mean_dist(const float *pts, const int32_t *count, int64_t capacity,
 
 // fused.h: the per-view call clears the state block and computes the bounding box inside launches it runs anyway
 void knn_grid_state_block(void *workspace, int64_t capacity, void **block, int64_t *bytes, unsigned **bbox, void **tab,
-                          int64_t *tab_bytes, int32_t **occ_count, int *occ_mult) {
+                          int64_t *tab_bytes, int32_t **occ_count, int *occ_mult, void **coarse, int64_t *coarse_bytes) {
   const GridWs ws = grid_ws_layout(workspace, capacity, 0);
   *block = ws.bbox;
   *bytes = ws.state_bytes;
@@ -1648,6 +1650,8 @@ void knn_grid_state_block(void *workspace, int64_t capacity, void **block, int64
   *tab_bytes = (int64_t)kTabWords * 16;
   *occ_count = ws.occ_count;
   *occ_mult = kSub;
+  *coarse = ws.cell_count2;
+  *coarse_bytes = align_up(((int64_t)kCoarseMaxCells + 1) * 4, 16);
 }
 int knn_grid_mean_dist_prepared(const float *pts, const int32_t *count, int64_t capacity, int K, float *avg_out, void *workspace,
                                 int64_t workspace_bytes, hipStream_t st) {
@@ -1655,7 +1659,7 @@ int knn_grid_mean_dist_prepared(const float *pts, const int32_t *count, int64_t 
 }
 
 // prepared: the state block is cleared and holds the points' bounding box already, the bit table and the quarter-cell counters
-// are cleared (no memset, no grid_bbox launch, no grid_tab_zero launch)
+// are cleared, and so are the second-level grid's counters (no memsets, no grid_bbox launch, no grid_tab_zero launch)
 static int knn_grid_search(const float *pts, const int32_t *count, int64_t capacity, int K, float *avg_out,
                            void *workspace, int64_t workspace_bytes, hipStream_t st, const float *qpts,
                            const int32_t *qcount, int64_t qcapacity, bool prepared) {
@@ -1683,6 +1687,11 @@ static int knn_grid_search(const float *pts, const int32_t *count, int64_t capac
       set_error("knn_grid memset: %s", hipGetErrorString(e));
       return PGDVS_ERR_LAUNCH;
     }
+    e = hipMemsetAsync(ws.cell_count2, 0x00, ((size_t)kCoarseMaxCells + 1) * 4, st);  // the second-level grid's counters
+    if (e != hipSuccess) {
+      set_error("knn_grid memset: %s", hipGetErrorString(e));
+      return PGDVS_ERR_LAUNCH;
+    }
     PGDVS_LAUNCH("grid_bbox", grid_bbox_kernel, dim3(gbb), dim3(256), 0, st, pts, count, ws.bbox);
   }
   // the cell size from the spacing of a thinned copy of the cloud (see grid_params_kernel)
@@ -1696,9 +1705,8 @@ static int knn_grid_search(const float *pts, const int32_t *count, int64_t capac
   if (!prepared) PGDVS_LAUNCH("grid_tab_zero", grid_tab_zero_kernel, dim3(512), dim3(256), 0, st, ws.gp, ws.tab, ws.occ_count);
   PGDVS_LAUNCH("grid_mark", grid_mark_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.cell_of, ws.tab);
   const unsigned nrb = (unsigned)cdiv(kTabWords, kRankWordsPerBlock);
-  PGDVS_LAUNCH("grid_rank", grid_rank_totals_kernel, dim3(nrb), dim3(1024), 0, st, ws.gp, (const uint4 *)ws.tab, ws.block_sums);
-  PGDVS_LAUNCH("grid_rank", grid_rank_kernel, dim3(nrb), dim3(1024), 0, st, ws.gp, ws.tab, (const int32_t *)ws.block_sums,
-               ws.nocc);
+  PGDVS_LAUNCH("grid_rank", grid_rank_kernel, dim3(nrb), dim3(1024), 0, st, ws.gp, ws.tab, ws.rank_state,
+               reinterpret_cast<int32_t *>(ws.rank_state + kRankBlocksMax), ws.scan_error, ws.nocc);
   PGDVS_LAUNCH("grid_occ_count", grid_occ_count_kernel, dim3(gpts), dim3(256), 0, st, ws.gp, ws.cell_of,
                (const uint4 *)ws.tab, ws.occ_count);
   const int64_t occ_cap = capacity < kGridMaxCells ? capacity : (int64_t)kGridMaxCells;
@@ -1755,11 +1763,9 @@ static int knn_grid_search(const float *pts, const int32_t *count, int64_t capac
   // kCoarseScale-times larger cells before anything is scanned exhaustively.  All of it is
   // gated on the device-side count of open queries.
   const int nb2 = kCoarseMaxCells / kScanTile;
-  PGDVS_LAUNCH("grid2_setup", grid_coarse_setup_kernel, dim3(256), dim3(256), 0, st, ws.gp, ws.bbox, ws.gp2,
-               kCoarseScale, kCoarseScaleMany, (const int32_t *)ws.fb_count, qpts ? qcount : (const int32_t *)nullptr,
-               kCoarseMaxCells, ws.cell_count2);
-  PGDVS_LAUNCH("grid2_count", grid_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp2, ws.cell_of,
-               ws.cell_count2, (const int32_t *)ws.fb_count);
+  PGDVS_LAUNCH("grid2_count", grid_coarse_count_kernel, dim3(gpts), dim3(256), 0, st, pts, ws.gp, ws.bbox, ws.gp2, kCoarseScale,
+               kCoarseScaleMany, (const int32_t *)ws.fb_count, qpts ? qcount : (const int32_t *)nullptr, kCoarseMaxCells, ws.cell_of,
+               ws.cell_count2);
   (void)nb2;
   PGDVS_LAUNCH("grid2_scan", grid_scan_kernel, dim3(kCoarseMaxCells / kScanTile + 1), dim3(1024), 0, st, ws.cell_count2,
                (const int32_t *)&ws.gp2->ncells, ws.cell_start2, ws.scan_state2, ws.scan_ticket + 1, ws.scan_error);

@@ -859,50 +859,6 @@ __global__ void __launch_bounds__(kBitTileWords) agg_count_kernel(const uint32_t
   if (threadIdx.x == 0) tile_cnt[(int64_t)f * tiles + blockIdx.x] = total;
 }
 
-// ... their running sum in (frame, tile) order: tile_off[u] = selected pixels of the later frames before entry u
-// (u = f * tiles + t, from u = tiles on); tile_off[S * tiles] = all of them.  One workgroup.
-// ... and the count the caller sees (what agg_finalize_kernel computes for the ordered chain).
-__global__ void __launch_bounds__(1024) agg_scan_kernel(const int32_t *__restrict__ tile_cnt, int64_t *__restrict__ tile_off,
-                                                        int64_t lo, int64_t hi, const int64_t *__restrict__ cnts,
-                                                        const int32_t *__restrict__ error, int64_t capacity,
-                                                        int64_t *__restrict__ count_out) {
-  __shared__ long long s_w[16];
-  __shared__ long long s_carry;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int64_t u0 = lo; u0 < hi; u0 += 4096) {
-    const int64_t u = u0 + (int64_t)tid * 4;
-    int v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = u + k < hi ? tile_cnt[u + k] : 0;
-    long long x = (long long)v[0] + v[1] + v[2] + v[3];
-    const long long mine = x;
-    for (int off = 1; off < 64; off <<= 1) {
-      const long long y = __shfl_up(x, off, 64);
-      if (lane >= off) x += y;
-    }
-    if (lane == 63) s_w[wave] = x;
-    __syncthreads();
-    long long before = s_carry;
-    for (int q = 0; q < wave; ++q) before += s_w[q];
-    long long run = before + x - mine;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (u + k < hi) tile_off[u + k] = run;
-      run += v[k];
-    }
-    __syncthreads();
-    if (tid == 1023) s_carry = run;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    tile_off[hi] = s_carry;
-    const long long n = cnts[1] + s_carry;
-    *count_out = *error ? -1 : (n > capacity ? capacity : n);
-  }
-}
-
 // ... and their rows, in the reference's order (frame, then row-major pixel: tmp_pcl[tmp_st_mask] :247-251): tile (t, f)
 // starts behind frame 0's rows and everything counted before it.
 struct RowsArgs {
@@ -914,11 +870,13 @@ struct RowsArgs {
   int P, W;
 };
 __global__ void __launch_bounds__(kBitTileWords)
-agg_rows_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles, const int64_t *__restrict__ tile_off,
+agg_rows_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles, const int32_t *__restrict__ tile_cnt,
                 const int64_t *__restrict__ cnts, const CamBlock *__restrict__ cams, RowsArgs a,
-                RowStage stage, int f_staged, uint4 *__restrict__ zero_extra, int zero_extra_n16) {
+                RowStage stage, int f_staged, uint4 *__restrict__ zero_extra, int zero_extra_n16,
+                const int32_t *__restrict__ error, int64_t *__restrict__ count_out) {
   __shared__ uint16_t s_list[kSelTile];
   __shared__ int s_wsum[4];
+  __shared__ long long s_before[4];
   __shared__ int s_cstart[kBitTileWords / 4];  // list position of every 128-pixel chunk's first selected pixel
   const int tid = threadIdx.x;
   // (round 6: the per-view call lets this launch clear the counters of the rasteriser that runs behind it -- one memset less
@@ -931,11 +889,27 @@ agg_rows_kernel(const uint32_t *__restrict__ sel, int64_t Wd, int tiles, const i
   const uint32_t bits = sel[(int64_t)f * Wd + (int64_t)t * kBitTileWords + tid];
   int total;
   int slot = block_excl_256(__popc(bits), s_wsum, total);
-  if (total == 0) return;
+  // (the last workgroup stays to leave the cloud's size)
+  const bool last_wg = blockIdx.y == gridDim.y - 1 && blockIdx.x == gridDim.x - 1;
+  if (total == 0 && !last_wg) return;
   if ((tid & 3) == 0) s_cstart[tid >> 2] = slot;
   for (uint32_t m = bits; m; m &= m - 1) s_list[slot++] = (uint16_t)((tid << 5) | __builtin_ctz(m));
+  // Round 6: the selected pixels of the later frames before this (frame, tile), added up HERE from agg_count's per-tile counts
+  // (entries tiles .. f * tiles + t - 1 of an L2-resident array: ~23 loads per thread at 1080p x 24 frames) -- until then a
+  // one-workgroup scan launch between agg_count and this one wrote the running sums; the workgroups of tiles that selected
+  // nothing have left by now.
+  long long before = 0;
+  for (int64_t u = (int64_t)tiles + tid; u < (int64_t)f * tiles + t; u += kBitTileWords) before += tile_cnt[u];
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+  if ((tid & 63) == 0) s_before[tid >> 6] = before;
   __syncthreads();
-  const int64_t pos0 = cnts[1] + tile_off[(int64_t)f * tiles + t];
+  before = (s_before[0] + s_before[1]) + (s_before[2] + s_before[3]);
+  if (last_wg && tid == 0) {  // the count the caller sees (what agg_finalize_kernel computes for the ordered chain)
+    const long long n = cnts[1] + before + total;
+    *count_out = *error ? -1 : (n > a.capacity ? a.capacity : n);
+  }
+  if (total == 0) return;
+  const int64_t pos0 = cnts[1] + before;
   // frames whose chain link unprojected its pixels (all but the last one) left their rows packed per 128-pixel chunk
   const bool from_stage = f < f_staged && stage.rows != nullptr;
   AppendSrc app;
@@ -1370,8 +1344,6 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
   }
   PGDVS_LAUNCH("agg_count", agg_count_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,
                (const uint32_t *)ws.sel, ws.Wd, tiles, ws.tile_cnt);
-  PGDVS_LAUNCH("agg_scan", agg_scan_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)ws.tile_cnt, ws.tile_off, (int64_t)tiles,
-               (int64_t)S * tiles, (const int64_t *)ws.cnts, (const int32_t *)ws.error, capacity, count_out);
   {
     RowsArgs ra;
     ra.depths = depths;
@@ -1382,9 +1354,9 @@ static int static_aggregate_impl(const float *rgbs, const float *depths, const u
     ra.P = (int)P;
     ra.W = W;
     PGDVS_LAUNCH("agg_rows", agg_rows_kernel, dim3((unsigned)tiles, (unsigned)(S - 1)), dim3(kBitTileWords), 0, st,
-                 (const uint32_t *)ws.sel, ws.Wd, tiles, (const int64_t *)ws.tile_off, (const int64_t *)ws.cnts,
+                 (const uint32_t *)ws.sel, ws.Wd, tiles, (const int32_t *)ws.tile_cnt, (const int64_t *)ws.cnts,
                  (const CamBlock *)ws.cams, ra, stage, stage.rows != nullptr ? S - 1 : 0, reinterpret_cast<uint4 *>(zero_extra),
-                 (int)(zero_extra_bytes / 16));
+                 (int)(zero_extra_bytes / 16), (const int32_t *)ws.error, count_out);
   }
   return check_launch("static_aggregate");
 }

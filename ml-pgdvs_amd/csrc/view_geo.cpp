@@ -297,9 +297,11 @@ int dyn_geometry(const pgdvs_view_geo_desc &d, const ViewWs &w, pgdvs_stream_t s
   if (d.remove_outlier) {
     ex.zero_a = w.keep;
     ex.chunk_cnt = w.chunk_cnt;
-    void *blk = nullptr, *tab = nullptr;
-    int64_t bytes = 0, tab_bytes = 0;
-    knn_grid_state_block(w.knn, P, &blk, &bytes, &bbox, &tab, &tab_bytes, &occ_count, &occ_mult);
+    void *blk = nullptr, *tab = nullptr, *coarse = nullptr;
+    int64_t bytes = 0, tab_bytes = 0, coarse_bytes = 0;
+    knn_grid_state_block(w.knn, P, &blk, &bytes, &bbox, &tab, &tab_bytes, &occ_count, &occ_mult, &coarse, &coarse_bytes);
+    ex.zero3 = reinterpret_cast<uint4 *>(coarse);
+    ex.n16_3 = (int)(coarse_bytes / 16);
     ex.zero0 = reinterpret_cast<uint4 *>(blk);
     ex.n16_0 = (int)(bytes / 16);
     ex.zero2 = reinterpret_cast<uint4 *>(tab);

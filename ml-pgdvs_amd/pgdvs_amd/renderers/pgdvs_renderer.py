@@ -127,7 +127,9 @@ class PGDVSRenderer(PGDVSBaseRenderer):
         if side is None:
             side = getattr(st, "default_side_stream", None)
             if side is None:
-                side = st.default_side_stream = torch.cuda.Stream(device=dev)
+                from ..runtime import stream_on_other_queue
+
+                side = st.default_side_stream = stream_on_other_queue(torch.cuda.current_stream(dev))
         elif side is False:
             side = None
         r = ops.view_geo_forward(

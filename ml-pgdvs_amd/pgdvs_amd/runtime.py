@@ -55,6 +55,39 @@ def stream_queue_groups(streams, cycles: int = 40000, links: int = 10):
     return groups
 
 
+def stream_on_other_queue(main, candidates: int = 5, cycles: int = 40000, links: int = 8):
+    """A new stream that does NOT share ``main``'s hardware queue (the renderer's default second stream: on the queue of the
+    stream it is forked from, the dynamic branch would run behind the static one instead of beside it -- 1.29 ms per view
+    instead of 1.02 in round 6's evaluator-shaped loop, depending on how many streams the process had created before).
+    Up to ``candidates`` fresh streams are tried with the pair test of ``stream_queue_groups``; the first one that runs side
+    by side with ``main`` is returned, the first one created if none does (or if the clock is too noisy to tell)."""
+    import time
+
+    def chains(ss):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for st in ss:
+            with torch.cuda.stream(st):
+                for _ in range(links):
+                    torch.cuda._sleep(cycles)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    dev = main.device
+    first = None
+    try:
+        chains([main])
+        single = min(chains([main]) for _ in range(3))
+        for _ in range(candidates):
+            st = torch.cuda.Stream(device=dev)
+            first = first or st
+            if min(chains([main, st]) for _ in range(2)) < 1.35 * single:
+                return st
+    except Exception:  # noqa: BLE001 -- an optimisation: any stream is correct
+        pass
+    return first or torch.cuda.Stream(device=dev)
+
+
 LAST_PROBE = {}  # the last probe's pair ratios (diagnostics: ResidentVideoRenderer.queue_probe, bench.py's detail record)
 
 

@@ -37,17 +37,17 @@ with open(out, "w") as fh:
     fh.write("#   default product path -- exact bf16x3 products in the view layers and the feed-forward blocks, fp32 matrix instruction elsewhere)\n")
     fh.write("#   kernel                              dispatches   us      (fp32 path)   MFMA insts   all vector insts   matrix pipe busy\n")
     for k in sorted(mean, key=lambda k_: -sum(dur.get(k_, [0]))):
-        if not dur.get(k) or "SQ_VALU_MFMA_BUSY_CYCLES" not in mean[k]:
+        if not k.startswith("gnt_") or not dur.get(k) or "SQ_VALU_MFMA_BUSY_CYCLES" not in mean[k]:
             continue
         us = sum(dur[k]) / len(dur[k])
         busy = mean[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * 2.4e9 * us * 1e-6)
         fh.write(f"#   {k:38s} {us:8.1f}   ( {0.0:7.1f})   {mean[k].get('SQ_INSTS_MFMA', 0) / 1e6:8.1f} M   {mean[k].get('SQ_INSTS_VALU', 0) / 1e6:8.1f} M   {100 * busy:10.1f} %\n")
     fh.write("#   (the fp32-path column is not measured in this pass: 0.0)\n")
-    for k in sorted(mean):
+    for k in sorted(k_ for k_ in mean if k_.startswith("gnt_")):
         fh.write(f"{k}  dispatches={max(len(s) for s in ndisp[k].values())}\n")
         for c, v in sorted(mean[k].items()):
             fh.write(f"    {c:24s} {v:16.1f}\n")
     fh.write("kernel durations (us): name calls mean total\n")
-    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+    for k, v in sorted(((k_, v_) for k_, v_ in dur.items() if k_.startswith("gnt_")), key=lambda kv: -sum(kv[1])):
         fh.write(f"    {k:40s} {len(v):6d} {sum(v) / len(v):10.1f} {sum(v):12.1f}\n")
 print("wrote", out)

@@ -110,6 +110,7 @@ constexpr int kSampleShift = 6;           // one point in 64
 constexpr int kSampleBlock = 4096;        // points per block of the sampling pass
 constexpr int kSampleSlots = 128;         // samples kept per block (64 expected, binomial: sd 8)
 constexpr int kSampleMaxQueries = 4096;   // samples whose nearest-sample distance is measured
+constexpr int kSampleWindowBlocks = 256;  // ... among the samples of this many blocks around their own (a million points)
 // cell size in units of the median nearest-sample distance for K + 1 = 51 (scaled with sqrt((K + 1) / 51) otherwise).
 // 1.5 reproduces the cell size the trial grid's tuned target gave on the benchmark's cloud (h = 4.0e-3: the pass takes
 // 168 us at 1.4, 159 at 1.5, 170 at 1.65; 400-650 of its 311 k queries go on to the ring search instead of 1900) and gives
@@ -187,9 +188,20 @@ grid_sample_nn_kernel(const int32_t *__restrict__ count, const float4 *__restric
   }
   const int self = qb * kSampleSlots + qk;
   const float4 me = samples[self];
-  const int nslots = nblocks * kSampleSlots;
+  // the samples of at most kSampleWindowBlocks blocks around the query's own (round 6, after the advisor's finding: every query
+  // scanned every slot -- 2 G distance evaluations for a 16 M-point cloud, just to pick a cell size).  Clouds of up to a million
+  // points are scanned in full as before; beyond that the window holds the query's neighbours whenever the cloud arrives in an
+  // order with spatial locality (depth maps in raster order), and otherwise the distance -- and with it the cell size -- comes out
+  // larger: slower, never wrong.
+  int b_lo = 0, b_hi = nblocks;
+  if (nblocks > kSampleWindowBlocks) {
+    b_lo = qb - kSampleWindowBlocks / 2;
+    b_lo = b_lo < 0 ? 0 : (b_lo > nblocks - kSampleWindowBlocks ? nblocks - kSampleWindowBlocks : b_lo);
+    b_hi = b_lo + kSampleWindowBlocks;
+  }
+  const int s_lo = b_lo * kSampleSlots, nslots = b_hi * kSampleSlots;
   float best = __builtin_inff();
-  for (int k0 = threadIdx.x; k0 < nslots; k0 += 4 * 256) {
+  for (int k0 = s_lo + threadIdx.x; k0 < nslots; k0 += 4 * 256) {
     float4 p[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {

@@ -1045,12 +1045,13 @@ static int64_t max_tiles_per_point(float radius, int H, int W) {
   return nx * ny;
 }
 
+constexpr double kSegLayoutDensity = 2.2;  // rows per pixel below which a workspace carries the direct pass's segments
 constexpr int kSegEntries = 4096;  // most entries per tile segment of the direct binning pass (the longest list of the 1080p x 24 benchmark: ~1900)
 struct RasterWs {
   int32_t *tile_count, *cursor, *offsets;
   int32_t *seg_cursor;  // [ntiles] entries per tile as the direct binning pass counted them (its per-tile cursor)
   float4 *seg_lists;    // [ntiles][seg_entries] (null: the workspace was sized without them)
-  int seg_entries;      // twice the average list the row bound allows, 256 .. kSegEntries: the block never outgrows 2 x the exact lists' 
+  int seg_entries;      // twice the average list the row bound allows, at least 256 and at most kSegEntries per tile
   int32_t *stats;  // [64] zeroed per call with the counters: [0] tiles the sorted path handed to the general path for equal depths,
                    // [1] a segment of the direct binning pass overflowed (the exact passes ran, the tile pass read their lists)
   unsigned *zmin;      // [H*W] per-pixel minimum depth of the point centres (bit patterns), filled per call
@@ -1084,9 +1085,13 @@ static RasterWs raster_ws_layout(void *base, int64_t n, int H, int W, float radi
   off += align_up(w.list_capacity * 16, 256);
   // the direct pass's segments: only where a segment is worth more than the average list can need (images of at least a
   // few tiles; tiny test images keep the exact passes alone) and the block stays below 2 GB
+  // ... and clouds the direct pass can take at all: below kSegLayoutDensity rows per pixel (the default of the runtime gate,
+  // option raster_bound_density; a workspace sized for a denser cloud -- 1080p x 48 frames: 0.53 GB of segments per lane -- goes
+  // straight to the exact passes and carries no segment block.  A caller that raises the runtime gate beyond this keeps
+  // correct results: without segments the exact passes run.)
   w.seg_lists = nullptr;
   w.seg_entries = 0;
-  if (ntiles >= 16 && n > 0) {
+  if (ntiles >= 16 && n > 0 && (double)n < kSegLayoutDensity * (double)H * (double)W) {
     int64_t se = align_up(2 * cdiv(w.list_capacity, ntiles), 256);
     se = se < 256 ? 256 : (se > kSegEntries ? kSegEntries : se);
     if (ntiles * se * 16 <= (2ll << 30)) {

@@ -75,10 +75,19 @@ class BaseRenderer(torch.nn.Module):
             # view) with room to spare; merged only while that is a tenth of the free memory
             m = merge // chunk_size
             n_all = int(n_coarse_samples_per_ray) + int(n_fine_samples_per_ray)
-            free = torch.cuda.mem_get_info(src_rgbs.device)[0]
-            while m > 1 and m * chunk_size * n_all * V * 900 > free // 10:
-                m -= 1
-            chunk_size *= m
+            # (the factor is worked out ONCE per (device, chunk size, samples, views) and kept: `mem_get_info` is a driver call,
+            # and what it reports moves with the caching allocator's state -- asked per forward, the launch structure of a
+            # view depended on it.  Memory the allocator holds but has free counts as free.)
+            key = (src_rgbs.device.index, int(chunk_size), n_all, int(V), merge)
+            cache = self.__dict__.setdefault("_merge_factor", {})
+            if key not in cache:
+                dev_free = torch.cuda.mem_get_info(src_rgbs.device)[0]
+                pooled = torch.cuda.memory_reserved(src_rgbs.device) - torch.cuda.memory_allocated(src_rgbs.device)
+                free = dev_free + max(int(pooled), 0)
+                while m > 1 and m * chunk_size * n_all * V * 900 > free // 10:
+                    m -= 1
+                cache[key] = m
+            chunk_size *= cache[key]
         outs, outs_fine = OrderedDict(), OrderedDict()
         # a chunk may straddle batch items (true batching, renderer.py:414-485): one job per (chunk, batch item)
         jobs = []

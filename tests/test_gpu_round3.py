@@ -168,7 +168,10 @@ def test_points_raster_row_bound_matches_capacity_sized_call():
     assert int(bnd["status"]) == 0
     ops.check_raster_status(bnd["status"])
     lib = _lib.load()
-    assert lib.pgdvs_points_raster_workspace_bytes(4500, H, W, 0.03) < lib.pgdvs_points_raster_workspace_bytes(20000, H, W, 0.03) / 3
+    # the workspace follows the row bound (its tile lists); the segments of the direct binning pass are only part of workspaces
+    # sized for sparse clouds (below 2.2 rows per pixel: round 6), so the proportion is checked between two sizes without them
+    ws = lib.pgdvs_points_raster_workspace_bytes
+    assert ws(4500, H, W, 0.03) < ws(20000, H, W, 0.03) and ws(20000, H, W, 0.03) < ws(100000, H, W, 0.03) / 3
     # exactly at the bound: fine
     assert int(ops.points_raster(pts, pts[:, 3:], cam, 0.03, 3, H, W, n_points_dev=cnt, row_bound=4000)["status"]) == 0
 

@@ -982,7 +982,6 @@ struct AggWs {
   unsigned *stat;  // [kAggStatWords] see ByteStamp::stat
   unsigned long long *desc;
   int32_t *tile_cnt;   // [S][tiles] pixels the later frames selected per (frame, tile)
-  int64_t *tile_off;   // [S * tiles + 1] their running sum
   uint8_t *occ;  // [S][P] one occupancy byte per (frame, pixel), zeroed per call
   uint32_t *sel;  // [S][Wd] selection bits of the later frames (zeroed per call; a link writes the 128-pixel chunks that select)
   float *stage_rows;  // [S][gx][4096][4] (depth, colour) of the later frames' selected pixels as the chain links leave them (see RowStage)
@@ -1006,8 +1005,6 @@ static AggWs agg_ws_layout(void *base, int S, int H, int W, int64_t capacity) {
   int64_t off = 0;
   w.tile_cnt = reinterpret_cast<int32_t *>(p + off);
   off += align_up((int64_t)S * tiles * 4, 256);
-  w.tile_off = reinterpret_cast<int64_t *>(p + off);
-  off += align_up(((int64_t)S * tiles + 1) * 8, 256);
   // the state block and, right behind it, the occupancy maps of frames 1 .. S-1 (frame 0 has none): ONE fill per call
   // clears both
   w.state = p + off;

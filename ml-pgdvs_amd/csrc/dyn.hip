@@ -159,7 +159,7 @@ dyn_warp_pixel(const int p, int H, int W, const float *__restrict__ dyn_mask1, c
   const float fw = (float)W, fh = (float)H;
   bool m = dyn_mask1[p] != 0.0f;
   if (use_fc) m = m && !(occ[p] > 0.0f);
-  mask_eff[p] = (uint8_t)m;
+  if (mask_eff != nullptr) mask_eff[p] = (uint8_t)m;  // (null in the per-view call: nothing reads it there)
   if (!m) {
     valid[p] = 0;
     return false;
@@ -184,7 +184,7 @@ dyn_warp_pixel(const int p, int H, int W, const float *__restrict__ dyn_mask1, c
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       pcl[(size_t)p * 3 + k] = X1[k];
-      rgbf[(size_t)p * 3 + k] = rgb1[(size_t)p * 3 + k];
+      if (rgbf != nullptr) rgbf[(size_t)p * 3 + k] = rgb1[(size_t)p * 3 + k];
     }
     return true;
   }
@@ -207,15 +207,20 @@ dyn_warp_pixel(const int p, int H, int W, const float *__restrict__ dyn_mask1, c
   float wse = (ix - (float)x0) * (iy - (float)y0);
   bool inx0 = x0 >= 0 && x0 < W, inx1 = x1 >= 0 && x1 < W;
   bool iny0 = y0 >= 0 && y0 < H, iny1 = y1 >= 0 && y1 < H;
-  float col[3];
+  // (rgbf == nullptr -- the per-view call with the softsplat renderer, round 6: the colours sampled from frame 2 only feed the
+  // mesh / point / tracker variants (pgdvs_renderer_dyn.py:129,177-190: the splat path splats frame-1 pixels), so neither the
+  // four gathers per valid pixel nor the 12-byte row are spent on them there)
+  float col[3] = {0.0f, 0.0f, 0.0f};
+  if (rgbf != nullptr) {
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float acc = 0.0f;
-    if (inx0 && iny0) acc = acc + rgb2[((size_t)y0 * W + x0) * 3 + k] * wnw;
-    if (inx1 && iny0) acc = acc + rgb2[((size_t)y0 * W + x1) * 3 + k] * wne;
-    if (inx0 && iny1) acc = acc + rgb2[((size_t)y1 * W + x0) * 3 + k] * wsw;
-    if (inx1 && iny1) acc = acc + rgb2[((size_t)y1 * W + x1) * 3 + k] * wse;
-    col[k] = acc;
+    for (int k = 0; k < 3; ++k) {
+      float acc = 0.0f;
+      if (inx0 && iny0) acc = acc + rgb2[((size_t)y0 * W + x0) * 3 + k] * wnw;
+      if (inx1 && iny0) acc = acc + rgb2[((size_t)y0 * W + x1) * 3 + k] * wne;
+      if (inx0 && iny1) acc = acc + rgb2[((size_t)y1 * W + x0) * 3 + k] * wsw;
+      if (inx1 && iny1) acc = acc + rgb2[((size_t)y1 * W + x1) * 3 + k] * wse;
+      col[k] = acc;
+    }
   }
   const float *Kinv2 = cam2 + PGDVS_CAM_KINV;
   const float *R2 = cam2 + PGDVS_CAM_R;
@@ -234,7 +239,7 @@ dyn_warp_pixel(const int p, int H, int W, const float *__restrict__ dyn_mask1, c
     d = d + R2[k * 3 + 2] * kq[2];
     float X2 = cam2[PGDVS_CAM_O + k] + d * dsamp;
     pcl[(size_t)p * 3 + k] = w1 * X1[k] + w2 * X2;
-    rgbf[(size_t)p * 3 + k] = col[k];
+    if (rgbf != nullptr) rgbf[(size_t)p * 3 + k] = col[k];
   }
   return true;
 }

@@ -70,8 +70,8 @@ struct ViewWs {
   int64_t agg_bytes;
   void *raster;
   int64_t raster_bytes;
-  uint8_t *mask_eff, *valid, *keep, *flag;
-  float *pcl, *rgbf, *pts, *avg, *thres;
+  uint8_t *valid, *keep;
+  float *pcl, *pts, *avg, *thres;
   int32_t *idx, *cnt;
   int32_t *chunk_cnt;  // [ceil(P / 256)] valid pixels per workgroup of dyn_warp_kernel (fused compaction)
   void *compact;
@@ -126,12 +126,9 @@ int view_layout(const pgdvs_view_geo_desc &d, void *base, ViewWs &w) {
   w.raster_bytes = pgdvs_points_raster_workspace_bytes(w.raster_rows, d.H, d.W, d.radius);
   if (w.raster_bytes < 0) return (int)w.raster_bytes;  // (message set by the query)
   w.raster = c.take<char>(w.raster_bytes);
-  w.mask_eff = c.take<uint8_t>(P);
   w.valid = c.take<uint8_t>(P);
   w.keep = c.take<uint8_t>(P);
-  w.flag = c.take<uint8_t>(P);
   w.pcl = c.take<float>(P * 12);
-  w.rgbf = c.take<float>(P * 12);
   w.flow_1_to_tgt = c.take<float>(P * 8);
   w.valid_mask = c.take<float>(P * 4);
   w.splat_bytes = pgdvs_dyn_splat_workspace_bytes(d.H, d.W);
@@ -312,7 +309,7 @@ int dyn_geometry(const pgdvs_view_geo_desc &d, const ViewWs &w, pgdvs_stream_t s
   }
   PGDVS_REQUIRE(d.dyn_mask1 && d.flow12 && d.depth1 && d.depth2 && d.rgb1 && d.rgb2, "pgdvs_view_geo_forward: null input pointer");
   VG_TRY(dyn_warp_fused(H, W, d.dyn_mask1, d.flow_occ, d.use_flow_consistency, d.flow12, d.depth1, d.depth2, d.rgb1, d.rgb2, cam1,
-                        cam2, w.times, w.mask_eff, w.valid, w.pcl, w.rgbf, ex, st));
+                        cam2, w.times, nullptr, w.valid, w.pcl, nullptr, ex, st));  // (no effective-mask map, no frame-2 colours: the splat path reads neither)
   const uint8_t *keep = w.valid;
   if (d.remove_outlier) {
     // pytorch3d's kNN + the statistical filter (pgdvs_renderer_dyn.py:401-457)

@@ -203,9 +203,11 @@ dyn_project_flag_kernel(int H, int W, const float *__restrict__ cam_tgt, const f
     fy = v - (float)y;
     vm = 1.0f;
   }
-  flow_1_to_tgt[p] = fx;
-  flow_1_to_tgt[(size_t)P + p] = fy;
-  valid_mask[p] = vm;
+  if (flow_1_to_tgt != nullptr) {  // (null: the scatter pass projects the kept points itself -- see dyn_splat_scatter_kernel<true>)
+    flow_1_to_tgt[p] = fx;
+    flow_1_to_tgt[(size_t)P + p] = fy;
+    valid_mask[p] = vm;
+  }
   if (!kept) return;
   SplatCorners c = splat_corners(x, y, fx, fy, H, W);
 #pragma unroll
@@ -265,13 +267,19 @@ __global__ void __launch_bounds__(256) splat_noise_field_kernel(int P, const uns
   for (int k = 0; k < 3; ++k) out[(size_t)k * P + p] = nz[k];
 }
 
+// kProject (the per-view call, round 6): the flow to the target and the validity of a source pixel are not read from the dense
+// planes A5 wrote (8 + 4 bytes per pixel written by one launch and read back by this one: 48 MB per view at 1080p) but worked
+// out here -- keep[p] ? projection of pcl[p] through project_point, the same operations on the same values as
+// project_flow_dense_kernel : zero flow, mask 0 -- for the 15 % of the pixels that are kept; the others cost one byte.
+template <bool kProject>
 __global__ void __launch_bounds__(256)
 dyn_splat_scatter_kernel(int H, int W, const float *__restrict__ rgb1,
                          const float *__restrict__ rgb2, const float *__restrict__ flow12,
                          const float *__restrict__ flow_1_to_tgt,
                          const float *__restrict__ valid_mask, const float *__restrict__ noise,
                          const unsigned long long *__restrict__ rng, float alpha, float *__restrict__ acc,
-                         const uint8_t *__restrict__ flags) {
+                         const uint8_t *__restrict__ flags, const float *__restrict__ cam_tgt,
+                         const float *__restrict__ pcl, const uint8_t *__restrict__ keep) {
   __shared__ float s_acc[5][kSplatWin * kSplatWin];
   __shared__ int s_org[2];
   const int P = H * W;
@@ -287,9 +295,26 @@ dyn_splat_scatter_kernel(int H, int W, const float *__restrict__ rgb1,
   float m = 0.0f;
   bool part = false;
   if (x < W && y < H) {
-    c = splat_corners(x, y, flow_1_to_tgt[p], flow_1_to_tgt[(size_t)P + p], H, W);
+    float fx, fy, vm;
+    if (kProject) {
+      fx = 0.0f;
+      fy = 0.0f;
+      vm = 0.0f;
+      if (keep[p]) {
+        float u, v;
+        project_point(cam_tgt + PGDVS_CAM_P, pcl[(size_t)p * 3], pcl[(size_t)p * 3 + 1], pcl[(size_t)p * 3 + 2], u, v);
+        fx = u - (float)x;
+        fy = v - (float)y;
+        vm = 1.0f;
+      }
+    } else {
+      fx = flow_1_to_tgt[p];
+      fy = flow_1_to_tgt[(size_t)P + p];
+      vm = valid_mask[p];
+    }
+    c = splat_corners(x, y, fx, fy, H, W);
     if (c.any) {
-      m = valid_mask[p];
+      m = vm;
       part = true;
       if (m == 0.0f) {
         bool wanted = false;
@@ -620,8 +645,9 @@ int dyn_splat_scatter_part(int H, int W, const float *rgb1, const float *rgb2, c
   PGDVS_LAUNCH("dyn_splat_flag", dyn_splat_flag_kernel, grid, block, 0, st, H, W, flow_1_to_tgt, valid_dyn_mask_1,
                flags, acc);
   const dim3 tgrid((unsigned)cdiv(W, kSplatTile), (unsigned)cdiv(H, kSplatTile));
-  PGDVS_LAUNCH("dyn_splat_scatter", dyn_splat_scatter_kernel, tgrid, block, 0, st, H, W, rgb1, rgb2, flow12,
-                     flow_1_to_tgt, valid_dyn_mask_1, noise, rng, alpha, acc, (const uint8_t *)flags);
+  PGDVS_LAUNCH("dyn_splat_scatter", dyn_splat_scatter_kernel<false>, tgrid, block, 0, st, H, W, rgb1, rgb2, flow12,
+                     flow_1_to_tgt, valid_dyn_mask_1, noise, rng, alpha, acc, (const uint8_t *)flags, (const float *)nullptr,
+                     (const float *)nullptr, (const uint8_t *)nullptr);
   return check_launch("dyn_splat_scatter");
 }
 
@@ -644,11 +670,12 @@ int dyn_splat_scatter_part_fused(int H, int W, const float *rgb1, const float *r
     }
   }
   dim3 grid((unsigned)cdiv(P, 256)), block(256);
+  // (flow_1_to_tgt / valid_mask: null = not materialised -- both passes project the kept points themselves)
   PGDVS_LAUNCH("dyn_project_flag", dyn_project_flag_kernel, grid, block, 0, st, H, W, cam_tgt, pcl, keep, flow_1_to_tgt, valid_mask,
                flags, acc);
   const dim3 tgrid((unsigned)cdiv(W, kSplatTile), (unsigned)cdiv(H, kSplatTile));
-  PGDVS_LAUNCH("dyn_splat_scatter", dyn_splat_scatter_kernel, tgrid, block, 0, st, H, W, rgb1, rgb2, flow12,
-               (const float *)flow_1_to_tgt, (const float *)valid_mask, noise, rng, alpha, acc, (const uint8_t *)flags);
+  PGDVS_LAUNCH("dyn_splat_scatter", dyn_splat_scatter_kernel<true>, tgrid, block, 0, st, H, W, rgb1, rgb2, flow12,
+               (const float *)nullptr, (const float *)nullptr, noise, rng, alpha, acc, (const uint8_t *)flags, cam_tgt, pcl, keep);
   return check_launch("dyn_splat_scatter");
 }
 

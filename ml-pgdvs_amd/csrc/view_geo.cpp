@@ -80,7 +80,6 @@ struct ViewWs {
   int64_t knn_bytes;
   void *outlier;
   int64_t outlier_bytes;
-  float *flow_1_to_tgt, *valid_mask;
   void *splat;
   int64_t splat_bytes;
   int64_t raster_rows;  // rows the tile lists are sized for
@@ -129,8 +128,6 @@ int view_layout(const pgdvs_view_geo_desc &d, void *base, ViewWs &w) {
   w.valid = c.take<uint8_t>(P);
   w.keep = c.take<uint8_t>(P);
   w.pcl = c.take<float>(P * 12);
-  w.flow_1_to_tgt = c.take<float>(P * 8);
-  w.valid_mask = c.take<float>(P * 4);
   w.splat_bytes = pgdvs_dyn_splat_workspace_bytes(d.H, d.W);
   w.splat = c.take<char>(w.splat_bytes);
   w.idx = nullptr;
@@ -321,8 +318,8 @@ int dyn_geometry(const pgdvs_view_geo_desc &d, const ViewWs &w, pgdvs_stream_t s
   // A5 + A6-A8, first half: projection, metric, flags and the scatter into the accumulators need the flows, not the static
   // image -- they run here, beside the static branch when there is a side stream; only the finish pass waits for the rasteriser
   const unsigned long long *rng = (d.noise == nullptr && d.rng_state != nullptr) ? reinterpret_cast<const unsigned long long *>(d.rng_state) : nullptr;
-  VG_TRY(dyn_splat_scatter_part_fused(H, W, d.rgb1, d.rgb2, d.flow12, cam_t, w.pcl, keep, w.flow_1_to_tgt, w.valid_mask, d.noise, rng,
-                                      d.alpha, w.splat, true, st));
+  VG_TRY(dyn_splat_scatter_part_fused(H, W, d.rgb1, d.rgb2, d.flow12, cam_t, w.pcl, keep, nullptr, nullptr, d.noise, rng, d.alpha,
+                                      w.splat, true, st));  // (the flow and validity planes of A5 are not materialised)
   return PGDVS_OK;
 }
 

@@ -155,7 +155,11 @@ raster_zmin_kernel(const float *__restrict__ pts, int64_t pts_stride, int64_t n_
     const float yc = (float)(H - 1) - ((p.y + offy) * (float)H - offy) / rc.range_y;
     const float xr = rintf(xc), yr = rintf(yc);
     if (!(xr >= 0.0f && xr <= (float)(W - 1) && yr >= 0.0f && yr <= (float)(H - 1))) continue;
-    atomicMin(&zmin[(size_t)(int)yr * W + (int)xr], __float_as_uint(p.z + 0.0f));
+    // (round 6: look before the atomic -- a minimum only falls, so a value read earlier, however stale, that is already <= this
+    // depth makes the atomic a no-op; with three or more points per pixel most of them are)
+    unsigned *cell = &zmin[(size_t)(int)yr * W + (int)xr];
+    const unsigned zb = __float_as_uint(p.z + 0.0f);
+    if (zb < *cell) atomicMin(cell, zb);  // (107 -> 84 us on the noisy-depth scene's 6.5 M points; an atomic load instead: the same)
   }
 }
 
